@@ -225,21 +225,31 @@ def gen_dpselect(vc, outdir):
               f"mask_rate={mask.float().mean():.3f}")
 
     # ---- hand-built edge cases (ties / zeros): compared by the documented rules ----
-    # plateau ties in dis (first-index rule): frames repeat in runs so cos==1 exactly
+    # plateau ties in dis (first-index rule): frames repeat in runs, each copy scaled by a
+    # distinct power of two so frames stay unique (indices recoverable) while the normalised vectors,
+    # hence the cosines, are bit-identical between pairs with the same pattern -> exact ties in dis.
     rng = np.random.default_rng(5)
     base = rng.standard_normal((6, 3, 16)).astype(np.float32)
-    # power-of-two scaled copies keep cosine bit-identical between pairs with the same pattern
-    order = [0, 1, 1, 2, 3, 3, 3, 4, 0, 0, 5, 1, 2, 2, 4, 5]
-    x = torch.from_numpy(base[order][None])
+    order = [0, 1, 1, 2, 3, 3, 3, 4, 0, 0, 5, 1, 2, 2, 4, 5, 3, 3, 0, 0]
+    T = len(order)
+    scale = (2.0 ** (np.arange(T) - 10)).astype(np.float32)
+    x = torch.from_numpy(base[order] * scale[:, None, None])[None]
     x[0, 3, 1] = 0.0  # a zero vector: cos = 0 -> dis = 1
     for sync in (True, False):
-        for tgt in (5, 16):
+        for tgt in (5, T):
             d32, d64 = dis_matrices(x)
             out, mask = vc.memory_bank_compress_keyframe(x.clone(), tgt, 3, sync=sync)
+            xin, outn = x.numpy(), out.numpy()
+            if sync:
+                idx = recover_frame_idx(xin[:, :, :1], outn[:, :, :1])[:, 0]
+            else:
+                # patch 1 of frame 3 is all-zero and unique, fine
+                idx = recover_frame_idx(xin, outn)
             np.savez_compressed(os.path.join(outdir, f"dpselect_edge_plateau_{'sync' if sync else 'async'}_t{tgt}.npz"),
-                                kind="raw", T=16, N=3, C=16, tgt=tgt, sync=sync, window=3, dtype="fp32",
-                                x=x.numpy(), out=out.numpy(), mask=mask.numpy(), dis32=d32, dis64=d64)
-            print(f"dpselect_edge_plateau sync={sync} t={tgt}: mask_sum={int(mask.sum())}")
+                                kind="raw", T=T, N=3, C=16, tgt=tgt, sync=sync, window=3, dtype="fp32",
+                                x=xin, out=outn, idx=idx, mask=mask.numpy(), dis32=d32, dis64=d64)
+            print(f"dpselect_edge_plateau sync={sync} t={tgt}: mask_sum={int(mask.sum())} "
+                  f"ties_in_dis={int((np.diff(np.sort(d32, axis=0), axis=0) == 0).sum())}")
 
     # N=1 async is a reference crash - record the exception type
     try:

@@ -1,0 +1,157 @@
+"""Pins the CPU oracle (oracle/) to the golden vectors produced by the Python reference.
+
+Bar (BASELINE.json north_star): selected frame indices and kept KV indices bit-exact; compressed
+values within 1e-5.  Fixtures are seeded to contain no fragile decision (margins stored in each
+file); exact-tie fixtures are compared by the documented rule instead (count + score equality).
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import synth
+from oracle import oracle as orc
+
+DP_FP32 = [n for n in gu.names("dpselect_") if "edge" not in n and "bf16" not in n]
+DP_BF16 = [n for n in gu.names("dpselect_") if "bf16" in n]
+PK = gu.names("pivotkv_")
+
+
+@pytest.mark.parametrize("name", DP_FP32)
+def test_dpselect_fp32_matches_reference(name):
+    g = gu.load(name)
+    x = gu.dpselect_input(g)
+    out, mask, idx, dis = orc.dpselect(x, int(g["tgt"]), int(g["window"]), bool(g["sync"]))
+    # distance: fp32 summation-order noise only
+    assert np.abs(dis - g["dis32"]).max() < 2e-6
+    assert np.abs(dis - g["dis64"]).max() < 2e-6
+    # indices bit-exact, mask bit-exact, frames are pure copies (crc of the whole output)
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(mask, g["mask"])
+    assert synth.checksum(out) == int(g["out_crc"])
+
+
+@pytest.mark.parametrize("name", DP_BF16)
+def test_dpselect_bf16_matches_reference(name):
+    g = gu.load(name)
+    x = gu.dpselect_input(g)  # uint16 bf16 bits
+    out, mask, idx, dis = orc.dpselect(x, int(g["tgt"]), int(g["window"]), bool(g["sync"]))
+    # bf16 distance has bf16 resolution (2^-8 near 1); the emulated rounding chain reproduces the
+    # reference up to one bf16 ulp of the cosine on rare elements
+    d = np.abs(dis - g["dis32"])
+    assert d.max() <= 2 ** -7 and (d > 0).mean() < 0.02
+    if (d == 0).all():
+        # bf16 distances tie massively; torch's top-k tie order is backend-specific,
+        # so the selected KEY multiset per row must match, and the peak flags of common picks too.
+        sync = bool(g["sync"])
+        _, _, keys = orc.dpselect_select(dis, int(g["tgt"]), int(g["window"]), sync)
+        ref_idx = g["idx"]
+        rows = [(keys, idx, ref_idx)] if sync else [(keys[n], idx[:, n], ref_idx[:, n]) for n in range(idx.shape[1])]
+        for krow, mine, theirs in rows:
+            np.testing.assert_array_equal(np.sort(krow[mine]), np.sort(krow[theirs]))
+        assert mask.sum() == g["mask"].sum()
+
+
+@pytest.mark.parametrize("sync", [True, False])
+@pytest.mark.parametrize("tgt", [5, 20])
+def test_dpselect_plateau_ties(sync, tgt):
+    """Hand-built exact ties in dis (repeated frames scaled by powers of two) and a zero vector.
+    The peak rule (first index wins) is pinned exactly via the ratio-1.0 mask; at t=5 the k-th
+    boundary may fall inside exact ties where torch's order is backend-specific:
+    there the selected KEY multiset must match."""
+    g = gu.load(f"dpselect_edge_plateau_{'sync' if sync else 'async'}_t{tgt}")
+    x = g["x"]
+    dis = orc.dpselect_dis(x[0])
+    # cos of identical directions is 1 +- 1 ulp depending on summation order: pin dis to 1 ulp, then
+    # pin the tie RULES of stencil and selection on the reference's own distance matrix.
+    assert np.abs(dis - g["dis32"]).max() <= 2.5e-7
+    assert dis[3, 1] == 1.0 and dis[4, 1] == 1.0  # zero vector -> cos 0
+    dis = g["dis32"]
+    idx, mask2d, keys = orc.dpselect_select(dis, tgt, 3, sync)
+    if tgt == 20:
+        np.testing.assert_array_equal(idx, g["idx"])
+        np.testing.assert_array_equal(mask2d.reshape(-1), g["mask"])
+        np.testing.assert_array_equal(orc.gather_frames(x[0], idx, sync)[None], g["out"])
+        return
+    ref_idx = g["idx"]
+    rows = [(keys, idx, ref_idx)] if sync else [(keys[n], idx[:, n], ref_idx[:, n]) for n in range(3)]
+    for krow, mine, theirs in rows:
+        np.testing.assert_array_equal(np.sort(krow[mine]), np.sort(krow[theirs]))
+
+
+def test_dpselect_async_n1_is_reference_crash():
+    g = gu.load("dpselect_edge_n1_async")
+    assert str(g["exception"]) == "IndexError"
+    with pytest.raises(IndexError):
+        orc.dpselect(np.zeros((1, 8, 1, 16), np.float32), 4, 3, sync=False)
+
+
+def _run_pivotkv(g):
+    Hq, Hkv, D = int(g["Hq"]), int(g["Hkv"]), int(g["D"])
+    sec = [int(s) for s in g["mrope_section"]] or None
+    rotary = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]))
+    cache = orc.OraclePivotKV(Hq, Hkv, D, float(g["ratio"]), bool(g["reforge"]))
+    layer = int(g["layer"])
+    for c in range(int(g["n_chunks"])):
+        q, k, v, pos, mask = gu.pivotkv_chunk_inputs(g, c)
+        cache.keypatches_mask_chunk = mask
+        prev_len = 0 if len(cache.key_cache) <= layer or len(cache.key_cache[layer]) == 0 \
+            else cache.key_cache[layer].shape[2]
+        kout, vout = cache.update(k, v, layer, q=q, position_ids=pos, rotary=rotary, mrope_section=sec)
+        assert kout.shape == (1, Hkv, prev_len + k.shape[2], D)
+        yield c, cache, k, v
+
+
+@pytest.mark.parametrize("name", PK)
+def test_pivotkv_matches_reference(name):
+    g = gu.load(name)
+    keep = int(g["keep"])
+    tie = bool(g["tie_case"])
+    for c, cache, k, v in _run_pivotkv(g):
+        pre = f"c{c}_"
+        last = cache.last
+        # score: fp32 noise vs the reference's own fp32 score and the fp64 recomputation
+        assert np.abs(last["score"] - g[pre + "score32"]).max() < 5e-6
+        assert np.abs(last["score"] - g[pre + "score64"]).max() < 5e-6
+        if tie:
+            # boundary inside exact 1.0 ties: same score multiset, canonical rule = lowest index first
+            s = g[pre + "score32"]
+            np.testing.assert_array_equal(np.sort(s[last["keep_idx"]]), np.sort(s[g[pre + "keep_idx"]]))
+            thr = np.sort(s)[::-1][keep - 1]
+            ties = np.nonzero(last["score"] == thr)[0]
+            picked = np.intersect1d(ties, last["keep_idx"])
+            np.testing.assert_array_equal(picked, ties[: len(picked)])
+            break  # later chunks depend on which tied tokens were kept
+        np.testing.assert_array_equal(last["keep_idx"], g[pre + "keep_idx"])
+        assert np.abs(last["kept_k"] - g[pre + "kept_k"]).max() <= 1e-5
+        if bool(g["raw"]):
+            np.testing.assert_array_equal(last["kept_v"], g[pre + "kept_v"])
+        else:
+            assert synth.checksum(last["kept_v"]) == int(g[pre + "kept_v_crc"])
+        layer = int(g["layer"])
+        assert cache.num_evicted_tokens[layer] == int(g[pre + "num_evicted"])
+        if bool(g["reforge"]):
+            np.testing.assert_array_equal(cache.position_cache[layer], g[pre + "position_cache"])
+    if not tie:
+        assert len(cache.position_cache) == int(g["position_cache_len"])
+        np.testing.assert_array_equal(np.array(cache.num_evicted_tokens), g["num_evicted_list"])
+
+
+def test_topk_ties_lowest_index_first():
+    v = np.array([1, 3, 3, 2, 3, 0, 3], dtype=np.float32)
+    import ctypes as C
+
+    idx = np.empty(3, dtype=np.int64)
+    rc = orc.lib().orc_topk_sorted(v.ctypes.data_as(C.c_void_p), len(v), 3, idx.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    np.testing.assert_array_equal(idx, [1, 2, 4])
+
+
+def test_position_rescale_float32_truncation():
+    # keep/k_len = 22/75 is not dyadic: float32 multiply then truncate
+    L, keep = 75, 22
+    pos = np.arange(L, dtype=np.int64)[None] * 3 + 11
+    idx = np.sort(np.random.default_rng(0).choice(L, keep, replace=False)).astype(np.int64)
+    out = orc.pivotkv_positions(pos, idx, True)
+    t = pos[0, idx]
+    want = t.min() + ((t - t.min()).astype(np.float32) * np.float32(keep / L)).astype(np.int64)
+    np.testing.assert_array_equal(out[0], want)
