@@ -1,0 +1,171 @@
+/*
+ * retake_hip.h — C ABI of libretake_hip.so: the MI355X (gfx950) implementation of ReTaKe's
+ * DPSelect + PivotKV hot path.
+ *
+ * The reference (SCZwangxiao/video-ReTaKe) is pure Python: its "FFI" for this path is the set of
+ * torch ATen calls inside two functions.  Each entry point below replaces one group of those call
+ * sites; the reference-side binding is a ctypes stub, and the shipped Python
+ * package `retake` (video-retake_amd/retake) is that binding behind the reference's own names
+ *   retake.visual_compression.memory_bank_compress_keyframe   (visual_compression.py:86-177)
+ *   retake.longvideo_cache.PivotKVCache.update                (longvideo_cache.py:217-323)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the current HIP device unless marked host;
+ *   - the library never allocates or frees device memory: outputs and workspaces are caller-owned;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *     re-entrant, and keeps no global mutable state besides the thread-local error string;
+ *   - return value 0 = success, negative = rtk_status; no C++ exception crosses the ABI;
+ *   - dtype: RTK_F32 or RTK_BF16 for the frame / q / k / v payloads; scores, distances and RoPE
+ *     tables are always fp32; indices are int64 and masks are 1 byte per element (torch.bool layout);
+ *   - strides are in ELEMENTS; the innermost (channel / head_dim) axis is always contiguous.
+ */
+#ifndef RETAKE_HIP_H
+#define RETAKE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rtk_stream_t; /* hipStream_t */
+
+enum rtk_dtype { RTK_F32 = 0, RTK_BF16 = 1 };
+
+enum rtk_status {
+    RTK_OK = 0,
+    RTK_EINVAL = -1,      /* bad argument (NULL pointer, non-positive size, unsupported dtype) -> ValueError   */
+    RTK_EUNSUPPORTED = -2,/* shape outside what the kernels support                      -> NotImplementedError */
+    RTK_EWORKSPACE = -3,  /* workspace too small                                          -> ValueError         */
+    RTK_EHIP = -4,        /* a HIP runtime call failed (message in rtk_last_error)        -> RuntimeError       */
+    RTK_EREFCRASH = -5    /* input on which the reference itself raises (N==1 async)      -> IndexError         */
+};
+
+/* ABI version (bumped on any signature change) and the thread-local message of the last failure. */
+int rtk_version(void);
+const char* rtk_last_error(void);
+/* Name of the code-object architecture this library was built for ("gfx950"). */
+const char* rtk_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * DPSelect  — replaces retake/visual_compression.py:100-175
+ * ------------------------------------------------------------------------------------------- */
+
+/* D1-D2  visual_compression.py:100-106  F.cosine_similarity(mb[:, :-1], mb[:, 1:], dim=-1),
+ * `1 - sim.float()`, cat(ones).   x [T,N,C] (contiguous) -> dis [T,N] fp32, row 0 = 1.0.
+ * RTK_BF16 reproduces the reference's bf16 rounding chain (norm, quotient, product, sum). */
+int rtk_dpselect_dis(const void* x, int T, int N, int C, int dtype, float* dis, rtk_stream_t stream);
+
+/* D3-D6  visual_compression.py:108-135 (sync) / :142-169 (async): patch mean, argrelmax peaks
+ * (max_pool1d_with_indices window, first index wins), +2 bonus, topk(tgt) + ascending sort.
+ *   dis   [T,N] fp32 (not modified)
+ *   idx   sync: [tgt] int64;  async: [tgt,N] int64 (column n = patch n)
+ *   mask  [tgt,N] bytes (keypatches_mask before .flatten())
+ *   keys  workspace AND output: async [N,T] fp32 — the keys after the +2 bonus; sync [2,T]: row 0 the
+ *         keys, row 1 the patch-mean distance dis.mean(1)
+ * Ties at the k-th boundary are taken lowest index first (torch's order is backend-specific).
+ * async with N == 1 returns RTK_EREFCRASH (the reference raises IndexError, :153-156). */
+int rtk_dpselect_select(const float* dis, int T, int N, int tgt, int window, int sync,
+                        int64_t* idx, uint8_t* mask, float* keys, rtk_stream_t stream);
+
+/* D7  visual_compression.py:138 (sync `mb[:, peaks]`) / :173 (async `mb.gather(1, ...)`).
+ * x [T,N,C] -> out [tgt,N,C]; idx as produced by rtk_dpselect_select. */
+int rtk_gather_frames(const void* x, int T, int N, int C, int dtype, const int64_t* idx, int tgt, int sync,
+                      void* out, rtk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RoPE tables — replaces longvideo_cache.py:68-74 (M-RoPE section merge) and, optionally, the
+ * rotary_emb_fn(...) calls at :249 and :298 when the rotary module is the standard
+ * inv_freq/attention_scaling kind.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Merge the [P,L,D] cos and sin returned by rotary_emb_fn (P = 3 for M-RoPE, 1 otherwise; dtype of
+ * q) into fp32 [L,D] tables.  sections = mrope_section (host pointer, nsec ints; NULL for P = 1);
+ * channel block i of `mrope_section*2` takes row i % 3. */
+int rtk_rope_merge(const void* cos_in, const void* sin_in, int P, int L, int D, int dtype,
+                   const int* sections_host, int nsec, float* cos_out, float* sin_out, rtk_stream_t stream);
+
+/* Build the merged fp32 [L,D] tables directly from position ids: cos(pos*inv_freq)*scaling.
+ * pos [P,L] int64 (row stride L), inv_freq [D/2] fp32.  round_bf16 != 0 rounds the table entries
+ * to bf16 (what a bf16 model's rotary module returns). */
+int rtk_rope_table(const int64_t* pos, int P, int L, const float* inv_freq, int D, float attention_scaling,
+                   const int* sections_host, int nsec, int round_bf16, float* cos_out, float* sin_out,
+                   rtk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * PivotKV — replaces retake/longvideo_cache.py:248-318
+ * ------------------------------------------------------------------------------------------- */
+
+/* Workspace (bytes) needed by rtk_pivotkv_score for these sizes. */
+size_t rtk_pivotkv_score_workspace_bytes(int Hq, int Hkv, int L, int D, int dtype);
+
+/* P2-P5  longvideo_cache.py:248-270.
+ *   q [Hq,L,D], k [Hkv,L,D]: element (h,l,d) at h*stride_h + l*stride_l + d  (post-RoPE, as the
+ *   attention patch hands them over).
+ *   cos/sin: fp32 [L,D] merged tables or NULL.  Non-NULL = pos_embed_reforge: q and k are first
+ *   un-rotated, x~ = ((x*cos) - (rotate_half(x)*sin)) / attention_scaling^2   (:76-78, :109-111).
+ *   score [L] fp32 = mean_g mean_{h in g} sum_i softmax_j(q~_h,i . k~_g,j / sqrt(D))  — keys are the
+ *   current chunk only, no causal mask (:264-270).
+ *   k_unrot (optional, may be NULL): receives k~ [Hkv,L,D] contiguous in `dtype` for rtk_pivotkv_evict.
+ * The [Hq,L,L] probability tensor is never materialised. */
+int rtk_pivotkv_score(const void* q, int64_t q_stride_h, int64_t q_stride_l,
+                      const void* k, int64_t k_stride_h, int64_t k_stride_l,
+                      int Hq, int Hkv, int L, int D, int dtype,
+                      const float* cos, const float* sin, float attention_scaling,
+                      float* score, void* k_unrot, void* workspace, size_t workspace_bytes,
+                      rtk_stream_t stream);
+
+/* P6-P7, P9-P10  longvideo_cache.py:272-277, :283-295.
+ *   score [L] fp32: entries with mask != 0 are overwritten with 1.0 IN PLACE (masked_fill_, :274);
+ *   mask may be NULL.
+ *   keep_idx [keep] int64 ascending = topk(keep).sort()  (ties: lowest index first)
+ *   rank [L] int32: position of token l in keep_idx, or -1 if evicted (feeds rtk_pivotkv_evict)
+ *   pos [P,L] int64 (P = 3 M-RoPE rows t,h,w or 1), may be NULL together with pos_out;
+ *   pos_out [P,keep] int64 = gathered ids; if reforge != 0 row 0 becomes
+ *       tmin + (int64)((float)(t - tmin) * (float)(keep / (double)L))        (:293-295)  */
+int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep,
+                       const int64_t* pos, int P, int reforge,
+                       int64_t* keep_idx, int32_t* rank, int64_t* pos_out, rtk_stream_t stream);
+
+/* P1, P8, P11, P13  longvideo_cache.py:238, :278-280, :297-306, :313-318 — the eviction scan.
+ * One pass over the chunk's K and V rows:
+ *   every row l is appended to the cache tail   k_tail/v_tail[h][l]      (the uncompressed view the
+ *                                                current layer's attention reads, :238)
+ *   rows with rank[l] >= 0 are also written to  k_kept/v_kept[h][rank[l]] (the compacted cache, :313-318)
+ * With reforge (cos_new != NULL) the kept K row is taken from k_unrot (un-rotated, as produced by
+ * rtk_pivotkv_score) and rotated forward with the fp32 [keep,D] tables of its NEW position:
+ *   k' = (k~*cos_new) + (rotate_half(k~)*sin_new)          (:80-81, :113-114)
+ * otherwise it is a plain copy of k.  V rows are plain copies.
+ * k_tail/v_tail may be NULL (no append wanted).  Destinations: element (h,r,d) at
+ * h*stride_h + r*D + d. */
+int rtk_pivotkv_evict(const void* k, int64_t k_stride_h, int64_t k_stride_l,
+                      const void* v, int64_t v_stride_h, int64_t v_stride_l,
+                      const void* k_unrot, int Hkv, int L, int D, int dtype,
+                      const int32_t* rank, int keep,
+                      const float* cos_new, const float* sin_new,
+                      void* k_tail, void* v_tail, int64_t tail_stride_h,
+                      void* k_kept, void* v_kept, int64_t kept_stride_h,
+                      rtk_stream_t stream);
+
+/* Row-block copy used to commit staged kept rows into the cache after the layer's attention has
+ * consumed the uncompressed view: dst[h][r][:] = src[h][r][:], r < rows. */
+int rtk_copy_rows(const void* src, int64_t src_stride_h, void* dst, int64_t dst_stride_h,
+                  int H, int rows, int D, int dtype, rtk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Measurement support (bench.py).  When enabled, every kernel launch of this library is bracketed
+ * by two hipEvents recorded on the launch stream; rtk_profile_collect() waits for them and folds
+ * the elapsed times into per-kernel totals.  Process-wide, off by default.
+ * ------------------------------------------------------------------------------------------- */
+int rtk_profile_enable(int on);
+int rtk_profile_collect(void);
+int rtk_profile_reset(void);
+int rtk_profile_num_kernels(void);
+const char* rtk_profile_kernel_name(int kernel_id);
+int rtk_profile_read(int kernel_id, long long* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RETAKE_HIP_H */

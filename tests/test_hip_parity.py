@@ -1,0 +1,343 @@
+"""HIP path vs the reference goldens and vs the CPU oracle — the parity gate (runs on the MI355X box).
+
+Everything here goes through the product's public surface (retake.visual_compression /
+retake.longvideo_cache), i.e. through the C ABI of libretake_hip.so.  Bar: frame and KV indices
+bit-exact, gathered frames / kept V byte-identical, kept K within 1e-5 (fp32).
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DP_FP32 = [n for n in gu.names("dpselect_") if "edge" not in n and "bf16" not in n]
+DP_BF16 = [n for n in gu.names("dpselect_") if "bf16" in n]
+PK = gu.names("pivotkv_")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+# ---------------------------------------------------------------------------------------------------
+# DPSelect
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", DP_FP32)
+def test_dpselect_fp32_golden(name):
+    import retake.visual_compression as vc
+
+    g = gu.load(name)
+    x = gu.dpselect_input(g)
+    xt = torch.from_numpy(x).to(dev())
+    out, mask, idx, dis, keys = vc.dpselect_stages(xt, int(g["tgt"]), int(g["window"]), bool(g["sync"]))
+    torch.cuda.synchronize()
+    assert np.abs(dis.cpu().numpy() - g["dis32"]).max() < 2e-6
+    np.testing.assert_array_equal(idx.cpu().numpy(), g["idx"])
+    np.testing.assert_array_equal(mask.flatten().cpu().numpy(), g["mask"])
+    assert synth.checksum(out.cpu().numpy()) == int(g["out_crc"])
+    # public entry point returns the same pair
+    out2, mask2 = vc.memory_bank_compress_keyframe(xt, int(g["tgt"]), int(g["window"]), sync=bool(g["sync"]))
+    assert out2.shape == out.shape and mask2.dtype == torch.bool and mask2.ndim == 1
+    assert torch.equal(out2, out) and torch.equal(mask2, mask.flatten())
+    assert out2.data_ptr() != xt.data_ptr()
+
+
+@pytest.mark.parametrize("name", DP_BF16)
+def test_dpselect_bf16_golden(name):
+    import retake.visual_compression as vc
+
+    g = gu.load(name)
+    x = gu.dpselect_input(g)  # uint16 bits
+    xt = torch.from_numpy(x.view(np.int16)).to(dev()).view(torch.bfloat16)
+    out, mask, idx, dis, keys = vc.dpselect_stages(xt, int(g["tgt"]), int(g["window"]), bool(g["sync"]))
+    d = np.abs(dis.cpu().numpy() - g["dis32"])
+    # the bf16 rounding chain of the reference is reproduced; a different fp32 summation order can
+    # flip the final bf16 rounding of a few sums by one ulp (2^-8 at most near 1)
+    assert d.max() <= 2 ** -7 and (d > 0).mean() < 0.02
+    sync = bool(g["sync"])
+    ref_idx = g["idx"]
+    k = keys.cpu().numpy()
+    idxn = idx.cpu().numpy()
+    if (d == 0).all():
+        rows = [(k[0], idxn, ref_idx)] if sync else [(k[n], idxn[:, n], ref_idx[:, n]) for n in range(idxn.shape[1])]
+        for krow, mine, theirs in rows:
+            np.testing.assert_array_equal(np.sort(krow[mine]), np.sort(krow[theirs]))
+
+
+@pytest.mark.parametrize("sync", [True, False])
+@pytest.mark.parametrize("tgt", [5, 20])
+def test_dpselect_tie_rules_on_reference_distance(sync, tgt):
+    """Exact ties in dis: the stencil's first-index rule and the selected key multiset."""
+    import ctypes as C
+
+    import retake._native as nv
+
+    g = gu.load(f"dpselect_edge_plateau_{'sync' if sync else 'async'}_t{tgt}")
+    dis = torch.from_numpy(g["dis32"]).to(dev())
+    T, N = dis.shape
+    idx = torch.empty((tgt,) if sync else (tgt, N), dtype=torch.int64, device=dev())
+    mask = torch.empty((tgt, N), dtype=torch.bool, device=dev())
+    keys = torch.empty((2, T) if sync else (N, T), dtype=torch.float32, device=dev())
+    nv.check(nv.lib.rtk_dpselect_select(nv.ptr(dis), T, N, tgt, 3, int(sync), nv.ptr(idx), nv.ptr(mask), nv.ptr(keys),
+                                        nv.stream()), "select")
+    o_idx, o_mask, o_keys = orc.dpselect_select(g["dis32"], tgt, 3, sync)
+    np.testing.assert_array_equal(idx.cpu().numpy(), o_idx)          # same canonical tie rule as the oracle
+    np.testing.assert_array_equal(mask.cpu().numpy(), o_mask)
+    np.testing.assert_array_equal(keys.cpu().numpy()[0] if sync else keys.cpu().numpy(), o_keys)
+    if tgt == 20:
+        np.testing.assert_array_equal(idx.cpu().numpy(), g["idx"])
+        np.testing.assert_array_equal(mask.flatten().cpu().numpy(), g["mask"])
+
+
+def test_dpselect_async_single_patch_raises_like_reference():
+    import retake.visual_compression as vc
+
+    with pytest.raises(IndexError):
+        vc.memory_bank_compress_keyframe(torch.randn(1, 8, 1, 16, device=dev()), 4, 3, sync=False)
+
+
+@pytest.mark.parametrize("T,N,C,tgt,sync", [(33, 7, 40, 11, False), (9, 3, 6, 9, True), (3, 2, 1000, 2, False),
+                                            (130, 5, 4100, 40, False), (17, 4, 18, 5, True)])
+def test_dpselect_odd_shapes_vs_oracle(T, N, C, tgt, sync):
+    """Ragged channel counts (generic kernel), tiny T, C beyond the register path."""
+    import retake.visual_compression as vc
+
+    x = synth.frames_video(900 + T + C, T, N, C)
+    out, mask, idx, dis, _ = vc.dpselect_stages(torch.from_numpy(x).to(dev()), tgt, 3, sync)
+    o_out, o_mask, o_idx, o_dis = orc.dpselect(x, tgt, 3, sync)
+    assert np.abs(dis.cpu().numpy() - o_dis).max() < 2e-6
+    # decisions can only differ where the oracle's own margin is at noise level
+    keys_gap = _min_decision_gap(o_dis, tgt, sync)
+    if keys_gap > 1e-5:
+        np.testing.assert_array_equal(idx.cpu().numpy(), o_idx)
+        np.testing.assert_array_equal(mask.flatten().cpu().numpy(), o_mask)
+        np.testing.assert_array_equal(out.cpu().numpy(), o_out)
+
+
+def _min_decision_gap(dis, tgt, sync):
+    rows = dis.mean(1, keepdims=True).T if sync else dis.T
+    gap = np.abs(np.diff(rows, axis=1)).min() if rows.shape[1] > 1 else np.inf
+    pk = (rows > np.concatenate([np.full((rows.shape[0], 1), -np.inf), rows[:, :-1]], 1)) & \
+         (rows >= np.concatenate([rows[:, 1:], np.full((rows.shape[0], 1), -np.inf)], 1))
+    keys = rows + 2.0 * pk
+    if tgt < rows.shape[1]:
+        s = -np.sort(-keys, axis=1)
+        gap = min(gap, (s[:, tgt - 1] - s[:, tgt]).min())
+    return gap
+
+
+def test_dpselect_window5_vs_oracle():
+    import retake.visual_compression as vc
+
+    x = synth.frames_video(77, 40, 6, 64)
+    out, mask, idx, dis, _ = vc.dpselect_stages(torch.from_numpy(x).to(dev()), 13, 5, False)
+    o_idx, o_mask, _ = orc.dpselect_select(dis.cpu().numpy(), 13, 5, False)
+    np.testing.assert_array_equal(idx.cpu().numpy(), o_idx)
+    np.testing.assert_array_equal(mask.cpu().numpy(), o_mask)
+
+
+# ---------------------------------------------------------------------------------------------------
+# PivotKV
+# ---------------------------------------------------------------------------------------------------
+def _make_cache(g, native_rope=False):
+    import retake.longvideo_cache as lc
+
+    Hq, Hkv, D = int(g["Hq"]), int(g["Hkv"]), int(g["D"])
+    llm = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=int(g["layer"]) + 1, num_attention_heads=Hq,
+                                num_key_value_heads=Hkv)
+    kw = {"kvcache_compression": True,
+          "kvcache_compression_kwargs": {"compression_ratio": float(g["ratio"]), "compression_method": "pivotkv",
+                                         "pos_embed_reforge": bool(g["reforge"]), "native_rope": native_rope}}
+    sec = [int(s) for s in g["mrope_section"]] or None
+    if sec is None:
+        cfg = types.SimpleNamespace(text_config=llm, longvideo_kwargs=kw)  # LLaVA-style config
+    else:
+        llm.longvideo_kwargs = kw
+        cfg = llm
+    cache = lc.build_kvcache(cfg)
+    assert isinstance(cache, lc.PivotKVCache)
+    return cache, sec
+
+
+@pytest.mark.parametrize("native_rope", [False, True])
+@pytest.mark.parametrize("name", PK)
+def test_pivotkv_golden(name, native_rope):
+    g = gu.load(name)
+    cache, sec = _make_cache(g, native_rope)
+    layer, keep, tie = int(g["layer"]), int(g["keep"]), bool(g["tie_case"])
+    rotary = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]), device=dev())
+    Hkv, D = int(g["Hkv"]), int(g["D"])
+    prev_len = 0
+    for c in range(int(g["n_chunks"])):
+        q, k, v, pos, mask = gu.pivotkv_chunk_inputs(g, c)
+        qt, kt, vt = (torch.from_numpy(a).to(dev()) for a in (q, k, v))
+        post = torch.from_numpy(pos).to(dev())
+        cache.keypatches_mask_chunk = torch.from_numpy(mask).to(dev()) if mask is not None else None
+        cache.kvcache_compression = True
+        kw = {"sin": None, "cos": None, "cache_position": None, "query_states": qt, "position_ids": post,
+              "rotary_emb": rotary}
+        if sec:
+            kw["mrope_section"] = list(sec)
+        kout, vout = cache.update(kt, vt, layer, kw)
+        assert set(kw) == {"sin", "cos", "cache_position"}          # the four keys are popped (A11)
+        L = k.shape[2]
+        assert kout.shape == (1, Hkv, prev_len + L, D) and vout.shape == kout.shape
+        assert torch.equal(kout[:, :, prev_len:], kt) and torch.equal(vout[:, :, prev_len:], vt)  # uncompressed
+        pre = f"c{c}_"
+        score = cache.last_scores.cpu().numpy()
+        idx = cache.last_keep_indices.cpu().numpy()
+        assert np.abs(score - g[pre + "score32"]).max() < 5e-6
+        if tie:
+            s = g[pre + "score32"]
+            np.testing.assert_array_equal(np.sort(s[idx]), np.sort(s[g[pre + "keep_idx"]]))
+            thr = np.sort(s)[::-1][keep - 1]
+            ties = np.nonzero(score == thr)[0]
+            picked = np.intersect1d(ties, idx)
+            np.testing.assert_array_equal(picked, ties[: len(picked)])   # lowest index first
+            return
+        np.testing.assert_array_equal(idx, g[pre + "keep_idx"])
+        kc, vc_ = cache.key_cache[layer], cache.value_cache[layer]      # commits the staged rows
+        assert kc.shape == (1, Hkv, prev_len + keep, D)
+        kept_k = kc[:, :, prev_len:].cpu().numpy()
+        kept_v = vc_[:, :, prev_len:].cpu().numpy()
+        tol = 1e-5 if not native_rope else 2e-5   # device sincosf vs torch's: <= 2 ulp on the tables
+        assert np.abs(kept_k - g[pre + "kept_k"]).max() <= tol
+        if bool(g["raw"]):
+            np.testing.assert_array_equal(kept_v, g[pre + "kept_v"])
+        else:
+            assert synth.checksum(kept_v) == int(g[pre + "kept_v_crc"])
+        assert cache.num_evicted_tokens[layer] == int(g[pre + "num_evicted"])
+        if bool(g["reforge"]):
+            np.testing.assert_array_equal(cache.position_cache[layer].cpu().numpy(), g[pre + "position_cache"])
+            assert int(cache.get_prev_temporal_idx(layer)) == int(g[pre + "position_cache"].reshape(-1, g[pre + "position_cache"].shape[-1])[0, -1])
+        prev_len += keep
+        assert cache.get_seq_length(layer) == prev_len
+    assert len(cache.position_cache) == int(g["position_cache_len"])
+    np.testing.assert_array_equal(np.array(cache.num_evicted_tokens), g["num_evicted_list"])
+
+
+def test_pivotkv_strided_qkv_layout():
+    """q/k/v as HF produces them: [1, L, H, D] memory viewed as [1, H, L, D] (token stride H*D)."""
+    g = gu.load("pivotkv_qwen_L256")
+    cache_a, sec = _make_cache(g)
+    cache_b, _ = _make_cache(g)
+    rotary = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]), device=dev())
+    q, k, v, pos, mask = gu.pivotkv_chunk_inputs(g, 0)
+    qt, kt, vt = (torch.from_numpy(a).to(dev()) for a in (q, k, v))
+    strided = [t.transpose(1, 2).contiguous().transpose(1, 2) for t in (qt, kt, vt)]
+    assert not strided[0].is_contiguous()
+    res = []
+    for cache, (a, b, c_) in ((cache_a, (qt, kt, vt)), (cache_b, strided)):
+        cache.keypatches_mask_chunk = torch.from_numpy(mask).to(dev())
+        kw = {"query_states": a, "position_ids": torch.from_numpy(pos).to(dev()), "rotary_emb": rotary,
+              "mrope_section": list(sec)}
+        cache.update(b, c_, 0, kw)
+        res.append((cache.last_keep_indices.clone(), cache.key_cache[0].clone(), cache.value_cache[0].clone()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+
+
+def test_pivotkv_text_then_video_then_decode():
+    """else-branch (reference :319-321): plain append + position bookkeeping around a compressed chunk."""
+    g = gu.load("pivotkv_small_mrope_reforge")
+    cache, sec = _make_cache(g)
+    rotary = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]), device=dev())
+    Hkv, D = int(g["Hkv"]), int(g["D"])
+    kt = torch.randn(1, Hkv, 5, D, device=dev())
+    vt = torch.randn(1, Hkv, 5, D, device=dev())
+    pos_text = torch.arange(5, device=dev())[None, None].repeat(3, 1, 1)
+    cache.kvcache_compression = False
+    ko, vo = cache.update(kt, vt, 0, {"position_ids": pos_text})
+    assert torch.equal(ko, kt) and cache.get_seq_length(0) == 5
+    assert torch.equal(cache.position_cache[0], pos_text)
+    q, k, v, pos, mask = gu.pivotkv_chunk_inputs(g, 0)
+    cache.kvcache_compression = True
+    cache.keypatches_mask_chunk = None
+    kw = {"query_states": torch.from_numpy(q).to(dev()), "position_ids": torch.from_numpy(pos).to(dev()),
+          "rotary_emb": rotary, "mrope_section": list(sec)}
+    ko, vo = cache.update(torch.from_numpy(k).to(dev()), torch.from_numpy(v).to(dev()), 0, kw)
+    keep = int(g["keep"])
+    assert ko.shape[2] == 5 + k.shape[2] and torch.equal(ko[:, :, :5], kt)
+    cache.after_forward()
+    assert cache.key_cache[0].shape[2] == 5 + keep and torch.equal(cache.key_cache[0][:, :, :5], kt)
+    cache.kvcache_compression = False
+    k1 = torch.randn(1, Hkv, 1, D, device=dev())
+    ko, vo = cache.update(k1, k1.clone(), 0, {"position_ids": pos_text[:, :, :1] + 100})
+    assert ko.shape[2] == 5 + keep + 1 and torch.equal(ko[:, :, -1:], k1)
+    assert cache.position_cache[0].shape[-1] == 5 + keep + 1
+
+
+@pytest.mark.parametrize("L", [6272, 2304])
+def test_pivotkv_full_chunk_vs_oracle_margin_aware(L):
+    """BASELINE geometry (Hq 28, Hkv 4, D 128), one (layer, chunk): HIP vs CPU oracle, fp32.
+    Index mismatches are only allowed where the oracle's own decision margin is at fp32-noise level."""
+    Hq, Hkv, D, ratio = 28, 4, 128, 0.25
+    S = synth.YARN_FACTOR4_ATTENTION_SCALING
+    inv_f = synth.inv_freq(D)
+    q0, k0, v = synth.qkv_chunk(4242 + L, Hq, Hkv, L, D)
+    gh = 14 if L == 6272 else 9
+    gw = 14 if L == 6272 else 16
+    pos = synth.mrope_position_ids(7, L // (gh * gw), gh, gw, hw0=7)
+    sec = [16, 24, 24]
+    rot_cpu = synth.RotaryStub(inv_f, S)
+    q = synth.rope_forward(torch.from_numpy(q0), torch.from_numpy(pos), rot_cpu, sec)
+    k = synth.rope_forward(torch.from_numpy(k0), torch.from_numpy(pos), rot_cpu, sec)
+    mask = np.random.default_rng(5).uniform(size=L) < 0.3
+    # oracle
+    oc = orc.OraclePivotKV(Hq, Hkv, D, ratio, True)
+    oc.keypatches_mask_chunk = mask
+    oc.update(k.numpy(), v, 0, q=q.numpy(), position_ids=pos, rotary=rot_cpu, mrope_section=sec)
+    # HIP
+    g = dict(Hq=Hq, Hkv=Hkv, D=D, layer=0, ratio=ratio, reforge=True, mrope_section=np.array(sec))
+    cache, _ = _make_cache(g)
+    cache.keypatches_mask_chunk = torch.from_numpy(mask).to(dev())
+    kw = {"query_states": q.to(dev()), "position_ids": torch.from_numpy(pos).to(dev()),
+          "rotary_emb": synth.RotaryStub(inv_f, S, device=dev()), "mrope_section": sec}
+    cache.update(k.to(dev()), torch.from_numpy(v).to(dev()), 0, kw)
+    score = cache.last_scores.cpu().numpy()
+    idx = cache.last_keep_indices.cpu().numpy()
+    so = oc.last["score"]
+    assert np.abs(score - so).max() < 5e-6
+    keep = max(1, int(ratio * L))
+    srt = np.sort(so)[::-1]
+    gap = srt[keep - 1] - srt[keep]
+    diff = np.setxor1d(idx, oc.last["keep_idx"])
+    if gap > 2e-5:
+        assert diff.size == 0
+    else:  # every disagreement must sit within noise of the threshold
+        assert np.abs(so[diff] - srt[keep - 1]).max() < 2e-5
+    if diff.size == 0:
+        kept_k = cache.key_cache[0].cpu().numpy()
+        assert np.abs(kept_k - oc.last["kept_k"]).max() <= 1e-5
+        np.testing.assert_array_equal(cache.value_cache[0].cpu().numpy(), oc.last["kept_v"])
+        np.testing.assert_array_equal(cache.position_cache[0].cpu().numpy(), oc.last["pos"])
+
+
+def test_pivotkv_bf16_tracks_fp32_oracle():
+    """bf16 production dtype: inputs bf16, fp32 accumulate.  Scores must track the fp32 oracle run on
+    the same bf16-valued inputs; kept sets overlap except near the threshold."""
+    Hq, Hkv, D, L, ratio = 28, 4, 128, 1024, 0.25
+    q0, k0, v = synth.qkv_chunk(99, Hq, Hkv, L, D)
+    qb = torch.from_numpy(q0).bfloat16()
+    kb = torch.from_numpy(k0).bfloat16()
+    vb = torch.from_numpy(v).bfloat16()
+    so = orc.pivotkv_score(qb.float().numpy()[0], kb.float().numpy()[0])
+    g = dict(Hq=Hq, Hkv=Hkv, D=D, layer=0, ratio=ratio, reforge=False, mrope_section=np.array([16, 24, 24]))
+    cache, _ = _make_cache(g)
+    pos = torch.from_numpy(synth.mrope_position_ids(0, L // 64, 8, 8)).to(dev())
+    kw = {"query_states": qb.to(dev()), "position_ids": pos, "rotary_emb": None, "mrope_section": [16, 24, 24]}
+    ko, vo = cache.update(kb.to(dev()), vb.to(dev()), 0, kw)
+    score = cache.last_scores.cpu().numpy()
+    assert np.abs(score - so).max() < 2e-5   # exact products, fp32 accumulation, fast exp2
+    idx = cache.last_keep_indices.cpu().numpy()
+    keep = L // 4
+    oi = np.argsort(-so, kind="stable")[:keep]
+    assert np.intersect1d(idx, oi).size >= keep - 2
+    kept_v = cache.value_cache[0]
+    assert torch.equal(kept_v[0, :, :, :].cpu(), vb[0][:, torch.from_numpy(idx)])

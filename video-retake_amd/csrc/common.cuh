@@ -1,0 +1,88 @@
+// common.cuh — shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "retake_hip.h"
+
+namespace rtk {
+
+constexpr int WAVE = 64;
+
+// ---- bf16 <-> f32 (round to nearest even, NaN quieted; identical to c10::BFloat16) ------------
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+// ---- wave reductions (all 64 lanes participate) -------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// order-preserving map float -> uint32 (larger float <=> larger key); -0 < +0 is harmless here
+__device__ __forceinline__ uint32_t f2key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// 16-byte vector types
+struct __attribute__((aligned(16))) u32x4 { uint32_t x, y, z, w; };
+
+}  // namespace rtk
+
+// ---- host-side error plumbing --------------------------------------------------------------------
+namespace rtk {
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+}  // namespace rtk
+
+// ---- optional per-kernel HIP-event timing (rtk_profile_*), used by bench.py ------------------------
+namespace rtk {
+enum KernelId {
+    KID_DIS = 0, KID_DPSEL, KID_GATHER, KID_ROPE, KID_UNROT, KID_PASS1, KID_PASS2, KID_FINALIZE, KID_PSEL, KID_EVICT,
+    KID_COPY, KID_COUNT
+};
+bool profile_on();
+void profile_begin(int kid, hipStream_t st);
+void profile_end(int kid, hipStream_t st);
+}  // namespace rtk
+
+// launch `kern` on `st`; when profiling is enabled the launch is bracketed by two hipEvents on `st`
+#define RTK_LAUNCH(kid, kern, grid, block, shmem, st, ...)                       \
+    do {                                                                         \
+        const bool prof__ = rtk::profile_on();                                   \
+        if (prof__) rtk::profile_begin(kid, st);                                 \
+        hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);           \
+        if (prof__) rtk::profile_end(kid, st);                                   \
+    } while (0)
+
+#define RTK_CHECK_ARG(cond, ...)                \
+    do {                                        \
+        if (!(cond)) {                          \
+            rtk::set_error(__VA_ARGS__);        \
+            return RTK_EINVAL;                  \
+        }                                       \
+    } while (0)
+
+#define RTK_LAUNCH_CHECK(what)                                  \
+    do {                                                        \
+        hipError_t e__ = hipGetLastError();                     \
+        if (e__ != hipSuccess) return rtk::hip_fail(e__, what); \
+    } while (0)

@@ -1,0 +1,358 @@
+// dpselect.hip — DPSelect on gfx950: adjacent-frame cosine distance, peak stencil + exact top-k,
+// frame gather.  Replaces retake/visual_compression.py:100-175.
+//
+// Roofline: HBM-bound.  The distance kernel reads every (frame, patch) embedding row exactly once
+// (plus one halo row per strip) — algorithmic bytes T*N*C*sizeof(elem) + 4*T*N — with 16-byte
+// coalesced loads, keeps the previous frame's normalised row in registers, and reduces with wave
+// shuffles.  The gather moves 2*t*N*C*sizeof(elem).  MFMA is not used: ~1 flop per byte.
+#include "common.cuh"
+#include "select.cuh"
+
+namespace rtk {
+
+// ------------------------------------------------------------------------------------------------
+// K1-K2: distance.  One wave walks `strip` consecutive frames of one patch position.
+// ------------------------------------------------------------------------------------------------
+template <int DT> struct Elem;
+template <> struct Elem<RTK_F32> {
+    static constexpr int PER_VEC = 4;
+    using vec_t = float4;
+    __device__ static void unpack(const vec_t& v, float* f) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+};
+template <> struct Elem<RTK_BF16> {
+    static constexpr int PER_VEC = 8;
+    using vec_t = u32x4;
+    __device__ static void unpack(const vec_t& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+};
+
+// VPL = 16-byte vectors per lane; a row has nvec = C / PER_VEC vectors, lane owns vec k*64+lane.
+template <int DT, int VPL>
+__global__ __launch_bounds__(256) void dis_kernel(const typename Elem<DT>::vec_t* __restrict__ x, int T, int N,
+                                                  int nvec, int strip, float* __restrict__ dis) {
+    using E = Elem<DT>;
+    constexpr int PV = E::PER_VEC;
+    constexpr int NE = VPL * PV;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int nstrips = (T + strip - 1) / strip;
+    const int n = wave % N;
+    const int s = wave / N;
+    if (s >= nstrips) return;
+    const int t0 = s * strip;
+    const int t1 = min(T, t0 + strip);
+    const size_t row_vecs = (size_t)nvec;
+    const size_t frame_vecs = (size_t)N * row_vecs;
+
+    typename E::vec_t raw[VPL];
+    float prevn[NE];
+    float cur[NE];
+
+    auto load_row = [&](int t) {
+        const typename E::vec_t* p = x + (size_t)t * frame_vecs + (size_t)n * row_vecs;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int v = k * WAVE + lane;
+            if (v < nvec) raw[k] = p[v];
+            else raw[k] = typename E::vec_t{};
+        }
+    };
+    // normalise the row held in raw[] into cur[] (x / max(||x||, eps)), reference rounding for bf16
+    auto normalise = [&]() {
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) E::unpack(raw[k], cur + k * PV);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) ss = fmaf(cur[e], cur[e], ss);
+        ss = wave_sum(ss);
+        float nrm = sqrtf(ss);
+        if (DT == RTK_BF16) {
+            nrm = rbf(nrm);
+            nrm = fmaxf(nrm, rbf(1e-8f));
+#pragma unroll
+            for (int e = 0; e < NE; ++e) cur[e] = rbf(cur[e] / nrm);
+        } else {
+            nrm = fmaxf(nrm, 1e-8f);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) cur[e] = cur[e] / nrm;
+        }
+    };
+
+    if (t0 == 0) {
+        if (lane == 0) dis[n] = 1.0f;  // torch.ones_like(dis[:1])   (:103-106)
+        load_row(0);
+    } else {
+        load_row(t0 - 1);  // halo
+    }
+    normalise();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) prevn[e] = cur[e];
+    const int tb = (t0 == 0) ? 1 : t0;
+    if (tb < t1) load_row(tb);
+    for (int t = tb; t < t1; ++t) {
+        normalise();
+        if (t + 1 < t1) load_row(t + 1);  // prefetch the next frame's row while reducing this one
+        float dot = 0.f;
+        if (DT == RTK_BF16) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) dot += rbf(prevn[e] * cur[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) dot = fmaf(prevn[e], cur[e], dot);
+        }
+        dot = wave_sum(dot);
+        if (DT == RTK_BF16) dot = rbf(dot);
+        if (lane == 0) dis[(size_t)t * N + n] = 1.0f - dot;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) prevn[e] = cur[e];
+    }
+}
+
+// Generic fallback: any C (scalar loads, two passes over each row through L2).  One wave per (t,n).
+template <int DT>
+__global__ __launch_bounds__(256) void dis_kernel_generic(const void* __restrict__ xv, int T, int N, int C,
+                                                          float* __restrict__ dis) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    if (wave >= (size_t)T * N) return;
+    const int t = (int)(wave / N), n = (int)(wave % N);
+    if (t == 0) {
+        if (lane == 0) dis[n] = 1.0f;
+        return;
+    }
+    auto ld = [&](size_t off) -> float {
+        if (DT == RTK_BF16) return bf2f(((const uint16_t*)xv)[off]);
+        return ((const float*)xv)[off];
+    };
+    const size_t a0 = ((size_t)(t - 1) * N + n) * C, b0 = ((size_t)t * N + n) * C;
+    float sa = 0.f, sb = 0.f;
+    for (int c = lane; c < C; c += WAVE) {
+        const float a = ld(a0 + c), b = ld(b0 + c);
+        sa = fmaf(a, a, sa);
+        sb = fmaf(b, b, sb);
+    }
+    float na = sqrtf(wave_sum(sa)), nb = sqrtf(wave_sum(sb));
+    float dot = 0.f;
+    if (DT == RTK_BF16) {
+        na = fmaxf(rbf(na), rbf(1e-8f));
+        nb = fmaxf(rbf(nb), rbf(1e-8f));
+        for (int c = lane; c < C; c += WAVE) dot += rbf(rbf(ld(a0 + c) / na) * rbf(ld(b0 + c) / nb));
+        dot = rbf(wave_sum(dot));
+    } else {
+        na = fmaxf(na, 1e-8f);
+        nb = fmaxf(nb, 1e-8f);
+        for (int c = lane; c < C; c += WAVE) dot = fmaf(ld(a0 + c) / na, ld(b0 + c) / nb, dot);
+        dot = wave_sum(dot);
+    }
+    if (lane == 0) dis[(size_t)t * N + n] = 1.0f - dot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3-K7, K9: per-row peak stencil + bonus + exact top-k + ordered emit.  One workgroup per row
+// (sync: the single patch-mean row; async: one row per patch position).
+// ------------------------------------------------------------------------------------------------
+// i is a peak iff arg-max over [i - w/2, i - w/2 + w - 1] ∩ [0,T) is i with first-index-wins ties
+// (max_pool1d_with_indices + `window_maxima[c] == c`, visual_compression.py:121-123,153-156).
+template <typename DFn>
+__device__ __forceinline__ bool is_peak(DFn d, int i, int T, int window) {
+    const float di = d(i);
+    int a = i - window / 2, b = a + window - 1;
+    a = max(a, 0);
+    b = min(b, T - 1);
+    bool pk = true;
+    for (int j = a; j <= b; ++j) {
+        if (j == i) continue;
+        const float dj = d(j);
+        pk = pk && (j < i ? (di > dj) : (di >= dj));
+    }
+    return pk;
+}
+
+constexpr int SEL_BLOCK = 256;
+
+__global__ __launch_bounds__(SEL_BLOCK) void dpselect_select_kernel(const float* __restrict__ dis, int T, int N,
+                                                                    int tgt, int window, int sync,
+                                                                    int64_t* __restrict__ idx,
+                                                                    uint8_t* __restrict__ mask,
+                                                                    float* __restrict__ keys) {
+    __shared__ SelectSmem sm;
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x;  // patch index in async mode, 0 in sync mode
+    float* krow = keys + (size_t)row * T;
+    float* raw = keys + (size_t)T;  // sync only: patch-mean distance
+    if (sync) {
+        // dis.mean(1)  (:110): one wave per frame row, fixed-order lane partials + shuffle tree
+        const int lane = tid & (WAVE - 1), wid = tid / WAVE;
+        for (int t = wid; t < T; t += SEL_BLOCK / WAVE) {
+            float s = 0.f;
+            for (int n = lane; n < N; n += WAVE) s += dis[(size_t)t * N + n];
+            s = wave_sum(s);
+            if (lane == 0) raw[t] = s / (float)N;
+        }
+        __syncthreads();
+    }
+    auto dfn = [&](int t) -> float { return sync ? raw[t] : dis[(size_t)t * N + row]; };
+    for (int t = tid; t < T; t += SEL_BLOCK) {
+        const float d = dfn(t);
+        krow[t] = is_peak(dfn, t, T, window) ? d + 2.0f : d;  // dis[peaks] += 2  (:133, :160)
+    }
+    __syncthreads();
+    auto key = [&](int t) -> uint32_t { return f2key(krow[t]); };
+    uint32_t thr;
+    int need_eq;
+    block_radix_threshold<SEL_BLOCK>(key, T, tgt, sm, thr, need_eq);
+    block_ordered_compact<SEL_BLOCK>(key, T, thr, need_eq, sm, [&](int r, int t) {
+        const uint8_t pk = is_peak(dfn, t, T, window) ? 1 : 0;
+        if (sync) {
+            idx[r] = t;
+            for (int n = 0; n < N; ++n) mask[(size_t)r * N + n] = pk;  // mask[:,None].repeat(1,N) (:140)
+        } else {
+            idx[(size_t)r * N + row] = t;   // peaks.transpose(0,1)   (:169)
+            mask[(size_t)r * N + row] = pk; // mask.gather(0, peaks)  (:175)
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: frame gather.  One wave per output row (t', n); 16-byte vectors, loads batched before stores.
+// ------------------------------------------------------------------------------------------------
+template <int UNROLL>
+__global__ __launch_bounds__(256) void gather_rows16_kernel(const u32x4* __restrict__ x, int T, int N, int rowvec,
+                                                            const int64_t* __restrict__ idx, int tgt, int sync,
+                                                            u32x4* __restrict__ out) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const size_t nw = ((size_t)gridDim.x * blockDim.x) / WAVE;
+    const size_t rows = (size_t)tgt * N;
+    for (size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE; r < rows; r += nw) {
+        const int tt = (int)(r / N), n = (int)(r % N);
+        const int64_t f = sync ? idx[tt] : idx[r];
+        const u32x4* src = x + ((size_t)f * N + n) * rowvec;
+        u32x4* dst = out + r * rowvec;
+        for (int v0 = 0; v0 < rowvec; v0 += UNROLL * WAVE) {
+            u32x4 buf[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int v = v0 + u * WAVE + lane;
+                if (v < rowvec) buf[u] = src[v];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int v = v0 + u * WAVE + lane;
+                if (v < rowvec) dst[v] = buf[u];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_bytes_kernel(const uint8_t* __restrict__ x, int T, int N,
+                                                                size_t rowbytes, const int64_t* __restrict__ idx,
+                                                                int tgt, int sync, uint8_t* __restrict__ out) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const size_t nw = ((size_t)gridDim.x * blockDim.x) / WAVE;
+    const size_t rows = (size_t)tgt * N;
+    for (size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE; r < rows; r += nw) {
+        const int tt = (int)(r / N), n = (int)(r % N);
+        const int64_t f = sync ? idx[tt] : idx[r];
+        const uint8_t* src = x + ((size_t)f * N + n) * rowbytes;
+        uint8_t* dst = out + r * rowbytes;
+        for (size_t b = lane; b < rowbytes; b += WAVE) dst[b] = src[b];
+    }
+}
+
+}  // namespace rtk
+
+using namespace rtk;
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+static int launch_dis(const void* x, int T, int N, int C, float* dis, hipStream_t st) {
+    constexpr int PV = Elem<DT>::PER_VEC;
+    using vec_t = typename Elem<DT>::vec_t;
+    const bool vec_ok = (C % PV == 0) && (((uintptr_t)x & 15) == 0);
+    const int nvec = C / PV;
+    const int vpl = (nvec + WAVE - 1) / WAVE;
+    if (!vec_ok || vpl > 16) {
+        const size_t waves = (size_t)T * N;
+        const unsigned grid = (unsigned)((waves * WAVE + 255) / 256);
+        RTK_LAUNCH(KID_DIS, dis_kernel_generic<DT>, dim3(grid), dim3(256), 0, st, x, T, N, C, dis);
+        RTK_LAUNCH_CHECK("dis_kernel_generic");
+        return RTK_OK;
+    }
+    // strip length: long enough that the halo re-read is small, short enough to fill 256 CUs
+    int strip = 32;
+    while (strip > 4 && (size_t)N * ((T + strip - 1) / strip) < 8192) strip >>= 1;
+    const size_t waves = (size_t)N * ((T + strip - 1) / strip);
+    const unsigned grid = (unsigned)((waves * WAVE + 255) / 256);
+    const vec_t* xv = (const vec_t*)x;
+#define RTK_DIS_CASE(V)                                                                                  \
+    RTK_LAUNCH(KID_DIS, (dis_kernel<DT, V>), dim3(grid), dim3(256), 0, st, xv, T, N, nvec, strip, dis); \
+    break;
+    switch (vpl) {
+        case 1: RTK_DIS_CASE(1)
+        case 2: RTK_DIS_CASE(2)
+        case 3: RTK_DIS_CASE(3)
+        case 4: RTK_DIS_CASE(4)
+        case 5: RTK_DIS_CASE(5)
+        case 6: RTK_DIS_CASE(6)
+        case 7: case 8: RTK_DIS_CASE(8)
+        case 9: case 10: RTK_DIS_CASE(10)
+        case 11: case 12: RTK_DIS_CASE(12)
+        case 13: case 14: RTK_DIS_CASE(14)
+        default: RTK_DIS_CASE(16)
+    }
+#undef RTK_DIS_CASE
+    RTK_LAUNCH_CHECK("dis_kernel");
+    return RTK_OK;
+}
+
+extern "C" int rtk_dpselect_dis(const void* x, int T, int N, int C, int dtype, float* dis, rtk_stream_t stream) {
+    RTK_CHECK_ARG(x && dis, "rtk_dpselect_dis: NULL pointer");
+    RTK_CHECK_ARG(T >= 1 && N >= 1 && C >= 1, "rtk_dpselect_dis: bad shape T=%d N=%d C=%d", T, N, C);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RTK_F32) return launch_dis<RTK_F32>(x, T, N, C, dis, st);
+    if (dtype == RTK_BF16) return launch_dis<RTK_BF16>(x, T, N, C, dis, st);
+    set_error("rtk_dpselect_dis: unsupported dtype %d", dtype);
+    return RTK_EINVAL;
+}
+
+extern "C" int rtk_dpselect_select(const float* dis, int T, int N, int tgt, int window, int sync, int64_t* idx,
+                                   uint8_t* mask, float* keys, rtk_stream_t stream) {
+    RTK_CHECK_ARG(dis && idx && mask && keys, "rtk_dpselect_select: NULL pointer");
+    RTK_CHECK_ARG(T >= 1 && N >= 1 && window >= 1, "rtk_dpselect_select: bad shape T=%d N=%d window=%d", T, N, window);
+    RTK_CHECK_ARG(tgt >= 1 && tgt <= T, "rtk_dpselect_select: tgt_mem_len %d out of range [1,%d]", tgt, T);
+    if (!sync && N == 1) {
+        set_error("DPSelect async mode with N == 1: the reference raises IndexError (visual_compression.py:153-156)");
+        return RTK_EREFCRASH;
+    }
+    RTK_LAUNCH(KID_DPSEL, dpselect_select_kernel, dim3(sync ? 1 : N), dim3(SEL_BLOCK), 0, (hipStream_t)stream, dis, T, N,
+                       tgt, window, sync, idx, mask, keys);
+    RTK_LAUNCH_CHECK("dpselect_select_kernel");
+    return RTK_OK;
+}
+
+extern "C" int rtk_gather_frames(const void* x, int T, int N, int C, int dtype, const int64_t* idx, int tgt, int sync,
+                                 void* out, rtk_stream_t stream) {
+    RTK_CHECK_ARG(x && idx && out, "rtk_gather_frames: NULL pointer");
+    RTK_CHECK_ARG(T >= 1 && N >= 1 && C >= 1 && tgt >= 1, "rtk_gather_frames: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_gather_frames: unsupported dtype %d", dtype);
+    const size_t esize = dtype == RTK_F32 ? 4 : 2;
+    const size_t rowbytes = (size_t)C * esize;
+    const size_t rows = (size_t)tgt * N;
+    const unsigned grid = (unsigned)std::min<size_t>((rows + 3) / 4, 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (rowbytes % 16 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+        RTK_LAUNCH(KID_GATHER, gather_rows16_kernel<4>, dim3(grid), dim3(256), 0, st, (const u32x4*)x, T, N,
+                           (int)(rowbytes / 16), idx, tgt, sync, (u32x4*)out);
+    } else {
+        RTK_LAUNCH(KID_GATHER, gather_rows_bytes_kernel, dim3(grid), dim3(256), 0, st, (const uint8_t*)x, T, N, rowbytes,
+                           idx, tgt, sync, (uint8_t*)out);
+    }
+    RTK_LAUNCH_CHECK("gather_rows_kernel");
+    return RTK_OK;
+}

@@ -1,0 +1,244 @@
+// pivotkv_evict.hip — PivotKV selection and eviction scan on gfx950.
+// Replaces longvideo_cache.py:272-318 (masked_fill_, topk+sort, the three gathers, the temporal-id
+// rescale, the forward re-rotation and the two torch.cat cache rebuilds).
+//
+// Roofline: HBM-bound byte shuffling.  The scan kernel touches every K and V row of the chunk
+// exactly once with 16-byte coalesced accesses (8 lanes per bf16 row-half pair), appends it to the
+// pre-allocated cache tail and, for the kept 1/ratio of the rows, also emits the compacted row —
+// algorithmic bytes per (layer, chunk): 2*Hkv*L*D*s read + 2*Hkv*keep*D*s written (+ the tail
+// append 2*Hkv*L*D*s, which the reference pays as an O(cache) torch.cat).
+#include "common.cuh"
+#include "select.cuh"
+
+namespace rtk {
+
+constexpr int PSEL_BLOCK = 1024;
+
+__global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_kernel(float* __restrict__ score,
+                                                                    const uint8_t* __restrict__ mask, int L, int keep,
+                                                                    const int64_t* __restrict__ pos, int P,
+                                                                    int reforge, int64_t* __restrict__ keep_idx,
+                                                                    int32_t* __restrict__ rank,
+                                                                    int64_t* __restrict__ pos_out) {
+    __shared__ SelectSmem sm;
+    __shared__ long long red[PSEL_BLOCK / WAVE];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L; i += PSEL_BLOCK) {
+        if (mask && mask[i]) score[i] = 1.0f;  // attn_weights.masked_fill_(mask, 1.)  (:274)
+        rank[i] = -1;
+    }
+    __syncthreads();
+    auto key = [&](int i) -> uint32_t { return f2key(score[i]); };
+    uint32_t thr;
+    int need_eq;
+    block_radix_threshold<PSEL_BLOCK>(key, L, keep, sm, thr, need_eq);
+    block_ordered_compact<PSEL_BLOCK>(key, L, thr, need_eq, sm, [&](int r, int i) {
+        keep_idx[r] = i;  // topk(keep).sort()  (:276-277)
+        rank[i] = r;
+        if (pos)
+            for (int p = 0; p < P; ++p) pos_out[(size_t)p * keep + r] = pos[(size_t)p * L + i];  // :283-288
+    });
+    if (!(pos && reforge)) return;
+    __syncthreads();
+    // min_temp_id = compressed_position_ids[0].min()  (:293)
+    long long mn = 0x7fffffffffffffffLL;
+    for (int r = tid; r < keep; r += PSEL_BLOCK) mn = min(mn, (long long)pos_out[r]);
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long t = __shfl_xor(mn, o, WAVE);
+        mn = min(mn, t);
+    }
+    if ((tid & (WAVE - 1)) == 0) red[tid / WAVE] = mn;
+    __syncthreads();
+    mn = red[0];
+    for (int w = 1; w < PSEL_BLOCK / WAVE; ++w) mn = min(mn, red[w]);
+    // comp_ratio = keep_len / k_len (python float) ; int64 * float -> float32 multiply ; .long() truncates (:294-295)
+    const float ratio = (float)((double)keep / (double)L);
+    for (int r = tid; r < keep; r += PSEL_BLOCK) {
+        const float f = (float)((long long)pos_out[r] - mn) * ratio;
+        pos_out[r] = mn + (long long)f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// eviction scan.  LPR lanes cooperate on one (head, token) row: lane c owns the 16-byte chunk c of the
+// first half of the row and its rotation partner in the second half.
+// ------------------------------------------------------------------------------------------------
+template <int DT> struct Row16;
+template <> struct Row16<RTK_F32> {
+    static constexpr int VE = 4;
+    __device__ static void unpack(const u32x4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    __device__ static u32x4 pack(const float* f) {
+        return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+    }
+    __device__ static float rnd(float x) { return x; }
+};
+template <> struct Row16<RTK_BF16> {
+    static constexpr int VE = 8;
+    __device__ static void unpack(const u32x4& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    __device__ static u32x4 pack(const float* f) {
+        return u32x4{(uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16), (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
+                     (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16), (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16)};
+    }
+    __device__ static float rnd(float x) { return rbf(x); }
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void evict_scan_kernel(const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
+                                                         const char* __restrict__ v, int64_t v_sh, int64_t v_sl,
+                                                         const char* __restrict__ k_unrot, int Hkv, int L, int D,
+                                                         const int32_t* __restrict__ rank, int keep,
+                                                         const float* __restrict__ cos_new,
+                                                         const float* __restrict__ sin_new, char* __restrict__ k_tail,
+                                                         char* __restrict__ v_tail, int64_t tail_sh,
+                                                         char* __restrict__ k_kept, char* __restrict__ v_kept,
+                                                         int64_t kept_sh) {
+    using R = Row16<DT>;
+    constexpr int VE = R::VE;
+    constexpr int ES = 16 / VE;
+    const int h2 = D / 2;
+    const int lpr = h2 / VE;  // lanes per row
+    const size_t total = (size_t)Hkv * L * lpr;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(id % lpr);
+        const size_t hl = id / lpr;
+        const int l = (int)(hl % L), h = (int)(hl / L);
+        const int d = c * VE;
+        const char* kr = k + ((size_t)h * k_sh + (size_t)l * k_sl) * ES;
+        const char* vr = v + ((size_t)h * v_sh + (size_t)l * v_sl) * ES;
+        const u32x4 k_lo = *(const u32x4*)(kr + (size_t)d * ES), k_hi = *(const u32x4*)(kr + (size_t)(d + h2) * ES);
+        const u32x4 v_lo = *(const u32x4*)(vr + (size_t)d * ES), v_hi = *(const u32x4*)(vr + (size_t)(d + h2) * ES);
+        const int r = rank[l];
+        if (k_tail) {  // DynamicCache.update append (:238)
+            char* kt = k_tail + ((size_t)h * tail_sh + (size_t)l * D) * ES;
+            char* vt = v_tail + ((size_t)h * tail_sh + (size_t)l * D) * ES;
+            *(u32x4*)(kt + (size_t)d * ES) = k_lo;
+            *(u32x4*)(kt + (size_t)(d + h2) * ES) = k_hi;
+            *(u32x4*)(vt + (size_t)d * ES) = v_lo;
+            *(u32x4*)(vt + (size_t)(d + h2) * ES) = v_hi;
+        }
+        if (r < 0) continue;  // evicted
+        char* kk = k_kept + ((size_t)h * kept_sh + (size_t)r * D) * ES;
+        char* vk = v_kept + ((size_t)h * kept_sh + (size_t)r * D) * ES;
+        *(u32x4*)(vk + (size_t)d * ES) = v_lo;  // torch.gather(value_states, 2, keep)  (:280)
+        *(u32x4*)(vk + (size_t)(d + h2) * ES) = v_hi;
+        if (!cos_new) {
+            *(u32x4*)(kk + (size_t)d * ES) = k_lo;  // torch.gather(key_states, 2, keep)  (:279)
+            *(u32x4*)(kk + (size_t)(d + h2) * ES) = k_hi;
+            continue;
+        }
+        // reforge: kept K = un-rotated row rotated forward at its new position (:297-306)
+        const char* ur = k_unrot + ((size_t)h * L + l) * D * ES;
+        float x1[VE], x2[VE], o1[VE], o2[VE];
+        R::unpack(*(const u32x4*)(ur + (size_t)d * ES), x1);
+        R::unpack(*(const u32x4*)(ur + (size_t)(d + h2) * ES), x2);
+        const float* cr = cos_new + (size_t)r * D;
+        const float* sr = sin_new + (size_t)r * D;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            const float c1 = cr[d + e], s1 = sr[d + e], c2 = cr[d + h2 + e], s2 = sr[d + h2 + e];
+            // (k*cos) + (rotate_half(k)*sin), one rounding per torch op, no fma contraction
+            o1[e] = R::rnd(__fadd_rn(R::rnd(__fmul_rn(x1[e], c1)), R::rnd(__fmul_rn(-x2[e], s1))));
+            o2[e] = R::rnd(__fadd_rn(R::rnd(__fmul_rn(x2[e], c2)), R::rnd(__fmul_rn(x1[e], s2))));
+        }
+        *(u32x4*)(kk + (size_t)d * ES) = R::pack(o1);
+        *(u32x4*)(kk + (size_t)(d + h2) * ES) = R::pack(o2);
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const char* __restrict__ src, int64_t src_sh_bytes,
+                                                        char* __restrict__ dst, int64_t dst_sh_bytes, int H,
+                                                        size_t row_block_bytes) {
+    // each head's [rows,D] block is contiguous: copy it as 16-byte vectors
+    const size_t vec_per_head = row_block_bytes / 16;
+    const size_t total = (size_t)H * vec_per_head;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
+        const size_t h = id / vec_per_head, i = id % vec_per_head;
+        *(u32x4*)(dst + h * dst_sh_bytes + i * 16) = *(const u32x4*)(src + h * src_sh_bytes + i * 16);
+    }
+}
+
+}  // namespace rtk
+
+using namespace rtk;
+
+extern "C" int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep, const int64_t* pos, int P,
+                                  int reforge, int64_t* keep_idx, int32_t* rank, int64_t* pos_out,
+                                  rtk_stream_t stream) {
+    RTK_CHECK_ARG(score && keep_idx && rank, "rtk_pivotkv_select: NULL pointer");
+    RTK_CHECK_ARG(L >= 1 && keep >= 1 && keep <= L, "rtk_pivotkv_select: keep=%d out of range for L=%d", keep, L);
+    RTK_CHECK_ARG((pos == nullptr) == (pos_out == nullptr), "rtk_pivotkv_select: pos and pos_out go together");
+    RTK_CHECK_ARG(!pos || P == 1 || P == 3, "rtk_pivotkv_select: P must be 1 or 3, got %d", P);
+    RTK_LAUNCH(KID_PSEL, pivotkv_select_kernel, dim3(1), dim3(PSEL_BLOCK), 0, (hipStream_t)stream, score, mask, L, keep,
+                       pos, P, reforge, keep_idx, rank, pos_out);
+    RTK_LAUNCH_CHECK("pivotkv_select_kernel");
+    return RTK_OK;
+}
+
+extern "C" int rtk_pivotkv_evict(const void* k, int64_t k_stride_h, int64_t k_stride_l, const void* v,
+                                 int64_t v_stride_h, int64_t v_stride_l, const void* k_unrot, int Hkv, int L, int D,
+                                 int dtype, const int32_t* rank, int keep, const float* cos_new, const float* sin_new,
+                                 void* k_tail, void* v_tail, int64_t tail_stride_h, void* k_kept, void* v_kept,
+                                 int64_t kept_stride_h, rtk_stream_t stream) {
+    RTK_CHECK_ARG(k && v && rank && k_kept && v_kept, "rtk_pivotkv_evict: NULL pointer");
+    RTK_CHECK_ARG(Hkv >= 1 && L >= 1 && keep >= 1 && keep <= L, "rtk_pivotkv_evict: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_evict: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG((cos_new == nullptr) == (sin_new == nullptr), "rtk_pivotkv_evict: cos_new and sin_new go together");
+    RTK_CHECK_ARG(!cos_new || k_unrot, "rtk_pivotkv_evict: reforge needs k_unrot");
+    RTK_CHECK_ARG((k_tail == nullptr) == (v_tail == nullptr), "rtk_pivotkv_evict: k_tail and v_tail go together");
+    const int ve = dtype == RTK_BF16 ? 8 : 4;
+    const int es = dtype == RTK_BF16 ? 2 : 4;
+    if (D % (2 * ve) != 0) {
+        set_error("rtk_pivotkv_evict: head_dim %d must be a multiple of %d for this dtype", D, 2 * ve);
+        return RTK_EUNSUPPORTED;
+    }
+    const bool aligned = (k_stride_h * es) % 16 == 0 && (k_stride_l * es) % 16 == 0 && (v_stride_h * es) % 16 == 0 &&
+                         (v_stride_l * es) % 16 == 0 && (tail_stride_h * es) % 16 == 0 && (kept_stride_h * es) % 16 == 0 &&
+                         (((uintptr_t)k | (uintptr_t)v | (uintptr_t)k_unrot | (uintptr_t)k_tail | (uintptr_t)v_tail |
+                           (uintptr_t)k_kept | (uintptr_t)v_kept) & 15) == 0;
+    if (!aligned) {
+        set_error("rtk_pivotkv_evict: pointers and strides must be 16-byte aligned");
+        return RTK_EUNSUPPORTED;
+    }
+    const size_t total = (size_t)Hkv * L * (D / 2 / ve);
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 16384);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RTK_BF16)
+        RTK_LAUNCH(KID_EVICT, evict_scan_kernel<RTK_BF16>, dim3(grid), dim3(256), 0, st, (const char*)k, k_stride_h,
+                           k_stride_l, (const char*)v, v_stride_h, v_stride_l, (const char*)k_unrot, Hkv, L, D, rank, keep,
+                           cos_new, sin_new, (char*)k_tail, (char*)v_tail, tail_stride_h, (char*)k_kept, (char*)v_kept,
+                           kept_stride_h);
+    else
+        RTK_LAUNCH(KID_EVICT, evict_scan_kernel<RTK_F32>, dim3(grid), dim3(256), 0, st, (const char*)k, k_stride_h,
+                           k_stride_l, (const char*)v, v_stride_h, v_stride_l, (const char*)k_unrot, Hkv, L, D, rank, keep,
+                           cos_new, sin_new, (char*)k_tail, (char*)v_tail, tail_stride_h, (char*)k_kept, (char*)v_kept,
+                           kept_stride_h);
+    RTK_LAUNCH_CHECK("evict_scan_kernel");
+    return RTK_OK;
+}
+
+extern "C" int rtk_copy_rows(const void* src, int64_t src_stride_h, void* dst, int64_t dst_stride_h, int H, int rows,
+                             int D, int dtype, rtk_stream_t stream) {
+    RTK_CHECK_ARG(src && dst, "rtk_copy_rows: NULL pointer");
+    RTK_CHECK_ARG(H >= 1 && rows >= 0 && D >= 1, "rtk_copy_rows: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_copy_rows: unsupported dtype %d", dtype);
+    if (rows == 0) return RTK_OK;
+    const size_t es = dtype == RTK_BF16 ? 2 : 4;
+    const size_t blk = (size_t)rows * D * es;
+    if (blk % 16 || (src_stride_h * es) % 16 || (dst_stride_h * es) % 16 || (((uintptr_t)src | (uintptr_t)dst) & 15)) {
+        set_error("rtk_copy_rows: blocks must be 16-byte aligned");
+        return RTK_EUNSUPPORTED;
+    }
+    const size_t total = (size_t)H * (blk / 16);
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 8192);
+    RTK_LAUNCH(KID_COPY, copy_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)src,
+                       (int64_t)(src_stride_h * es), (char*)dst, (int64_t)(dst_stride_h * es), H, blk);
+    RTK_LAUNCH_CHECK("copy_rows_kernel");
+    return RTK_OK;
+}

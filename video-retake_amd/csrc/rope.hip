@@ -1,0 +1,115 @@
+// rope.hip — RoPE cos/sin tables for PivotKV's un-rotate / re-rotate steps.
+// Replaces longvideo_cache.py:68-74 (M-RoPE section merge) and optionally the rotary_emb_fn calls
+// at :249 and :298 for the standard inv_freq * position / attention_scaling rotary modules.
+#include "common.cuh"
+
+namespace rtk {
+
+struct RowSel {
+    uint8_t row[256];  // which of the P position rows (t/h/w) feeds channel d
+};
+
+static int make_rowsel(RowSel& rs, int P, int D, const int* sections, int nsec, const char* who) {
+    if (D > 256 || (D & 1)) {
+        set_error("%s: head_dim %d unsupported (must be even and <= 256)", who, D);
+        return RTK_EUNSUPPORTED;
+    }
+    for (int d = 0; d < D; ++d) rs.row[d] = 0;
+    if (P == 1) return RTK_OK;
+    if (P != 3 || !sections || nsec < 1) {
+        set_error("%s: P=%d needs mrope sections", who, P);
+        return RTK_EINVAL;
+    }
+    int tot = 0;
+    for (int i = 0; i < nsec; ++i) tot += sections[i];
+    if (2 * tot != D) {
+        set_error("%s: sum(mrope_section)*2 = %d != head_dim %d", who, 2 * tot, D);
+        return RTK_EINVAL;
+    }
+    int d = 0;
+    for (int rep = 0; rep < 2; ++rep)
+        for (int i = 0; i < nsec; ++i)
+            for (int c = 0; c < sections[i]; ++c, ++d) rs.row[d] = (uint8_t)((rep * nsec + i) % 3);
+    return RTK_OK;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void rope_merge_kernel(const void* __restrict__ cin, const void* __restrict__ sin_,
+                                                         int L, int D, RowSel rs, float* __restrict__ cos_out,
+                                                         float* __restrict__ sin_out) {
+    const size_t n = (size_t)L * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const size_t src = (size_t)rs.row[d] * n + i;
+        if (DT == RTK_BF16) {
+            cos_out[i] = bf2f(((const uint16_t*)cin)[src]);
+            sin_out[i] = bf2f(((const uint16_t*)sin_)[src]);
+        } else {
+            cos_out[i] = ((const float*)cin)[src];
+            sin_out[i] = ((const float*)sin_)[src];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rope_table_kernel(const int64_t* __restrict__ pos, int L, int D,
+                                                         const float* __restrict__ inv_freq, float scaling,
+                                                         RowSel rs, int round_bf16, float* __restrict__ cos_out,
+                                                         float* __restrict__ sin_out) {
+    const size_t n = (size_t)L * D;
+    const int h2 = D / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const size_t l = i / D;
+        const float p = (float)pos[(size_t)rs.row[d] * L + l];
+        const float ang = p * inv_freq[d < h2 ? d : d - h2];
+        float s, c;
+        sincosf(ang, &s, &c);
+        c *= scaling;
+        s *= scaling;
+        if (round_bf16) {
+            c = rbf(c);
+            s = rbf(s);
+        }
+        cos_out[i] = c;
+        sin_out[i] = s;
+    }
+}
+
+}  // namespace rtk
+
+using namespace rtk;
+
+extern "C" int rtk_rope_merge(const void* cos_in, const void* sin_in, int P, int L, int D, int dtype,
+                              const int* sections_host, int nsec, float* cos_out, float* sin_out,
+                              rtk_stream_t stream) {
+    RTK_CHECK_ARG(cos_in && sin_in && cos_out && sin_out, "rtk_rope_merge: NULL pointer");
+    RTK_CHECK_ARG(L >= 1 && D >= 2, "rtk_rope_merge: bad shape L=%d D=%d", L, D);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_rope_merge: unsupported dtype %d", dtype);
+    RowSel rs;
+    int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_rope_merge");
+    if (rc) return rc;
+    const unsigned grid = (unsigned)std::min<size_t>(((size_t)L * D + 255) / 256, 4096);
+    if (dtype == RTK_BF16)
+        RTK_LAUNCH(KID_ROPE, rope_merge_kernel<RTK_BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, cos_in, sin_in, L,
+                           D, rs, cos_out, sin_out);
+    else
+        RTK_LAUNCH(KID_ROPE, rope_merge_kernel<RTK_F32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, cos_in, sin_in, L,
+                           D, rs, cos_out, sin_out);
+    RTK_LAUNCH_CHECK("rope_merge_kernel");
+    return RTK_OK;
+}
+
+extern "C" int rtk_rope_table(const int64_t* pos, int P, int L, const float* inv_freq, int D, float attention_scaling,
+                              const int* sections_host, int nsec, int round_bf16, float* cos_out, float* sin_out,
+                              rtk_stream_t stream) {
+    RTK_CHECK_ARG(pos && inv_freq && cos_out && sin_out, "rtk_rope_table: NULL pointer");
+    RTK_CHECK_ARG(L >= 1 && D >= 2, "rtk_rope_table: bad shape L=%d D=%d", L, D);
+    RowSel rs;
+    int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_rope_table");
+    if (rc) return rc;
+    const unsigned grid = (unsigned)std::min<size_t>(((size_t)L * D + 255) / 256, 4096);
+    RTK_LAUNCH(KID_ROPE, rope_table_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pos, L, D, inv_freq,
+                       attention_scaling, rs, round_bf16, cos_out, sin_out);
+    RTK_LAUNCH_CHECK("rope_table_kernel");
+    return RTK_OK;
+}

@@ -1,0 +1,116 @@
+"""ctypes binding of libretake_hip.so (C ABI in include/retake_hip.h).
+
+The HIP library is the product path: there is NO CPU or eager fallback.  Importing this module
+without the built library, or calling into it with non-ROCm tensors, raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libretake_hip.so")
+ABI_VERSION = 1
+
+RTK_F32, RTK_BF16 = 0, 1
+RTK_EINVAL, RTK_EUNSUPPORTED, RTK_EWORKSPACE, RTK_EHIP, RTK_EREFCRASH = -1, -2, -3, -4, -5
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+_SIGNATURES = {
+    "rtk_version": (C.c_int, []),
+    "rtk_last_error": (C.c_char_p, []),
+    "rtk_arch": (C.c_char_p, []),
+    "rtk_dpselect_dis": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "rtk_dpselect_select": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rtk_gather_frames": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "rtk_rope_merge": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "rtk_rope_table": (C.c_int, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _vp, _vp, _vp]),
+    "rtk_pivotkv_score_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "rtk_pivotkv_score": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp,
+                                    _vp, _sz, _vp]),
+    "rtk_pivotkv_select": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "rtk_pivotkv_evict": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp,
+                                    _vp, _i64, _vp, _vp, _i64, _vp]),
+    "rtk_copy_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "rtk_profile_enable": (C.c_int, [_i]),
+    "rtk_profile_collect": (C.c_int, []),
+    "rtk_profile_reset": (C.c_int, []),
+    "rtk_profile_num_kernels": (C.c_int, []),
+    "rtk_profile_kernel_name": (C.c_char_p, [_i]),
+    "rtk_profile_read": (C.c_int, [_i, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+            "(or `make -C video-retake_amd/csrc`). The retake package has no CPU/eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = stale library
+        fn.restype, fn.argtypes = res, args
+    if lib.rtk_version() != ABI_VERSION:
+        raise ImportError(f"libretake_hip.so ABI {lib.rtk_version()} != expected {ABI_VERSION}: rebuild")
+    return lib
+
+
+lib = _load()
+
+
+class RetakeHipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    """Map an rtk_status to the exception class the reference raises for the same condition."""
+    if rc == 0:
+        return
+    msg = f"{what}: {lib.rtk_last_error().decode(errors='replace')}"
+    if rc == RTK_EREFCRASH:
+        raise IndexError(msg)
+    if rc == RTK_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc in (RTK_EINVAL, RTK_EWORKSPACE):
+        raise ValueError(msg)
+    raise RetakeHipError(msg)
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return RTK_F32
+    if t.dtype == torch.bfloat16:
+        return RTK_BF16
+    raise NotImplementedError(f"retake HIP kernels support float32 and bfloat16, got {t.dtype}")
+
+
+def require_device(*tensors: torch.Tensor):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("retake HIP path needs ROCm device tensors (no CPU fallback); got a "
+                               f"{t.device} tensor")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_read() -> dict:
+    """{kernel name: (launches, total_ms)} accumulated since the last rtk_profile_reset()."""
+    check(lib.rtk_profile_collect(), "rtk_profile_collect")
+    out = {}
+    for kid in range(lib.rtk_profile_num_kernels()):
+        n, ms = C.c_longlong(0), C.c_double(0.0)
+        check(lib.rtk_profile_read(kid, C.byref(n), C.byref(ms)), "rtk_profile_read")
+        if n.value:
+            out[lib.rtk_profile_kernel_name(kid).decode()] = (n.value, ms.value)
+    return out

@@ -1,0 +1,72 @@
+"""DPSelect on MI355X.  Same entry point as the reference's retake/visual_compression.py.
+
+`memory_bank_compress_keyframe` keeps the reference's signature and return tuple
+(visual_compression.py:86, :177); the three stages run as HIP kernels:
+    rtk_dpselect_dis     adjacent-frame cosine distance          (:100-106)
+    rtk_dpselect_select  peaks + bonus + top-k + sorted indices  (:108-135 / :142-169)
+    rtk_gather_frames    frame gather                            (:138 / :173)
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as nv
+
+__all__ = ["memory_bank_compress_keyframe", "memory_bank_compress_MALLM", "memory_bank_compress_MALLM_hard",
+           "dpselect_stages"]
+
+
+def dpselect_stages(memory_bank: torch.Tensor, tgt_mem_len: int, window_size: int = 3, sync: bool = True):
+    """Runs the three kernels and also returns the intermediates (dis [T,N], idx, keys) for tests/bench."""
+    if memory_bank.ndim != 4:
+        raise ValueError(f"memory_bank must be [B,T,N,C], got {tuple(memory_bank.shape)}")
+    B, T, N, Cc = memory_bank.shape
+    assert B == 1, "DPSelect uses the first batch entry's similarity only (visual_compression.py:101); bsz must be 1"
+    nv.require_device(memory_bank)
+    tgt_mem_len = int(tgt_mem_len)
+    x = memory_bank[0]
+    if not x.is_contiguous():
+        x = x.contiguous()
+    dt = nv.dtype_code(x)
+    dev = x.device
+    if not sync and N == 1:
+        # same failure as the reference: `.squeeze()` drops the patch axis (visual_compression.py:153-156)
+        raise IndexError("memory_bank_compress_keyframe: sync=False with a single patch position (N == 1)")
+    with torch.cuda.device(dev):
+        st = nv.stream()
+        dis = torch.empty((T, N), dtype=torch.float32, device=dev)
+        nv.check(nv.lib.rtk_dpselect_dis(nv.ptr(x), T, N, Cc, dt, nv.ptr(dis), st), "rtk_dpselect_dis")
+        idx = torch.empty((tgt_mem_len,) if sync else (tgt_mem_len, N), dtype=torch.int64, device=dev)
+        mask = torch.empty((tgt_mem_len, N), dtype=torch.bool, device=dev)
+        keys = torch.empty((2, T) if sync else (N, T), dtype=torch.float32, device=dev)
+        nv.check(nv.lib.rtk_dpselect_select(nv.ptr(dis), T, N, tgt_mem_len, int(window_size), int(bool(sync)),
+                                            nv.ptr(idx), nv.ptr(mask), nv.ptr(keys), st), "rtk_dpselect_select")
+        out = torch.empty((1, tgt_mem_len, N, Cc), dtype=x.dtype, device=dev)
+        nv.check(nv.lib.rtk_gather_frames(nv.ptr(x), T, N, Cc, dt, nv.ptr(idx), tgt_mem_len, int(bool(sync)),
+                                          nv.ptr(out), st), "rtk_gather_frames")
+    return out, mask, idx, dis, keys
+
+
+def memory_bank_compress_keyframe(memory_bank: torch.Tensor, tgt_mem_len: int, window_size: int = 3,
+                                  sync: bool = True) -> tuple:
+    """DPSelect (reference: visual_compression.py:86-177).
+
+    Args:
+        memory_bank: [B=1, T, N, C] frame embeddings (float32 or bfloat16, on the ROCm device)
+        tgt_mem_len: number of frames to keep
+        window_size: argrelmax window (the callers pass 3)
+        sync: True = one frame set for all patch positions; False = per-patch frame sets
+    Returns:
+        compressed_memory_bank [1, t, N, C] (fresh tensor), keypatches_mask.flatten() [t*N] bool
+    """
+    out, mask, _, _, _ = dpselect_stages(memory_bank, tgt_mem_len, window_size, sync)
+    return out, mask.flatten()
+
+
+def memory_bank_compress_MALLM(memory_bank, compression_size, sync: bool = False):
+    # SURVEY §8(f) rank 4 ("next"): used by no shipped config (all use compression_method "Keyframe").
+    raise NotImplementedError("compression_method 'MA-LLM' is not implemented in the MI355X build yet")
+
+
+def memory_bank_compress_MALLM_hard(memory_bank, sync: bool = False):
+    raise NotImplementedError("compression_method 'MA-LLM-hard' is not implemented in the MI355X build yet")
