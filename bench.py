@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s through DPSelect + PivotKV at 2048 frames on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W] [--dtype bf16|fp32] [--frames 2048]
+
+One "step" = one pass of the hot path over one synthetic 2048-frame video, inputs resident in HBM:
+    DPSelect on [1, 2048, 196, 1280] frame embeddings (shipped default: ratio 1.0, patch_sync False)
+    + PivotKVCache.update for every (chunk, layer): 64 chunks x 28 layers, L = 6272 tokens per chunk,
+      Hq 28 / Hkv 4 / D 128, ratio 0.25 (4x KV compression), pos_embed_reforge, M-RoPE [16,24,24],
+      YaRN attention_scaling 1.1386, key-patch mask from DPSelect.
+All of it goes through the product's plugin surface (retake.visual_compression /
+retake.longvideo_cache), i.e. the C ABI of libretake_hip.so.  N > 1: one process per GPU over RCCL,
+the video's frame chunks are sharded across ranks (strong scaling), see retake/sharded.py.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, measured with HIP events on
+the launch stream inside the timed region (rtk_profile_*); `cpu_baseline` times the CPU oracle
+(oracle/, test infrastructure) on a bounded sample of the same workload on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "video-retake_amd"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, MI355X_MICROARCH.md
+
+Hq, Hkv, D = 28, 4, 128
+N_PATCH, C_EMB = 196, 1280
+FRAMES_PER_CHUNK = 32
+LAYERS = 28
+RATIO = 0.25
+MROPE = [16, 24, 24]
+A_SCALE = 0.1 * math.log(4.0) + 1.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--frames", type=int, default=2048)
+    ap.add_argument("--layers", type=int, default=LAYERS)
+    ap.add_argument("--pool", type=int, default=48, help="distinct resident (q,k,v) sets cycled over the calls")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-updates", type=int, default=2)
+    return ap.parse_args()
+
+
+class Rotary:
+    """inv_freq * position rotary module with YaRN attention_scaling (what HF's rotary modules compute)."""
+
+    def __init__(self, device):
+        self.inv_freq = (1.0 / (1e6 ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))).to(device)
+        self.attention_scaling = A_SCALE
+
+    def __call__(self, x, position_ids):
+        inv = self.inv_freq[None, None, :, None].expand(3, position_ids.shape[1], -1, 1)
+        freqs = (inv @ position_ids[:, :, None, :].float()).transpose(2, 3)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        return (emb.cos() * self.attention_scaling).to(x.dtype), (emb.sin() * self.attention_scaling).to(x.dtype)
+
+
+def make_cache_config(layers):
+    return types.SimpleNamespace(
+        hidden_size=Hq * D, num_hidden_layers=layers, num_attention_heads=Hq, num_key_value_heads=Hkv,
+        longvideo_kwargs={"kvcache_compression": True,
+                          "kvcache_compression_kwargs": {"compression_ratio": RATIO, "compression_method": "pivotkv",
+                                                         "pos_embed_reforge": True, "native_rope": True}})
+
+
+def chunk_position_ids(c, device):
+    L = FRAMES_PER_CHUNK * N_PATCH
+    t = torch.arange(FRAMES_PER_CHUNK, device=device).repeat_interleave(N_PATCH) + FRAMES_PER_CHUNK * c + 16
+    h = torch.arange(14, device=device).repeat_interleave(14).repeat(FRAMES_PER_CHUNK) + 16
+    w = torch.arange(14, device=device).repeat(14 * FRAMES_PER_CHUNK) + 16
+    return torch.stack([t, h, w]).view(3, 1, L)
+
+
+def run_video(frames, pool, masks, pos_base, rotary, layers, tdtype):
+    """One step on one GPU: DPSelect + all (chunk, layer) PivotKV updates.  Returns retained tokens."""
+    import retake.longvideo_cache as lc
+    import retake.visual_compression as vc
+
+    T = frames.shape[1]
+    out, mask = vc.memory_bank_compress_keyframe(frames, T, 3, sync=False)
+    n_chunks = T // FRAMES_PER_CHUNK
+    L = FRAMES_PER_CHUNK * N_PATCH
+    cache = lc.build_kvcache(make_cache_config(layers))
+    retained = 0
+    call = 0
+    for c in range(n_chunks):
+        cache.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
+        cache.kvcache_compression = True
+        for layer in range(layers):
+            q, k, v = pool[call % len(pool)]
+            call += 1
+            # what the attention patch does (qwen2_vl.py:68-73), without a host sync
+            pos = pos_base[c]
+            prev = cache.get_prev_temporal_idx(layer)
+            if not isinstance(prev, int):
+                pos = pos.clone()
+                pos[0, 0, :] += prev + 1 - pos[0, 0, 0]
+            kw = {"query_states": q, "position_ids": pos, "rotary_emb": rotary, "mrope_section": MROPE}
+            cache.update(k, v, layer, kw)
+        cache.after_forward()
+        retained += layers * max(1, int(RATIO * L))
+    return retained, cache
+
+
+def cpu_baseline(args, frames_cpu_sample, n_updates):
+    """Times the CPU oracle on a bounded sample and extrapolates to the full workload."""
+    from oracle import oracle as orc
+    import synth
+
+    cores = orc.num_threads()
+    L = FRAMES_PER_CHUNK * N_PATCH
+    Ts = frames_cpu_sample.shape[1]
+    t0 = time.perf_counter()
+    orc.dpselect(frames_cpu_sample, Ts, 3, False)
+    t_dp = time.perf_counter() - t0
+    inv_f = synth.inv_freq(D)
+    rot = synth.RotaryStub(inv_f, A_SCALE)
+    q0, k0, v = synth.qkv_chunk(123, Hq, Hkv, L, D)
+    pos = synth.mrope_position_ids(16, FRAMES_PER_CHUNK, 14, 14, hw0=16)
+    q = synth.rope_forward(torch.from_numpy(q0), torch.from_numpy(pos), rot, MROPE).numpy()
+    k = synth.rope_forward(torch.from_numpy(k0), torch.from_numpy(pos), rot, MROPE).numpy()
+    oc = orc.OraclePivotKV(Hq, Hkv, D, RATIO, True)
+    t0 = time.perf_counter()
+    for i in range(n_updates):
+        oc.update(k, v, i, q=q, position_ids=pos, rotary=rot, mrope_section=MROPE)
+    t_up = (time.perf_counter() - t0) / n_updates
+    n_chunks = args.frames // FRAMES_PER_CHUNK
+    total = t_dp * (args.frames / Ts) + t_up * n_chunks * args.layers
+    return {"value": args.frames / total, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ (C+OpenMP, fp32): DPSelect on {Ts} of {args.frames} frames ({t_dp:.2f} s) + "
+                      f"{n_updates} PivotKV updates at L={L} ({t_up:.2f} s each), extrapolated to "
+                      f"{n_chunks}x{args.layers} updates",
+            "dpselect_s_per_2048": t_dp * (args.frames / Ts), "pivotkv_update_s": t_up}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or args.gpus > 1:
+        from retake import sharded
+
+        return sharded.bench_main(args, rank, world, local_rank)
+
+    import retake._native as nv
+
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    tdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    es = 2 if args.dtype == "bf16" else 4
+    T = args.frames
+    L = FRAMES_PER_CHUNK * N_PATCH
+    n_chunks = T // FRAMES_PER_CHUNK
+    gen = torch.Generator(device=dev).manual_seed(0)
+    frames = torch.randn((1, T, N_PATCH, C_EMB), generator=gen, device=dev, dtype=torch.float32).to(tdtype)
+    pool = []
+    for i in range(min(args.pool, n_chunks * args.layers)):
+        q = (1.7 * torch.randn((1, Hq, L, D), generator=gen, device=dev, dtype=torch.float32)).to(tdtype)
+        k = (1.7 * torch.randn((1, Hkv, L, D), generator=gen, device=dev, dtype=torch.float32)).to(tdtype)
+        v = (1.7 * torch.randn((1, Hkv, L, D), generator=gen, device=dev, dtype=torch.float32)).to(tdtype)
+        pool.append((q, k, v))
+    pos_base = [chunk_position_ids(c, dev) for c in range(n_chunks)]
+    rotary = Rotary(dev)
+    masks = None
+
+    for _ in range(args.warmup):
+        run_video(frames, pool, masks, pos_base, rotary, args.layers, tdtype)
+    torch.cuda.synchronize()
+    use_events = not args.no_kernel_events
+    if use_events:
+        nv.check(nv.lib.rtk_profile_reset(), "profile_reset")
+        nv.check(nv.lib.rtk_profile_enable(1), "profile_enable")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    retained = 0
+    for _ in range(args.steps):
+        r, cache = run_video(frames, pool, masks, pos_base, rotary, args.layers, tdtype)
+        retained += r
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = {}
+    if use_events:
+        nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
+        prof = nv.profile_read()
+
+    ms_per_step = dt / args.steps * 1e3
+    fps = T * args.steps / dt
+    out = {
+        "metric": "frames/sec through DPSelect+PivotKV @2048 frames; retained-KV-tokens/sec",
+        "value": fps, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "retained_kv_tokens_per_s": retained / dt,
+        "config": {"workload": f"Qwen2-VL-7B geometry, {T}-frame synthetic video: DPSelect (async, ratio 1.0) on "
+                               f"[1,{T},{N_PATCH},{C_EMB}] + PivotKV 4x on {n_chunks} chunks x {args.layers} layers, "
+                               f"L={L}, Hq={Hq}, Hkv={Hkv}, D={D}, reforge+M-RoPE (BASELINE configs[2])",
+                   "frames": T, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L, "keep": int(RATIO * L),
+                   "input_pool_sets": len(pool), "parallelism": "1 GPU"},
+    }
+    if prof:
+        kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in prof.items()}
+        out["kernels"] = kern
+        flops = 2.0 * Hq * L * L * D                     # one Q K^T per launch
+        dom = max(("score_pass1", "score_pass2"), key=lambda k: kern[k]["total_ms"])
+        avg_s = kern[dom]["avg_us"] * 1e-6
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": peak,
+                           "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / peak, "traffic": None,
+                           "algorithmic_flops_per_launch": flops}
+        # HBM-bound kernels of the path, same convention (algorithmic bytes per launch / avg duration)
+        keep = int(RATIO * L)
+        ev_bytes = 5 * L + 2 * Hkv * L * D * es + 2 * Hkv * keep * D * es + 8 * 3 * (L + keep)
+        dp_bytes = T * N_PATCH * C_EMB * es + 4 * T * N_PATCH
+        ga_bytes = 2 * T * N_PATCH * C_EMB * es
+        extra = {}
+        for name, key, b in (("evict_scan", "evict_scan", ev_bytes), ("dpselect_dis", "dpselect_dis", dp_bytes),
+                             ("gather_frames", "gather_frames", ga_bytes)):
+            if key in kern:
+                gbs = b / (kern[key]["avg_us"] * 1e-6) / 1e9
+                extra[name] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b}
+        out["roofline_hbm_kernels"] = extra
+    if not args.no_cpu_baseline:
+        sample_T = 128
+        out["cpu_baseline"] = cpu_baseline(args, frames[:, :sample_T].float().cpu().numpy(), args.cpu_sample_updates)
+        out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of rtk_pivotkv_score (and friends) at BASELINE geometry; prints per-kernel avg µs.
+    python tools/bench_score.py [--dtype bf16|fp32] [--L 6272] [--iters 20]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "video-retake_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+
+import retake._native as nv
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--L", type=int, default=6272)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--check", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    td = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    Hq, Hkv, D, L = 28, 4, 128, a.L
+    g = torch.Generator(device=dev).manual_seed(0)
+    sets = [tuple((1.7 * torch.randn((1, h, L, D), generator=g, device=dev)).to(td) for h in (Hq, Hkv)) for _ in range(6)]
+    cos = torch.rand((L, D), generator=g, device=dev)
+    sin = (1 - cos * cos).sqrt()
+    dt = nv.dtype_code(sets[0][0])
+    wsb = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
+    ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
+    wsp = (ws.data_ptr() + 255) & ~255
+    score = torch.empty(L, dtype=torch.float32, device=dev)
+    kun = torch.empty((Hkv, L, D), dtype=td, device=dev)
+    st = nv.stream()
+
+    def run(q, k):
+        nv.check(nv.lib.rtk_pivotkv_score(nv.ptr(q), q.stride(1), q.stride(2), nv.ptr(k), k.stride(1), k.stride(2), Hq, Hkv,
+                                          L, D, dt, nv.ptr(cos), nv.ptr(sin), 1.1386, nv.ptr(score), nv.ptr(kun),
+                                          C.c_void_p(wsp), wsb, st), "score")
+    for i in range(3):
+        run(*sets[i % len(sets)])
+    torch.cuda.synchronize()
+    nv.lib.rtk_profile_reset()
+    nv.lib.rtk_profile_enable(1)
+    for i in range(a.iters):
+        run(*sets[i % len(sets)])
+    torch.cuda.synchronize()
+    nv.lib.rtk_profile_enable(0)
+    prof = nv.profile_read()
+    flops = 2.0 * Hq * L * L * D
+    for k, (n, ms) in prof.items():
+        us = ms / n * 1e3
+        extra = f"  {flops / (us * 1e-6) / 1e12:7.1f} TFLOP/s" if k.startswith("score_pass") else ""
+        print(f"{k:16s} n={n:4d} avg={us:9.1f} us{extra}")
+    print("score mean", float(score.mean()), "min", float(score.min()), "max", float(score.max()))
+
+
+if __name__ == "__main__":
+    main()

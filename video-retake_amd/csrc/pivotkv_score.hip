@@ -94,7 +94,6 @@ template <> struct MM<RTK_BF16> {
     static constexpr int ESIZE = 2;
     static constexpr int CHUNKS = 16;            // per row
     static constexpr int NREG = 8;               // 16-byte registers per lane for a 32-row fragment
-    static constexpr int STAGE = (TILE_ROWS * CHUNKS) / SC_BLOCK;  // 4 chunks per thread per tile
     __device__ static __forceinline__ int chunk_of(int r, int hf) { return 2 * r + hf; }
     __device__ static __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
@@ -106,7 +105,6 @@ template <> struct MM<RTK_F32> {
     static constexpr int ESIZE = 4;
     static constexpr int CHUNKS = 32;
     static constexpr int NREG = 16;
-    static constexpr int STAGE = (TILE_ROWS * CHUNKS) / SC_BLOCK;  // 8
     __device__ static __forceinline__ int chunk_of(int r, int hf) { return 16 * hf + r; }
     __device__ static __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
@@ -114,6 +112,14 @@ template <> struct MM<RTK_F32> {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
     }
+};
+
+template <int DT> struct Tile {
+    using M = MM<DT>;
+    static constexpr int ROWB = M::CHUNKS * 16;                    // bytes per row (256 / 512)
+    static constexpr int BYTES = TILE_ROWS * ROWB;                 // one LDS tile
+    static constexpr int STAGE = (TILE_ROWS * M::CHUNKS) / SC_BLOCK;  // 16-byte chunks per thread per tile (4 / 8)
+    static constexpr int ROWS_PER_STEP = SC_BLOCK / M::CHUNKS;     // rows between a thread's consecutive chunks (16 / 8)
 };
 
 // accumulator register r of lane (half hf) holds output row  m = (r&3) + 8*(r>>2) + 4*hf
@@ -131,204 +137,280 @@ __device__ __forceinline__ void load_reg_frag(const char* __restrict__ base, int
     for (int r = 0; r < M::NREG; ++r) rf[r] = ok ? p[M::chunk_of(r, hf)] : u32x4{0, 0, 0, 0};
 }
 
-// Streamed tile: global -> registers (issue early) ...
-template <int DT>
-__device__ __forceinline__ void stage_load(const char* __restrict__ base, int row0, int row_end, int tid, u32x4* st) {
+// Per-thread constants of the streamed-tile pipeline, computed once per kernel:
+//   frag_off[r]  LDS byte offset (inside a tile, block 0) of this lane's r-th A-fragment chunk
+//   st_off[u]    LDS byte offset where this thread stores its u-th staged chunk
+//   src_off      byte offset (inside a tile's 64 source rows) of this thread's first staged chunk
+// 16-byte chunks are XOR-swizzled by (row & 15): the 16 lanes of every ds_read_b128 lane group address
+// 16 distinct rows (mod 16) => 16 distinct 16-byte bank slots; no bank conflicts (SQ_LDS_BANK_CONFLICT = 0).
+template <int DT> struct Pipe {
     using M = MM<DT>;
+    using T = Tile<DT>;
+    int frag_off[M::NREG];
+    int st_off[T::STAGE];
+    int src_off;
+    int srow;  // first staged row of this thread inside the tile
+    __device__ __forceinline__ void init(int tid, int lane) {
+        const int row = lane & 31, hf = lane >> 5;
 #pragma unroll
-    for (int u = 0; u < M::STAGE; ++u) {
-        const int c = tid + SC_BLOCK * u;
-        const int row = c / M::CHUNKS, ch = c % M::CHUNKS;
-        const int grow = row0 + row;
-        st[u] = (grow < row_end) ? ((const u32x4*)(base + (size_t)grow * HD * M::ESIZE))[ch] : u32x4{0, 0, 0, 0};
-    }
-}
-// ... registers -> LDS (write late), 16-byte chunks XOR-swizzled by (row & 15): the 16 lanes of every
-// ds_read_b128 lane group address 16 distinct rows (mod 16) => 16 distinct 16-byte bank slots.
-template <int DT>
-__device__ __forceinline__ void stage_store(char* lds, int tid, const u32x4* st) {
-    using M = MM<DT>;
+        for (int r = 0; r < M::NREG; ++r) frag_off[r] = row * T::ROWB + ((M::chunk_of(r, hf) ^ (row & 15)) * 16);
+        srow = tid / M::CHUNKS;
+        const int ch = tid % M::CHUNKS;
+        src_off = srow * T::ROWB + ch * 16;
 #pragma unroll
-    for (int u = 0; u < M::STAGE; ++u) {
-        const int c = tid + SC_BLOCK * u;
-        const int row = c / M::CHUNKS, ch = c % M::CHUNKS;
-        *(u32x4*)(lds + (size_t)row * (M::CHUNKS * 16) + (size_t)((ch ^ (row & 15)) * 16)) = st[u];
+        for (int u = 0; u < T::STAGE; ++u) {
+            const int rr = srow + u * T::ROWS_PER_STEP;
+            st_off[u] = rr * T::ROWB + ((ch ^ (rr & 15)) * 16);
+        }
     }
-}
+    // global -> registers (issued early, consumed late); rows >= rows_left are zero-filled
+    template <bool FULL>
+    __device__ __forceinline__ void load(const char* __restrict__ tile_src, int rows_left, u32x4* st) const {
+#pragma unroll
+        for (int u = 0; u < T::STAGE; ++u) {
+            const u32x4* p = (const u32x4*)(tile_src + src_off + (size_t)u * T::ROWS_PER_STEP * T::ROWB);
+            if (FULL) st[u] = *p;
+            else st[u] = (srow + u * T::ROWS_PER_STEP < rows_left) ? *p : u32x4{0, 0, 0, 0};
+        }
+    }
+    __device__ __forceinline__ void store(char* lds_tile, const u32x4* st) const {
+#pragma unroll
+        for (int u = 0; u < T::STAGE; ++u) *(u32x4*)(lds_tile + st_off[u]) = st[u];
+    }
+    // acc += A(32 LDS rows of block `blk`) x B(register fragment)
+    __device__ __forceinline__ void mma_block(f32x16& acc, const char* lds_tile, int blk, const u32x4* rf) const {
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) {
+            const u32x4 a = *(const u32x4*)(lds_tile + blk * 32 * T::ROWB + frag_off[r]);
+            M::mma(acc, a, rf[r]);
+        }
+    }
+};
 
-// acc += A(32 LDS rows starting at blk_row) x B(register fragment)
-template <int DT>
-__device__ __forceinline__ void block_mma(f32x16& acc, const char* lds, int blk_row, int lane, const u32x4* rf) {
-    using M = MM<DT>;
-    const int row = blk_row + (lane & 31), hf = lane >> 5;
-    const char* rp = lds + (size_t)row * (M::CHUNKS * 16);
-    const int sw = row & 15;
-#pragma unroll
-    for (int r = 0; r < M::NREG; ++r) {
-        const u32x4 a = *(const u32x4*)(rp + ((M::chunk_of(r, hf) ^ sw) * 16));
-        M::mma(acc, a, rf[r]);
-    }
+__device__ __forceinline__ float max16(const f32x16& a) {
+    return fmaxf(fmaxf(fmaxf(fmaxf(a[0], a[1]), a[2]), fmaxf(fmaxf(a[3], a[4]), a[5])),
+                 fmaxf(fmaxf(fmaxf(fmaxf(a[6], a[7]), a[8]), fmaxf(fmaxf(a[9], a[10]), a[11])),
+                       fmaxf(fmaxf(fmaxf(a[12], a[13]), a[14]), a[15])));
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 1: lse[h,i] = log sum_j exp(q_hi . k_gj / sqrt(D))      (natural log for fp32, log2 for bf16)
-// grid (ceil(L/128), Hq), 256 threads; wave w keeps query rows i0 + 32w + (lane&31) in registers.
+// pass 1: partial row log-sum-exp over one key split
+//   lse_part[ks,h,i] = log sum_{j in split ks} exp(q_hi . k_gj / sqrt(D))   (log2 domain for bf16)
+// grid (ceil(L/128), Hq, KS), 256 threads; wave w keeps query rows i0 + 32w + (lane&31) in registers.
 // ------------------------------------------------------------------------------------------------
+template <int DT>
+struct RowStat {  // online max / sum of one query row, over the keys this lane sees
+    float m, sum;  // bf16: m = raw dot-product max, sum of exp2((x - m) * c2);  fp32: m = max logit, sum of exp(x - m)
+    __device__ __forceinline__ void init() { m = -INFINITY; sum = 0.f; }
+    template <bool RAGGED>
+    __device__ __forceinline__ void update(f32x16& a0, f32x16& a1, int j0, int j_end, int hf, float c2, float sqrt_d) {
+        if (DT == RTK_F32) {  // the reference's operation order: logits = dot / sqrt(D), natural exp
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a0[r] = __fdiv_rn(a0[r], sqrt_d); a1[r] = __fdiv_rn(a1[r], sqrt_d); }
+        }
+        if (RAGGED) {  // keys >= j_end do not exist
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (j0 + acc_row(r, hf) >= j_end) a0[r] = -INFINITY;
+                if (j0 + 32 + acc_row(r, hf) >= j_end) a1[r] = -INFINITY;
+            }
+        }
+        const float mn = fmaxf(m, fmaxf(max16(a0), max16(a1)));
+        if (RAGGED && mn == -INFINITY) return;
+        float add = 0.f;
+        if (DT == RTK_BF16) {
+            const float nb = -mn * c2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(fmaf(a0[r], c2, nb));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(fmaf(a1[r], c2, nb));
+            sum = sum * __builtin_amdgcn_exp2f((m - mn) * c2) + add;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) add += expf(a0[r] - mn);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) add += expf(a1[r] - mn);
+            sum = sum * expf(m - mn) + add;
+        }
+        m = mn;
+    }
+    // merge with the other half-wave (disjoint key subsets of the same row) and take the log
+    __device__ __forceinline__ float finish(float c2) const {
+        const float m2 = __shfl_xor(m, 32, WAVE), s2 = __shfl_xor(sum, 32, WAVE);
+        const float mm = fmaxf(m, m2);
+        if (mm == -INFINITY) return -INFINITY;  // no key seen (cannot happen for a non-empty split)
+        if (DT == RTK_BF16) {
+            const float tot = sum * __builtin_amdgcn_exp2f((m - mm) * c2) + s2 * __builtin_amdgcn_exp2f((m2 - mm) * c2);
+            return mm * c2 + __builtin_amdgcn_logf(tot);  // v_log_f32 = log2
+        }
+        const float tot = sum * expf(m - mm) + s2 * expf(m2 - mm);
+        return mm + logf(tot);
+    }
+};
+
 template <int DT>
 __global__ __launch_bounds__(SC_BLOCK) void score_pass1_kernel(const char* __restrict__ q, const char* __restrict__ k,
-                                                               int Hq, int Hkv, int L, float* __restrict__ lse) {
+                                                               int Hq, int Hkv, int L, int keys_per_split,
+                                                               float* __restrict__ lse_part) {
     using M = MM<DT>;
-    constexpr int TILE_BYTES = TILE_ROWS * M::CHUNKS * 16;
+    using T = Tile<DT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE, hf = lane >> 5;
-    const int h = blockIdx.y, g = h / (Hq / Hkv);
+    const int h = blockIdx.y, g = h / (Hq / Hkv), ks = blockIdx.z;
     const int i0 = blockIdx.x * REG_ROWS + wid * 32;
+    const int jb = ks * keys_per_split, je = min(L, jb + keys_per_split);
     const char* qh = q + (size_t)h * L * HD * M::ESIZE;
-    const char* kg = k + (size_t)g * L * HD * M::ESIZE;
+    const char* kg = k + ((size_t)g * L + jb) * HD * M::ESIZE;
 
+    Pipe<DT> pp;
+    pp.init(tid, lane);
     u32x4 qf[M::NREG];
     load_reg_frag<DT>(qh, i0, L, lane, qf);
 
-    u32x4 st[M::STAGE];
-    const int ntiles = (L + TILE_ROWS - 1) / TILE_ROWS;
-    stage_load<DT>(kg, 0, L, tid, st);
-    stage_store<DT>(smem, tid, st);
+    const int nkeys = je - jb;
+    const int nfull = nkeys / TILE_ROWS;              // full tiles
+    const int ntiles = (nkeys + TILE_ROWS - 1) / TILE_ROWS;
+    const float sqrt_d = sqrtf((float)HD);
+    const float c2 = 1.4426950408889634f / sqrt_d;    // bf16: log2(e)/sqrt(D) folded into the exp2 argument
+    RowStat<DT> rs;
+    rs.init();
+
+    u32x4 st[T::STAGE];
+    if (nfull > 0) pp.template load<true>(kg, TILE_ROWS, st);
+    else pp.template load<false>(kg, nkeys, st);
+    pp.store(smem, st);
     __syncthreads();
 
-    // bf16: base-2 domain with the 1/sqrt(D) folded into the scale; fp32: the reference's own
-    // operation order (logits / sqrt(D), natural exp).
-    const float sqrt_d = sqrtf((float)HD);
-    const float c2 = 1.4426950408889634f / sqrt_d;
-    float m = -INFINITY, sum = 0.f;
-    for (int jt = 0; jt < ntiles; ++jt) {
-        const char* cur = smem + (size_t)(jt & 1) * TILE_BYTES;
-        if (jt + 1 < ntiles) stage_load<DT>(kg, (jt + 1) * TILE_ROWS, L, tid, st);
+    auto step = [&](int jt, int buf) {
+        const char* cur = smem + buf * T::BYTES;
+        char* nxt = smem + (buf ^ 1) * T::BYTES;
+        const bool have_next = jt + 1 < ntiles;
+        if (have_next) {
+            const char* src = kg + (size_t)(jt + 1) * T::BYTES;
+            if (jt + 1 < nfull) pp.template load<true>(src, TILE_ROWS, st);
+            else pp.template load<false>(src, nkeys - (jt + 1) * TILE_ROWS, st);
+        }
         f32x16 acc0 = {0}, acc1 = {0};
-        block_mma<DT>(acc0, cur, 0, lane, qf);
-        block_mma<DT>(acc1, cur, 32, lane, qf);
-        float v[32];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            v[r] = (DT == RTK_BF16) ? acc0[r] * c2 : __fdiv_rn(acc0[r], sqrt_d);
-            v[16 + r] = (DT == RTK_BF16) ? acc1[r] * c2 : __fdiv_rn(acc1[r], sqrt_d);
-        }
-        const int j0 = jt * TILE_ROWS;
-        if (j0 + TILE_ROWS > L) {  // ragged last tile: keys >= L do not exist
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (j0 + acc_row(r, hf) >= L) v[r] = -INFINITY;
-                if (j0 + 32 + acc_row(r, hf) >= L) v[16 + r] = -INFINITY;
-            }
-        }
-        float mx = v[0];
-#pragma unroll
-        for (int r = 1; r < 32; ++r) mx = fmaxf(mx, v[r]);
-        const float mn = fmaxf(m, mx);
-        if (mn > -INFINITY) {
-            float add = 0.f;
-            if (DT == RTK_BF16) {
-#pragma unroll
-                for (int r = 0; r < 32; ++r) add += __builtin_amdgcn_exp2f(v[r] - mn);
-                sum = sum * __builtin_amdgcn_exp2f(m - mn) + add;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 32; ++r) add += expf(v[r] - mn);
-                sum = sum * expf(m - mn) + add;
-            }
-            m = mn;
-        }
-        if (jt + 1 < ntiles) stage_store<DT>(smem + (size_t)((jt + 1) & 1) * TILE_BYTES, tid, st);
+        pp.mma_block(acc0, cur, 0, qf);
+        pp.mma_block(acc1, cur, 1, qf);
+        if (jt < nfull) rs.template update<false>(acc0, acc1, 0, 0, hf, c2, sqrt_d);
+        else rs.template update<true>(acc0, acc1, jt * TILE_ROWS, nkeys, hf, c2, sqrt_d);
+        if (have_next) pp.store(nxt, st);
         __syncthreads();
+    };
+    int jt = 0;
+    for (; jt + 1 < ntiles; jt += 2) {  // two tiles per trip: LDS buffer offsets become immediates
+        step(jt, 0);
+        step(jt + 1, 1);
     }
-    // the two halves of the wave saw disjoint key subsets of the same query row
-    const float m2 = __shfl_xor(m, 32, WAVE), s2 = __shfl_xor(sum, 32, WAVE);
-    const float mm = fmaxf(m, m2);
-    float out;
-    if (DT == RTK_BF16) {
-        const float tot = sum * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
-        out = mm + __builtin_amdgcn_logf(tot);  // v_log_f32 = log2
-    } else {
-        const float tot = sum * expf(m - mm) + s2 * expf(m2 - mm);
-        out = mm + logf(tot);
-    }
+    if (jt < ntiles) step(jt, 0);
+
+    const float out = rs.finish(c2);
     const int i = i0 + (lane & 31);
-    if (hf == 0 && i < L) lse[(size_t)h * L + i] = out;
+    if (hf == 0 && i < L) lse_part[((size_t)ks * Hq + h) * L + i] = out;
 }
 
 // ------------------------------------------------------------------------------------------------
 // pass 2: partial[g,split,j] = sum_{h in g} sum_{i in split} exp(s_hij - lse[h,i])
 // grid (ceil(L/128), Hkv, RS); wave w keeps keys j0 + 32w + (lane&31) in registers.
+// lse[h,i] is combined on the fly from pass 1's KS partials while the query tile is staged.
 // ------------------------------------------------------------------------------------------------
+// lse[h,i] = log sum_ks exp(lse_part[ks,h,i]), written over split 0 (one thread per row: no hazard)
+template <int DT>
+__global__ __launch_bounds__(256) void lse_combine_kernel(float* __restrict__ lse_part, size_t n, int KS) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float v[8];
+    float mx = -INFINITY;
+    for (int s = 0; s < KS; ++s) {
+        v[s] = lse_part[(size_t)s * n + idx];
+        mx = fmaxf(mx, v[s]);
+    }
+    float tot = 0.f;
+    for (int s = 0; s < KS; ++s) tot += (DT == RTK_BF16) ? __builtin_amdgcn_exp2f(v[s] - mx) : expf(v[s] - mx);
+    lse_part[idx] = mx + ((DT == RTK_BF16) ? __builtin_amdgcn_logf(tot) : logf(tot));
+}
+
 template <int DT>
 __global__ __launch_bounds__(SC_BLOCK) void score_pass2_kernel(const char* __restrict__ q, const char* __restrict__ k,
                                                                const float* __restrict__ lse, int Hq, int Hkv, int L,
                                                                int rows_per_split, float* __restrict__ partial) {
     using M = MM<DT>;
-    constexpr int TILE_BYTES = TILE_ROWS * M::CHUNKS * 16;
+    using T = Tile<DT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* lse_s = (float*)(smem + 2 * TILE_BYTES);  // [2][TILE_ROWS]
+    float* lse_s = (float*)(smem + 2 * T::BYTES);  // [2][TILE_ROWS]
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE, hf = lane >> 5;
     const int g = blockIdx.y, G = Hq / Hkv, rs = blockIdx.z, RS = gridDim.z;
     const int j0 = blockIdx.x * REG_ROWS + wid * 32;
     const char* kg = k + (size_t)g * L * HD * M::ESIZE;
     const int ib = rs * rows_per_split, ie = min(L, ib + rows_per_split);
-    const int tiles_per_head = (ie > ib) ? (ie - ib + TILE_ROWS - 1) / TILE_ROWS : 0;
+    const int nrows = ie - ib;
+    const int tiles_per_head = (nrows + TILE_ROWS - 1) / TILE_ROWS;   // >= 1: empty splits are not launched
+    const int full_per_head = nrows / TILE_ROWS;
     const int ntiles = tiles_per_head * G;
 
+    Pipe<DT> pp;
+    pp.init(tid, lane);
     u32x4 kf[M::NREG];
     load_reg_frag<DT>(kg, j0, L, lane, kf);
 
-    auto tile_src = [&](int it, const char*& qh, const float*& lh, int& row0) {
-        const int hh = it / tiles_per_head, tt = it % tiles_per_head;
-        const int h = g * G + hh;
-        qh = q + (size_t)h * L * HD * M::ESIZE;
-        lh = lse + (size_t)h * L;
-        row0 = ib + tt * TILE_ROWS;
-    };
-
-    u32x4 st[M::STAGE];
-    float lst = 0.f;
     const float sqrt_d = sqrtf((float)HD);
     const float c2 = 1.4426950408889634f / sqrt_d;
     float col = 0.f;
-    if (ntiles > 0) {
-        const char* qh; const float* lh; int row0;
-        tile_src(0, qh, lh, row0);
-        stage_load<DT>(qh, row0, ie, tid, st);
-        if (tid < TILE_ROWS) lse_s[tid] = (row0 + tid < ie) ? lh[row0 + tid] : INFINITY;
-        stage_store<DT>(smem, tid, st);
-        __syncthreads();
-        for (int it = 0; it < ntiles; ++it) {
-            const char* cur = smem + (size_t)(it & 1) * TILE_BYTES;
-            const float* lcur = lse_s + (it & 1) * TILE_ROWS;
-            if (it + 1 < ntiles) {
-                tile_src(it + 1, qh, lh, row0);
-                stage_load<DT>(qh, row0, ie, tid, st);
-                if (tid < TILE_ROWS) lst = (row0 + tid < ie) ? lh[row0 + tid] : INFINITY;
-            }
+    u32x4 st[T::STAGE];
+    float lst = 0.f;
+
+    // cursor of the tile being prefetched: head index and row tile inside the split
+    int nh = 0, nt = 0;
+    const char* nsrc = q + ((size_t)(g * G) * L + ib) * HD * M::ESIZE;   // first row of the split, head g*G
+    const float* nlse = lse + (size_t)(g * G) * L + ib;
+    auto issue = [&]() {  // loads tile (nh, nt) and its lse element, then advances the cursor
+        if (nt < full_per_head) pp.template load<true>(nsrc + (size_t)nt * T::BYTES, TILE_ROWS, st);
+        else pp.template load<false>(nsrc + (size_t)nt * T::BYTES, nrows - nt * TILE_ROWS, st);
+        if (tid < TILE_ROWS) lst = (nt * TILE_ROWS + tid < nrows) ? nlse[nt * TILE_ROWS + tid] : INFINITY;
+        if (++nt == tiles_per_head) {
+            nt = 0;
+            ++nh;
+            nsrc += (size_t)L * HD * M::ESIZE;
+            nlse += L;
+        }
+    };
+    auto step = [&](bool have_next, int buf) {
+        const char* cur = smem + buf * T::BYTES;
+        const float* lcur = lse_s + buf * TILE_ROWS;
+        if (have_next) issue();
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                f32x16 acc = {0};
-                block_mma<DT>(acc, cur, blk * 32, lane, kf);
+        for (int blk = 0; blk < 2; ++blk) {
+            f32x16 acc = {0};
+            pp.mma_block(acc, cur, blk, kf);
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const float4 l4 = *(const float4*)(lcur + blk * 32 + 8 * r4 + 4 * hf);
-                    const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 l4 = *(const float4*)(lcur + blk * 32 + 8 * r4 + 4 * hf);
+                const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const float a = acc[4 * r4 + rr];
-                        if (DT == RTK_BF16) col += __builtin_amdgcn_exp2f(fmaf(a, c2, -ls[rr]));
-                        else col += expf(__fdiv_rn(a, sqrt_d) - ls[rr]);
-                    }
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float a = acc[4 * r4 + rr];
+                    if (DT == RTK_BF16) col += __builtin_amdgcn_exp2f(fmaf(a, c2, -ls[rr]));
+                    else col += expf(__fdiv_rn(a, sqrt_d) - ls[rr]);
                 }
             }
-            if (it + 1 < ntiles) {
-                stage_store<DT>(smem + (size_t)((it + 1) & 1) * TILE_BYTES, tid, st);
-                if (tid < TILE_ROWS) lse_s[((it + 1) & 1) * TILE_ROWS + tid] = lst;
-            }
-            __syncthreads();
         }
+        if (have_next) {
+            pp.store(smem + (buf ^ 1) * T::BYTES, st);
+            if (tid < TILE_ROWS) lse_s[(buf ^ 1) * TILE_ROWS + tid] = lst;
+        }
+        __syncthreads();
+    };
+    issue();
+    pp.store(smem, st);
+    if (tid < TILE_ROWS) lse_s[tid] = lst;
+    __syncthreads();
+    int it = 0;
+    for (; it + 2 < ntiles; it += 2) {
+        step(true, 0);
+        step(true, 1);
     }
+    for (; it < ntiles; ++it) step(it + 1 < ntiles, it & 1);
     col += __shfl_xor(col, 32, WAVE);
     const int j = j0 + (lane & 31);
     if (hf == 0 && j < L) partial[((size_t)g * RS + rs) * L + j] = col;
@@ -420,27 +502,33 @@ __global__ __launch_bounds__(256) void score_finalize_kernel(const float* __rest
     score[j] = tot / (float)Hkv;
 }
 
-static int pick_row_splits(int L, int Hkv) {
-    const int jt = (L + REG_ROWS - 1) / REG_ROWS;
-    int rs = (1024 + jt * Hkv - 1) / (jt * Hkv);
-    const int max_rs = (L + TILE_ROWS - 1) / TILE_ROWS;
-    rs = std::max(1, std::min(std::min(rs, 16), max_rs));
-    return rs;
+// Work decomposition.  Both passes are cut into >= ~3000 workgroups (about 4 rounds over 256 CUs x 3
+// resident workgroups) so the last round's tail stays small; the splits depend on the shape only,
+// so results are deterministic.
+#ifndef RTK_TARGET_WGS
+#define RTK_TARGET_WGS 3072
+#endif
+constexpr int TARGET_WGS = RTK_TARGET_WGS;
+static int pick_splits(int tiles_fixed, int heads, int stream_tiles, int cap) {
+    int s = (TARGET_WGS + tiles_fixed * heads - 1) / (tiles_fixed * heads);
+    return std::max(1, std::min(std::min(s, cap), stream_tiles));
 }
 
 struct ScoreWs {
     size_t q_off, k_off, lse_off, part_off, total;
-    int RS;
+    int RS, KS;
 };
 static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
     const size_t es = dtype == RTK_BF16 ? 2 : 4;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     ScoreWs w;
-    w.RS = (D == HD) ? pick_row_splits(L, Hkv) : 1;
+    const int reg_tiles = (L + REG_ROWS - 1) / REG_ROWS, stream_tiles = (L + TILE_ROWS - 1) / TILE_ROWS;
+    w.RS = (D == HD) ? pick_splits(reg_tiles, Hkv, stream_tiles, 32) : 1;
+    w.KS = (D == HD) ? pick_splits(reg_tiles, Hq, stream_tiles, 8) : 1;
     w.q_off = 0;
     w.k_off = al((size_t)Hq * L * D * es);
     w.lse_off = w.k_off + al((size_t)Hkv * L * D * es);
-    w.part_off = w.lse_off + al((size_t)Hq * L * 4);
+    w.part_off = w.lse_off + al((size_t)w.KS * Hq * L * 4);
     w.total = w.part_off + al((size_t)Hkv * w.RS * L * 4);
     return w;
 }
@@ -472,18 +560,30 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         RTK_LAUNCH_CHECK("unrotate_pack_kernel");
     }
     const int G = Hq / Hkv;
+    int rs_n = 1;
     if (D == HD) {
-        using M = MM<DT>;
-        constexpr int TILE_BYTES = TILE_ROWS * M::CHUNKS * 16;
+        constexpr int TILE_BYTES = Tile<DT>::BYTES;
+        constexpr int LDS1 = 2 * TILE_BYTES, LDS2 = 2 * TILE_BYTES + 2 * TILE_ROWS * (int)sizeof(float);
+        static bool attr_set = false;  // > 64 KiB of dynamic LDS (fp32 tiles) needs the opt-in once
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)score_pass1_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+            (void)hipFuncSetAttribute((const void*)score_pass2_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+            attr_set = true;
+        }
         const int jt = (L + REG_ROWS - 1) / REG_ROWS;
-        RTK_LAUNCH(KID_PASS1, score_pass1_kernel<DT>, dim3(jt, Hq), dim3(SC_BLOCK), 2 * TILE_BYTES, st, (const char*)qt,
-                           (const char*)kt, Hq, Hkv, L, lse);
+        auto per_split = [](int n, int parts) { return (((n + parts - 1) / parts + TILE_ROWS - 1) / TILE_ROWS) * TILE_ROWS; };
+        const int kps = per_split(L, w.KS), rps = per_split(L, w.RS);
+        const int ks_n = (L + kps - 1) / kps;  // non-empty splits only
+        rs_n = (L + rps - 1) / rps;
+        RTK_LAUNCH(KID_PASS1, score_pass1_kernel<DT>, dim3(jt, Hq, ks_n), dim3(SC_BLOCK), LDS1, st, (const char*)qt,
+                   (const char*)kt, Hq, Hkv, L, kps, lse);
         RTK_LAUNCH_CHECK("score_pass1_kernel");
-        int rows_per_split = (L + w.RS - 1) / w.RS;
-        rows_per_split = ((rows_per_split + TILE_ROWS - 1) / TILE_ROWS) * TILE_ROWS;
-        RTK_LAUNCH(KID_PASS2, score_pass2_kernel<DT>, dim3(jt, Hkv, w.RS), dim3(SC_BLOCK),
-                           2 * TILE_BYTES + 2 * TILE_ROWS * sizeof(float), st, (const char*)qt, (const char*)kt, lse, Hq,
-                           Hkv, L, rows_per_split, part);
+        if (ks_n > 1) {
+            const size_t n = (size_t)Hq * L;
+            RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<DT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lse, n, ks_n);
+        }
+        RTK_LAUNCH(KID_PASS2, score_pass2_kernel<DT>, dim3(jt, Hkv, rs_n), dim3(SC_BLOCK), LDS2, st, (const char*)qt,
+                   (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, part);
         RTK_LAUNCH_CHECK("score_pass2_kernel");
     } else {
         RTK_LAUNCH(KID_PASS1, score_pass1_generic<DT>, dim3(L, Hq), dim3(256), D * sizeof(float), st, (const void*)qt,
@@ -492,7 +592,7 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                            (const void*)qt, (const void*)kt, lse, Hq, Hkv, L, D, part);
         RTK_LAUNCH_CHECK("score_generic");
     }
-    RTK_LAUNCH(KID_FINALIZE, score_finalize_kernel, dim3((L + 255) / 256), dim3(256), 0, st, part, Hkv, w.RS, G, L, score);
+    RTK_LAUNCH(KID_FINALIZE, score_finalize_kernel, dim3((L + 255) / 256), dim3(256), 0, st, part, Hkv, rs_n, G, L, score);
     RTK_LAUNCH_CHECK("score_finalize_kernel");
     return RTK_OK;
 }
