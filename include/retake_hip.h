@@ -148,6 +148,13 @@ int rtk_pivotkv_evict(const void* k, int64_t k_stride_h, int64_t k_stride_l,
                       void* k_kept, void* v_kept, int64_t kept_stride_h,
                       rtk_stream_t stream);
 
+/* P13 (second half)  longvideo_cache.py:313-318: commits the staged kept K and V rows of one layer over
+ * the head of the uncompressed tail, once the layer's attention has consumed that view.  One launch:
+ * dst[h][r][:] = stage[h][r][:], r < rows, for both tensors. */
+int rtk_pivotkv_commit(const void* k_stage, const void* v_stage, int64_t stage_stride_h,
+                       void* k_dst, void* v_dst, int64_t dst_stride_h,
+                       int H, int rows, int D, int dtype, rtk_stream_t stream);
+
 /* Row-block copy used to commit staged kept rows into the cache after the layer's attention has
  * consumed the uncompressed view: dst[h][r][:] = src[h][r][:], r < rows. */
 int rtk_copy_rows(const void* src, int64_t src_stride_h, void* dst, int64_t dst_stride_h,

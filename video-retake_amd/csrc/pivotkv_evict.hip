@@ -59,6 +59,143 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_kernel(float* __res
     }
 }
 
+// Fast path for L <= 1024*E: every thread owns E CONSECUTIVE tokens and keeps their keys in registers,
+// so the four radix passes never touch memory again and the ordered compaction is two block-wide
+// exclusive scans (ownership ranges are ordered by index, so emitting in (thread, element) order is
+// ascending index order).
+__device__ __forceinline__ int block_excl_scan_1024(int v, uint32_t* wtot /*[16]*/, int tid) {
+    const int lane = tid & (WAVE - 1), wid = tid / WAVE;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int t = __shfl_up(inc, o, WAVE);
+        if (lane >= o) inc += t;
+    }
+    if (lane == WAVE - 1) wtot[wid] = (uint32_t)inc;
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < PSEL_BLOCK / WAVE; ++w)
+        if (w < wid) before += (int)wtot[w];
+    __syncthreads();  // wtot may be reused by the next scan
+    return before + inc - v;
+}
+
+template <int E>
+__global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* __restrict__ score,
+                                                                         const uint8_t* __restrict__ mask, int L,
+                                                                         int keep, const int64_t* __restrict__ pos,
+                                                                         int P, int reforge,
+                                                                         int64_t* __restrict__ keep_idx,
+                                                                         int32_t* __restrict__ rank,
+                                                                         int64_t* __restrict__ pos_out) {
+    __shared__ SelectSmem sm;
+    __shared__ uint32_t wtot[PSEL_BLOCK / WAVE];
+    __shared__ long long red[PSEL_BLOCK / WAVE];
+    const int tid = threadIdx.x;
+    const int per = (L + PSEL_BLOCK - 1) / PSEL_BLOCK;  // <= E
+    const int base = tid * per;
+    uint32_t key[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = base + e;
+        key[e] = 0;
+        if (e < per && i < L) {
+            float sc = score[i];
+            if (mask && mask[i]) {  // attn_weights.masked_fill_(mask, 1.)  (:274)
+                sc = 1.0f;
+                score[i] = sc;
+            }
+            key[e] = f2key(sc);
+        }
+    }
+    auto valid = [&](int e) { return e < per && base + e < L; };
+    // exact k-th largest key: 4 radix passes of 8 bits over the register-resident keys
+    uint32_t prefix = 0, pmask = 0;
+    int kk = keep;
+#pragma unroll 1
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) sm.hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (valid(e) && (key[e] & pmask) == prefix) atomicAdd(&sm.hist[(key[e] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (tid < WAVE) {
+            const int lane = tid;
+            const uint32_t h0 = sm.hist[4 * lane], h1 = sm.hist[4 * lane + 1], h2 = sm.hist[4 * lane + 2],
+                           h3 = sm.hist[4 * lane + 3];
+            const uint32_t mine = h0 + h1 + h2 + h3;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const uint32_t t = __shfl_down(incl, o, WAVE);
+                if (lane + o < WAVE) incl += t;
+            }
+            const uint32_t above = incl - mine;
+            if (above < (uint32_t)kk && (uint32_t)kk <= incl) {
+                uint32_t c = above;
+                int b;
+                if ((uint32_t)kk <= c + h3) { b = 3; }
+                else { c += h3; if ((uint32_t)kk <= c + h2) { b = 2; }
+                else { c += h2; if ((uint32_t)kk <= c + h1) { b = 1; }
+                else { c += h1; b = 0; } } }
+                sm.bcast[0] = prefix | ((uint32_t)(4 * lane + b) << shift);
+                sm.bcast[1] = (uint32_t)kk - c;
+            }
+        }
+        __syncthreads();
+        prefix = sm.bcast[0];
+        kk = (int)sm.bcast[1];
+        pmask |= 255u << shift;
+    }
+    const uint32_t thr = prefix;
+    const int need_eq = kk;
+    int cnt_eq = 0, cnt_gt = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (!valid(e)) continue;
+        cnt_eq += key[e] == thr;
+        cnt_gt += key[e] > thr;
+    }
+    const int eq_before = block_excl_scan_1024(cnt_eq, wtot, tid);
+    const int eq_take = max(0, min(cnt_eq, need_eq - eq_before));  // ties: lowest index first
+    int r = block_excl_scan_1024(cnt_gt + eq_take, wtot, tid);
+    int eq_seen = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (!valid(e)) continue;
+        const int i = base + e;
+        bool sel = key[e] > thr;
+        if (key[e] == thr) sel = eq_seen++ < eq_take;
+        if (sel) {
+            keep_idx[r] = i;  // topk(keep).sort()  (:276-277)
+            if (pos)
+                for (int p = 0; p < P; ++p) pos_out[(size_t)p * keep + r] = pos[(size_t)p * L + i];  // :283-288
+            rank[i] = r++;
+        } else {
+            rank[i] = -1;
+        }
+    }
+    if (!(pos && reforge)) return;
+    __syncthreads();
+    long long mn = 0x7fffffffffffffffLL;  // min_temp_id = compressed_position_ids[0].min()  (:293)
+    for (int rr = tid; rr < keep; rr += PSEL_BLOCK) mn = min(mn, (long long)pos_out[rr]);
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long t = __shfl_xor(mn, o, WAVE);
+        mn = min(mn, t);
+    }
+    if ((tid & (WAVE - 1)) == 0) red[tid / WAVE] = mn;
+    __syncthreads();
+    mn = red[0];
+    for (int w = 1; w < PSEL_BLOCK / WAVE; ++w) mn = min(mn, red[w]);
+    const float ratio = (float)((double)keep / (double)L);  // :294-295, float32 multiply then truncation
+    for (int rr = tid; rr < keep; rr += PSEL_BLOCK) {
+        const float f = (float)((long long)pos_out[rr] - mn) * ratio;
+        pos_out[rr] = mn + (long long)f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // eviction scan.  LPR lanes cooperate on one (head, token) row: lane c owns the 16-byte chunk c of the
 // first half of the row and its rotation partner in the second half.
@@ -164,9 +301,47 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const char* __restrict__
     }
 }
 
+// commit: both staged blocks (K and V) in one launch; blockIdx.y selects the tensor
+__global__ __launch_bounds__(256) void commit_rows_kernel(const char* __restrict__ ks, const char* __restrict__ vs,
+                                                          int64_t src_sh_bytes, char* __restrict__ kd,
+                                                          char* __restrict__ vd, int64_t dst_sh_bytes, int H,
+                                                          size_t row_block_bytes) {
+    const char* src = blockIdx.y ? vs : ks;
+    char* dst = blockIdx.y ? vd : kd;
+    const size_t vec_per_head = row_block_bytes / 16;
+    const size_t total = (size_t)H * vec_per_head;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
+        const size_t h = id / vec_per_head, i = id % vec_per_head;
+        *(u32x4*)(dst + h * dst_sh_bytes + i * 16) = *(const u32x4*)(src + h * src_sh_bytes + i * 16);
+    }
+}
+
 }  // namespace rtk
 
 using namespace rtk;
+
+extern "C" int rtk_pivotkv_commit(const void* k_stage, const void* v_stage, int64_t stage_stride_h, void* k_dst,
+                                  void* v_dst, int64_t dst_stride_h, int H, int rows, int D, int dtype,
+                                  rtk_stream_t stream) {
+    RTK_CHECK_ARG(k_stage && v_stage && k_dst && v_dst, "rtk_pivotkv_commit: NULL pointer");
+    RTK_CHECK_ARG(H >= 1 && rows >= 0 && D >= 1, "rtk_pivotkv_commit: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_commit: unsupported dtype %d", dtype);
+    if (rows == 0) return RTK_OK;
+    const size_t es = dtype == RTK_BF16 ? 2 : 4;
+    const size_t blk = (size_t)rows * D * es;
+    if (blk % 16 || (stage_stride_h * es) % 16 || (dst_stride_h * es) % 16 ||
+        (((uintptr_t)k_stage | (uintptr_t)v_stage | (uintptr_t)k_dst | (uintptr_t)v_dst) & 15)) {
+        set_error("rtk_pivotkv_commit: blocks must be 16-byte aligned");
+        return RTK_EUNSUPPORTED;
+    }
+    const size_t total = (size_t)H * (blk / 16);
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
+    RTK_LAUNCH(KID_COPY, commit_rows_kernel, dim3(grid, 2), dim3(256), 0, (hipStream_t)stream, (const char*)k_stage,
+               (const char*)v_stage, (int64_t)(stage_stride_h * es), (char*)k_dst, (char*)v_dst,
+               (int64_t)(dst_stride_h * es), H, blk);
+    RTK_LAUNCH_CHECK("commit_rows_kernel");
+    return RTK_OK;
+}
 
 extern "C" int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep, const int64_t* pos, int P,
                                   int reforge, int64_t* keep_idx, int32_t* rank, int64_t* pos_out,
@@ -175,8 +350,18 @@ extern "C" int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int 
     RTK_CHECK_ARG(L >= 1 && keep >= 1 && keep <= L, "rtk_pivotkv_select: keep=%d out of range for L=%d", keep, L);
     RTK_CHECK_ARG((pos == nullptr) == (pos_out == nullptr), "rtk_pivotkv_select: pos and pos_out go together");
     RTK_CHECK_ARG(!pos || P == 1 || P == 3, "rtk_pivotkv_select: P must be 1 or 3, got %d", P);
-    RTK_LAUNCH(KID_PSEL, pivotkv_select_kernel, dim3(1), dim3(PSEL_BLOCK), 0, (hipStream_t)stream, score, mask, L, keep,
-                       pos, P, reforge, keep_idx, rank, pos_out);
+    hipStream_t st = (hipStream_t)stream;
+#define RTK_PSEL_FAST(E)                                                                                          \
+    RTK_LAUNCH(KID_PSEL, pivotkv_select_fast_kernel<E>, dim3(1), dim3(PSEL_BLOCK), 0, st, score, mask, L, keep, pos, \
+               P, reforge, keep_idx, rank, pos_out)
+    const int per = (L + PSEL_BLOCK - 1) / PSEL_BLOCK;
+    if (per <= 2) RTK_PSEL_FAST(2);
+    else if (per <= 8) RTK_PSEL_FAST(8);
+    else if (per <= 32) RTK_PSEL_FAST(32);
+    else
+        RTK_LAUNCH(KID_PSEL, pivotkv_select_kernel, dim3(1), dim3(PSEL_BLOCK), 0, st, score, mask, L, keep, pos, P,
+                   reforge, keep_idx, rank, pos_out);
+#undef RTK_PSEL_FAST
     RTK_LAUNCH_CHECK("pivotkv_select_kernel");
     return RTK_OK;
 }

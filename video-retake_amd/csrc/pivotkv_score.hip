@@ -18,6 +18,12 @@
 // (conflict-free ds_read_b128) with the next tile's global loads in flight during the MFMAs.
 #include "common.cuh"
 
+// LLVM sched_group_barrier masks
+#define SGB_VALU 0x2
+#define SGB_MFMA 0x8
+#define SGB_DS_READ 0x100
+#define SGB_TRANS 0x400
+
 namespace rtk {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -29,10 +35,101 @@ constexpr int REG_ROWS = 128; // rows held in registers per workgroup (32 per wa
 constexpr int SC_BLOCK = 256;
 
 // ------------------------------------------------------------------------------------------------
-// un-rotate + pack:  x [H,L,D] strided -> out [H,L,D] contiguous (same dtype)
+// un-rotate + pack:  q [Hq,L,D] and k [Hkv,L,D] (strided) -> contiguous [H,L,D] copies (same dtype)
 //   cos == NULL: plain copy;  else ((x*cos) - (rotate_half(x)*sin)) / a^2  with one rounding per
 //   torch op (bf16: every intermediate is a bf16 tensor; fp32: no fma contraction).
+// One thread owns a 16-byte chunk of the first half of a token row plus its rotation partner in the
+// second half, keeps that token's cos/sin in registers and walks UNROT_HEADS heads with it.
 // ------------------------------------------------------------------------------------------------
+template <int DT> struct Vec16;
+template <> struct Vec16<RTK_F32> {
+    static constexpr int VE = 4;
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+    }
+};
+template <> struct Vec16<RTK_BF16> {
+    static constexpr int VE = 8;
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        return u32x4{(uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16), (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
+                     (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16), (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16)};
+    }
+};
+
+constexpr int UNROT_HEADS = 8;
+
+template <int DT>
+__global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __restrict__ q, int64_t q_sh, int64_t q_sl,
+                                                                const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
+                                                                int Hq, int Hkv, int L, int D,
+                                                                const float* __restrict__ cosv,
+                                                                const float* __restrict__ sinv, float a2,
+                                                                char* __restrict__ q_out, char* __restrict__ k_out) {
+    using V = Vec16<DT>;
+    constexpr int VE = V::VE;
+    constexpr int ES = 16 / VE;
+    const int h2 = D / 2, lpr = h2 / VE;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= L * lpr) return;
+    const int l = id / lpr, d = (id - l * lpr) * VE;
+    // blockIdx.y walks head groups: first the q groups, then the k groups
+    const int qgroups = (Hq + UNROT_HEADS - 1) / UNROT_HEADS;
+    const bool is_q = (int)blockIdx.y < qgroups;
+    const int hg = is_q ? blockIdx.y : blockIdx.y - qgroups;
+    const int H = is_q ? Hq : Hkv;
+    const char* src = is_q ? q : k;
+    char* dst = is_q ? q_out : k_out;
+    const int64_t sh = is_q ? q_sh : k_sh, sl = is_q ? q_sl : k_sl;
+    float c1[VE], s1[VE], c2[VE], s2[VE];
+    if (cosv) {
+#pragma unroll
+        for (int e = 0; e < VE; e += 4) {
+            *(float4*)(c1 + e) = *(const float4*)(cosv + (size_t)l * D + d + e);
+            *(float4*)(s1 + e) = *(const float4*)(sinv + (size_t)l * D + d + e);
+            *(float4*)(c2 + e) = *(const float4*)(cosv + (size_t)l * D + d + h2 + e);
+            *(float4*)(s2 + e) = *(const float4*)(sinv + (size_t)l * D + d + h2 + e);
+        }
+    }
+    const int hb = hg * UNROT_HEADS, he = min(H, hb + UNROT_HEADS);
+#pragma unroll 4
+    for (int h = hb; h < he; ++h) {
+        const char* row = src + ((size_t)h * sh + (size_t)l * sl) * ES;
+        const u32x4 lo = *(const u32x4*)(row + (size_t)d * ES), hi = *(const u32x4*)(row + (size_t)(d + h2) * ES);
+        char* orow = dst + ((size_t)h * L + l) * D * ES;
+        if (!cosv) {
+            *(u32x4*)(orow + (size_t)d * ES) = lo;
+            *(u32x4*)(orow + (size_t)(d + h2) * ES) = hi;
+            continue;
+        }
+        float x1[VE], x2[VE], o1[VE], o2[VE];
+        V::unpack(lo, x1);
+        V::unpack(hi, x2);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            // rotate_half(x)[d] = -x2, rotate_half(x)[d+h2] = x1   (longvideo_cache.py:28-32)
+            if (DT == RTK_BF16) {
+                o1[e] = rbf(rbf(rbf(x1[e] * c1[e]) - rbf(-x2[e] * s1[e])) / a2);
+                o2[e] = rbf(rbf(rbf(x2[e] * c2[e]) - rbf(x1[e] * s2[e])) / a2);
+            } else {
+                o1[e] = __fdiv_rn(__fsub_rn(__fmul_rn(x1[e], c1[e]), __fmul_rn(-x2[e], s1[e])), a2);
+                o2[e] = __fdiv_rn(__fsub_rn(__fmul_rn(x2[e], c2[e]), __fmul_rn(x1[e], s2[e])), a2);
+            }
+        }
+        *(u32x4*)(orow + (size_t)d * ES) = V::pack(o1);
+        *(u32x4*)(orow + (size_t)(d + h2) * ES) = V::pack(o2);
+    }
+}
+
+// scalar fallback (any even head_dim, any alignment)
 template <int DT>
 __global__ __launch_bounds__(256) void unrotate_pack_kernel(const void* __restrict__ xv, int64_t stride_h,
                                                             int64_t stride_l, int H, int L, int D,
@@ -61,7 +158,6 @@ __global__ __launch_bounds__(256) void unrotate_pack_kernel(const void* __restri
         if (cosv) {
             const float c1 = cosv[(size_t)l * D + d], s1 = sinv[(size_t)l * D + d];
             const float c2 = cosv[(size_t)l * D + d + h2], s2 = sinv[(size_t)l * D + d + h2];
-            // rotate_half(x)[d] = -x2, rotate_half(x)[d+h2] = x1   (longvideo_cache.py:28-32)
             if (DT == RTK_BF16) {
                 o1 = rbf(rbf(rbf(x1 * c1) - rbf(-x2 * s1)) / a2);
                 o2 = rbf(rbf(rbf(x2 * c2) - rbf(x1 * s2)) / a2);
@@ -177,6 +273,15 @@ template <int DT> struct Pipe {
 #pragma unroll
         for (int u = 0; u < T::STAGE; ++u) *(u32x4*)(lds_tile + st_off[u]) = st[u];
     }
+    // explicit two-step form: fetch all A fragments of a block, then run the MFMAs on them
+    __device__ __forceinline__ void read_frags(u32x4* a, const char* lds_tile, int blk) const {
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) a[r] = *(const u32x4*)(lds_tile + blk * 32 * T::ROWB + frag_off[r]);
+    }
+    __device__ __forceinline__ void mma_frags(f32x16& acc, const u32x4* a, const u32x4* rf) const {
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) M::mma(acc, a[r], rf[r]);
+    }
     // acc += A(32 LDS rows of block `blk`) x B(register fragment)
     __device__ __forceinline__ void mma_block(f32x16& acc, const char* lds_tile, int blk, const u32x4* rf) const {
 #pragma unroll
@@ -281,6 +386,8 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass1_kernel(const char* __res
     pp.store(smem, st);
     __syncthreads();
 
+    // Occupancy (3 waves per SIMD at ~150 VGPRs) hides the MFMA -> softmax dependency here; an explicit
+    // in-wave software pipeline (as in pass 2) was measured equal for bf16 and slower for fp32.
     auto step = [&](int jt, int buf) {
         const char* cur = smem + buf * T::BYTES;
         char* nxt = smem + (buf ^ 1) * T::BYTES;
@@ -331,6 +438,21 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(float* __restrict__ ls
     lse_part[idx] = mx + ((DT == RTK_BF16) ? __builtin_amdgcn_logf(tot) : logf(tot));
 }
 
+// col += sum_r exp(acc[r]*scale - ls[r]) for one 32x32 block (16 values per lane)
+template <int DT>
+__device__ __forceinline__ void colsum_block(float& col, const f32x16& acc, const float* ls, float c2, float sqrt_d) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (DT == RTK_BF16) col += __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -ls[r]));
+        else col += expf(__fdiv_rn(acc[r], sqrt_d) - ls[r]);
+    }
+}
+// this lane's 16 row normalisers of block `blk` (rows (r&3) + 8*(r>>2) + 4*hf)
+__device__ __forceinline__ void load_ls(float* ls, const float* lcur, int blk, int hf) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) *(float4*)(ls + 4 * r4) = *(const float4*)(lcur + blk * 32 + 8 * r4 + 4 * hf);
+}
+
 template <int DT>
 __global__ __launch_bounds__(SC_BLOCK) void score_pass2_kernel(const char* __restrict__ q, const char* __restrict__ k,
                                                                const float* __restrict__ lse, int Hq, int Hkv, int L,
@@ -360,41 +482,68 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass2_kernel(const char* __res
     u32x4 st[T::STAGE];
     float lst = 0.f;
 
-    // cursor of the tile being prefetched: head index and row tile inside the split
-    int nh = 0, nt = 0;
+    // cursor of the tile being prefetched: row tile inside the split, source pointers of the current head
+    int nt = 0;
     const char* nsrc = q + ((size_t)(g * G) * L + ib) * HD * M::ESIZE;   // first row of the split, head g*G
     const float* nlse = lse + (size_t)(g * G) * L + ib;
-    auto issue = [&]() {  // loads tile (nh, nt) and its lse element, then advances the cursor
+    auto issue = [&]() {  // loads tile nt of the cursor head and its lse element, then advances the cursor
         if (nt < full_per_head) pp.template load<true>(nsrc + (size_t)nt * T::BYTES, TILE_ROWS, st);
         else pp.template load<false>(nsrc + (size_t)nt * T::BYTES, nrows - nt * TILE_ROWS, st);
         if (tid < TILE_ROWS) lst = (nt * TILE_ROWS + tid < nrows) ? nlse[nt * TILE_ROWS + tid] : INFINITY;
         if (++nt == tiles_per_head) {
             nt = 0;
-            ++nh;
             nsrc += (size_t)L * HD * M::ESIZE;
             nlse += L;
         }
     };
+    // Software pipeline inside the wave: while the matrix pipe runs the 8 MFMAs of one 32-row block, the
+    // VALU finishes the previous block (fma + exp2 + add per value).  `pend` / `pls` carry the second
+    // block of a tile across the barrier into the next tile's first MFMA group.
+    f32x16 pend = {0};
+    float pls[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pls[r] = INFINITY;  // exp(-inf) = 0: nothing pending yet
     auto step = [&](bool have_next, int buf) {
         const char* cur = smem + buf * T::BYTES;
         const float* lcur = lse_s + buf * TILE_ROWS;
         if (have_next) issue();
+        u32x4 a0[M::NREG], a1[M::NREG];
+        pp.read_frags(a0, cur, 0);
+        pp.read_frags(a1, cur, 1);
+        float ls0[16], ls1[16];
+        load_ls(ls0, lcur, 0, hf);
+        load_ls(ls1, lcur, 1, hf);
+        __builtin_amdgcn_sched_barrier(0);             // keep the LDS reads ahead of the MFMA chain
+        f32x16 acc0 = {0};
+        pp.mma_frags(acc0, a0, kf);                    // matrix pipe: block 0 ...
+        colsum_block<DT>(col, pend, pls, c2, sqrt_d);  // ... VALU: previous tile's block 1
+        // The empty asm statements are ordered against the sched_barrier fences (both have side effects)
+        // and need their operand computed: they pin this phase's MFMA chain and VALU chain inside it.
+        asm volatile("" : "+v"(acc0), "+v"(col));
+        if (DT == RTK_BF16) {
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            f32x16 acc = {0};
-            pp.mma_block(acc, cur, blk, kf);
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 l4 = *(const float4*)(lcur + blk * 32 + 8 * r4 + 4 * hf);
-                const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const float a = acc[4 * r4 + rr];
-                    if (DT == RTK_BF16) col += __builtin_amdgcn_exp2f(fmaf(a, c2, -ls[rr]));
-                    else col += expf(__fdiv_rn(a, sqrt_d) - ls[rr]);
-                }
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(SGB_VALU, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(SGB_TRANS, 2, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        pend = f32x16{0};
+        pp.mma_frags(pend, a1, kf);                    // matrix pipe: block 1 ...
+        colsum_block<DT>(col, acc0, ls0, c2, sqrt_d);  // ... VALU: block 0
+        asm volatile("" : "+v"(pend), "+v"(col));
+        if (DT == RTK_BF16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(SGB_VALU, 4, 1);
+                __builtin_amdgcn_sched_group_barrier(SGB_TRANS, 2, 1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pls[r] = ls1[r];
         if (have_next) {
             pp.store(smem + (buf ^ 1) * T::BYTES, st);
             if (tid < TILE_ROWS) lse_s[(buf ^ 1) * TILE_ROWS + tid] = lst;
@@ -411,6 +560,7 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass2_kernel(const char* __res
         step(true, 1);
     }
     for (; it < ntiles; ++it) step(it + 1 < ntiles, it & 1);
+    colsum_block<DT>(col, pend, pls, c2, sqrt_d);  // drain the pipeline
     col += __shfl_xor(col, 32, WAVE);
     const int j = j0 + (lane & 31);
     if (hf == 0 && j < L) partial[((size_t)g * RS + rs) * L + j] = col;
@@ -489,14 +639,24 @@ __global__ __launch_bounds__(256) void score_pass2_generic(const void* __restric
 }
 
 // finalize: score[j] = mean_g( (sum_split partial[g,split,j]) / G )      (longvideo_cache.py:269-270)
-__global__ __launch_bounds__(256) void score_finalize_kernel(const float* __restrict__ partial, int Hkv, int RS, int G,
-                                                             int L, float* __restrict__ score) {
+// fixed summation order; loads are issued eight at a time so the kernel is not latency-serialised
+__global__ __launch_bounds__(64) void score_finalize_kernel(const float* __restrict__ partial, int Hkv, int RS, int G,
+                                                            int L, float* __restrict__ score) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= L) return;
     float tot = 0.f;
     for (int g = 0; g < Hkv; ++g) {
+        const float* p = partial + (size_t)g * RS * L + j;
         float gs = 0.f;
-        for (int r = 0; r < RS; ++r) gs += partial[((size_t)g * RS + r) * L + j];
+        int r = 0;
+        for (; r + 8 <= RS; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(r + u) * L];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gs += v[u];
+        }
+        for (; r < RS; ++r) gs += p[(size_t)r * L];
         tot += gs / (float)G;
     }
     score[j] = tot / (float)Hkv;
@@ -552,11 +712,24 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
     float* part = (float*)(ws + w.part_off);
     const float a2 = (float)((double)a * (double)a);  // python float ** 2, then an fp32 tensor / scalar
     {
-        const size_t nq = (size_t)Hq * L * (D / 2), nk = (size_t)Hkv * L * (D / 2);
-        RTK_LAUNCH(KID_UNROT, unrotate_pack_kernel<DT>, dim3((unsigned)std::min<size_t>((nq + 255) / 256, 8192)), dim3(256),
-                   0, st, q, qsh, qsl, Hq, L, D, cosv, sinv, a2, (void*)qt);
-        RTK_LAUNCH(KID_UNROT, unrotate_pack_kernel<DT>, dim3((unsigned)std::min<size_t>((nk + 255) / 256, 8192)), dim3(256),
-                   0, st, k, ksh, ksl, Hkv, L, D, cosv, sinv, a2, (void*)kt);
+        constexpr int VE = Vec16<DT>::VE;
+        const int es = 16 / VE;
+        const bool vec_ok = (D % (2 * VE) == 0) && ((qsh * es) % 16 == 0) && ((qsl * es) % 16 == 0) &&
+                            ((ksh * es) % 16 == 0) && ((ksl * es) % 16 == 0) &&
+                            ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)qt | (uintptr_t)kt) & 15) == 0) &&
+                            (!cosv || (((uintptr_t)cosv | (uintptr_t)sinv) & 15) == 0);
+        if (vec_ok) {
+            const int threads = L * (D / 2 / VE);
+            const int groups = (Hq + UNROT_HEADS - 1) / UNROT_HEADS + (Hkv + UNROT_HEADS - 1) / UNROT_HEADS;
+            RTK_LAUNCH(KID_UNROT, unrotate_pack_vec_kernel<DT>, dim3((threads + 255) / 256, groups), dim3(256), 0, st,
+                       (const char*)q, qsh, qsl, (const char*)k, ksh, ksl, Hq, Hkv, L, D, cosv, sinv, a2, qt, kt);
+        } else {
+            const size_t nq = (size_t)Hq * L * (D / 2), nk = (size_t)Hkv * L * (D / 2);
+            RTK_LAUNCH(KID_UNROT, unrotate_pack_kernel<DT>, dim3((unsigned)std::min<size_t>((nq + 255) / 256, 8192)),
+                       dim3(256), 0, st, q, qsh, qsl, Hq, L, D, cosv, sinv, a2, (void*)qt);
+            RTK_LAUNCH(KID_UNROT, unrotate_pack_kernel<DT>, dim3((unsigned)std::min<size_t>((nk + 255) / 256, 8192)),
+                       dim3(256), 0, st, k, ksh, ksl, Hkv, L, D, cosv, sinv, a2, (void*)kt);
+        }
         RTK_LAUNCH_CHECK("unrotate_pack_kernel");
     }
     const int G = Hq / Hkv;
@@ -592,7 +765,7 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                            (const void*)qt, (const void*)kt, lse, Hq, Hkv, L, D, part);
         RTK_LAUNCH_CHECK("score_generic");
     }
-    RTK_LAUNCH(KID_FINALIZE, score_finalize_kernel, dim3((L + 255) / 256), dim3(256), 0, st, part, Hkv, rs_n, G, L, score);
+    RTK_LAUNCH(KID_FINALIZE, score_finalize_kernel, dim3((L + 63) / 64), dim3(64), 0, st, part, Hkv, rs_n, G, L, score);
     RTK_LAUNCH_CHECK("score_finalize_kernel");
     return RTK_OK;
 }

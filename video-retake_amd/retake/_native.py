@@ -36,6 +36,7 @@ _SIGNATURES = {
     "rtk_pivotkv_evict": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp,
                                     _vp, _i64, _vp, _vp, _i64, _vp]),
     "rtk_copy_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "rtk_pivotkv_commit": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "rtk_profile_enable": (C.c_int, [_i]),
     "rtk_profile_collect": (C.c_int, []),
     "rtk_profile_reset": (C.c_int, []),

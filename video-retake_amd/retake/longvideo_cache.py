@@ -344,10 +344,9 @@ class PivotKVCache(DynamicCache):
             s = nv.stream()
             dt = nv.dtype_code(st.k)
             sst = st.k_stage.shape[2] * D  # staging head stride (its capacity may exceed this chunk's keep)
-            nv.check(nv.lib.rtk_copy_rows(nv.ptr(st.k_stage), sst, C.c_void_p(st.k.data_ptr() + off), cap * D, H,
-                                          keep, D, dt, s), "rtk_copy_rows")
-            nv.check(nv.lib.rtk_copy_rows(nv.ptr(st.v_stage), sst, C.c_void_p(st.v.data_ptr() + off), cap * D, H,
-                                          keep, D, dt, s), "rtk_copy_rows")
+            nv.check(nv.lib.rtk_pivotkv_commit(nv.ptr(st.k_stage), nv.ptr(st.v_stage), sst,
+                                               C.c_void_p(st.k.data_ptr() + off), C.c_void_p(st.v.data_ptr() + off),
+                                               cap * D, H, keep, D, dt, s), "rtk_pivotkv_commit")
         st.length += keep
         st.pending = 0
         st.pending_keep = 0
