@@ -1,0 +1,219 @@
+"""Host-side glue against the reference goldens and its documented behaviour."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+
+def _me(cfg):
+    return types.SimpleNamespace(config=cfg)
+
+
+def _glue_cfg():
+    return types.SimpleNamespace(
+        video_token_id=151656, vision_config=types.SimpleNamespace(spatial_merge_size=2, temporal_patch_size=1),
+        longvideo_kwargs={"chunked_prefill_frames": 8, "visual_compression": True,
+                          "visual_compression_kwargs": {"compression_ratio": 0.5, "compression_method": "Keyframe",
+                                                        "patch_sync": False, "return_keyframe_mask": True},
+                          "kvcache_compression": True,
+                          "kvcache_compression_kwargs": {"compression_ratio": 0.5, "compression_method": "pivotkv"}})
+
+
+def test_segment_input_ids_matches_reference():
+    import retake.qwen2_vl as q
+
+    g = gu.load("glue_qwen2vl")
+    me = _me(_glue_cfg())
+    for ids_key, pre in (("ids", "seg"), ("ids2", "seg2")):
+        seg = q.retake_Qwen2VLForConditionalGeneration_segment_input_ids(me, torch.from_numpy(g[ids_key]))
+        assert [s for s, _, _ in seg] == g[pre + "_s"].tolist()
+        assert [e for _, e, _ in seg] == g[pre + "_e"].tolist()
+        assert [t for _, _, t in seg] == g[pre + "_t"].tolist()
+
+
+def test_get_chunk_size_matches_reference():
+    import retake.qwen2_vl as q
+
+    g = gu.load("glue_qwen2vl")
+    cfg = _glue_cfg()
+    assert q.retake_Qwen2VLForConditionalGeneration_get_chunk_size(_me(cfg), cfg, torch.from_numpy(g["thw"])) == int(g["chunk_size"])
+    cfg.longvideo_kwargs = {}
+    assert q.retake_Qwen2VLForConditionalGeneration_get_chunk_size(_me(cfg), cfg, torch.from_numpy(g["thw"])) is None
+
+
+def test_forge_input_chunks_matches_reference():
+    import retake.qwen2_vl as q
+
+    g = gu.load("glue_qwen2vl")
+    S = g["ids"].shape[1]
+    pos = torch.arange(S)[None, None].repeat(3, 1, 1)
+    am = torch.ones(1, S, dtype=torch.long)
+    cp = torch.arange(S)
+    ie = torch.arange(S * 2, dtype=torch.float32).reshape(1, S, 2)
+    seg = list(zip(g["seg_s"].tolist(), g["seg_e"].tolist(), g["seg_t"].tolist()))
+    out = q.retake_Qwen2VLForConditionalGeneration_forge_input_chunks(_me(_glue_cfg()), 9, 21, seg, cp, pos, am, None, ie)
+    for name, t in zip(["cp", "pos", "am", "ie"], out[:4]):
+        np.testing.assert_array_equal(t.numpy(), g["fic_" + name])
+    assert out[4] is None
+
+
+def test_forge_input_chunks_prompt_guided():
+    import retake.qwen2_vl as q
+
+    cfg = _glue_cfg()
+    cfg.longvideo_kwargs["kvcache_compression_kwargs"]["prompt_guided_compression"] = True
+    S = 20
+    seg = [(0, 3, "text"), (3, 15, "video"), (15, 20, "text")]
+    pos = torch.arange(S)[None, None].repeat(3, 1, 1) + 100
+    am = torch.ones(1, S, dtype=torch.long)
+    cp = torch.arange(S)
+    ie = torch.arange(S, dtype=torch.float32).reshape(1, S, 1)
+    cpc, posc, amc, iec, pl = q.retake_Qwen2VLForConditionalGeneration_forge_input_chunks(_me(cfg), 3, 7, seg, cp, pos,
+                                                                                        am, None, ie)
+    assert pl == 5 and iec.shape[1] == 4 + 5 and amc.shape[1] == 7 + 5 and cpc.shape[0] == 7 + 5
+    # prompt ids continue right after the chunk's last temporal id (reference :509-510)
+    assert posc[0, 0, 4].item() == posc[0, 0, 3].item() + 1
+
+
+def test_llava_helpers():
+    import retake.llava_onevision as lo
+
+    cfg = types.SimpleNamespace(video_token_index=9, vision_config=types.SimpleNamespace(patch_size=14),
+                                longvideo_kwargs={"chunked_prefill_frames": 32})
+    me = types.SimpleNamespace(config=cfg, pool_stride=2)
+    ids = torch.tensor([[1, 9, 9, 9, 2, 2]])
+    assert lo.retake_LlavaOnevisionForConditionalGeneration_segment_input_ids(me, ids) == [(0, 1, "text"), (1, 4, "video"),
+                                                                                        (4, 6, "text")]
+    pv = torch.zeros(1, 64, 3, 384, 384)
+    # min(32, 64) * ceil(27/2)^2 = 32 * 196
+    assert lo.retake_LlavaOnevisionForConditionalGeneration_get_chunk_size(me, cfg, pv) == 32 * 196
+    S = 12
+    pos = torch.arange(S)[None]
+    out = lo.retake_LlavaOnevisionForConditionalGeneration_forge_input_chunks(
+        me, 2, 6, [(0, 2, "text"), (2, 10, "video"), (10, 12, "text")], pos, torch.arange(S), torch.ones(1, S),
+        None, torch.zeros(1, S, 4))
+    assert out[0].tolist() == [[2, 3, 4, 5]] and out[1].shape[0] == 6 and out[2].shape[1] == 6 and out[4] is None
+
+
+def test_dynamic_compression_ratio():
+    from retake import _prefill
+
+    cfg = types.SimpleNamespace(longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
+        "dynamic_compression_ratio": True, "max_input_length": 40000, "compression_ratio": 0.5}})
+    _prefill.apply_dynamic_compression_ratio(cfg, 30000)
+    assert cfg.longvideo_kwargs["kvcache_compression_kwargs"]["compression_ratio"] == 1
+    _prefill.apply_dynamic_compression_ratio(cfg, 401409)
+    assert cfg.longvideo_kwargs["kvcache_compression_kwargs"]["compression_ratio"] == 40000 / 401409
+
+
+class _FakeCache:
+    def __init__(self):
+        self.kvcache_compression = True
+        self.keypatches_mask_chunk = None
+        self.log = []
+
+
+def test_chunked_prefill_driver_order_and_mask_slices():
+    from retake import _prefill
+
+    cache = _FakeCache()
+    mask = torch.zeros(1, 30, dtype=torch.bool)
+    mask[0, 5:25:3] = True
+    segs = [(0, 5, "text"), (5, 25, "video"), (25, 30, "text")]
+
+    def run_text(s, e):
+        cache.log.append(("text", s, e, cache.kvcache_compression, cache.keypatches_mask_chunk))
+        return {"past_key_values": cache}
+
+    def run_chunk(ss, ee):
+        cache.log.append(("video", ss, ee, cache.kvcache_compression, cache.keypatches_mask_chunk.clone()))
+        return {"past_key_values": cache}
+
+    _prefill.run_chunked_prefill(segs, 8, cache, mask, run_text, run_chunk)
+    kinds = [(k, s, e, c) for k, s, e, c, _ in cache.log]
+    assert kinds == [("text", 0, 5, False), ("video", 5, 13, True), ("video", 13, 21, True), ("video", 21, 25, True),
+                     ("text", 25, 30, False)]
+    assert torch.equal(cache.log[1][4], mask[0, 5:13]) and torch.equal(cache.log[3][4], mask[0, 21:25])
+    assert cache.keypatches_mask_chunk is None and cache.kvcache_compression is False  # off for decoding
+
+
+def test_monkeypatch_surface():
+    import retake.monkeypatch as mp
+
+    with pytest.raises(NotImplementedError):
+        mp.patch_qwen2vl("snapkv")
+    with pytest.raises(NotImplementedError):
+        mp.patch_llava_onevision("other")
+    cfg = types.SimpleNamespace(rope_scaling={"type": "mrope", "mrope_section": [16, 24, 24]})
+    exp = {"scaling_factor": 4, "longvideo_kwargs": {"kvcache_compression": True}}
+    mp.patch_qwen2vl_config(cfg, exp)
+    assert cfg.rope_scaling == {"mrope_section": [16, 24, 24], "rope_type": "yarn", "factor": 4, "beta_fast": 32.0,
+                                "beta_slow": 1.0}
+    assert cfg.longvideo_kwargs == {"kvcache_compression": True}
+    cfg2 = types.SimpleNamespace(text_config=types.SimpleNamespace())
+    mp.patch_llava_onevision_config(cfg2, exp)
+    assert cfg2.text_config.rope_scaling["rope_type"] == "yarn" and cfg2.longvideo_kwargs["kvcache_compression"]
+    cfg3 = types.SimpleNamespace(rope_scaling={"type": "mrope"})
+    mp.patch_qwen2vl_config(cfg3, {})
+    assert cfg3.rope_scaling == {"type": "mrope"} and cfg3.longvideo_kwargs == {}
+
+
+def test_patch_rebinds_hf_classes():
+    import transformers.models.qwen2_vl.modeling_qwen2_vl as m
+
+    import retake.monkeypatch as mp
+    import retake.qwen2_vl as q
+
+    saved = {k: m.Qwen2VLForConditionalGeneration.__dict__.get(k) for k in
+             ("forward", "compress_video_tokens", "segment_input_ids", "get_chunk_size", "forge_input_chunks")}
+    att_saved = m.Qwen2VLAttention.forward
+    try:
+        mp.patch_qwen2vl("retake")
+        assert m.Qwen2VLForConditionalGeneration.forward is q.retake_Qwen2VLForConditionalGeneration_forward
+        assert m.Qwen2VLForConditionalGeneration.segment_input_ids is q.retake_Qwen2VLForConditionalGeneration_segment_input_ids
+        assert m.Qwen2VLAttention.forward is q.retake_Qwen2VLAttention_forward
+    finally:
+        m.Qwen2VLAttention.forward = att_saved
+        for k, v in saved.items():
+            if v is None:
+                delattr(m.Qwen2VLForConditionalGeneration, k)
+            else:
+                setattr(m.Qwen2VLForConditionalGeneration, k, v)
+
+
+class _StubAttention(torch.nn.Module):
+    def __init__(self, hidden=64, heads=4, kv_heads=2):
+        super().__init__()
+        import synth
+
+        self.num_heads, self.num_key_value_heads, self.head_dim = heads, kv_heads, hidden // heads
+        self.num_key_value_groups = heads // kv_heads
+        self.hidden_size, self.layer_idx, self.attention_dropout = hidden, 0, 0.0
+        self.q_proj = torch.nn.Linear(hidden, hidden)
+        self.k_proj = torch.nn.Linear(hidden, kv_heads * self.head_dim)
+        self.v_proj = torch.nn.Linear(hidden, kv_heads * self.head_dim)
+        self.o_proj = torch.nn.Linear(hidden, hidden, bias=False)
+        self.rope_scaling = {"mrope_section": [2, 3, 3]}
+        self.rotary_emb = synth.RotaryStub(synth.inv_freq(self.head_dim), 1.0)
+
+
+def test_qwen2vl_attention_patch_eager_equals_sdpa_and_appends_to_cache():
+    import retake.longvideo_cache as lc
+    import retake.qwen2_vl as q
+
+    torch.manual_seed(0)
+    att = _StubAttention().eval()
+    x = torch.randn(1, 6, 64)
+    pos = torch.arange(6)[None, None].repeat(3, 1, 1)
+    causal = torch.full((6, 6), float("-inf")).triu(1)[None, None]
+    c1, c2 = lc.DynamicCache(), lc.DynamicCache()
+    with torch.no_grad():
+        o1, w1, _ = q.retake_Qwen2VLAttention_forward(att, x, causal, pos.clone(), c1, output_attentions=True,
+                                                      cache_position=torch.arange(6))
+        o2, w2, _ = q.retake_Qwen2VLSdpaAttention_forward(att, x, causal, pos.clone(), c2,
+                                                          cache_position=torch.arange(6))
+    assert torch.allclose(o1, o2, atol=1e-5) and w1.shape == (1, 4, 6, 6) and w2 is None
+    assert c1.key_cache[0].shape == (1, 2, 6, 16) and torch.equal(c1.key_cache[0], c2.key_cache[0])

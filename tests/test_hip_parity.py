@@ -341,3 +341,30 @@ def test_pivotkv_bf16_tracks_fp32_oracle():
     assert np.intersect1d(idx, oi).size >= keep - 2
     kept_v = cache.value_cache[0]
     assert torch.equal(kept_v[0, :, :, :].cpu(), vb[0][:, torch.from_numpy(idx)])
+
+
+# ---------------------------------------------------------------------------------------------------
+# glue: compress_video_tokens (DPSelect inside) against the reference golden
+# ---------------------------------------------------------------------------------------------------
+def test_qwen2vl_compress_video_tokens_golden():
+    import retake.qwen2_vl as q
+
+    g = gu.load("glue_qwen2vl")
+    cfg = types.SimpleNamespace(
+        video_token_id=151656, vision_config=types.SimpleNamespace(spatial_merge_size=2, temporal_patch_size=1),
+        longvideo_kwargs={"visual_compression": True,
+                          "visual_compression_kwargs": {"compression_ratio": 0.5, "compression_method": "Keyframe",
+                                                        "patch_sync": False, "return_keyframe_mask": True}})
+    me = types.SimpleNamespace(config=cfg)
+    ids = torch.from_numpy(g["ids"]).to(dev())
+    S = ids.shape[1]
+    out = q.retake_Qwen2VLForConditionalGeneration_compress_video_tokens(
+        me, input_ids=ids, attention_mask=torch.ones(1, S, dtype=torch.long, device=dev()),
+        video_embeds=torch.from_numpy(g["cvt_in_emb"]).to(dev()), cache_position=torch.arange(S, device=dev()),
+        position_ids=torch.arange(S, device=dev())[None, None].repeat(3, 1, 1), labels=None,
+        video_grid_thw=torch.from_numpy(g["thw"]).to(dev()))
+    for name, t in zip(["ids", "am", "emb", "cp", "pos", "labels", "mask"], out):
+        if t is None:
+            assert "cvt_" + name not in g.files
+        else:
+            np.testing.assert_array_equal(t.cpu().numpy(), g["cvt_" + name])
