@@ -110,11 +110,9 @@ def run_video(frames, pool, masks, pos_base, rotary, layers, tdtype):
             q, k, v = pool[call % len(pool)]
             call += 1
             # what the attention patch does (qwen2_vl.py:68-73), without a host sync
-            pos = pos_base[c]
-            prev = cache.get_prev_temporal_idx(layer)
-            if not isinstance(prev, int):
-                pos = pos.clone()
-                pos[0, 0, :] += prev + 1 - pos[0, 0, 0]
+            pos = pos_base[c].clone()
+            prev = cache.get_prev_temporal_idx(layer)   # -1 (int) on the first chunk, a 0-d tensor afterwards
+            pos[0, 0, :] += (prev + 1) - pos[0, 0, 0]
             kw = {"query_states": q, "position_ids": pos, "rotary_emb": rotary, "mrope_section": MROPE}
             cache.update(k, v, layer, kw)
         cache.after_forward()
@@ -158,7 +156,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or args.gpus > 1:
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched without torchrun: start the ranks as child processes (nothing here has touched the GPU yet)
+        import socket
+        import subprocess
+
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if world > 1 or os.environ.get("RETAKE_FORCE_SHARDED") == "1":  # the env switch runs the sharded path at N=1
         from retake import sharded
 
         return sharded.bench_main(args, rank, world, local_rank)

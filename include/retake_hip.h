@@ -93,6 +93,14 @@ int rtk_rope_table(const int64_t* pos, int P, int L, const float* inv_freq, int 
                    const int* sections_host, int nsec, int round_bf16, float* cos_out, float* sin_out,
                    rtk_stream_t stream);
 
+/* In-place k <- R(delta) k on the temporal channels (position row 0; every channel when P = 1) of keys
+ * that are already rotated: k [H, n, D] with head stride `stride_h`, delta = one int64 in device
+ * memory.  Used by the multi-GPU sharding (retake/sharded.py): ranks compress their chunks at
+ * provisional temporal ids; once the global offsets are known, R(p + delta) = R(delta) R(p)
+ * (longvideo_cache.py:80-81 composed with the continuity shift of qwen2_vl.py:68-73). */
+int rtk_rope_shift(void* k, int64_t stride_h, int H, int n, int D, int dtype, const int64_t* delta_dev,
+                   const float* inv_freq, int P, const int* sections_host, int nsec, rtk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * PivotKV — replaces retake/longvideo_cache.py:248-318
  * ------------------------------------------------------------------------------------------- */

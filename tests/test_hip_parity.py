@@ -368,3 +368,67 @@ def test_qwen2vl_compress_video_tokens_golden():
             assert "cvt_" + name not in g.files
         else:
             np.testing.assert_array_equal(t.cpu().numpy(), g["cvt_" + name])
+
+
+# ---------------------------------------------------------------------------------------------------
+# multi-GPU sharding, numerics of the block fix-up (single process, blocks run one after the other)
+# ---------------------------------------------------------------------------------------------------
+def test_sharded_blocks_reproduce_sequential_cache():
+    """Two blocks compressed independently from provisional temporal id 0, then shifted by R(delta), must
+    equal one cache that saw all chunks in order: same kept indices and ids, V identical, K within 1e-5."""
+    import torch.distributed as dist
+
+    import bench as B
+    from retake import sharded
+
+    if not dist.is_initialized():
+        import os
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+    layers, n_chunks, gh, gw, gpc = 2, 4, 8, 8, 4
+    L = gpc * gh * gw
+    inv_f = synth.inv_freq(B.D)
+    rot = synth.RotaryStub(inv_f, B.A_SCALE, device=dev())
+    cfg = B.make_cache_config(layers)
+    cfg.longvideo_kwargs["kvcache_compression_kwargs"]["native_rope"] = False
+    data = {}
+    for c in range(n_chunks):
+        for l in range(layers):
+            q0, k0, v = synth.qkv_chunk(7000 + 10 * c + l, B.Hq, B.Hkv, L, B.D)
+            data[c, l] = tuple(torch.from_numpy(a).to(dev()) for a in (q0, k0, v))
+    masks = [torch.from_numpy(np.random.default_rng(c).uniform(size=L) < 0.3).to(dev()) for c in range(n_chunks)]
+
+    def run(cache, chunks):
+        for c in chunks:
+            cache.keypatches_mask_chunk = masks[c]
+            cache.kvcache_compression = True
+            for l in range(layers):
+                q0, k0, v = data[c, l]
+                pos = torch.from_numpy(synth.mrope_position_ids(40 + gpc * c, gpc, gh, gw, hw0=3)).to(dev())
+                prev = cache.get_prev_temporal_idx(l)
+                pos[0, 0, :] += (prev + 1) - pos[0, 0, 0]
+                q = synth.rope_forward(q0, pos, rot, B.MROPE)
+                k = synth.rope_forward(k0, pos, rot, B.MROPE)
+                cache.update(k, v, l, {"query_states": q, "position_ids": pos, "rotary_emb": rot,
+                                       "mrope_section": B.MROPE})
+            cache.after_forward()
+
+    import retake.longvideo_cache as lc
+
+    seq = lc.build_kvcache(cfg)
+    run(seq, range(n_chunks))
+    a = sharded.ShardedPivotKV(cfg, first_start=0)
+    run(a.cache, [0, 1])
+    ka, va, pa = a.finalize(torch.from_numpy(inv_f), B.MROPE, assemble=False)
+    b = sharded.ShardedPivotKV(cfg, first_start=torch.stack([p[0, 0, -1] for p in pa]) + 1)
+    run(b.cache, [2, 3])
+    kb, vb, pb = b.finalize(torch.from_numpy(inv_f), B.MROPE, assemble=False)
+    for l in range(layers):
+        k_all = torch.cat([ka[l], kb[l]], dim=2)
+        v_all = torch.cat([va[l], vb[l]], dim=2)
+        p_all = torch.cat([pa[l], pb[l]], dim=-1)
+        assert torch.equal(p_all, seq.position_cache[l])
+        assert torch.equal(v_all, seq.value_cache[l])
+        assert (k_all - seq.key_cache[l]).abs().max().item() <= 1e-5

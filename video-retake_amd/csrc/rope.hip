@@ -75,9 +75,68 @@ __global__ __launch_bounds__(256) void rope_table_kernel(const int64_t* __restri
     }
 }
 
+// In-place extra rotation of already-rotated keys by `delta` temporal steps: k <- R(delta) k on the
+// channels fed by position row 0 (all channels for 1-D RoPE).  R(a+b) = R(a) R(b), so keys rotated at
+// provisional ids become keys rotated at ids + delta (8-GPU sharding: each rank compresses its chunks
+// before the global temporal offsets are known).  delta is read from device memory.
+template <int DT>
+__global__ __launch_bounds__(256) void rope_shift_kernel(void* __restrict__ kv, int64_t stride_h, int H, int n, int D,
+                                                         const int64_t* __restrict__ delta,
+                                                         const float* __restrict__ inv_freq, RowSel rs) {
+    const int h2 = D / 2;
+    const size_t total = (size_t)H * n * h2;
+    const float dl = (float)delta[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % h2);
+        if (rs.row[d] != 0) continue;
+        const size_t hr = i / h2;
+        const int r = (int)(hr % n), h = (int)(hr / n);
+        const size_t off = (size_t)h * stride_h + (size_t)r * D;
+        float s, c;
+        sincosf(dl * inv_freq[d], &s, &c);
+        float x1, x2;
+        if (DT == RTK_BF16) {
+            x1 = bf2f(((uint16_t*)kv)[off + d]);
+            x2 = bf2f(((uint16_t*)kv)[off + d + h2]);
+        } else {
+            x1 = ((float*)kv)[off + d];
+            x2 = ((float*)kv)[off + d + h2];
+        }
+        const float o1 = x1 * c - x2 * s, o2 = x2 * c + x1 * s;
+        if (DT == RTK_BF16) {
+            ((uint16_t*)kv)[off + d] = f2bf(o1);
+            ((uint16_t*)kv)[off + d + h2] = f2bf(o2);
+        } else {
+            ((float*)kv)[off + d] = o1;
+            ((float*)kv)[off + d + h2] = o2;
+        }
+    }
+}
+
 }  // namespace rtk
 
 using namespace rtk;
+
+extern "C" int rtk_rope_shift(void* k, int64_t stride_h, int H, int n, int D, int dtype, const int64_t* delta_dev,
+                              const float* inv_freq, int P, const int* sections_host, int nsec, rtk_stream_t stream) {
+    RTK_CHECK_ARG(k && delta_dev && inv_freq, "rtk_rope_shift: NULL pointer");
+    RTK_CHECK_ARG(H >= 1 && n >= 0 && D >= 2, "rtk_rope_shift: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_rope_shift: unsupported dtype %d", dtype);
+    if (n == 0) return RTK_OK;
+    RowSel rs;
+    int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_rope_shift");
+    if (rc) return rc;
+    const size_t total = (size_t)H * n * (D / 2);
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 8192);
+    if (dtype == RTK_BF16)
+        RTK_LAUNCH(KID_ROPE, rope_shift_kernel<RTK_BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k, stride_h, H, n,
+                   D, delta_dev, inv_freq, rs);
+    else
+        RTK_LAUNCH(KID_ROPE, rope_shift_kernel<RTK_F32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k, stride_h, H, n,
+                   D, delta_dev, inv_freq, rs);
+    RTK_LAUNCH_CHECK("rope_shift_kernel");
+    return RTK_OK;
+}
 
 extern "C" int rtk_rope_merge(const void* cos_in, const void* sin_in, int P, int L, int D, int dtype,
                               const int* sections_host, int nsec, float* cos_out, float* sin_out,

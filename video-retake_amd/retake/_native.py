@@ -29,6 +29,7 @@ _SIGNATURES = {
     "rtk_gather_frames": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "rtk_rope_merge": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "rtk_rope_table": (C.c_int, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _vp, _vp, _vp]),
+    "rtk_rope_shift": (C.c_int, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "rtk_pivotkv_score_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "rtk_pivotkv_score": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp,
                                     _vp, _sz, _vp]),

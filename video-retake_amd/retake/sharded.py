@@ -1,0 +1,272 @@
+"""One long video sharded over the GPUs of a node (BASELINE.json configs[3]).
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+The video's frame chunks are split into contiguous blocks, one per rank:
+
+  DPSelect   every rank computes the distance rows of its frames (one halo frame on the left), the
+             [T, N] distance matrix is all-gathered (T*N*4 bytes, 1.6 MB at 2048x196), and the cheap
+             stencil + top-k runs redundantly on every rank — deterministic, so all ranks hold the
+             same indices and key-patch mask.  (Frame gather: ratio 1.0, the shipped default, keeps
+             every frame in place; a ratio < 1 gather across ranks is not implemented yet.)
+  PivotKV    (chunk, layer) scoring only reads the chunk's own q/k (longvideo_cache.py:264), so a rank
+             runs `PivotKVCache.update` on its chunks with PROVISIONAL temporal ids starting at 0.
+             Selection and the id rescale are translation invariant; the only coupling between blocks
+             is the temporal offset of a block = last compressed temporal id of the previous block + 1
+             (qwen2_vl.py:68-73).  `finalize` all-gathers one int64 per (rank, layer), takes the
+             exclusive prefix, rotates each rank's kept keys by R(delta) (RoPE composes:
+             R(p + delta) = R(delta) R(p)), shifts the stored ids, and (optionally) all-gathers the
+             kept K / V / ids so every rank holds the full compressed cache.
+
+No collective sits inside the scoring path; the exchanges are one small all-gather per video
+(distances), one tiny all-gather per video (offsets) and one all-gather per layer (cache assembly).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+import time
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+# ---------------------------------------------------------------------------------------------------
+# host logic (device independent; exercised by the gloo tests)
+# ---------------------------------------------------------------------------------------------------
+def shard_chunks(n_chunks: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced chunk blocks [c0, c1) per rank (first `n_chunks % world` ranks get one more)."""
+    base, extra = divmod(n_chunks, world)
+    out, c = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((c, c + n))
+        c += n
+    return out
+
+
+def exchange_temporal_offsets(local_last: torch.Tensor, first_start: int = 0, group=None) -> torch.Tensor:
+    """local_last [layers] int64 = last PROVISIONAL temporal id of this rank's block per layer (block ids
+    start at 0; -1 if the block kept nothing).  Returns delta [layers] int64 for this rank: the true start
+    of the block, i.e. first_start + sum over previous ranks of (last + 1)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    gathered = [torch.empty_like(local_last) for _ in range(world)]
+    dist.all_gather(gathered, local_last.contiguous(), group=group)
+    spans = torch.stack(gathered) + 1                      # [world, layers]
+    prefix = torch.cumsum(spans, dim=0) - spans            # exclusive
+    return prefix[rank] + first_start
+
+
+def all_gather_cat(t: torch.Tensor, dim: int, group=None) -> torch.Tensor:
+    """All-gather equally shaped tensors and concatenate along `dim` in rank order."""
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous(), group=group)
+    return torch.cat(parts, dim=dim)
+
+
+def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
+    """[rows_local, ...] -> [world*rows_local, ...] in rank order (distance rows)."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if local.is_cuda:
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    else:  # gloo has no all_gather_into_tensor on every build
+        parts = list(out.chunk(world, dim=0))
+        dist.all_gather(parts, local.contiguous(), group=group)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# device path
+# ---------------------------------------------------------------------------------------------------
+def dpselect_sharded(frames_local: torch.Tensor, has_halo: bool, tgt_mem_len: int, window_size: int = 3,
+                     sync: bool = False, group=None):
+    """frames_local [1, T_loc (+1 halo frame in front), N, C].  Returns (compressed_local, mask_flat_global,
+    idx_global, dis_global).  tgt_mem_len must equal the total frame count (ratio 1.0)."""
+    from . import _native as nv
+
+    nv.require_device(frames_local)
+    world = dist.get_world_size(group)
+    x = frames_local[0].contiguous()
+    Tl, N, Cc = x.shape
+    dev = x.device
+    dt = nv.dtype_code(x)
+    with torch.cuda.device(dev):
+        st = nv.stream()
+        dis_l = torch.empty((Tl, N), dtype=torch.float32, device=dev)
+        nv.check(nv.lib.rtk_dpselect_dis(nv.ptr(x), Tl, N, Cc, dt, nv.ptr(dis_l), st), "rtk_dpselect_dis")
+        own = dis_l[1:] if has_halo else dis_l      # the halo frame only feeds the first own row
+        dis = all_gather_rows(own, group)
+        T = dis.shape[0]
+        if tgt_mem_len != T:
+            raise NotImplementedError("sharded DPSelect: frame gather across ranks (ratio < 1) is not implemented")
+        idx = torch.empty((T,) if sync else (T, N), dtype=torch.int64, device=dev)
+        mask = torch.empty((T, N), dtype=torch.bool, device=dev)
+        keys = torch.empty((2, T) if sync else (N, T), dtype=torch.float32, device=dev)
+        nv.check(nv.lib.rtk_dpselect_select(nv.ptr(dis), T, N, T, int(window_size), int(bool(sync)), nv.ptr(idx),
+                                            nv.ptr(mask), nv.ptr(keys), st), "rtk_dpselect_select")
+        # ratio 1.0: every frame is kept at its own index -> the local output is a copy of the own frames
+        own_x = x[1:] if has_halo else x
+        rank = dist.get_rank(group)
+        T_own = own_x.shape[0]
+        idx_l = (idx[rank * T_own:(rank + 1) * T_own] - rank * T_own).contiguous()
+        out = torch.empty((1, T_own, N, Cc), dtype=x.dtype, device=dev)
+        nv.check(nv.lib.rtk_gather_frames(nv.ptr(own_x.contiguous()), T_own, N, Cc, dt, nv.ptr(idx_l), T_own,
+                                          int(bool(sync)), nv.ptr(out), st), "rtk_gather_frames")
+    return out, mask.flatten(), idx, dis
+
+
+class ShardedPivotKV:
+    """A rank's share of one video's PivotKV compression (see the module docstring)."""
+
+    def __init__(self, config, group=None, first_start: int = 0):
+        from .longvideo_cache import PivotKVCache
+
+        self.cache = PivotKVCache(config)
+        self.group = group
+        self.first_start = first_start
+
+    def update(self, key_states, value_states, layer_idx, cache_kwargs):
+        return self.cache.update(key_states, value_states, layer_idx, cache_kwargs)
+
+    def finalize(self, inv_freq: torch.Tensor, mrope_section: Optional[List[int]], assemble: bool = True):
+        """Exchange offsets, rotate/shift this rank's block to its true temporal position, and optionally
+        all-gather the full compressed cache.  Returns (keys, values, position_ids) lists per layer."""
+        from . import _native as nv
+
+        cache = self.cache
+        cache.after_forward()
+        n_layers = len(cache.position_cache)
+        dev = cache.position_cache[0].device
+        last = torch.stack([pc.reshape(-1, pc.shape[-1])[0, -1] for pc in cache.position_cache])   # [layers]
+        delta = exchange_temporal_offsets(last, self.first_start, self.group)                      # [layers]
+        sec = (C.c_int * len(mrope_section))(*mrope_section) if mrope_section else None
+        nsec = len(mrope_section) if mrope_section else 0
+        keys, values, pos = [], [], []
+        with torch.cuda.device(dev):
+            st = nv.stream()
+            inv = inv_freq.to(device=dev, dtype=torch.float32).contiguous()
+            for layer in range(n_layers):
+                k, v = cache.key_cache[layer], cache.value_cache[layer]
+                kbuf = cache._layers[layer].k
+                P = 3 if cache.position_cache[layer].ndim == 3 else 1
+                nv.check(nv.lib.rtk_rope_shift(nv.ptr(kbuf), kbuf.shape[2] * kbuf.shape[3], k.shape[1], k.shape[2],
+                                               k.shape[3], nv.dtype_code(k), C.c_void_p(delta[layer:].data_ptr()),
+                                               nv.ptr(inv), P, sec, nsec, st), "rtk_rope_shift")
+                pc = cache.position_cache[layer]
+                if P == 3:
+                    pc[0] += delta[layer]
+                else:
+                    pc += delta[layer]
+                if assemble:
+                    keys.append(all_gather_cat(k, 2, self.group))
+                    values.append(all_gather_cat(v, 2, self.group))
+                    pos.append(all_gather_cat(pc, -1, self.group))
+                else:
+                    keys.append(k)
+                    values.append(v)
+                    pos.append(pc)
+        return keys, values, pos
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py --gpus N  (strong scaling: one video, chunks sharded over the ranks)
+# ---------------------------------------------------------------------------------------------------
+def bench_main(args, rank: int, world: int, local_rank: int):
+    import bench as B
+    from . import _native as nv
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    tdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    T = args.frames
+    n_chunks = T // B.FRAMES_PER_CHUNK
+    L = B.FRAMES_PER_CHUNK * B.N_PATCH
+    c0, c1 = shard_chunks(n_chunks, world)[rank]
+    assert n_chunks % world == 0, "bench shards whole chunks evenly"
+    f0, f1 = c0 * B.FRAMES_PER_CHUNK, c1 * B.FRAMES_PER_CHUNK
+    halo = 1 if rank > 0 else 0
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    frames = torch.randn((1, f1 - f0 + halo, B.N_PATCH, B.C_EMB), generator=gen, device=dev).to(tdtype)
+    if world > 1:  # make the halo frame equal to the left neighbour's last frame
+        last = frames[:, -1].contiguous()
+        recv = torch.empty_like(last)
+        ops = []
+        if rank + 1 < world:
+            ops.append(dist.P2POp(dist.isend, last, rank + 1))
+        if rank > 0:
+            ops.append(dist.P2POp(dist.irecv, recv, rank - 1))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if rank > 0:
+            frames[:, 0] = recv
+    n_calls = (c1 - c0) * args.layers
+    pool = []
+    for _ in range(min(args.pool, n_calls)):
+        pool.append(tuple((1.7 * torch.randn((1, h, L, B.D), generator=gen, device=dev)).to(tdtype)
+                          for h in (B.Hq, B.Hkv, B.Hkv)))
+    pos_base = [B.chunk_position_ids(c, dev) for c in range(c0, c1)]
+    rotary = B.Rotary(dev)
+
+    def step():
+        out, mask, idx, dis = dpselect_sharded(frames, halo == 1, T, 3, sync=False)
+        sh = ShardedPivotKV(B.make_cache_config(args.layers))
+        cache = sh.cache
+        call = 0
+        for ci, c in enumerate(range(c0, c1)):
+            cache.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
+            cache.kvcache_compression = True
+            for layer in range(args.layers):
+                q, k, v = pool[call % len(pool)]
+                call += 1
+                pos = pos_base[ci]
+                prev = cache.get_prev_temporal_idx(layer)
+                pos = pos.clone()
+                pos[0, 0, :] += (prev + 1) - pos[0, 0, 0]   # block-local ids start at 0 (provisional)
+                cache.update(k, v, layer, {"query_states": q, "position_ids": pos, "rotary_emb": rotary,
+                                           "mrope_section": B.MROPE})
+            cache.after_forward()
+        keys, values, pos = sh.finalize(rotary.inv_freq, B.MROPE, assemble=True)
+        return (c1 - c0) * args.layers * max(1, int(B.RATIO * L)), keys
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    retained = 0
+    for _ in range(args.steps):
+        r, keys = step()
+        retained += r
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    tot = torch.tensor([float(retained)], dtype=torch.float64, device=dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt = float(dt.item())
+    if rank == 0:
+        out = {
+            "metric": "frames/sec through DPSelect+PivotKV @2048 frames; retained-KV-tokens/sec",
+            "value": T * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "retained_kv_tokens_per_s": float(tot.item()) / dt,
+            "config": {"workload": f"Qwen2-VL-7B geometry, one {T}-frame synthetic video sharded by frame chunk over "
+                                   f"{world} GPUs: DPSelect (distance rows all-gathered) + PivotKV 4x on "
+                                   f"{n_chunks} chunks x {args.layers} layers, L={L}; offsets + per-layer cache "
+                                   f"all-gather over RCCL (BASELINE configs[3])",
+                       "frames": T, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L,
+                       "parallelism": f"chunk-sharded x{world}", "assembled_cache_tokens": int(keys[0].shape[2])},
+        }
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
