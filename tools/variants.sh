@@ -3,7 +3,7 @@
 # Output: video-retake_amd/retake/_lib/variants/libretake_hip_<name>.so   (select with RETAKE_HIP_LIB=...)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-SRC=$ROOT/video-retake_amd/csrc
+SRC=${RTK_SRC:-$ROOT/video-retake_amd/csrc}
 OUT=$ROOT/video-retake_amd/retake/_lib/variants
 mkdir -p $OUT
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$SRC -ffp-contract=on -fno-fast-math"

@@ -33,6 +33,7 @@ constexpr int HD = 128;       // head_dim of the MFMA path
 constexpr int TILE_ROWS = 64; // rows of the streamed LDS tile
 constexpr int REG_ROWS = 128; // rows held in registers per workgroup (32 per wave)
 constexpr int SC_BLOCK = 256;
+constexpr int NXCD = 8;      // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8
 
 // ------------------------------------------------------------------------------------------------
 // un-rotate + pack:  q [Hq,L,D] and k [Hkv,L,D] (strided) -> contiguous [H,L,D] copies (same dtype)
@@ -356,13 +357,33 @@ struct RowStat {  // online max / sum of one query row, over the keys this lane 
 template <int DT>
 __global__ __launch_bounds__(SC_BLOCK) void score_pass1_kernel(const char* __restrict__ q, const char* __restrict__ k,
                                                                int Hq, int Hkv, int L, int keys_per_split,
+                                                               int row_tiles, int xcd_remap,
                                                                float* __restrict__ lse_part) {
     using M = MM<DT>;
     using T = Tile<DT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE, hf = lane >> 5;
-    const int h = blockIdx.y, g = h / (Hq / Hkv), ks = blockIdx.z;
-    const int i0 = blockIdx.x * REG_ROWS + wid * 32;
+    // XCD-aware decode of a 1-D grid (block b runs on XCD b % 8): all workgroups that stream the same
+    // key split of the same KV group share an XCD, so the split stays resident in that XCD's L2.
+    const int G = Hq / Hkv;
+    int bx, h, ks;
+    {
+        const int per_group = row_tiles * G;                 // workgroups sharing one (g, ks) key stream
+        int grp, w;
+        if (xcd_remap) {  // only when the group count is a multiple of 8 (balanced XCDs)
+            const int xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+            grp = xcd + NXCD * (slot / per_group);
+            w = slot % per_group;
+        } else {
+            grp = blockIdx.x / per_group;
+            w = blockIdx.x % per_group;
+        }
+        ks = grp / Hkv;
+        h = (grp % Hkv) * G + w / row_tiles;
+        bx = w % row_tiles;
+    }
+    const int g = h / G;
+    const int i0 = bx * REG_ROWS + wid * 32;
     const int jb = ks * keys_per_split, je = min(L, jb + keys_per_split);
     const char* qh = q + (size_t)h * L * HD * M::ESIZE;
     const char* kg = k + ((size_t)g * L + jb) * HD * M::ESIZE;
@@ -456,14 +477,31 @@ __device__ __forceinline__ void load_ls(float* ls, const float* lcur, int blk, i
 template <int DT>
 __global__ __launch_bounds__(SC_BLOCK) void score_pass2_kernel(const char* __restrict__ q, const char* __restrict__ k,
                                                                const float* __restrict__ lse, int Hq, int Hkv, int L,
-                                                               int rows_per_split, float* __restrict__ partial) {
+                                                               int rows_per_split, int col_tiles, int RS,
+                                                               int xcd_remap, float* __restrict__ partial) {
     using M = MM<DT>;
     using T = Tile<DT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lse_s = (float*)(smem + 2 * T::BYTES);  // [2][TILE_ROWS]
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE, hf = lane >> 5;
-    const int g = blockIdx.y, G = Hq / Hkv, rs = blockIdx.z, RS = gridDim.z;
-    const int j0 = blockIdx.x * REG_ROWS + wid * 32;
+    // XCD-aware decode (block b runs on XCD b % 8): the col_tiles workgroups that stream the same query
+    // rows (same KV group, same row split) share an XCD and therefore its L2.
+    const int G = Hq / Hkv;
+    int bx, g, rs;
+    {
+        int grp;
+        if (xcd_remap) {
+            const int xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+            grp = xcd + NXCD * (slot / col_tiles);           // (g, rs) pair index
+            bx = slot % col_tiles;
+        } else {
+            grp = blockIdx.x / col_tiles;
+            bx = blockIdx.x % col_tiles;
+        }
+        g = grp % Hkv;
+        rs = grp / Hkv;
+    }
+    const int j0 = bx * REG_ROWS + wid * 32;
     const char* kg = k + (size_t)g * L * HD * M::ESIZE;
     const int ib = rs * rows_per_split, ie = min(L, ib + rows_per_split);
     const int nrows = ie - ib;
@@ -669,9 +707,17 @@ __global__ __launch_bounds__(64) void score_finalize_kernel(const float* __restr
 #define RTK_TARGET_WGS 3072
 #endif
 constexpr int TARGET_WGS = RTK_TARGET_WGS;
-static int pick_splits(int tiles_fixed, int heads, int stream_tiles, int cap) {
+static int pick_splits(int tiles_fixed, int heads, int stream_tiles, int cap, int Hkv) {
     int s = (TARGET_WGS + tiles_fixed * heads - 1) / (tiles_fixed * heads);
-    return std::max(1, std::min(std::min(s, cap), stream_tiles));
+    s = std::max(1, std::min(std::min(s, cap), stream_tiles));
+    // prefer a split count whose NON-EMPTY splits make Hkv*splits a multiple of the XCD count (balanced
+    // XCD-aware mapping); splits are whole 64-row tiles, so check the effective count
+    for (int t = s; t <= std::min(cap, stream_tiles) && t <= s + 8; ++t) {
+        const int per = (((stream_tiles + t - 1) / t));          // tiles per split
+        const int eff = (stream_tiles + per - 1) / per;
+        if ((Hkv * eff) % NXCD == 0) return t;
+    }
+    return s;
 }
 
 struct ScoreWs {
@@ -683,8 +729,8 @@ static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     ScoreWs w;
     const int reg_tiles = (L + REG_ROWS - 1) / REG_ROWS, stream_tiles = (L + TILE_ROWS - 1) / TILE_ROWS;
-    w.RS = (D == HD) ? pick_splits(reg_tiles, Hkv, stream_tiles, 32) : 1;
-    w.KS = (D == HD) ? pick_splits(reg_tiles, Hq, stream_tiles, 8) : 1;
+    w.RS = (D == HD) ? pick_splits(reg_tiles, Hkv, stream_tiles, 32, Hkv) : 1;
+    w.KS = (D == HD) ? pick_splits(reg_tiles, Hq, stream_tiles, 8, Hkv) : 1;
     w.q_off = 0;
     w.k_off = al((size_t)Hq * L * D * es);
     w.lse_off = w.k_off + al((size_t)Hkv * L * D * es);
@@ -748,15 +794,16 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         const int kps = per_split(L, w.KS), rps = per_split(L, w.RS);
         const int ks_n = (L + kps - 1) / kps;  // non-empty splits only
         rs_n = (L + rps - 1) / rps;
-        RTK_LAUNCH(KID_PASS1, score_pass1_kernel<DT>, dim3(jt, Hq, ks_n), dim3(SC_BLOCK), LDS1, st, (const char*)qt,
-                   (const char*)kt, Hq, Hkv, L, kps, lse);
+        RTK_LAUNCH(KID_PASS1, score_pass1_kernel<DT>, dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
+                   (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse);
         RTK_LAUNCH_CHECK("score_pass1_kernel");
         if (ks_n > 1) {
             const size_t n = (size_t)Hq * L;
             RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<DT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lse, n, ks_n);
         }
-        RTK_LAUNCH(KID_PASS2, score_pass2_kernel<DT>, dim3(jt, Hkv, rs_n), dim3(SC_BLOCK), LDS2, st, (const char*)qt,
-                   (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, part);
+        RTK_LAUNCH(KID_PASS2, score_pass2_kernel<DT>, dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
+                   (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
+                   (int)((Hkv * rs_n) % NXCD == 0), part);
         RTK_LAUNCH_CHECK("score_pass2_kernel");
     } else {
         RTK_LAUNCH(KID_PASS1, score_pass1_generic<DT>, dim3(L, Hq), dim3(256), D * sizeof(float), st, (const void*)qt,
