@@ -43,7 +43,9 @@ __device__ __forceinline__ uint32_t f2key(float f) {
 }
 
 // 16-byte vector types
-struct __attribute__((aligned(16))) u32x4 { uint32_t x, y, z, w; };
+// native 4 x u32 vector: loads/stores are first-class 16-byte operations (a struct would be copied with
+// llvm.memcpy, which keeps register staging arrays in scratch memory)
+using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
 
 }  // namespace rtk
 

@@ -16,6 +16,8 @@
 // reduction over the streamed operand is lane-local over the 16 accumulator registers plus one
 // cross-half shuffle.  The streamed operand goes HBM/L2 -> registers -> XOR-swizzled LDS tile
 // (conflict-free ds_read_b128) with the next tile's global loads in flight during the MFMAs.
+#include <type_traits>
+
 #include "common.cuh"
 
 // LLVM sched_group_barrier masks
@@ -237,7 +239,7 @@ __device__ __forceinline__ void load_reg_frag(const char* __restrict__ base, int
 // Per-thread constants of the streamed-tile pipeline, computed once per kernel:
 //   frag_off[r]  LDS byte offset (inside a tile, block 0) of this lane's r-th A-fragment chunk
 //   st_off[u]    LDS byte offset where this thread stores its u-th staged chunk
-//   src_off      byte offset (inside a tile's 64 source rows) of this thread's first staged chunk
+//   srow/src_col first staged row of this thread inside a tile and its byte column
 // 16-byte chunks are XOR-swizzled by (row & 15): the 16 lanes of every ds_read_b128 lane group address
 // 16 distinct rows (mod 16) => 16 distinct 16-byte bank slots; no bank conflicts (SQ_LDS_BANK_CONFLICT = 0).
 template <int DT> struct Pipe {
@@ -245,29 +247,33 @@ template <int DT> struct Pipe {
     using T = Tile<DT>;
     int frag_off[M::NREG];
     int st_off[T::STAGE];
-    int src_off;
-    int srow;  // first staged row of this thread inside the tile
+    int src_col;  // byte offset of this thread's chunk inside a row
+    int srow;     // first staged row of this thread inside the tile
     __device__ __forceinline__ void init(int tid, int lane) {
         const int row = lane & 31, hf = lane >> 5;
 #pragma unroll
         for (int r = 0; r < M::NREG; ++r) frag_off[r] = row * T::ROWB + ((M::chunk_of(r, hf) ^ (row & 15)) * 16);
         srow = tid / M::CHUNKS;
         const int ch = tid % M::CHUNKS;
-        src_off = srow * T::ROWB + ch * 16;
+        src_col = ch * 16;
 #pragma unroll
         for (int u = 0; u < T::STAGE; ++u) {
             const int rr = srow + u * T::ROWS_PER_STEP;
             st_off[u] = rr * T::ROWB + ((ch ^ (rr & 15)) * 16);
         }
     }
-    // global -> registers (issued early, consumed late); rows >= rows_left are zero-filled
-    template <bool FULL>
-    __device__ __forceinline__ void load(const char* __restrict__ tile_src, int rows_left, u32x4* st) const {
+    // global -> registers (issued early, consumed late).  Branch-free: rows past `last_row` (ragged tile,
+    // end of the matrix) re-read row `last_row` — finite filler whose logits the callers mask out — so the
+    // compiler can keep COUNTED vmcnt waits across the software pipeline (a load inside a conditional
+    // forces vmcnt(0) at the join).
+    __device__ __forceinline__ void load(const char* __restrict__ mat, int first_row, int last_row, u32x4* st) const {
+#ifdef RTK_ABLATE_GLOAD  // ablation builds only: no global traffic in the steady state
+        if (first_row > 4096) return;
+#endif
 #pragma unroll
         for (int u = 0; u < T::STAGE; ++u) {
-            const u32x4* p = (const u32x4*)(tile_src + src_off + (size_t)u * T::ROWS_PER_STEP * T::ROWB);
-            if (FULL) st[u] = *p;
-            else st[u] = (srow + u * T::ROWS_PER_STEP < rows_left) ? *p : u32x4{0, 0, 0, 0};
+            const int row = min(first_row + srow + u * T::ROWS_PER_STEP, last_row);
+            st[u] = *(const u32x4*)(mat + (size_t)row * T::ROWB + src_col);
         }
     }
     __device__ __forceinline__ void store(char* lds_tile, const u32x4* st) const {
@@ -276,10 +282,20 @@ template <int DT> struct Pipe {
     }
     // explicit two-step form: fetch all A fragments of a block, then run the MFMAs on them
     __device__ __forceinline__ void read_frags(u32x4* a, const char* lds_tile, int blk) const {
+#ifdef RTK_ABLATE_LDSREAD  // ablation builds only: fragments stay whatever they were
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) asm volatile("" : "+v"(a[r]));
+        return;
+#endif
 #pragma unroll
         for (int r = 0; r < M::NREG; ++r) a[r] = *(const u32x4*)(lds_tile + blk * 32 * T::ROWB + frag_off[r]);
     }
     __device__ __forceinline__ void mma_frags(f32x16& acc, const u32x4* a, const u32x4* rf) const {
+#ifdef RTK_ABLATE_MFMA  // ablation builds only: keep the operand traffic, skip the matrix pipe
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) acc[r] += __uint_as_float(a[r].x) * __uint_as_float(rf[r].y);
+        return;
+#endif
 #pragma unroll
         for (int r = 0; r < M::NREG; ++r) M::mma(acc, a[r], rf[r]);
     }
@@ -354,7 +370,17 @@ struct RowStat {  // online max / sum of one query row, over the keys this lane 
     }
 };
 
-template <int DT>
+// Per-dtype kernel shape (both knobs were measured on MI355X at L = 6272):
+//   NB = 32-row register blocks per wave.  NB = 2 halves the LDS reads, barriers and staging per MFMA but
+//        needs ~250 VGPRs (1-2 waves per SIMD): no gain over NB = 1 with 2-3 waves.
+//   PF = how many streamed tiles ahead the global loads run (register staging sets, counted vmcnt waits).
+//        PF = 2 did not help either: the kernels are bound by instruction issue, not by load latency.
+template <int DT> struct RegBlocks {
+    static constexpr int NB = 1;
+    static constexpr int PF = 1;
+};
+
+template <int DT, int NB>
 __global__ __launch_bounds__(SC_BLOCK) void score_pass1_kernel(const char* __restrict__ q, const char* __restrict__ k,
                                                                int Hq, int Hkv, int L, int keys_per_split,
                                                                int row_tiles, int xcd_remap,
@@ -383,59 +409,95 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass1_kernel(const char* __res
         bx = w % row_tiles;
     }
     const int g = h / G;
-    const int i0 = bx * REG_ROWS + wid * 32;
+    const int i0 = bx * (REG_ROWS * NB) + wid * (32 * NB);   // this wave's NB*32 query rows
     const int jb = ks * keys_per_split, je = min(L, jb + keys_per_split);
     const char* qh = q + (size_t)h * L * HD * M::ESIZE;
-    const char* kg = k + ((size_t)g * L + jb) * HD * M::ESIZE;
-
     Pipe<DT> pp;
     pp.init(tid, lane);
-    u32x4 qf[M::NREG];
-    load_reg_frag<DT>(qh, i0, L, lane, qf);
+    u32x4 qf[NB][M::NREG];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) load_reg_frag<DT>(qh, i0 + 32 * nb, L, lane, qf[nb]);
 
     const int nkeys = je - jb;
     const int nfull = nkeys / TILE_ROWS;              // full tiles
     const int ntiles = (nkeys + TILE_ROWS - 1) / TILE_ROWS;
     const float sqrt_d = sqrtf((float)HD);
     const float c2 = 1.4426950408889634f / sqrt_d;    // bf16: log2(e)/sqrt(D) folded into the exp2 argument
-    RowStat<DT> rs;
-    rs.init();
+    RowStat<DT> rs[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) rs[nb].init();
 
-    u32x4 st[T::STAGE];
-    if (nfull > 0) pp.template load<true>(kg, TILE_ROWS, st);
-    else pp.template load<false>(kg, nkeys, st);
-    pp.store(smem, st);
+    constexpr int PF = RegBlocks<DT>::PF;
+    u32x4 stA[T::STAGE], stB[T::STAGE];   // staging registers: set A holds even tiles, set B odd tiles (PF == 2)
+    const char* kmat = k + (size_t)g * L * HD * M::ESIZE;
+#define RTK_LOAD_TILE(t, dst) pp.load(kmat, jb + (t) * TILE_ROWS, L - 1, dst)
+    RTK_LOAD_TILE(0, stA);
+    pp.store(smem, stA);
+    if (PF == 2 && ntiles > 1) RTK_LOAD_TILE(1, stB);
     __syncthreads();
 
-    // Occupancy (3 waves per SIMD at ~150 VGPRs) hides the MFMA -> softmax dependency here; an explicit
-    // in-wave software pipeline (as in pass 2) was measured equal for bf16 and slower for fp32.
-    auto step = [&](int jt, int buf) {
-        const char* cur = smem + buf * T::BYTES;
-        char* nxt = smem + (buf ^ 1) * T::BYTES;
-        const bool have_next = jt + 1 < ntiles;
-        if (have_next) {
-            const char* src = kg + (size_t)(jt + 1) * T::BYTES;
-            if (jt + 1 < nfull) pp.template load<true>(src, TILE_ROWS, st);
-            else pp.template load<false>(src, nkeys - (jt + 1) * TILE_ROWS, st);
-        }
-        f32x16 acc0 = {0}, acc1 = {0};
-        pp.mma_block(acc0, cur, 0, qf);
-        pp.mma_block(acc1, cur, 1, qf);
-        if (jt < nfull) rs.template update<false>(acc0, acc1, 0, 0, hf, c2, sqrt_d);
-        else rs.template update<true>(acc0, acc1, jt * TILE_ROWS, nkeys, hf, c2, sqrt_d);
-        if (have_next) pp.store(nxt, st);
-        __syncthreads();
-    };
-    int jt = 0;
-    for (; jt + 1 < ntiles; jt += 2) {  // two tiles per trip: LDS buffer offsets become immediates
-        step(jt, 0);
-        step(jt + 1, 1);
+    // Every A fragment read from LDS feeds NB MFMAs (one per register block).  The MFMA -> softmax
+    // dependency is hidden by the other waves on the SIMD (an explicit in-wave pipeline as in pass 2
+    // measured equal here).  Tile jt is computed from LDS buffer jt & 1 while the loads of tile jt + PF are
+    // in flight; tile jt + 1 (loaded one step earlier when PF == 2) is written to the other buffer.
+    // ISSUE / STORE are compile-time in the steady-state loop: no load sits inside a conditional there.
+#define RTK_STEP1(JT, PAR, ISSUE, STORE) \
+    { \
+        constexpr int par = PAR; \
+        const char* cur = smem + par * T::BYTES; \
+        char* nxt = smem + (par ^ 1) * T::BYTES; \
+        if constexpr (ISSUE) { \
+            if constexpr (PF == 2 && par == 1) RTK_LOAD_TILE((JT) + PF, stB); \
+            else RTK_LOAD_TILE((JT) + PF, stA); \
+        } \
+        f32x16 acc0[NB], acc1[NB]; \
+        { \
+            u32x4 a[M::NREG]; \
+            pp.read_frags(a, cur, 0); \
+_Pragma("unroll") \
+            for (int nb = 0; nb < NB; ++nb) { acc0[nb] = f32x16{0}; pp.mma_frags(acc0[nb], a, qf[nb]); } \
+            pp.read_frags(a, cur, 1); \
+_Pragma("unroll") \
+            for (int nb = 0; nb < NB; ++nb) { acc1[nb] = f32x16{0}; pp.mma_frags(acc1[nb], a, qf[nb]); } \
+        } \
+_Pragma("unroll") \
+        for (int nb = 0; nb < NB; ++nb) { \
+            if ((JT) < nfull) rs[nb].template update<false>(acc0[nb], acc1[nb], 0, 0, hf, c2, sqrt_d); \
+            else rs[nb].template update<true>(acc0[nb], acc1[nb], (JT) * TILE_ROWS, nkeys, hf, c2, sqrt_d); \
+        } \
+        if constexpr (STORE) { \
+            if constexpr (PF == 2 && par == 0) pp.store(nxt, stB); \
+            else pp.store(nxt, stA); \
+        } \
+        __syncthreads(); \
     }
-    if (jt < ntiles) step(jt, 0);
+    int jt = 0;
+    for (; jt + PF + 1 < ntiles; jt += 2) {  // steady state, two tiles per trip (parities are constants)
+        RTK_STEP1(jt, 0, true, true)
+        RTK_STEP1(jt + 1, 1, true, true)
+    }
+    // tail: at most PF + 1 tiles; jt is even here, so the parities are known statically (a run-time parity
+    // would make the compiler select between the two staging sets through memory)
+#define RTK_TAIL(PAR)                                              \
+    if (jt < ntiles) {                                             \
+        if (jt + PF < ntiles) RTK_STEP1(jt, PAR, true, true)       \
+        else if (jt + 1 < ntiles) RTK_STEP1(jt, PAR, false, true)  \
+        else RTK_STEP1(jt, PAR, false, false)                      \
+        ++jt;                                                      \
+    }
+    RTK_TAIL(0)
+    RTK_TAIL(1)
+    RTK_TAIL(0)
+#undef RTK_TAIL
+#undef RTK_STEP1
+#undef RTK_LOAD_TILE
 
-    const float out = rs.finish(c2);
-    const int i = i0 + (lane & 31);
-    if (hf == 0 && i < L) lse_part[((size_t)ks * Hq + h) * L + i] = out;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const float out = rs[nb].finish(c2);
+        const int i = i0 + 32 * nb + (lane & 31);
+        if (hf == 0 && i < L) lse_part[((size_t)ks * Hq + h) * L + i] = out;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -462,6 +524,11 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(float* __restrict__ ls
 // col += sum_r exp(acc[r]*scale - ls[r]) for one 32x32 block (16 values per lane)
 template <int DT>
 __device__ __forceinline__ void colsum_block(float& col, const f32x16& acc, const float* ls, float c2, float sqrt_d) {
+#ifdef RTK_ABLATE_SM  // ablation builds only (tools/variants.sh): keep the MFMAs alive, skip the softmax VALU
+    asm volatile("" ::"v"(acc));
+    col += ls[0];
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         if (DT == RTK_BF16) col += __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -ls[r]));
@@ -474,7 +541,7 @@ __device__ __forceinline__ void load_ls(float* ls, const float* lcur, int blk, i
     for (int r4 = 0; r4 < 4; ++r4) *(float4*)(ls + 4 * r4) = *(const float4*)(lcur + blk * 32 + 8 * r4 + 4 * hf);
 }
 
-template <int DT>
+template <int DT, int NB>
 __global__ __launch_bounds__(SC_BLOCK) void score_pass2_kernel(const char* __restrict__ q, const char* __restrict__ k,
                                                                const float* __restrict__ lse, int Hq, int Hkv, int L,
                                                                int rows_per_split, int col_tiles, int RS,
@@ -501,107 +568,146 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass2_kernel(const char* __res
         g = grp % Hkv;
         rs = grp / Hkv;
     }
-    const int j0 = bx * REG_ROWS + wid * 32;
+    const int j0 = bx * (REG_ROWS * NB) + wid * (32 * NB);   // this wave's NB*32 keys
     const char* kg = k + (size_t)g * L * HD * M::ESIZE;
     const int ib = rs * rows_per_split, ie = min(L, ib + rows_per_split);
     const int nrows = ie - ib;
     const int tiles_per_head = (nrows + TILE_ROWS - 1) / TILE_ROWS;   // >= 1: empty splits are not launched
-    const int full_per_head = nrows / TILE_ROWS;
     const int ntiles = tiles_per_head * G;
 
     Pipe<DT> pp;
     pp.init(tid, lane);
-    u32x4 kf[M::NREG];
-    load_reg_frag<DT>(kg, j0, L, lane, kf);
+    u32x4 kf[NB][M::NREG];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) load_reg_frag<DT>(kg, j0 + 32 * nb, L, lane, kf[nb]);
 
     const float sqrt_d = sqrtf((float)HD);
     const float c2 = 1.4426950408889634f / sqrt_d;
-    float col = 0.f;
-    u32x4 st[T::STAGE];
-    float lst = 0.f;
+    float col[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) col[nb] = 0.f;
+    constexpr int PF = RegBlocks<DT>::PF;
+    u32x4 stA[T::STAGE], stB[T::STAGE];   // staging register sets: even / odd tiles (only A when PF == 1)
+    float lstA = 0.f, lstB = 0.f;
 
     // cursor of the tile being prefetched: row tile inside the split, source pointers of the current head
     int nt = 0;
-    const char* nsrc = q + ((size_t)(g * G) * L + ib) * HD * M::ESIZE;   // first row of the split, head g*G
-    const float* nlse = lse + (size_t)(g * G) * L + ib;
-    auto issue = [&]() {  // loads tile nt of the cursor head and its lse element, then advances the cursor
-        if (nt < full_per_head) pp.template load<true>(nsrc + (size_t)nt * T::BYTES, TILE_ROWS, st);
-        else pp.template load<false>(nsrc + (size_t)nt * T::BYTES, nrows - nt * TILE_ROWS, st);
-        if (tid < TILE_ROWS) lst = (nt * TILE_ROWS + tid < nrows) ? nlse[nt * TILE_ROWS + tid] : INFINITY;
-        if (++nt == tiles_per_head) {
-            nt = 0;
-            nsrc += (size_t)L * HD * M::ESIZE;
-            nlse += L;
-        }
-    };
-    // Software pipeline inside the wave: while the matrix pipe runs the 8 MFMAs of one 32-row block, the
-    // VALU finishes the previous block (fma + exp2 + add per value).  `pend` / `pls` carry the second
-    // block of a tile across the barrier into the next tile's first MFMA group.
-    f32x16 pend = {0};
+    const int last_row = Hq * L - 1;  // last row of the whole q~ buffer (clamp target for ragged tiles)
+    int nrow0 = (g * G) * L + ib;     // first buffer row of the cursor head's split
+    // loads the cursor tile (+ this thread's lse element) into one staging set, then advances the cursor;
+    // rows past the split end get lse = +inf: exp(s - inf) = 0 whatever filler the tile holds
+#define RTK_ISSUE(st, lst)                                                              \
+    {                                                                                   \
+        pp.load(q, nrow0 + nt * TILE_ROWS, last_row, st);                               \
+        const int r__ = nt * TILE_ROWS + (tid & (TILE_ROWS - 1));                       \
+        lst = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : INFINITY;               \
+        const bool wrap__ = (nt + 1 == tiles_per_head);                                 \
+        nt = wrap__ ? 0 : nt + 1;                                                       \
+        nrow0 += wrap__ ? L : 0;                                                        \
+    }
+    // Software pipeline inside the wave: while the matrix pipe runs the 8*NB MFMAs of one 32-row block,
+    // the VALU finishes the previous block (fma + exp2 + add per value; the row normalisers are shared by
+    // the NB register blocks).  `pend` / `pls` carry a tile's second block across the barrier into the
+    // next tile's first MFMA group.
+    f32x16 pend[NB];
     float pls[16];
 #pragma unroll
+    for (int nb = 0; nb < NB; ++nb) pend[nb] = f32x16{0};
+#pragma unroll
     for (int r = 0; r < 16; ++r) pls[r] = INFINITY;  // exp(-inf) = 0: nothing pending yet
-    auto step = [&](bool have_next, int buf) {
-        const char* cur = smem + buf * T::BYTES;
-        const float* lcur = lse_s + buf * TILE_ROWS;
-        if (have_next) issue();
-        u32x4 a0[M::NREG], a1[M::NREG];
-        pp.read_frags(a0, cur, 0);
-        pp.read_frags(a1, cur, 1);
-        float ls0[16], ls1[16];
-        load_ls(ls0, lcur, 0, hf);
-        load_ls(ls1, lcur, 1, hf);
-        __builtin_amdgcn_sched_barrier(0);             // keep the LDS reads ahead of the MFMA chain
-        f32x16 acc0 = {0};
-        pp.mma_frags(acc0, a0, kf);                    // matrix pipe: block 0 ...
-        colsum_block<DT>(col, pend, pls, c2, sqrt_d);  // ... VALU: previous tile's block 1
-        // The empty asm statements are ordered against the sched_barrier fences (both have side effects)
-        // and need their operand computed: they pin this phase's MFMA chain and VALU chain inside it.
-        asm volatile("" : "+v"(acc0), "+v"(col));
-        if (DT == RTK_BF16) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(SGB_VALU, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(SGB_TRANS, 2, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        pend = f32x16{0};
-        pp.mma_frags(pend, a1, kf);                    // matrix pipe: block 1 ...
-        colsum_block<DT>(col, acc0, ls0, c2, sqrt_d);  // ... VALU: block 0
-        asm volatile("" : "+v"(pend), "+v"(col));
-        if (DT == RTK_BF16) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(SGB_VALU, 4, 1);
-                __builtin_amdgcn_sched_group_barrier(SGB_TRANS, 2, 1);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pls[r] = ls1[r];
-        if (have_next) {
-            pp.store(smem + (buf ^ 1) * T::BYTES, st);
-            if (tid < TILE_ROWS) lse_s[(buf ^ 1) * TILE_ROWS + tid] = lst;
-        }
-        __syncthreads();
-    };
-    issue();
-    pp.store(smem, st);
-    if (tid < TILE_ROWS) lse_s[tid] = lst;
+#define RTK_STEP2(BUF, ISSUE, STORE) \
+    { \
+        constexpr int buf = BUF; \
+        const char* cur = smem + buf * T::BYTES; \
+        const float* lcur = lse_s + buf * TILE_ROWS; \
+        if constexpr (ISSUE) { \
+            if constexpr (PF == 2 && buf == 1) RTK_ISSUE(stB, lstB) \
+            else RTK_ISSUE(stA, lstA) \
+        } \
+        u32x4 a0[M::NREG], a1[M::NREG]; \
+        pp.read_frags(a0, cur, 0); \
+        pp.read_frags(a1, cur, 1); \
+        float ls0[16], ls1[16]; \
+        load_ls(ls0, lcur, 0, hf); \
+        load_ls(ls1, lcur, 1, hf); \
+        __builtin_amdgcn_sched_barrier(0); \
+        f32x16 acc0[NB]; \
+_Pragma("unroll") \
+        for (int nb = 0; nb < NB; ++nb) { \
+            acc0[nb] = f32x16{0}; \
+            pp.mma_frags(acc0[nb], a0, kf[nb]); \
+            colsum_block<DT>(col[nb], pend[nb], pls, c2, sqrt_d); \
+            asm volatile("" : "+v"(acc0[nb]), "+v"(col[nb])); \
+        } \
+        if (DT == RTK_BF16) { \
+_Pragma("unroll") \
+            for (int i = 0; i < 8 * NB; ++i) { \
+                __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0); \
+                __builtin_amdgcn_sched_group_barrier(SGB_VALU, 4, 0); \
+                __builtin_amdgcn_sched_group_barrier(SGB_TRANS, 2, 0); \
+            } \
+        } \
+        __builtin_amdgcn_sched_barrier(0); \
+_Pragma("unroll") \
+        for (int nb = 0; nb < NB; ++nb) { \
+            pend[nb] = f32x16{0}; \
+            pp.mma_frags(pend[nb], a1, kf[nb]); \
+            colsum_block<DT>(col[nb], acc0[nb], ls0, c2, sqrt_d); \
+            asm volatile("" : "+v"(pend[nb]), "+v"(col[nb])); \
+        } \
+        if (DT == RTK_BF16) { \
+_Pragma("unroll") \
+            for (int i = 0; i < 8 * NB; ++i) { \
+                __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 1); \
+                __builtin_amdgcn_sched_group_barrier(SGB_VALU, 4, 1); \
+                __builtin_amdgcn_sched_group_barrier(SGB_TRANS, 2, 1); \
+            } \
+        } \
+        __builtin_amdgcn_sched_barrier(0); \
+_Pragma("unroll") \
+        for (int r = 0; r < 16; ++r) pls[r] = ls1[r]; \
+        if constexpr (STORE) { \
+            if constexpr (PF == 2 && buf == 0) { \
+                pp.store(smem + (buf ^ 1) * T::BYTES, stB); \
+                if (tid < TILE_ROWS) lse_s[(buf ^ 1) * TILE_ROWS + tid] = lstB; \
+            } else { \
+                pp.store(smem + (buf ^ 1) * T::BYTES, stA); \
+                if (tid < TILE_ROWS) lse_s[(buf ^ 1) * TILE_ROWS + tid] = lstA; \
+            } \
+        } \
+        __syncthreads(); \
+    }
+    RTK_ISSUE(stA, lstA)
+    pp.store(smem, stA);
+    if (tid < TILE_ROWS) lse_s[tid] = lstA;
+    if (PF == 2 && ntiles > 1) RTK_ISSUE(stB, lstB)
     __syncthreads();
     int it = 0;
-    for (; it + 2 < ntiles; it += 2) {
-        step(true, 0);
-        step(true, 1);
+    for (; it + PF + 1 < ntiles; it += 2) {  // steady state: loads are unconditional => counted vmcnt waits
+        RTK_STEP2(0, true, true)
+        RTK_STEP2(1, true, true)
     }
-    for (; it < ntiles; ++it) step(it + 1 < ntiles, it & 1);
-    colsum_block<DT>(col, pend, pls, c2, sqrt_d);  // drain the pipeline
-    col += __shfl_xor(col, 32, WAVE);
-    const int j = j0 + (lane & 31);
-    if (hf == 0 && j < L) partial[((size_t)g * RS + rs) * L + j] = col;
+    // tail: at most PF + 1 tiles; `it` is even here, so the parities are static
+#define RTK_TAIL(PAR)                                        \
+    if (it < ntiles) {                                       \
+        if (it + PF < ntiles) RTK_STEP2(PAR, true, true)     \
+        else if (it + 1 < ntiles) RTK_STEP2(PAR, false, true) \
+        else RTK_STEP2(PAR, false, false)                    \
+        ++it;                                                \
+    }
+    RTK_TAIL(0)
+    RTK_TAIL(1)
+    RTK_TAIL(0)
+#undef RTK_TAIL
+#undef RTK_STEP2
+#undef RTK_ISSUE
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        colsum_block<DT>(col[nb], pend[nb], pls, c2, sqrt_d);  // drain the pipeline
+        col[nb] += __shfl_xor(col[nb], 32, WAVE);
+        const int j = j0 + 32 * nb + (lane & 31);
+        if (hf == 0 && j < L) partial[((size_t)g * RS + rs) * L + j] = col[nb];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -728,7 +834,8 @@ static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
     const size_t es = dtype == RTK_BF16 ? 2 : 4;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     ScoreWs w;
-    const int reg_tiles = (L + REG_ROWS - 1) / REG_ROWS, stream_tiles = (L + TILE_ROWS - 1) / TILE_ROWS;
+    const int nbr = REG_ROWS * (dtype == RTK_BF16 ? RegBlocks<RTK_BF16>::NB : RegBlocks<RTK_F32>::NB);
+    const int reg_tiles = (L + nbr - 1) / nbr, stream_tiles = (L + TILE_ROWS - 1) / TILE_ROWS;
     w.RS = (D == HD) ? pick_splits(reg_tiles, Hkv, stream_tiles, 32, Hkv) : 1;
     w.KS = (D == HD) ? pick_splits(reg_tiles, Hq, stream_tiles, 8, Hkv) : 1;
     w.q_off = 0;
@@ -782,26 +889,27 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
     int rs_n = 1;
     if (D == HD) {
         constexpr int TILE_BYTES = Tile<DT>::BYTES;
+        constexpr int NBR = RegBlocks<DT>::NB;
         constexpr int LDS1 = 2 * TILE_BYTES, LDS2 = 2 * TILE_BYTES + 2 * TILE_ROWS * (int)sizeof(float);
         static bool attr_set = false;  // > 64 KiB of dynamic LDS (fp32 tiles) needs the opt-in once
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)score_pass1_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
-            (void)hipFuncSetAttribute((const void*)score_pass2_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+            (void)hipFuncSetAttribute((const void*)score_pass1_kernel<DT, NBR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+            (void)hipFuncSetAttribute((const void*)score_pass2_kernel<DT, NBR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
             attr_set = true;
         }
-        const int jt = (L + REG_ROWS - 1) / REG_ROWS;
+        const int jt = (L + REG_ROWS * NBR - 1) / (REG_ROWS * NBR);
         auto per_split = [](int n, int parts) { return (((n + parts - 1) / parts + TILE_ROWS - 1) / TILE_ROWS) * TILE_ROWS; };
         const int kps = per_split(L, w.KS), rps = per_split(L, w.RS);
         const int ks_n = (L + kps - 1) / kps;  // non-empty splits only
         rs_n = (L + rps - 1) / rps;
-        RTK_LAUNCH(KID_PASS1, score_pass1_kernel<DT>, dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
+        RTK_LAUNCH(KID_PASS1, (score_pass1_kernel<DT, NBR>), dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
                    (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse);
         RTK_LAUNCH_CHECK("score_pass1_kernel");
         if (ks_n > 1) {
             const size_t n = (size_t)Hq * L;
             RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<DT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lse, n, ks_n);
         }
-        RTK_LAUNCH(KID_PASS2, score_pass2_kernel<DT>, dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
+        RTK_LAUNCH(KID_PASS2, (score_pass2_kernel<DT, NBR>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
                    (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
                    (int)((Hkv * rs_n) % NXCD == 0), part);
         RTK_LAUNCH_CHECK("score_pass2_kernel");
