@@ -174,6 +174,7 @@ int rtk_copy_rows(const void* src, int64_t src_stride_h, void* dst, int64_t dst_
  * the elapsed times into per-kernel totals.  Process-wide, off by default.
  * ------------------------------------------------------------------------------------------- */
 int rtk_profile_enable(int on);
+int rtk_profile_enable_mask(unsigned kernel_id_mask);   /* bit k = time kernel id k only; 0 = off */
 int rtk_profile_collect(void);
 int rtk_profile_reset(void);
 int rtk_profile_num_kernels(void);

@@ -145,7 +145,7 @@ def test_dpselect_window5_vs_oracle():
 # ---------------------------------------------------------------------------------------------------
 # PivotKV
 # ---------------------------------------------------------------------------------------------------
-def _make_cache(g, native_rope=False):
+def _make_cache(g, native_rope=False, overlap_streams=0):
     import retake.longvideo_cache as lc
 
     Hq, Hkv, D = int(g["Hq"]), int(g["Hkv"]), int(g["D"])
@@ -153,7 +153,8 @@ def _make_cache(g, native_rope=False):
                                 num_key_value_heads=Hkv)
     kw = {"kvcache_compression": True,
           "kvcache_compression_kwargs": {"compression_ratio": float(g["ratio"]), "compression_method": "pivotkv",
-                                         "pos_embed_reforge": bool(g["reforge"]), "native_rope": native_rope}}
+                                         "pos_embed_reforge": bool(g["reforge"]), "native_rope": native_rope,
+                                         "overlap_streams": overlap_streams}}
     sec = [int(s) for s in g["mrope_section"]] or None
     if sec is None:
         cfg = types.SimpleNamespace(text_config=llm, longvideo_kwargs=kw)  # LLaVA-style config
@@ -165,11 +166,11 @@ def _make_cache(g, native_rope=False):
     return cache, sec
 
 
-@pytest.mark.parametrize("native_rope", [False, True])
+@pytest.mark.parametrize("native_rope,overlap", [(False, 0), (True, 0), (False, 2)])
 @pytest.mark.parametrize("name", PK)
-def test_pivotkv_golden(name, native_rope):
+def test_pivotkv_golden(name, native_rope, overlap):
     g = gu.load(name)
-    cache, sec = _make_cache(g, native_rope)
+    cache, sec = _make_cache(g, native_rope, overlap)
     layer, keep, tie = int(g["layer"]), int(g["keep"]), bool(g["tie_case"])
     rotary = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]), device=dev())
     Hkv, D = int(g["Hkv"]), int(g["D"])
@@ -190,6 +191,7 @@ def test_pivotkv_golden(name, native_rope):
         assert kout.shape == (1, Hkv, prev_len + L, D) and vout.shape == kout.shape
         assert torch.equal(kout[:, :, prev_len:], kt) and torch.equal(vout[:, :, prev_len:], vt)  # uncompressed
         pre = f"c{c}_"
+        torch.cuda.synchronize()   # worker streams (overlap > 0) write the diagnostic scratch views
         score = cache.last_scores.cpu().numpy()
         idx = cache.last_keep_indices.cpu().numpy()
         assert np.abs(score - g[pre + "score32"]).max() < 5e-6

@@ -6,10 +6,12 @@ import sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(f"value={d['value']:.1f} {d['unit']}  ms_per_step={d['ms_per_step']:.1f}  n_gpus={d['n_gpus']} dtype={d['dtype']}")
 tot = 0.0
-for k, v in d.get("kernels", {}).items():
+for k, v in (d.get("kernels") or d.get("kernels_untimed_single_stream", {})).items():
     print(f"  {k:18s} n={v['launches']:5d} avg={v['avg_us']:8.1f} us total={v['total_ms']:8.1f} ms")
     tot += v["total_ms"]
-print(f"  kernel total {tot:.1f} ms over {d['steps']} step(s)")
+print(f"  kernel total {tot:.1f} ms (untimed single-stream segment)")
+for k, v in d.get("kernels_timed_region", {}).items():
+    print(f"  [timed] {k:18s} n={v['launches']:5d} avg={v['avg_us']:8.1f} us total={v['total_ms']:8.1f} ms")
 for k in ("roofline", "roofline_hbm_kernels", "cpu_baseline", "speedup_vs_cpu_baseline"):
     if k in d:
         print(k, d[k])

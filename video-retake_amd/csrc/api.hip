@@ -29,14 +29,14 @@ static const char* const kKernelNames[KID_COUNT] = {"dpselect_dis", "dpselect_se
                                                     "pivotkv_select", "evict_scan", "copy_rows"};
 struct ProfRec { int kid; hipEvent_t a, b; };
 static std::mutex g_pm;
-static bool g_prof = false;
+static unsigned g_prof = 0;  // bit k set = time kernel id k
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 static double g_total_ms[KID_COUNT];
 static long long g_count[KID_COUNT];
 static thread_local hipEvent_t g_open = nullptr;
 
-bool profile_on() { return g_prof; }
+bool profile_on(int kid) { return (g_prof >> kid) & 1u; }
 static hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -59,7 +59,13 @@ void profile_end(int kid, hipStream_t st) {
 
 extern "C" int rtk_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(rtk::g_pm);
-    rtk::g_prof = on != 0;
+    rtk::g_prof = on ? 0xffffffffu : 0u;
+    return RTK_OK;
+}
+// Time only the kernels whose id bit is set (ids = index into rtk_profile_kernel_name); 0 disables.
+extern "C" int rtk_profile_enable_mask(unsigned mask) {
+    std::lock_guard<std::mutex> lk(rtk::g_pm);
+    rtk::g_prof = mask;
     return RTK_OK;
 }
 // Waits for the recorded events, folds them into per-kernel totals and recycles them.

@@ -61,7 +61,7 @@ enum KernelId {
     KID_DIS = 0, KID_DPSEL, KID_GATHER, KID_ROPE, KID_UNROT, KID_PASS1, KID_PASS2, KID_FINALIZE, KID_PSEL, KID_EVICT,
     KID_COPY, KID_COUNT
 };
-bool profile_on();
+bool profile_on(int kid);
 void profile_begin(int kid, hipStream_t st);
 void profile_end(int kid, hipStream_t st);
 }  // namespace rtk
@@ -69,7 +69,7 @@ void profile_end(int kid, hipStream_t st);
 // launch `kern` on `st`; when profiling is enabled the launch is bracketed by two hipEvents on `st`
 #define RTK_LAUNCH(kid, kern, grid, block, shmem, st, ...)                       \
     do {                                                                         \
-        const bool prof__ = rtk::profile_on();                                   \
+        const bool prof__ = rtk::profile_on(kid);                                   \
         if (prof__) rtk::profile_begin(kid, st);                                 \
         hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);           \
         if (prof__) rtk::profile_end(kid, st);                                   \

@@ -39,6 +39,7 @@ _SIGNATURES = {
     "rtk_copy_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "rtk_pivotkv_commit": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "rtk_profile_enable": (C.c_int, [_i]),
+    "rtk_profile_enable_mask": (C.c_int, [C.c_uint]),
     "rtk_profile_collect": (C.c_int, []),
     "rtk_profile_reset": (C.c_int, []),
     "rtk_profile_num_kernels": (C.c_int, []),
@@ -105,6 +106,10 @@ def ptr(t):
 
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_kernel_ids() -> dict:
+    return {lib.rtk_profile_kernel_name(k).decode(): k for k in range(lib.rtk_profile_num_kernels())}
 
 
 def profile_read() -> dict:

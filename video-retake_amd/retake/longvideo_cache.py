@@ -142,7 +142,7 @@ DynamicCache = _HFDynamicCache if _hf_dynamic_cache_is_legacy() else _ListDynami
 class _LayerStore:
     """One layer's pre-allocated K/V buffers [1, Hkv, cap, D] plus the staged kept rows."""
 
-    __slots__ = ("k", "v", "length", "pending", "k_stage", "v_stage", "pending_keep")
+    __slots__ = ("k", "v", "length", "pending", "k_stage", "v_stage", "pending_keep", "pending_event", "pending_pos")
 
     def __init__(self):
         self.k = self.v = None
@@ -150,6 +150,16 @@ class _LayerStore:
         self.pending = 0         # uncompressed chunk tokens sitting at [length, length+pending)
         self.k_stage = self.v_stage = None
         self.pending_keep = 0
+        self.pending_event = None  # side-stream completion of the staged rows (overlap_streams > 0)
+        self.pending_pos = None    # compressed position ids not yet appended to position_cache
+
+
+class _Side:
+    """A worker stream with its own scratch buffers (overlap_streams > 0)."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.ws: Dict[str, torch.Tensor] = {}
 
 
 class _CacheView:
@@ -215,7 +225,14 @@ class PivotKVCache(DynamicCache):
         # MI355X build option: compute cos/sin tables in a HIP kernel from rotary_emb.inv_freq instead of
         # calling the rotary module (valid for the default / YaRN inv_freq*position rotary modules)
         self.native_rope = bool(kv_compression_kwargs.get("native_rope", False))
-        self.position_cache: List[torch.Tensor] = []
+        # MI355X build option: run scoring / selection / eviction of each update on one of N worker HIP
+        # streams.  Only the tail append stays on the caller's stream (it is all the layer's attention
+        # needs); the staged rows are committed after waiting for the worker's event.  Independent
+        # updates then overlap on the GPU (the one-workgroup select kernel hides under MFMA kernels).
+        self.overlap_streams = int(kv_compression_kwargs.get("overlap_streams", 0))
+        self._sides: List[_Side] = []
+        self._side_rr = 0
+        self._position_cache: List[torch.Tensor] = []
         self.num_evicted_tokens: List[int] = []
         self.keypatches_mask_chunk = None
         self._ws: Dict[str, torch.Tensor] = {}
@@ -273,6 +290,18 @@ class PivotKVCache(DynamicCache):
         for i in range(len(self)):
             yield self[i]
 
+    @property
+    def position_cache(self):
+        """Per-layer position ids of the cached tokens (reference :143).  Reading it flushes deferred work."""
+        for i in range(len(self._layers)):
+            if self._layers[i].pending_pos is not None:
+                self._commit(i)
+        return self._position_cache
+
+    @position_cache.setter
+    def position_cache(self, value):
+        self._position_cache = value
+
     # ---- hooks (reference :146-150): after_forward is where deferred compaction is flushed -------
     def before_forward(self, **kwargs):
         pass
@@ -294,20 +323,23 @@ class PivotKVCache(DynamicCache):
     def update_position_ids(self, position_ids: torch.Tensor, layer_idx: int):
         """position_cache[layer] = cat(prev, position_ids, dim=-1), padding skipped layers with []
         (longvideo_cache.py:179-209)."""
-        if len(self.position_cache) <= layer_idx:
-            self.position_cache.extend([[] for _ in range(layer_idx - len(self.position_cache))])
-            self.position_cache.append(position_ids)
-        elif len(self.position_cache[layer_idx]) == 0:
-            self.position_cache[layer_idx] = position_ids
+        pc = self._position_cache
+        if len(pc) <= layer_idx:
+            pc.extend([[] for _ in range(layer_idx - len(pc))])
+            pc.append(position_ids)
+        elif len(pc[layer_idx]) == 0:
+            pc[layer_idx] = position_ids
         else:
-            self.position_cache[layer_idx] = torch.cat([self.position_cache[layer_idx], position_ids], dim=-1)
-        return self.position_cache[layer_idx]
+            pc[layer_idx] = torch.cat([pc[layer_idx], position_ids], dim=-1)
+        return pc[layer_idx]
 
     def get_prev_temporal_idx(self, layer_idx: int):
         """Last temporal id stored for the layer, -1 if none (longvideo_cache.py:211-215)."""
-        if len(self.position_cache) <= layer_idx:
+        if len(self._layers) > layer_idx and self._layers[layer_idx].pending_pos is not None:
+            self._commit(layer_idx)  # ids of the previous chunk are still on a worker stream
+        if len(self._position_cache) <= layer_idx:
             return -1
-        cache_layer = self.position_cache[layer_idx]
+        cache_layer = self._position_cache[layer_idx]
         return cache_layer[0, 0, -1] if cache_layer.ndim == 3 else cache_layer[0, -1]
 
     # ---- storage -------------------------------------------------------------------------------
@@ -341,6 +373,13 @@ class PivotKVCache(DynamicCache):
         cap = st.k.shape[2]
         off = st.length * D * st.k.element_size()
         with torch.cuda.device(st.k.device):
+            if st.pending_event is not None:  # staged rows were produced on a worker stream
+                torch.cuda.current_stream().wait_event(st.pending_event)
+                st.pending_event = None
+            if st.pending_pos is not None:
+                st.pending_pos.record_stream(torch.cuda.current_stream())
+                self.update_position_ids(st.pending_pos, layer_idx)
+                st.pending_pos = None
             s = nv.stream()
             dt = nv.dtype_code(st.k)
             sst = st.k_stage.shape[2] * D  # staging head stride (its capacity may exceed this chunk's keep)
@@ -351,21 +390,31 @@ class PivotKVCache(DynamicCache):
         st.pending = 0
         st.pending_keep = 0
 
-    def _buf(self, name: str, shape, dtype, device) -> torch.Tensor:
-        t = self._ws.get(name)
+    def _next_side(self, device) -> Optional[_Side]:
+        if self.overlap_streams <= 0:
+            return None
+        while len(self._sides) < self.overlap_streams:
+            self._sides.append(_Side(device))
+        side = self._sides[self._side_rr % len(self._sides)]
+        self._side_rr += 1
+        return side
+
+    def _buf(self, name: str, shape, dtype, device, ws: Optional[dict] = None) -> torch.Tensor:
+        ws = self._ws if ws is None else ws
+        t = ws.get(name)
         n = 1
         for s in shape:
             n *= s
         if t is None or t.numel() < n or t.dtype != dtype or t.device != device:
             t = torch.empty(max(n, 1), dtype=dtype, device=device)
-            self._ws[name] = t
+            ws[name] = t
         return t[:n].view(*shape)
 
-    def _rope_tables(self, name, rotary_emb_fn, x_like, position_ids, mrope_section, n, D):
+    def _rope_tables(self, name, rotary_emb_fn, x_like, position_ids, mrope_section, n, D, ws=None):
         """fp32 [n, D] cos/sin tables of `position_ids`, section-merged (reference :249 + :68-74)."""
         dev = x_like.device
-        cos_t = self._buf(name + "_cos", (n, D), torch.float32, dev)
-        sin_t = self._buf(name + "_sin", (n, D), torch.float32, dev)
+        cos_t = self._buf(name + "_cos", (n, D), torch.float32, dev, ws)
+        sin_t = self._buf(name + "_sin", (n, D), torch.float32, dev, ws)
         P = 3 if position_ids.ndim == 3 else 1
         sec = (C.c_int * len(mrope_section))(*mrope_section) if mrope_section else None
         nsec = len(mrope_section) if mrope_section else 0
@@ -446,17 +495,29 @@ class PivotKVCache(DynamicCache):
                 raise ValueError("q/k/v must be contiguous along head_dim")
         keep_len = max(1, int(self.compression_ratio * q_len))  # evict new tokens only (reference :263)
 
-        with torch.cuda.device(dev):
+        mask = getattr(self, "keypatches_mask_chunk", None)
+        if mask is not None:
+            nv.require_device(mask)
+            if mask.dtype != torch.bool or not mask.is_contiguous():
+                mask = mask.to(torch.bool).contiguous()
+            assert mask.numel() == L, "keypatches_mask_chunk must have one entry per chunk token"
+        if st.k_stage is None or st.k_stage.shape[2] < keep_len or st.k_stage.dtype != key_states.dtype:
+            st.k_stage = torch.empty((1, Hkv, keep_len, D), dtype=key_states.dtype, device=dev)
+            st.v_stage = torch.empty((1, Hkv, keep_len, D), dtype=key_states.dtype, device=dev)
+
+        def compress(ws, append_tail: bool):
+            """score -> select -> eviction scan on the CURRENT stream, scratch from `ws`."""
             s = nv.stream()
             cos_t = sin_t = None
             if self.pos_embed_reforge:
-                cos_t, sin_t = self._rope_tables("old", rotary_emb_fn, value_states, position_ids, mrope_section, L, D)
+                cos_t, sin_t = self._rope_tables("old", rotary_emb_fn, value_states, position_ids, mrope_section, L, D,
+                                                 ws)
             # 2) score (reference :248-270)
             ws_bytes = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
-            ws = self._buf("score_ws", (ws_bytes + 256,), torch.uint8, dev)
-            ws_ptr = (ws.data_ptr() + 255) & ~255
-            score = self._buf("score", (L,), torch.float32, dev)
-            k_unrot = self._buf("k_unrot", (Hkv, L, D), key_states.dtype, dev)
+            wsb = self._buf("score_ws", (ws_bytes + 256,), torch.uint8, dev, ws)
+            ws_ptr = (wsb.data_ptr() + 255) & ~255
+            score = self._buf("score", (L,), torch.float32, dev, ws)
+            k_unrot = self._buf("k_unrot", (Hkv, L, D), key_states.dtype, dev, ws)
             nv.check(nv.lib.rtk_pivotkv_score(
                 nv.ptr(query_states), query_states.stride(1), query_states.stride(2),
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
@@ -464,14 +525,8 @@ class PivotKVCache(DynamicCache):
                 float(getattr(rotary_emb_fn, "attention_scaling", 1.0)) if self.pos_embed_reforge else 1.0,
                 nv.ptr(score), nv.ptr(k_unrot), C.c_void_p(ws_ptr), ws_bytes, s), "rtk_pivotkv_score")
             # 3) mask override + top-k + position ids (reference :272-295)
-            mask = getattr(self, "keypatches_mask_chunk", None)
-            if mask is not None:
-                nv.require_device(mask)
-                if mask.dtype != torch.bool or not mask.is_contiguous():
-                    mask = mask.to(torch.bool).contiguous()
-                assert mask.numel() == L, "keypatches_mask_chunk must have one entry per chunk token"
-            keep_idx = self._buf("keep_idx", (keep_len,), torch.int64, dev)
-            rank = self._buf("rank", (L,), torch.int32, dev)
+            keep_idx = self._buf("keep_idx", (keep_len,), torch.int64, dev, ws)
+            rank = self._buf("rank", (L,), torch.int32, dev, ws)
             pos_in = pos_out = None
             Pn = 0
             if position_ids is not None:
@@ -479,39 +534,57 @@ class PivotKVCache(DynamicCache):
                 pos_in = position_ids.reshape(Pn, L)
                 if not pos_in.is_contiguous():
                     pos_in = pos_in.contiguous()
-                # fresh tensor: it becomes part of position_cache
-                pos_out = torch.empty((Pn, keep_len), dtype=torch.int64, device=dev)
+                pos_out = torch.empty((Pn, keep_len), dtype=torch.int64, device=dev)  # becomes part of position_cache
             nv.check(nv.lib.rtk_pivotkv_select(nv.ptr(score), nv.ptr(mask), L, keep_len, nv.ptr(pos_in), Pn,
                                                int(bool(self.pos_embed_reforge)), nv.ptr(keep_idx), nv.ptr(rank),
                                                nv.ptr(pos_out), s), "rtk_pivotkv_select")
-            compressed_position_ids = None
+            cpos = None
             if pos_out is not None:
-                compressed_position_ids = pos_out.view(3, 1, keep_len) if Pn == 3 else pos_out.view(1, keep_len)
-            # 4) eviction scan: append + gather (+ re-rotate at the new ids) (reference :238, :278-306)
+                cpos = pos_out.view(3, 1, keep_len) if Pn == 3 else pos_out.view(1, keep_len)
+            # 4) eviction scan: (append +) gather (+ re-rotate at the new ids) (reference :238, :278-306)
             cos_n = sin_n = None
             if self.pos_embed_reforge:
-                cos_n, sin_n = self._rope_tables("new", rotary_emb_fn, value_states[:, :, :1], compressed_position_ids,
-                                                 mrope_section, keep_len, D)
-            if st.k_stage is None or st.k_stage.shape[2] < keep_len or st.k_stage.dtype != key_states.dtype:
-                st.k_stage = torch.empty((1, Hkv, keep_len, D), dtype=key_states.dtype, device=dev)
-                st.v_stage = torch.empty((1, Hkv, keep_len, D), dtype=key_states.dtype, device=dev)
+                cos_n, sin_n = self._rope_tables("new", rotary_emb_fn, value_states[:, :, :1], cpos, mrope_section,
+                                                 keep_len, D, ws)
             cap = st.k.shape[2]
             esz = st.k.element_size()
+            k_tail = C.c_void_p(st.k.data_ptr() + P0 * D * esz) if append_tail else None
+            v_tail = C.c_void_p(st.v.data_ptr() + P0 * D * esz) if append_tail else None
             nv.check(nv.lib.rtk_pivotkv_evict(
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
                 nv.ptr(value_states), value_states.stride(1), value_states.stride(2),
                 nv.ptr(k_unrot), Hkv, L, D, dt, nv.ptr(rank), keep_len, nv.ptr(cos_n), nv.ptr(sin_n),
-                C.c_void_p(st.k.data_ptr() + P0 * D * esz), C.c_void_p(st.v.data_ptr() + P0 * D * esz), cap * D,
-                nv.ptr(st.k_stage), nv.ptr(st.v_stage), st.k_stage.shape[2] * D, s), "rtk_pivotkv_evict")
+                k_tail, v_tail, cap * D, nv.ptr(st.k_stage), nv.ptr(st.v_stage), st.k_stage.shape[2] * D, s),
+                "rtk_pivotkv_evict")
+            self.last_keep_indices = keep_idx  # scratch views, valid until the worker's next update (diagnostics)
+            self.last_scores = score
+            return cpos
 
-        # bookkeeping (reference :308-310)
-        if self.pos_embed_reforge:
-            self.update_position_ids(compressed_position_ids, layer_idx)
-        self.update_num_evicted_tokens(k_len - keep_len, layer_idx)
+        with torch.cuda.device(dev):
+            side = self._next_side(dev)
+            if side is None:
+                compressed_position_ids = compress(self._ws, append_tail=True)
+                if self.pos_embed_reforge:  # bookkeeping (reference :308-309)
+                    self.update_position_ids(compressed_position_ids, layer_idx)
+            else:
+                main = torch.cuda.current_stream()
+                st.k[:, :, P0:P0 + n_new].copy_(key_states)      # the append is all this layer's attention needs
+                st.v[:, :, P0:P0 + n_new].copy_(value_states)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                for t in (query_states, key_states, value_states, position_ids, mask):
+                    if t is not None:
+                        t.record_stream(side.stream)
+                with torch.cuda.stream(side.stream):
+                    side.stream.wait_event(ready)
+                    compressed_position_ids = compress(side.ws, append_tail=False)
+                    done = torch.cuda.Event()
+                    done.record(side.stream)
+                st.pending_event = done
+                st.pending_pos = compressed_position_ids if self.pos_embed_reforge else None
+        self.update_num_evicted_tokens(k_len - keep_len, layer_idx)  # reference :310
         st.pending = n_new
         st.pending_keep = keep_len
-        self.last_keep_indices = keep_idx  # workspace view, valid until the next update (tests / diagnostics)
-        self.last_scores = score
         return st.k[:, :, :P0 + n_new], st.v[:, :, :P0 + n_new]
 
 
