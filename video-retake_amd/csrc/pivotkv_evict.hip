@@ -96,10 +96,13 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* 
     const int per = (L + PSEL_BLOCK - 1) / PSEL_BLOCK;  // <= E
     const int base = tid * per;
     uint32_t key[E];
+    long long t0[E];   // temporal ids of this thread's tokens (reforge): tmin and the rescale need no re-read
+    const bool rf = pos && reforge;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = base + e;
         key[e] = 0;
+        t0[e] = 0;
         if (e < per && i < L) {
             float sc = score[i];
             if (mask && mask[i]) {  // attn_weights.masked_fill_(mask, 1.)  (:274)
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* 
                 score[i] = sc;
             }
             key[e] = f2key(sc);
+            if (rf) t0[e] = pos[i];
         }
     }
     auto valid = [&](int e) { return e < per && base + e < L; };
@@ -117,9 +121,25 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* 
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (tid < 256) sm.hist[tid] = 0;
         __syncthreads();
+        // Scores cluster (mean 1.0), so in the leading passes most lanes of a wave hit the SAME bin and plain
+        // LDS atomics would serialise 64-way.  Peel up to two popular digits per wave with a ballot (one
+        // atomic each, adding the population count); the remaining lanes use ordinary atomics.
 #pragma unroll
-        for (int e = 0; e < E; ++e)
-            if (valid(e) && (key[e] & pmask) == prefix) atomicAdd(&sm.hist[(key[e] >> shift) & 255u], 1u);
+        for (int e = 0; e < E; ++e) {
+            const bool m = valid(e) && (key[e] & pmask) == prefix;
+            const uint32_t d = (key[e] >> shift) & 255u;
+            unsigned long long todo = __ballot(m);
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                if (todo == 0) break;                                   // wave-uniform
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t dl = __shfl(d, leader, WAVE);
+                const unsigned long long grp = __ballot(m && d == dl) & todo;
+                if ((tid & (WAVE - 1)) == leader) atomicAdd(&sm.hist[dl], (uint32_t)__popcll(grp));
+                todo &= ~grp;
+            }
+            if ((todo >> (tid & (WAVE - 1))) & 1ull) atomicAdd(&sm.hist[d], 1u);
+        }
         __syncthreads();
         if (tid < WAVE) {
             const int lane = tid;
@@ -161,38 +181,48 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* 
     const int eq_before = block_excl_scan_1024(cnt_eq, wtot, tid);
     const int eq_take = max(0, min(cnt_eq, need_eq - eq_before));  // ties: lowest index first
     int r = block_excl_scan_1024(cnt_gt + eq_take, wtot, tid);
-    int eq_seen = 0;
+    // selection flags of this thread's tokens (bit e), and min_temp_id over the kept tokens (:293)
+    unsigned selbits = 0;
+    long long mn = 0x7fffffffffffffffLL;
+    {
+        int eq_seen = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (!valid(e)) continue;
+            bool sel = key[e] > thr;
+            if (key[e] == thr) sel = eq_seen++ < eq_take;
+            if (sel) {
+                selbits |= 1u << e;
+                mn = min(mn, t0[e]);
+            }
+        }
+    }
+    if (rf) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long t = __shfl_xor(mn, o, WAVE);
+            mn = min(mn, t);
+        }
+        if ((tid & (WAVE - 1)) == 0) red[tid / WAVE] = mn;
+        __syncthreads();
+        mn = red[0];
+        for (int w = 1; w < PSEL_BLOCK / WAVE; ++w) mn = min(mn, red[w]);
+    }
+    const float ratio = (float)((double)keep / (double)L);  // comp_ratio = keep_len / k_len (:294)
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         if (!valid(e)) continue;
         const int i = base + e;
-        bool sel = key[e] > thr;
-        if (key[e] == thr) sel = eq_seen++ < eq_take;
-        if (sel) {
+        if ((selbits >> e) & 1u) {
             keep_idx[r] = i;  // topk(keep).sort()  (:276-277)
-            if (pos)
-                for (int p = 0; p < P; ++p) pos_out[(size_t)p * keep + r] = pos[(size_t)p * L + i];  // :283-288
+            if (pos) {
+                // row 0: gathered id, rescaled when reforging: int64 -> float32 multiply -> truncation (:293-295)
+                pos_out[r] = rf ? mn + (long long)((float)(t0[e] - mn) * ratio) : (long long)pos[i];
+                for (int p = 1; p < P; ++p) pos_out[(size_t)p * keep + r] = pos[(size_t)p * L + i];  // :283-288
+            }
             rank[i] = r++;
         } else {
             rank[i] = -1;
         }
-    }
-    if (!(pos && reforge)) return;
-    __syncthreads();
-    long long mn = 0x7fffffffffffffffLL;  // min_temp_id = compressed_position_ids[0].min()  (:293)
-    for (int rr = tid; rr < keep; rr += PSEL_BLOCK) mn = min(mn, (long long)pos_out[rr]);
-    for (int o = 32; o > 0; o >>= 1) {
-        const long long t = __shfl_xor(mn, o, WAVE);
-        mn = min(mn, t);
-    }
-    if ((tid & (WAVE - 1)) == 0) red[tid / WAVE] = mn;
-    __syncthreads();
-    mn = red[0];
-    for (int w = 1; w < PSEL_BLOCK / WAVE; ++w) mn = min(mn, red[w]);
-    const float ratio = (float)((double)keep / (double)L);  // :294-295, float32 multiply then truncation
-    for (int rr = tid; rr < keep; rr += PSEL_BLOCK) {
-        const float f = (float)((long long)pos_out[rr] - mn) * ratio;
-        pos_out[rr] = mn + (long long)f;
     }
 }
 

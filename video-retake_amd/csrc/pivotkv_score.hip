@@ -28,6 +28,13 @@
 
 namespace rtk {
 
+#ifdef RTK_TIMING  // instrumentation builds only (tools/variants.sh): per-phase wave cycles of score_pass1
+__device__ unsigned long long g_timing[8];
+#define RTK_T(var) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#else
+#define RTK_T(var)
+#endif
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
@@ -68,7 +75,7 @@ template <> struct Vec16<RTK_BF16> {
     }
 };
 
-constexpr int UNROT_HEADS = 8;
+constexpr int UNROT_HEADS = 4;
 
 template <int DT>
 __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __restrict__ q, int64_t q_sh, int64_t q_sl,
@@ -102,20 +109,29 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
             *(float4*)(s2 + e) = *(const float4*)(sinv + (size_t)l * D + d + h2 + e);
         }
     }
-    const int hb = hg * UNROT_HEADS, he = min(H, hb + UNROT_HEADS);
-#pragma unroll 4
-    for (int h = hb; h < he; ++h) {
+    const int hb = hg * UNROT_HEADS;
+    // all loads first (UNROT_HEADS independent row pairs in flight), then the arithmetic and the stores
+    u32x4 lo[UNROT_HEADS], hi[UNROT_HEADS];
+#pragma unroll
+    for (int u = 0; u < UNROT_HEADS; ++u) {
+        const int h = min(hb + u, H - 1);
         const char* row = src + ((size_t)h * sh + (size_t)l * sl) * ES;
-        const u32x4 lo = *(const u32x4*)(row + (size_t)d * ES), hi = *(const u32x4*)(row + (size_t)(d + h2) * ES);
+        lo[u] = *(const u32x4*)(row + (size_t)d * ES);
+        hi[u] = *(const u32x4*)(row + (size_t)(d + h2) * ES);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROT_HEADS; ++u) {
+        const int h = hb + u;
+        if (h >= H) break;
         char* orow = dst + ((size_t)h * L + l) * D * ES;
         if (!cosv) {
-            *(u32x4*)(orow + (size_t)d * ES) = lo;
-            *(u32x4*)(orow + (size_t)(d + h2) * ES) = hi;
+            *(u32x4*)(orow + (size_t)d * ES) = lo[u];
+            *(u32x4*)(orow + (size_t)(d + h2) * ES) = hi[u];
             continue;
         }
         float x1[VE], x2[VE], o1[VE], o2[VE];
-        V::unpack(lo, x1);
-        V::unpack(hi, x2);
+        V::unpack(lo[u], x1);
+        V::unpack(hi[u], x2);
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
             // rotate_half(x)[d] = -x2, rotate_half(x)[d+h2] = x1   (longvideo_cache.py:28-32)
@@ -375,9 +391,15 @@ struct RowStat {  // online max / sum of one query row, over the keys this lane 
 //        needs ~250 VGPRs (1-2 waves per SIMD): no gain over NB = 1 with 2-3 waves.
 //   PF = how many streamed tiles ahead the global loads run (register staging sets, counted vmcnt waits).
 //        PF = 2 did not help either: the kernels are bound by instruction issue, not by load latency.
+#ifndef RTK_NB_BF16
+#define RTK_NB_BF16 1
+#endif
+#ifndef RTK_PF_BF16
+#define RTK_PF_BF16 1
+#endif
 template <int DT> struct RegBlocks {
-    static constexpr int NB = 1;
-    static constexpr int PF = 1;
+    static constexpr int NB = (DT == RTK_BF16) ? RTK_NB_BF16 : 1;
+    static constexpr int PF = (DT == RTK_BF16) ? RTK_PF_BF16 : 1;
 };
 
 template <int DT, int NB>
@@ -441,6 +463,17 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass1_kernel(const char* __res
     // measured equal here).  Tile jt is computed from LDS buffer jt & 1 while the loads of tile jt + PF are
     // in flight; tile jt + 1 (loaded one step earlier when PF == 2) is written to the other buffer.
     // ISSUE / STORE are compile-time in the steady-state loop: no load sits inside a conditional there.
+#ifdef RTK_TIMING
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0, tnow = 0;
+    RTK_T(tprev);
+#define RTK_TM(k) { RTK_T(tnow); tacc[k] += tnow - tprev; tprev = tnow; }
+#define RTK_TA(x, y) asm volatile("" : "+v"(x), "+v"(y));
+#define RTK_TS(x) asm volatile("" : "+v"(x));
+#else
+#define RTK_TM(k)
+#define RTK_TA(x, y)
+#define RTK_TS(x)
+#endif
 #define RTK_STEP1(JT, PAR, ISSUE, STORE) \
     { \
         constexpr int par = PAR; \
@@ -450,6 +483,7 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass1_kernel(const char* __res
             if constexpr (PF == 2 && par == 1) RTK_LOAD_TILE((JT) + PF, stB); \
             else RTK_LOAD_TILE((JT) + PF, stA); \
         } \
+        RTK_TM(0) \
         f32x16 acc0[NB], acc1[NB]; \
         { \
             u32x4 a[M::NREG]; \
@@ -460,16 +494,20 @@ _Pragma("unroll") \
 _Pragma("unroll") \
             for (int nb = 0; nb < NB; ++nb) { acc1[nb] = f32x16{0}; pp.mma_frags(acc1[nb], a, qf[nb]); } \
         } \
+        RTK_TA(acc0[0], acc1[0]) RTK_TM(1) \
 _Pragma("unroll") \
         for (int nb = 0; nb < NB; ++nb) { \
             if ((JT) < nfull) rs[nb].template update<false>(acc0[nb], acc1[nb], 0, 0, hf, c2, sqrt_d); \
             else rs[nb].template update<true>(acc0[nb], acc1[nb], (JT) * TILE_ROWS, nkeys, hf, c2, sqrt_d); \
         } \
+        RTK_TS(rs[0].sum) RTK_TM(2) \
         if constexpr (STORE) { \
             if constexpr (PF == 2 && par == 0) pp.store(nxt, stB); \
             else pp.store(nxt, stA); \
         } \
+        RTK_TM(3) \
         __syncthreads(); \
+        RTK_TM(4) \
     }
     int jt = 0;
     for (; jt + PF + 1 < ntiles; jt += 2) {  // steady state, two tiles per trip (parities are constants)
@@ -491,6 +529,11 @@ _Pragma("unroll") \
 #undef RTK_TAIL
 #undef RTK_STEP1
 #undef RTK_LOAD_TILE
+#ifdef RTK_TIMING
+    if (lane == 0 && blockIdx.x % 64 == 7)
+        for (int kk = 0; kk < 5; ++kk) atomicAdd(&g_timing[kk], tacc[kk]);
+    if (lane == 0 && blockIdx.x % 64 == 7) atomicAdd(&g_timing[7], (unsigned long long)ntiles);
+#endif
 
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -849,6 +892,14 @@ static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
 }  // namespace rtk
 
 using namespace rtk;
+
+#ifdef RTK_TIMING
+extern "C" int rtk_debug_read_timing(unsigned long long* out8, int reset) {
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(rtk::g_timing), 64);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(rtk::g_timing), z, 64); }
+    return 0;
+}
+#endif
 
 extern "C" size_t rtk_pivotkv_score_workspace_bytes(int Hq, int Hkv, int L, int D, int dtype) {
     if (Hq < 1 || Hkv < 1 || L < 1 || D < 1) return 0;
