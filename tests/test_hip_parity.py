@@ -434,3 +434,77 @@ def test_sharded_blocks_reproduce_sequential_cache():
         assert torch.equal(p_all, seq.position_cache[l])
         assert torch.equal(v_all, seq.value_cache[l])
         assert (k_all - seq.key_cache[l]).abs().max().item() <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties (the oracle is too slow / too big here)
+# ---------------------------------------------------------------------------------------------------
+def test_dpselect_full_size_properties():
+    """[1, 2048, 196, 1280]: ratio 1.0 is the identity with a peak mask that obeys the stencil; ratio 0.5
+    keeps sorted, distinct frames per patch, prefers peaks, and is idempotent on its own selection."""
+    import retake.visual_compression as vc
+
+    T, N, C = 2048, 196, 1280
+    g = torch.Generator(device=dev()).manual_seed(3)
+    x = torch.randn((1, T, N, C), generator=g, device=dev())
+    out, mask, idx, dis, keys = vc.dpselect_stages(x, T, 3, False)
+    assert torch.equal(out, x)                                      # SURVEY A4
+    assert torch.equal(idx, torch.arange(T, device=dev())[:, None].expand(T, N))
+    d = dis.t()                                                     # [N, T]
+    left = torch.cat([torch.full((N, 1), -float("inf"), device=dev()), d[:, :-1]], 1)
+    right = torch.cat([d[:, 1:], torch.full((N, 1), -float("inf"), device=dev())], 1)
+    peaks = (d > left) & (d >= right)
+    assert torch.equal(mask.t(), peaks)                             # stencil == argrelmax rule
+    assert torch.equal(keys, d + 2.0 * peaks)                       # +2 bonus in fp32
+    assert float(dis[0].min()) == 1.0 and float(dis[0].max()) == 1.0
+    # cosine of consecutive rows, recomputed with torch on a slice (same formula, other summation order)
+    ref = 1 - torch.nn.functional.cosine_similarity(x[0, 99:131], x[0, 100:132], dim=-1)
+    assert (dis[100:132] - ref).abs().max().item() < 2e-6
+    t = T // 2
+    out2, mask2, idx2, _, keys2 = vc.dpselect_stages(x, t, 3, False)
+    assert bool((idx2[1:] > idx2[:-1]).all())                       # ascending, distinct per patch
+    kth = torch.gather(keys2, 1, idx2.t())                          # keys of the kept frames [N, t]
+    dropped = torch.ones((N, T), dtype=torch.bool, device=dev()).scatter_(1, idx2.t(), False)
+    assert bool((kth.min(1).values >= torch.where(dropped, keys2, torch.tensor(-1.0, device=dev())).max(1).values).all())
+    assert torch.equal(out2[0], torch.gather(x[0], 0, idx2[:, :, None].expand(t, N, C)))
+    assert torch.equal(mask2, torch.gather(peaks.t(), 0, idx2))
+
+
+def test_pivotkv_full_size_invariants():
+    """One layer, 8 chunks of L = 6272 (bf16): cache length, sorted kept indices, V rows are copies of the
+    chunk's rows at those indices, temporal ids are dense and monotone after reforging, scores mean 1."""
+    import bench as B
+    import retake.longvideo_cache as lc
+
+    L = B.FRAMES_PER_CHUNK * B.N_PATCH
+    keep = int(B.RATIO * L)
+    g = torch.Generator(device=dev()).manual_seed(11)
+    cache = lc.build_kvcache(B.make_cache_config(1))
+    rot = B.Rotary(dev())
+    last_t = -1
+    for c in range(8):
+        q, k, v = ((1.7 * torch.randn((1, h, L, B.D), generator=g, device=dev())).bfloat16() for h in (B.Hq, B.Hkv, B.Hkv))
+        pos = B.chunk_position_ids(c, dev()).clone()
+        prev = cache.get_prev_temporal_idx(0)
+        pos[0, 0, :] += (prev + 1) - pos[0, 0, 0]
+        cache.keypatches_mask_chunk = None
+        cache.update(k, v, 0, {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": B.MROPE})
+        torch.cuda.synchronize()
+        idx = cache.last_keep_indices.clone()
+        score = cache.last_scores.clone()
+        assert abs(float(score.mean()) - 1.0) < 1e-4                 # total softmax mass L over L columns (A12)
+        assert bool((idx[1:] > idx[:-1]).all()) and idx.numel() == keep
+        thr = score[idx].min()
+        rest = torch.ones(L, dtype=torch.bool, device=dev())
+        rest[idx] = False
+        assert float(score[rest].max()) <= float(thr)                # a true top-k
+        vc_ = cache.value_cache[0]
+        assert vc_.shape[2] == (c + 1) * keep
+        assert torch.equal(vc_[0, :, c * keep:], v[0][:, idx])
+        pc = cache.position_cache[0]
+        t_new = pc[0, 0, c * keep:]
+        assert int(t_new[0]) >= last_t + 1 and bool((t_new[1:] >= t_new[:-1]).all())
+        assert int(t_new[-1]) - int(t_new[0]) <= B.FRAMES_PER_CHUNK * B.RATIO   # 32 grids squeezed into <= 8 ids
+        assert torch.equal(pc[1:, 0, c * keep:], pos[1:, 0][:, idx])             # h / w ids untouched
+        last_t = int(t_new[-1])
+    assert cache.num_evicted_tokens == [8 * (L - keep)]

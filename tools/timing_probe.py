@@ -36,3 +36,20 @@ for it in range(3):
     for n, x in zip(names, v[:5]):
         print(f"   {n:20s} {x / tiles:9.1f} cycles/tile  ({100 * x / tot:5.1f} %)")
     print(f"   total per tile {tot / tiles:9.1f}")
+
+# ---- select kernel phases (single workgroup) ----
+if hasattr(lib, "rtk_debug_read_select_timing"):
+    keep = L // 4
+    mask = torch.rand(L, device=dev) < 0.3
+    pos = torch.arange(L, device=dev)[None].repeat(3, 1).contiguous()
+    keep_idx = torch.empty(keep, dtype=torch.int64, device=dev)
+    rank = torch.empty(L, dtype=torch.int32, device=dev)
+    pos_out = torch.empty((3, keep), dtype=torch.int64, device=dev)
+    for it in range(3):
+        nv.check(nv.lib.rtk_pivotkv_select(nv.ptr(score), nv.ptr(mask), L, keep, nv.ptr(pos), 3, 1, nv.ptr(keep_idx), nv.ptr(rank),
+                                           nv.ptr(pos_out), nv.stream()), "select")
+        torch.cuda.synchronize()
+        lib.rtk_debug_read_select_timing(out)
+        v = list(out)
+        print("select phases (cycles): load", v[1] - v[0], "radix", v[2] - v[1], "scan+min", v[3] - v[2], "emit", v[4] - v[3],
+              "total", v[4] - v[0])
