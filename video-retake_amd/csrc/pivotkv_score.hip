@@ -255,7 +255,7 @@ __device__ __forceinline__ void load_reg_frag(const char* __restrict__ base, int
 // Per-thread constants of the streamed-tile pipeline, computed once per kernel:
 //   frag_off[r]  LDS byte offset (inside a tile, block 0) of this lane's r-th A-fragment chunk
 //   st_off[u]    LDS byte offset where this thread stores its u-th staged chunk
-//   srow/src_col first staged row of this thread inside a tile and its byte column
+//   voff[u]      byte offset of the u-th staged chunk inside the tile's source rows (buffer-load voffset)
 // 16-byte chunks are XOR-swizzled by (row & 15): the 16 lanes of every ds_read_b128 lane group address
 // 16 distinct rows (mod 16) => 16 distinct 16-byte bank slots; no bank conflicts (SQ_LDS_BANK_CONFLICT = 0).
 template <int DT> struct Pipe {
@@ -263,34 +263,31 @@ template <int DT> struct Pipe {
     using T = Tile<DT>;
     int frag_off[M::NREG];
     int st_off[T::STAGE];
-    int src_col;  // byte offset of this thread's chunk inside a row
-    int srow;     // first staged row of this thread inside the tile
+    int voff[T::STAGE];  // byte offsets of this thread's staged chunks inside a tile's source rows
+    int srow;            // first staged row of this thread inside the tile
     __device__ __forceinline__ void init(int tid, int lane) {
         const int row = lane & 31, hf = lane >> 5;
 #pragma unroll
         for (int r = 0; r < M::NREG; ++r) frag_off[r] = row * T::ROWB + ((M::chunk_of(r, hf) ^ (row & 15)) * 16);
         srow = tid / M::CHUNKS;
         const int ch = tid % M::CHUNKS;
-        src_col = ch * 16;
 #pragma unroll
         for (int u = 0; u < T::STAGE; ++u) {
             const int rr = srow + u * T::ROWS_PER_STEP;
             st_off[u] = rr * T::ROWB + ((ch ^ (rr & 15)) * 16);
+            voff[u] = rr * T::ROWB + ch * 16;
         }
     }
-    // global -> registers (issued early, consumed late).  Branch-free: rows past `last_row` (ragged tile,
-    // end of the matrix) re-read row `last_row` — finite filler whose logits the callers mask out — so the
-    // compiler can keep COUNTED vmcnt waits across the software pipeline (a load inside a conditional
-    // forces vmcnt(0) at the join).
-    __device__ __forceinline__ void load(const char* __restrict__ mat, int first_row, int last_row, u32x4* st) const {
-#ifdef RTK_ABLATE_GLOAD  // ablation builds only: no global traffic in the steady state
-        if (first_row > 4096) return;
-#endif
+    // global -> registers (issued early, consumed late) through a buffer descriptor: the per-thread byte
+    // offsets are precomputed once, the tile offset travels in an SGPR, so a tile costs STAGE
+    // buffer_load_dwordx4 and no address arithmetic.  Branch-free: rows past the end of the matrix are out
+    // of the descriptor's range and read as zeros; rows past the caller's valid range hold finite filler
+    // whose logits the callers mask out.  (A load inside a conditional would force vmcnt(0) at the join.)
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int first_row, u32x4* st) const {
+        const int soff = first_row * T::ROWB;
 #pragma unroll
-        for (int u = 0; u < T::STAGE; ++u) {
-            const int row = min(first_row + srow + u * T::ROWS_PER_STEP, last_row);
-            st[u] = *(const u32x4*)(mat + (size_t)row * T::ROWB + src_col);
-        }
+        for (int u = 0; u < T::STAGE; ++u)
+            st[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[u], soff, 0));
     }
     __device__ __forceinline__ void store(char* lds_tile, const u32x4* st) const {
 #pragma unroll
@@ -451,8 +448,10 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass1_kernel(const char* __res
 
     constexpr int PF = RegBlocks<DT>::PF;
     u32x4 stA[T::STAGE], stB[T::STAGE];   // staging registers: set A holds even tiles, set B odd tiles (PF == 2)
-    const char* kmat = k + (size_t)g * L * HD * M::ESIZE;
-#define RTK_LOAD_TILE(t, dst) pp.load(kmat, jb + (t) * TILE_ROWS, L - 1, dst)
+    // descriptor over this KV group's [L, 128] key matrix (wave-uniform: kernel arguments and blockIdx only)
+    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(k + (size_t)g * L * HD * M::ESIZE), 0, L * HD * M::ESIZE, 0x00020000);
+#define RTK_LOAD_TILE(t, dst) pp.load(krsrc, jb + (t) * TILE_ROWS, dst)
     RTK_LOAD_TILE(0, stA);
     pp.store(smem, stA);
     if (PF == 2 && ntiles > 1) RTK_LOAD_TILE(1, stB);
@@ -572,6 +571,8 @@ __device__ __forceinline__ void colsum_block(float& col, const f32x16& acc, cons
     col += ls[0];
     return;
 #endif
+    // scalar fma / exp2 / add per logit: v_pk_fma_f32 / v_pk_add_f32 were measured 5-7 % SLOWER here
+    // (packed f32 ops cost extra issue slots beside MFMAs)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         if (DT == RTK_BF16) col += __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -ls[r]));
@@ -635,13 +636,14 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass2_kernel(const char* __res
 
     // cursor of the tile being prefetched: row tile inside the split, source pointers of the current head
     int nt = 0;
-    const int last_row = Hq * L - 1;  // last row of the whole q~ buffer (clamp target for ragged tiles)
+    const int last_row = Hq * L - 1;  // last row of the whole q~ buffer
+    const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, Hq * L * HD * M::ESIZE, 0x00020000);
     int nrow0 = (g * G) * L + ib;     // first buffer row of the cursor head's split
     // loads the cursor tile (+ this thread's lse element) into one staging set, then advances the cursor;
     // rows past the split end get lse = +inf: exp(s - inf) = 0 whatever filler the tile holds
 #define RTK_ISSUE(st, lst)                                                              \
     {                                                                                   \
-        pp.load(q, nrow0 + nt * TILE_ROWS, last_row, st);                               \
+        pp.load(qrsrc, nrow0 + nt * TILE_ROWS, st);                                     \
         const int r__ = nt * TILE_ROWS + (tid & (TILE_ROWS - 1));                       \
         lst = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : INFINITY;               \
         const bool wrap__ = (nt + 1 == tiles_per_head);                                 \
