@@ -128,7 +128,8 @@ int rtk_pivotkv_score(const void* q, int64_t q_stride_h, int64_t q_stride_l,
  *   score [L] fp32: entries with mask != 0 are overwritten with 1.0 IN PLACE (masked_fill_, :274);
  *   mask may be NULL.
  *   keep_idx [keep] int64 ascending = topk(keep).sort()  (ties: lowest index first)
- *   rank [L] int32: position of token l in keep_idx, or -1 if evicted (feeds rtk_pivotkv_evict)
+ *   rank [L] int32: position of token l in keep_idx, or -1 if evicted (inverse map, for callers that
+ *        scan tokens in order)
  *   pos [P,L] int64 (P = 3 M-RoPE rows t,h,w or 1), may be NULL together with pos_out;
  *   pos_out [P,keep] int64 = gathered ids; if reforge != 0 row 0 becomes
  *       tmin + (int64)((float)(t - tmin) * (float)(keep / (double)L))        (:293-295)  */
@@ -137,10 +138,11 @@ int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep,
                        int64_t* keep_idx, int32_t* rank, int64_t* pos_out, rtk_stream_t stream);
 
 /* P1, P8, P11, P13  longvideo_cache.py:238, :278-280, :297-306, :313-318 — the eviction scan.
- * One pass over the chunk's K and V rows:
+ * One launch over the chunk's K and V rows:
  *   every row l is appended to the cache tail   k_tail/v_tail[h][l]      (the uncompressed view the
  *                                                current layer's attention reads, :238)
- *   rows with rank[l] >= 0 are also written to  k_kept/v_kept[h][rank[l]] (the compacted cache, :313-318)
+ *   row keep_idx[r] is also written to          k_kept/v_kept[h][r]      (the compacted cache, :313-318)
+ *   keep_idx [keep] int64 ascending, as produced by rtk_pivotkv_select
  * With reforge (cos_new != NULL) the kept K row is taken from k_unrot (un-rotated, as produced by
  * rtk_pivotkv_score) and rotated forward with the fp32 [keep,D] tables of its NEW position:
  *   k' = (k~*cos_new) + (rotate_half(k~)*sin_new)          (:80-81, :113-114)
@@ -150,7 +152,7 @@ int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep,
 int rtk_pivotkv_evict(const void* k, int64_t k_stride_h, int64_t k_stride_l,
                       const void* v, int64_t v_stride_h, int64_t v_stride_l,
                       const void* k_unrot, int Hkv, int L, int D, int dtype,
-                      const int32_t* rank, int keep,
+                      const int64_t* keep_idx, int keep,
                       const float* cos_new, const float* sin_new,
                       void* k_tail, void* v_tail, int64_t tail_stride_h,
                       void* k_kept, void* v_kept, int64_t kept_stride_h,

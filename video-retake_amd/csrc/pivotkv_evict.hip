@@ -2,9 +2,9 @@
 // Replaces longvideo_cache.py:272-318 (masked_fill_, topk+sort, the three gathers, the temporal-id
 // rescale, the forward re-rotation and the two torch.cat cache rebuilds).
 //
-// Roofline: HBM-bound byte shuffling.  The scan kernel touches every K and V row of the chunk
-// exactly once with 16-byte coalesced accesses (8 lanes per bf16 row-half pair), appends it to the
-// pre-allocated cache tail and, for the kept 1/ratio of the rows, also emits the compacted row —
+// Roofline: HBM-bound byte shuffling.  One launch with two roles: the append blocks copy every K and
+// V row of the chunk to the pre-allocated cache tail with 16-byte coalesced accesses, the kept blocks
+// gather the kept 1/ratio of the rows (through keep_idx) into the compacted staging rows —
 // algorithmic bytes per (layer, chunk): 2*Hkv*L*D*s read + 2*Hkv*keep*D*s written (+ the tail
 // append 2*Hkv*L*D*s, which the reference pays as an O(cache) torch.cat).
 #include "common.cuh"
@@ -267,66 +267,86 @@ template <> struct Row16<RTK_BF16> {
     __device__ static float rnd(float x) { return rbf(x); }
 };
 
+// Two roles in one launch, so neither waits on the other's dependent loads:
+//   blocks [0, append_blocks)   append: every 16-byte chunk of the chunk's K and V rows -> cache tail
+//   blocks [append_blocks, ...) kept:   row r of the compacted cache <- token keep_idx[r]
+//                                       (V copy; K copy, or un-rotated K re-rotated at its new position)
 template <int DT>
 __global__ __launch_bounds__(256) void evict_scan_kernel(const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
                                                          const char* __restrict__ v, int64_t v_sh, int64_t v_sl,
                                                          const char* __restrict__ k_unrot, int Hkv, int L, int D,
-                                                         const int32_t* __restrict__ rank, int keep,
+                                                         const int64_t* __restrict__ keep_idx, int keep,
                                                          const float* __restrict__ cos_new,
                                                          const float* __restrict__ sin_new, char* __restrict__ k_tail,
                                                          char* __restrict__ v_tail, int64_t tail_sh,
                                                          char* __restrict__ k_kept, char* __restrict__ v_kept,
-                                                         int64_t kept_sh) {
+                                                         int64_t kept_sh, int append_blocks) {
     using R = Row16<DT>;
     constexpr int VE = R::VE;
     constexpr int ES = 16 / VE;
-    const int h2 = D / 2;
-    const int lpr = h2 / VE;  // lanes per row
-    const size_t total = (size_t)Hkv * L * lpr;
-    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(id % lpr);
-        const size_t hl = id / lpr;
-        const int l = (int)(hl % L), h = (int)(hl / L);
-        const int d = c * VE;
-        const char* kr = k + ((size_t)h * k_sh + (size_t)l * k_sl) * ES;
-        const char* vr = v + ((size_t)h * v_sh + (size_t)l * v_sl) * ES;
-        const u32x4 k_lo = *(const u32x4*)(kr + (size_t)d * ES), k_hi = *(const u32x4*)(kr + (size_t)(d + h2) * ES);
-        const u32x4 v_lo = *(const u32x4*)(vr + (size_t)d * ES), v_hi = *(const u32x4*)(vr + (size_t)(d + h2) * ES);
-        const int r = rank[l];
-        if (k_tail) {  // DynamicCache.update append (:238)
-            char* kt = k_tail + ((size_t)h * tail_sh + (size_t)l * D) * ES;
-            char* vt = v_tail + ((size_t)h * tail_sh + (size_t)l * D) * ES;
-            *(u32x4*)(kt + (size_t)d * ES) = k_lo;
-            *(u32x4*)(kt + (size_t)(d + h2) * ES) = k_hi;
-            *(u32x4*)(vt + (size_t)d * ES) = v_lo;
-            *(u32x4*)(vt + (size_t)(d + h2) * ES) = v_hi;
+    if ((int)blockIdx.x < append_blocks) {  // ---- append (DynamicCache.update, :238) ----
+        const int cpr = D / VE;             // 16-byte chunks per row
+        const size_t total = (size_t)Hkv * L * cpr;
+        for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+             id += (size_t)append_blocks * blockDim.x) {
+            const int c = (int)(id % cpr);
+            const size_t hl = id / cpr;
+            const int l = (int)(hl % L), h = (int)(hl / L);
+            const u32x4 kk = *(const u32x4*)(k + ((size_t)h * k_sh + (size_t)l * k_sl + (size_t)c * VE) * ES);
+            const u32x4 vv = *(const u32x4*)(v + ((size_t)h * v_sh + (size_t)l * v_sl + (size_t)c * VE) * ES);
+            const size_t dst = ((size_t)h * tail_sh + (size_t)l * D + (size_t)c * VE) * ES;
+            *(u32x4*)(k_tail + dst) = kk;
+            *(u32x4*)(v_tail + dst) = vv;
         }
-        if (r < 0) continue;  // evicted
+        return;
+    }
+    // ---- kept rows ----
+    const int h2 = D / 2;
+    const int lpr = h2 / VE;  // lanes per row: lane c owns chunk c of the first half + its rotation partner
+    const size_t total = (size_t)Hkv * keep * lpr;
+    const size_t nthreads = (size_t)(gridDim.x - append_blocks) * blockDim.x;
+    for (size_t id = (size_t)(blockIdx.x - append_blocks) * blockDim.x + threadIdx.x; id < total; id += nthreads) {
+        const int c = (int)(id % lpr);
+        const size_t hr = id / lpr;
+        const int r = (int)(hr % keep), h = (int)(hr / keep);
+        const int l = (int)keep_idx[r];
+        const int d = c * VE;
+        const char* vr = v + ((size_t)h * v_sh + (size_t)l * v_sl) * ES;
+        const u32x4 v_lo = *(const u32x4*)(vr + (size_t)d * ES), v_hi = *(const u32x4*)(vr + (size_t)(d + h2) * ES);
         char* kk = k_kept + ((size_t)h * kept_sh + (size_t)r * D) * ES;
         char* vk = v_kept + ((size_t)h * kept_sh + (size_t)r * D) * ES;
+        if (!cos_new) {  // torch.gather(key_states, 2, keep)  (:279)
+            const char* kr = k + ((size_t)h * k_sh + (size_t)l * k_sl) * ES;
+            const u32x4 k_lo = *(const u32x4*)(kr + (size_t)d * ES), k_hi = *(const u32x4*)(kr + (size_t)(d + h2) * ES);
+            *(u32x4*)(kk + (size_t)d * ES) = k_lo;
+            *(u32x4*)(kk + (size_t)(d + h2) * ES) = k_hi;
+        } else {         // reforge: kept K = un-rotated row rotated forward at its new position (:297-306)
+            const char* ur = k_unrot + ((size_t)h * L + l) * D * ES;
+            const u32x4 u_lo = *(const u32x4*)(ur + (size_t)d * ES), u_hi = *(const u32x4*)(ur + (size_t)(d + h2) * ES);
+            const float* cr = cos_new + (size_t)r * D;
+            const float* sr = sin_new + (size_t)r * D;
+            float c1[VE], s1[VE], c2[VE], s2[VE];
+#pragma unroll
+            for (int e = 0; e < VE; e += 4) {
+                *(float4*)(c1 + e) = *(const float4*)(cr + d + e);
+                *(float4*)(s1 + e) = *(const float4*)(sr + d + e);
+                *(float4*)(c2 + e) = *(const float4*)(cr + d + h2 + e);
+                *(float4*)(s2 + e) = *(const float4*)(sr + d + h2 + e);
+            }
+            float x1[VE], x2[VE], o1[VE], o2[VE];
+            R::unpack(u_lo, x1);
+            R::unpack(u_hi, x2);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                // (k*cos) + (rotate_half(k)*sin), one rounding per torch op, no fma contraction
+                o1[e] = R::rnd(__fadd_rn(R::rnd(__fmul_rn(x1[e], c1[e])), R::rnd(__fmul_rn(-x2[e], s1[e]))));
+                o2[e] = R::rnd(__fadd_rn(R::rnd(__fmul_rn(x2[e], c2[e])), R::rnd(__fmul_rn(x1[e], s2[e]))));
+            }
+            *(u32x4*)(kk + (size_t)d * ES) = R::pack(o1);
+            *(u32x4*)(kk + (size_t)(d + h2) * ES) = R::pack(o2);
+        }
         *(u32x4*)(vk + (size_t)d * ES) = v_lo;  // torch.gather(value_states, 2, keep)  (:280)
         *(u32x4*)(vk + (size_t)(d + h2) * ES) = v_hi;
-        if (!cos_new) {
-            *(u32x4*)(kk + (size_t)d * ES) = k_lo;  // torch.gather(key_states, 2, keep)  (:279)
-            *(u32x4*)(kk + (size_t)(d + h2) * ES) = k_hi;
-            continue;
-        }
-        // reforge: kept K = un-rotated row rotated forward at its new position (:297-306)
-        const char* ur = k_unrot + ((size_t)h * L + l) * D * ES;
-        float x1[VE], x2[VE], o1[VE], o2[VE];
-        R::unpack(*(const u32x4*)(ur + (size_t)d * ES), x1);
-        R::unpack(*(const u32x4*)(ur + (size_t)(d + h2) * ES), x2);
-        const float* cr = cos_new + (size_t)r * D;
-        const float* sr = sin_new + (size_t)r * D;
-#pragma unroll
-        for (int e = 0; e < VE; ++e) {
-            const float c1 = cr[d + e], s1 = sr[d + e], c2 = cr[d + h2 + e], s2 = sr[d + h2 + e];
-            // (k*cos) + (rotate_half(k)*sin), one rounding per torch op, no fma contraction
-            o1[e] = R::rnd(__fadd_rn(R::rnd(__fmul_rn(x1[e], c1)), R::rnd(__fmul_rn(-x2[e], s1))));
-            o2[e] = R::rnd(__fadd_rn(R::rnd(__fmul_rn(x2[e], c2)), R::rnd(__fmul_rn(x1[e], s2))));
-        }
-        *(u32x4*)(kk + (size_t)d * ES) = R::pack(o1);
-        *(u32x4*)(kk + (size_t)(d + h2) * ES) = R::pack(o2);
     }
 }
 
@@ -416,10 +436,10 @@ extern "C" int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int 
 
 extern "C" int rtk_pivotkv_evict(const void* k, int64_t k_stride_h, int64_t k_stride_l, const void* v,
                                  int64_t v_stride_h, int64_t v_stride_l, const void* k_unrot, int Hkv, int L, int D,
-                                 int dtype, const int32_t* rank, int keep, const float* cos_new, const float* sin_new,
-                                 void* k_tail, void* v_tail, int64_t tail_stride_h, void* k_kept, void* v_kept,
-                                 int64_t kept_stride_h, rtk_stream_t stream) {
-    RTK_CHECK_ARG(k && v && rank && k_kept && v_kept, "rtk_pivotkv_evict: NULL pointer");
+                                 int dtype, const int64_t* keep_idx, int keep, const float* cos_new,
+                                 const float* sin_new, void* k_tail, void* v_tail, int64_t tail_stride_h, void* k_kept,
+                                 void* v_kept, int64_t kept_stride_h, rtk_stream_t stream) {
+    RTK_CHECK_ARG(k && v && keep_idx && k_kept && v_kept, "rtk_pivotkv_evict: NULL pointer");
     RTK_CHECK_ARG(Hkv >= 1 && L >= 1 && keep >= 1 && keep <= L, "rtk_pivotkv_evict: bad shape");
     RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_evict: unsupported dtype %d", dtype);
     RTK_CHECK_ARG((cos_new == nullptr) == (sin_new == nullptr), "rtk_pivotkv_evict: cos_new and sin_new go together");
@@ -434,24 +454,26 @@ extern "C" int rtk_pivotkv_evict(const void* k, int64_t k_stride_h, int64_t k_st
     const bool aligned = (k_stride_h * es) % 16 == 0 && (k_stride_l * es) % 16 == 0 && (v_stride_h * es) % 16 == 0 &&
                          (v_stride_l * es) % 16 == 0 && (tail_stride_h * es) % 16 == 0 && (kept_stride_h * es) % 16 == 0 &&
                          (((uintptr_t)k | (uintptr_t)v | (uintptr_t)k_unrot | (uintptr_t)k_tail | (uintptr_t)v_tail |
-                           (uintptr_t)k_kept | (uintptr_t)v_kept) & 15) == 0;
+                           (uintptr_t)k_kept | (uintptr_t)v_kept | (uintptr_t)cos_new | (uintptr_t)sin_new) & 15) == 0;
     if (!aligned) {
         set_error("rtk_pivotkv_evict: pointers and strides must be 16-byte aligned");
         return RTK_EUNSUPPORTED;
     }
-    const size_t total = (size_t)Hkv * L * (D / 2 / ve);
-    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 16384);
+    const size_t append_chunks = k_tail ? (size_t)Hkv * L * (D / ve) : 0;
+    const size_t kept_threads = (size_t)Hkv * keep * (D / 2 / ve);
+    const unsigned append_blocks = (unsigned)std::min<size_t>((append_chunks + 255) / 256, 8192);
+    const unsigned kept_blocks = (unsigned)std::min<size_t>((kept_threads + 255) / 256, 8192);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RTK_BF16)
-        RTK_LAUNCH(KID_EVICT, evict_scan_kernel<RTK_BF16>, dim3(grid), dim3(256), 0, st, (const char*)k, k_stride_h,
-                           k_stride_l, (const char*)v, v_stride_h, v_stride_l, (const char*)k_unrot, Hkv, L, D, rank, keep,
-                           cos_new, sin_new, (char*)k_tail, (char*)v_tail, tail_stride_h, (char*)k_kept, (char*)v_kept,
-                           kept_stride_h);
+        RTK_LAUNCH(KID_EVICT, evict_scan_kernel<RTK_BF16>, dim3(append_blocks + kept_blocks), dim3(256), 0, st,
+                   (const char*)k, k_stride_h, k_stride_l, (const char*)v, v_stride_h, v_stride_l, (const char*)k_unrot,
+                   Hkv, L, D, keep_idx, keep, cos_new, sin_new, (char*)k_tail, (char*)v_tail, tail_stride_h,
+                   (char*)k_kept, (char*)v_kept, kept_stride_h, (int)append_blocks);
     else
-        RTK_LAUNCH(KID_EVICT, evict_scan_kernel<RTK_F32>, dim3(grid), dim3(256), 0, st, (const char*)k, k_stride_h,
-                           k_stride_l, (const char*)v, v_stride_h, v_stride_l, (const char*)k_unrot, Hkv, L, D, rank, keep,
-                           cos_new, sin_new, (char*)k_tail, (char*)v_tail, tail_stride_h, (char*)k_kept, (char*)v_kept,
-                           kept_stride_h);
+        RTK_LAUNCH(KID_EVICT, evict_scan_kernel<RTK_F32>, dim3(append_blocks + kept_blocks), dim3(256), 0, st,
+                   (const char*)k, k_stride_h, k_stride_l, (const char*)v, v_stride_h, v_stride_l, (const char*)k_unrot,
+                   Hkv, L, D, keep_idx, keep, cos_new, sin_new, (char*)k_tail, (char*)v_tail, tail_stride_h,
+                   (char*)k_kept, (char*)v_kept, kept_stride_h, (int)append_blocks);
     RTK_LAUNCH_CHECK("evict_scan_kernel");
     return RTK_OK;
 }

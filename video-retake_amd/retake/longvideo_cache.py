@@ -553,7 +553,7 @@ class PivotKVCache(DynamicCache):
             nv.check(nv.lib.rtk_pivotkv_evict(
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
                 nv.ptr(value_states), value_states.stride(1), value_states.stride(2),
-                nv.ptr(k_unrot), Hkv, L, D, dt, nv.ptr(rank), keep_len, nv.ptr(cos_n), nv.ptr(sin_n),
+                nv.ptr(k_unrot), Hkv, L, D, dt, nv.ptr(keep_idx), keep_len, nv.ptr(cos_n), nv.ptr(sin_n),
                 k_tail, v_tail, cap * D, nv.ptr(st.k_stage), nv.ptr(st.v_stage), st.k_stage.shape[2] * D, s),
                 "rtk_pivotkv_evict")
             self.last_keep_indices = keep_idx  # scratch views, valid until the worker's next update (diagnostics)
