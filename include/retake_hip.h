@@ -87,9 +87,10 @@ int rtk_rope_merge(const void* cos_in, const void* sin_in, int P, int L, int D, 
                    const int* sections_host, int nsec, float* cos_out, float* sin_out, rtk_stream_t stream);
 
 /* Build the merged fp32 [L,D] tables directly from position ids: cos(pos*inv_freq)*scaling.
- * pos [P,L] int64 (row stride L), inv_freq [D/2] fp32.  round_bf16 != 0 rounds the table entries
- * to bf16 (what a bf16 model's rotary module returns). */
-int rtk_rope_table(const int64_t* pos, int P, int L, const float* inv_freq, int D, float attention_scaling,
+ * pos [P,L] int64 (row p at pos + p*pos_stride, pos_stride >= L), inv_freq [D/2] fp32.  round_bf16 != 0
+ * rounds the table entries to bf16 (what a bf16 model's rotary module returns). */
+int rtk_rope_table(const int64_t* pos, int64_t pos_stride, int P, int L, const float* inv_freq, int D,
+                   float attention_scaling,
                    const int* sections_host, int nsec, int round_bf16, float* cos_out, float* sin_out,
                    rtk_stream_t stream);
 
@@ -129,13 +130,19 @@ int rtk_pivotkv_score(const void* q, int64_t q_stride_h, int64_t q_stride_l,
  *   mask may be NULL.
  *   keep_idx [keep] int64 ascending = topk(keep).sort()  (ties: lowest index first)
  *   rank [L] int32: position of token l in keep_idx, or -1 if evicted (inverse map, for callers that
- *        scan tokens in order)
+ *        scan tokens in order); may be NULL when a workspace is given
  *   pos [P,L] int64 (P = 3 M-RoPE rows t,h,w or 1), may be NULL together with pos_out;
- *   pos_out [P,keep] int64 = gathered ids; if reforge != 0 row 0 becomes
- *       tmin + (int64)((float)(t - tmin) * (float)(keep / (double)L))        (:293-295)  */
+ *   pos_out [P,keep] int64 (row p at pos_out + p*pos_out_stride, pos_out_stride >= keep) = gathered ids;
+ *       if reforge != 0 row 0 becomes
+ *       tmin + (int64)((float)(t - tmin) * (float)(keep / (double)L))        (:293-295)
+ *   workspace: rtk_pivotkv_select_workspace_bytes(L) bytes of device scratch.  With it the selection runs
+ *       chip-wide (rank-by-counting over ~L/32 workgroups + an ordered emit); without it (NULL) on one
+ *       workgroup (radix select).  Same exact result either way. */
+size_t rtk_pivotkv_select_workspace_bytes(int L);
 int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep,
                        const int64_t* pos, int P, int reforge,
-                       int64_t* keep_idx, int32_t* rank, int64_t* pos_out, rtk_stream_t stream);
+                       int64_t* keep_idx, int32_t* rank, int64_t* pos_out, int64_t pos_out_stride,
+                       void* workspace, size_t workspace_bytes, rtk_stream_t stream);
 
 /* P1, P8, P11, P13  longvideo_cache.py:238, :278-280, :297-306, :313-318 — the eviction scan.
  * One launch over the chunk's K and V rows:
@@ -169,6 +176,68 @@ int rtk_pivotkv_commit(const void* k_stage, const void* v_stage, int64_t stage_s
  * consumed the uncompressed view: dst[h][r][:] = src[h][r][:], r < rows. */
 int rtk_copy_rows(const void* src, int64_t src_stride_h, void* dst, int64_t dst_stride_h,
                   int H, int rows, int D, int dtype, rtk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Chunk-batched cache maintenance.  The reference rebuilds every layer's cache with two torch.cat per
+ * (layer, chunk) (longvideo_cache.py:238, :313-318) and calls cache.after_forward() once per video
+ * chunk (qwen2_vl.py:715-716).  Here `update` appends the chunk to the pre-allocated cache tail and
+ * records which rows survive; the gather / re-rotation / compaction of every layer of the chunk runs
+ * as ONE launch each from after_forward (or from whatever touches the cache first).
+ * ------------------------------------------------------------------------------------------- */
+
+/* P1  longvideo_cache.py:238 (DynamicCache.update -> torch.cat): K and V rows of the chunk
+ * (element (h,l,d) at h*stride_h + l*stride_l + d) -> k_tail/v_tail (element (h,l,d) at
+ * h*tail_stride_h + l*D + d), the uncompressed view the current layer's attention reads. */
+int rtk_pivotkv_append(const void* k, int64_t k_stride_h, int64_t k_stride_l,
+                       const void* v, int64_t v_stride_h, int64_t v_stride_l,
+                       int Hkv, int L, int D, int dtype,
+                       void* k_tail, void* v_tail, int64_t tail_stride_h, rtk_stream_t stream);
+
+/* One (layer, chunk) unit of a batched eviction.  Strides in elements. */
+typedef struct rtk_evict_unit {
+    const void* k_src;        /* K rows of the chunk, element (h,l,d) at h*k_src_stride_h + l*D + d.  With cos_new:
+                                 the UN-rotated k~ written by rtk_pivotkv_score; without: the rotated rows */
+    int64_t k_src_stride_h;
+    const void* v_src;        /* V rows of the chunk, element (h,l,d) at h*v_src_stride_h + l*D + d */
+    int64_t v_src_stride_h;
+    const int64_t* keep_idx;  /* [keep] ascending, from rtk_pivotkv_select */
+    const float* cos_new;     /* fp32 [keep,D] tables of the NEW positions of the kept rows, or NULL (no reforge) */
+    const float* sin_new;
+    void* k_dst;              /* kept row (h,r) at h*k_dst_stride_h + r*D; must not alias k_src */
+    int64_t k_dst_stride_h;
+    void* v_dst;              /* kept row (h,r) at h*v_dst_stride_h + r*D; must not alias v_src */
+    int64_t v_dst_stride_h;
+    const int64_t* pos_src;   /* optional: ids of the kept rows [P,keep] (row stride pos_src_stride) ... */
+    int64_t pos_src_stride;
+    int64_t* pos_dst;         /* ... copied to the layer's position cache tail (row stride pos_dst_stride) */
+    int64_t pos_dst_stride;
+} rtk_evict_unit;
+#define RTK_EVICT_MAX_UNITS 28   /* units per launch (the array travels as a kernel argument); more = more launches */
+
+/* P8, P9, P11, P12  longvideo_cache.py:278-288, :297-310 for n_units (layer, chunk) units that share
+ * Hkv, D, keep, P and dtype:  K: k' = (k~*cos_new) + (rotate_half(k~)*sin_new) (or a copy), V: copy,
+ * position ids: copy.  `units` is a HOST array. */
+int rtk_pivotkv_evict_batched(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P,
+                              int dtype, rtk_stream_t stream);
+
+typedef struct rtk_copy_unit {
+    const void* src;
+    int64_t src_stride_h_bytes;
+    void* dst;
+    int64_t dst_stride_h_bytes;
+} rtk_copy_unit;
+#define RTK_COPY_MAX_UNITS 64
+
+/* P13  longvideo_cache.py:313-318 for n_units staged row blocks: dst[h][r][:] = src[h][r][:], r < rows.
+ * `units` is a HOST array. */
+int rtk_pivotkv_commit_batched(const rtk_copy_unit* units, int n_units, int H, int rows, int D, int dtype,
+                               rtk_stream_t stream);
+
+/* G1  qwen2_vl.py:68-73 / llava_onevision.py:68-72, without the host round trip of the reference's
+ * `if position_ids[0,0,0] != prev + 1`:  t[0:n] += (prev + 1) - t[0]  in place, where t is the temporal
+ * row of the chunk's position ids and prev = *prev_dev (device memory: the last temporal id the layer's
+ * cache holds) or -1 when prev_dev is NULL. */
+int rtk_position_shift(int64_t* temporal_ids, int n, const int64_t* prev_dev, rtk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement support (bench.py).  When enabled, every kernel launch of this library is bracketed

@@ -37,7 +37,7 @@ def test_argument_validation_without_gpu():
     # NULL pointers / bad sizes are rejected on the host before any launch
     assert nv.lib.rtk_dpselect_dis(None, 4, 4, 4, 0, None, None) == nv.RTK_EINVAL
     assert b"NULL" in nv.lib.rtk_last_error()
-    assert nv.lib.rtk_pivotkv_select(None, None, 8, 9, None, 0, 0, None, None, None, None) == nv.RTK_EINVAL
+    assert nv.lib.rtk_pivotkv_select(None, None, 8, 9, None, 0, 0, None, None, None, 0, None, 0, None) == nv.RTK_EINVAL
     assert nv.lib.rtk_pivotkv_score_workspace_bytes(28, 4, 6272, 128, 1) > 28 * 6272 * 128 * 2
     with pytest.raises(ValueError):
         nv.check(nv.RTK_EINVAL, "x")

@@ -345,6 +345,161 @@ def test_pivotkv_bf16_tracks_fp32_oracle():
     assert torch.equal(kept_v[0, :, :, :].cpu(), vb[0][:, torch.from_numpy(idx)])
 
 
+@pytest.mark.parametrize("reforge", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pivotkv_batched_flush_equals_per_layer_flush(reforge, dtype):
+    """Deferred eviction: 3 layers x 3 chunks flushed once per chunk from after_forward (one batched launch
+    for all layers) must leave exactly the cache that flushing after every single update leaves."""
+    import retake.longvideo_cache as lc
+
+    Hq, Hkv, D, L, layers, n_chunks = 28, 4, 128, 320, 3, 3
+    sec = [16, 24, 24]
+    inv_f = synth.inv_freq(D)
+    rot = synth.RotaryStub(inv_f, synth.YARN_FACTOR4_ATTENTION_SCALING, device=dev())
+
+    def cfg():
+        return types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=layers, num_attention_heads=Hq,
+                                     num_key_value_heads=Hkv,
+                                     longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
+                                         "compression_ratio": 0.25, "compression_method": "pivotkv",
+                                         "pos_embed_reforge": reforge}})
+
+    def run(cache, eager):
+        for c in range(n_chunks):
+            pos = torch.from_numpy(synth.mrope_position_ids(10 + 5 * c, 5, 8, 8, hw0=2)).to(dev())
+            cache.keypatches_mask_chunk = torch.from_numpy(np.random.default_rng(c).uniform(size=L) < 0.3).to(dev())
+            cache.kvcache_compression = True
+            for l in range(layers):
+                q0, k0, v = synth.qkv_chunk(500 + 10 * c + l, Hq, Hkv, L, D)
+                cache.shift_temporal_ids_(pos, l)
+                q = synth.rope_forward(torch.from_numpy(q0).to(dev()), pos, rot, sec).to(dtype)
+                k = synth.rope_forward(torch.from_numpy(k0).to(dev()), pos, rot, sec).to(dtype)
+                vt = torch.from_numpy(v).to(dev()).to(dtype)
+                ko, vo = cache.update(k, vt, l, {"query_states": q, "position_ids": pos, "rotary_emb": rot,
+                                                 "mrope_section": sec})
+                assert torch.equal(ko[:, :, -L:], k) and torch.equal(vo[:, :, -L:], vt)
+                if eager:
+                    _ = cache.key_cache[l]          # flushes this single unit now
+            cache.after_forward()
+        return cache
+
+    a = run(lc.build_kvcache(cfg()), eager=False)
+    b = run(lc.build_kvcache(cfg()), eager=True)
+    keep = L // 4
+    for l in range(layers):
+        assert a.key_cache[l].shape == (1, Hkv, n_chunks * keep, D)
+        assert torch.equal(a.key_cache[l], b.key_cache[l])
+        assert torch.equal(a.value_cache[l], b.value_cache[l])
+        if reforge:
+            assert torch.equal(a.position_cache[l], b.position_cache[l])
+    assert a.num_evicted_tokens == b.num_evicted_tokens == [n_chunks * (L - keep)] * layers
+    assert len(a.position_cache) == (layers if reforge else 0)
+
+
+@pytest.mark.parametrize("L,keep,P,reforge,ties", [(6272, 1568, 3, 1, False), (2304, 576, 1, 1, False),
+                                                   (1000, 333, 3, 0, True), (515, 1, 0, 0, True), (4099, 4098, 3, 1, True)])
+def test_select_chipwide_equals_one_workgroup_and_oracle(L, keep, P, reforge, ties):
+    """rtk_pivotkv_select: the rank-by-counting path (workspace given) and the one-workgroup radix path must
+    produce identical keep_idx / rank / ids, equal to the CPU oracle's canonical top-k (ties: lowest index
+    first), on ragged sizes, exact ties and a key-patch mask."""
+    import retake._native as nv
+
+    rng = np.random.default_rng(L + keep)
+    score = rng.normal(1.0, 0.2, size=L).astype(np.float32)
+    if ties:
+        score = np.round(score * 8) / 8            # many exact ties, also across the k-th boundary
+    mask = rng.uniform(size=L) < 0.3
+    pos = np.stack([np.sort(rng.integers(100, 140, size=L)), rng.integers(0, 14, size=L), rng.integers(0, 14, size=L)])[:max(P, 1)]
+    outs = []
+    for use_ws in (True, False):
+        sc = torch.from_numpy(score.copy()).to(dev())
+        mk = torch.from_numpy(mask).to(dev())
+        ps = torch.from_numpy(pos.astype(np.int64)).to(dev()) if P else None
+        keep_idx = torch.full((keep,), -7, dtype=torch.int64, device=dev())
+        rank = torch.full((L,), -7, dtype=torch.int32, device=dev())
+        ld = keep + 5
+        pos_out = torch.full((P, ld), -7, dtype=torch.int64, device=dev()) if P else None
+        wsb = nv.lib.rtk_pivotkv_select_workspace_bytes(L)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev()) if use_ws else None
+        nv.check(nv.lib.rtk_pivotkv_select(nv.ptr(sc), nv.ptr(mk), L, keep, nv.ptr(ps), P, reforge, nv.ptr(keep_idx),
+                                           nv.ptr(rank), nv.ptr(pos_out), ld, nv.ptr(ws), wsb if use_ws else 0,
+                                           nv.stream()), "select")
+        torch.cuda.synchronize()
+        outs.append((sc.cpu().numpy(), keep_idx.cpu().numpy(), rank.cpu().numpy(),
+                     pos_out.cpu().numpy() if P else None))
+    (sa, ia, ra, pa), (sb, ib, rb, pb) = outs
+    np.testing.assert_array_equal(sa, sb)
+    np.testing.assert_array_equal(ia, ib)
+    np.testing.assert_array_equal(ra, rb)
+    if P:
+        np.testing.assert_array_equal(pa[:, :keep], pb[:, :keep])
+        assert (pa[:, keep:] == -7).all()
+    # canonical rule restated: masked scores are 1.0; larger first, then lower index
+    s2 = score.copy()
+    s2[mask] = 1.0
+    np.testing.assert_array_equal(sa, s2)
+    order = np.lexsort((np.arange(L), -s2.astype(np.float64)))
+    want = np.sort(order[:keep])
+    np.testing.assert_array_equal(ia, want)
+    inv = np.full(L, -1, dtype=np.int32)
+    inv[want] = np.arange(keep)
+    np.testing.assert_array_equal(ra, inv)
+    if P:
+        g = pos[:, want].astype(np.int64)
+        if reforge:
+            tmin = g[0].min()
+            g[0] = tmin + ((g[0] - tmin).astype(np.float32) * np.float32(keep / L)).astype(np.int64)
+        np.testing.assert_array_equal(pa[:, :keep], g)
+
+
+def test_evict_batched_abi_vs_torch_gather():
+    """rtk_pivotkv_append / rtk_pivotkv_evict_batched / rtk_pivotkv_commit_batched straight through the C ABI:
+    5 units, no reforge -> K and V rows must be byte-identical to torch.gather; ids copied."""
+    import ctypes as C
+
+    import retake._native as nv
+
+    Hkv, L, D, keep, n = 4, 200, 128, 50, 5
+    g = torch.Generator(device=dev()).manual_seed(5)
+    cap = 700
+    units = (nv.EvictUnit * n)()
+    copies = (nv.CopyUnit * (2 * n))()
+    hold = []
+    for i in range(n):
+        k = torch.randn((1, L, Hkv, D), generator=g, device=dev()).bfloat16().transpose(1, 2)   # HF layout
+        v = torch.randn((1, L, Hkv, D), generator=g, device=dev()).bfloat16().transpose(1, 2)
+        kc = torch.zeros((1, Hkv, cap, D), dtype=torch.bfloat16, device=dev())
+        vc_ = torch.zeros_like(kc)
+        P0 = 37 * i
+        nv.check(nv.lib.rtk_pivotkv_append(nv.ptr(k), k.stride(1), k.stride(2), nv.ptr(v), v.stride(1), v.stride(2), Hkv,
+                                           L, D, nv.RTK_BF16, C.c_void_p(kc.data_ptr() + P0 * D * 2),
+                                           C.c_void_p(vc_.data_ptr() + P0 * D * 2), cap * D, nv.stream()), "append")
+        assert torch.equal(kc[:, :, P0:P0 + L], k) and torch.equal(vc_[:, :, P0:P0 + L], v)
+        idx = torch.sort(torch.randperm(L, generator=g, device=dev())[:keep]).values
+        ks = torch.empty((Hkv, keep, D), dtype=torch.bfloat16, device=dev())
+        vs = torch.empty_like(ks)
+        pos_src = torch.randint(0, 1000, (3, keep), generator=g, device=dev())
+        pos_dst = torch.zeros((3, 90), dtype=torch.int64, device=dev())
+        u = units[i]
+        u.k_src, u.k_src_stride_h = kc.data_ptr() + P0 * D * 2, cap * D
+        u.v_src, u.v_src_stride_h = vc_.data_ptr() + P0 * D * 2, cap * D
+        u.keep_idx = idx.data_ptr()
+        u.k_dst, u.k_dst_stride_h, u.v_dst, u.v_dst_stride_h = ks.data_ptr(), keep * D, vs.data_ptr(), keep * D
+        u.pos_src, u.pos_src_stride, u.pos_dst, u.pos_dst_stride = pos_src.data_ptr(), keep, pos_dst.data_ptr() + 8 * 7, 90
+        for j, (src, dst) in enumerate(((ks, kc), (vs, vc_))):
+            cu = copies[2 * i + j]
+            cu.src, cu.src_stride_h_bytes = src.data_ptr(), keep * D * 2
+            cu.dst, cu.dst_stride_h_bytes = dst.data_ptr() + P0 * D * 2, cap * D * 2
+        hold.append((k, v, kc, vc_, idx, ks, vs, pos_src, pos_dst, P0))
+    nv.check(nv.lib.rtk_pivotkv_evict_batched(units, n, Hkv, D, keep, 3, nv.RTK_BF16, nv.stream()), "evict_batched")
+    nv.check(nv.lib.rtk_pivotkv_commit_batched(copies, 2 * n, Hkv, keep, D, nv.RTK_BF16, nv.stream()), "commit_batched")
+    torch.cuda.synchronize()
+    for k, v, kc, vc_, idx, ks, vs, pos_src, pos_dst, P0 in hold:
+        assert torch.equal(kc[0, :, P0:P0 + keep], k[0][:, idx]) and torch.equal(vc_[0, :, P0:P0 + keep], v[0][:, idx])
+        assert torch.equal(kc[0, :, P0 + keep:P0 + L], k[0][:, keep:])           # the rest of the tail is untouched
+        assert torch.equal(pos_dst[:, 7:7 + keep], pos_src) and int(pos_dst[:, :7].abs().sum()) == 0
+
+
 # ---------------------------------------------------------------------------------------------------
 # glue: compress_video_tokens (DPSelect inside) against the reference golden
 # ---------------------------------------------------------------------------------------------------
@@ -485,8 +640,11 @@ def test_pivotkv_full_size_invariants():
     for c in range(8):
         q, k, v = ((1.7 * torch.randn((1, h, L, B.D), generator=g, device=dev())).bfloat16() for h in (B.Hq, B.Hkv, B.Hkv))
         pos = B.chunk_position_ids(c, dev()).clone()
+        expect = pos.clone()
         prev = cache.get_prev_temporal_idx(0)
-        pos[0, 0, :] += (prev + 1) - pos[0, 0, 0]
+        expect[0, 0, :] += (prev + 1) - expect[0, 0, 0]              # the reference's rule (qwen2_vl.py:68-73)
+        cache.shift_temporal_ids_(pos, 0)                            # device-side, no host sync
+        assert torch.equal(pos, expect)
         cache.keypatches_mask_chunk = None
         cache.update(k, v, 0, {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": B.MROPE})
         torch.cuda.synchronize()

@@ -47,7 +47,7 @@ if hasattr(lib, "rtk_debug_read_select_timing"):
     pos_out = torch.empty((3, keep), dtype=torch.int64, device=dev)
     for it in range(3):
         nv.check(nv.lib.rtk_pivotkv_select(nv.ptr(score), nv.ptr(mask), L, keep, nv.ptr(pos), 3, 1, nv.ptr(keep_idx), nv.ptr(rank),
-                                           nv.ptr(pos_out), nv.stream()), "select")
+                                           nv.ptr(pos_out), keep, None, 0, nv.stream()), "select")
         torch.cuda.synchronize()
         lib.rtk_debug_read_select_timing(out)
         v = list(out)

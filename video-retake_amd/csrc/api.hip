@@ -26,7 +26,8 @@ int hip_fail(hipError_t e, const char* what) {
 namespace rtk {
 static const char* const kKernelNames[KID_COUNT] = {"dpselect_dis", "dpselect_select", "gather_frames", "rope_table",
                                                     "unrotate_pack", "score_pass1", "score_pass2", "score_finalize",
-                                                    "pivotkv_select", "evict_scan", "copy_rows"};
+                                                    "pivotkv_select", "evict_scan", "copy_rows", "append",
+                                                    "evict_batched", "commit_batched", "position_shift", "pivotkv_emit"};
 struct ProfRec { int kid; hipEvent_t a, b; };
 static std::mutex g_pm;
 static unsigned g_prof = 0;  // bit k set = time kernel id k
@@ -103,6 +104,6 @@ extern "C" int rtk_profile_read(int kid, long long* count, double* total_ms) {
     return RTK_OK;
 }
 
-extern "C" int rtk_version(void) { return 1; }
+extern "C" int rtk_version(void) { return 2; }
 extern "C" const char* rtk_last_error(void) { return rtk::g_err; }
 extern "C" const char* rtk_arch(void) { return "gfx950"; }

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_kernel(float* __res
                                                                     const int64_t* __restrict__ pos, int P,
                                                                     int reforge, int64_t* __restrict__ keep_idx,
                                                                     int32_t* __restrict__ rank,
-                                                                    int64_t* __restrict__ pos_out) {
+                                                                    int64_t* __restrict__ pos_out, int64_t pos_ld) {
     __shared__ SelectSmem sm;
     __shared__ long long red[PSEL_BLOCK / WAVE];
     const int tid = threadIdx.x;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_kernel(float* __res
         keep_idx[r] = i;  // topk(keep).sort()  (:276-277)
         rank[i] = r;
         if (pos)
-            for (int p = 0; p < P; ++p) pos_out[(size_t)p * keep + r] = pos[(size_t)p * L + i];  // :283-288
+            for (int p = 0; p < P; ++p) pos_out[(size_t)p * pos_ld + r] = pos[(size_t)p * L + i];  // :283-288
     });
     if (!(pos && reforge)) return;
     __syncthreads();
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* 
                                                                          int P, int reforge,
                                                                          int64_t* __restrict__ keep_idx,
                                                                          int32_t* __restrict__ rank,
-                                                                         int64_t* __restrict__ pos_out) {
+                                                                         int64_t* __restrict__ pos_out, int64_t pos_ld) {
     __shared__ SelectSmem sm;
     __shared__ uint32_t wtot[PSEL_BLOCK / WAVE];
     __shared__ long long red[PSEL_BLOCK / WAVE];
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* 
             if (pos) {
                 // row 0: gathered id, rescaled when reforging: int64 -> float32 multiply -> truncation (:293-295)
                 pos_out[r] = rf ? mn + (long long)((float)(t0[e] - mn) * ratio) : (long long)pos[i];
-                for (int p = 1; p < P; ++p) pos_out[(size_t)p * keep + r] = pos[(size_t)p * L + i];  // :283-288
+                for (int p = 1; p < P; ++p) pos_out[(size_t)p * pos_ld + r] = pos[(size_t)p * L + i];  // :283-288
             }
             rank[i] = r++;
         } else {
@@ -235,6 +235,166 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* 
         }
     }
     RTK_ST(4)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chip-wide selection (the default path): the same exact result as the one-workgroup kernels above, in two
+// launches that use every CU instead of one.
+//   rank kernel  every workgroup loads ALL L keys into LDS and ranks RANK_TOK tokens by counting:
+//                rank_i = #{j : key_j > key_i  or  (key_j == key_i and j < i)}   (ties: lowest index first)
+//                token i is kept  <=>  rank_i < keep.                 O(L^2) compares over ~L/32 workgroups
+//   emit kernel  ascending compaction: position of a kept token = number of kept tokens before it
+//                (= topk(keep).sort()), id gather and temporal rescale
+// Integer compares only: bit-reproducible and independent of the launch geometry.
+// ------------------------------------------------------------------------------------------------
+constexpr int RANK_TOK = 64;           // tokens ranked per workgroup (one per lane of a wave)
+constexpr int RANK_SEG = 16;           // waves per workgroup, each scanning one segment of the keys
+constexpr int RANK_BLOCK = RANK_TOK * RANK_SEG;
+
+__global__ __launch_bounds__(RANK_BLOCK) void pivotkv_rank_kernel(float* __restrict__ score,
+                                                           const uint8_t* __restrict__ mask, int L, int keep,
+                                                           const int64_t* __restrict__ pos, int reforge,
+                                                           uint8_t* __restrict__ sel, int32_t* __restrict__ blk_cnt,
+                                                           int64_t* __restrict__ blk_tmin, int vec_ok) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t rk_keys[];  // [n4 * 4] keys (zero padded) + [RANK_SEG][RANK_TOK] counts
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * RANK_TOK;
+    const int n4 = ((L + RANK_TOK - 1) / RANK_TOK) * (RANK_TOK / 4);   // keys padded to whole workgroup ranges
+    int* part = (int*)(rk_keys + (size_t)n4 * 4);
+    // every key of the chunk -> LDS (no global store in this loop: the loads pipeline freely).  Masked
+    // tokens take the key of 1.0 (attn_weights.masked_fill_(mask, 1.), :274); padding keys are 0, smaller
+    // than every real key, and only ever compared with '>'.
+    const uint32_t one_key = f2key(1.0f);
+    for (int j4 = tid; j4 < n4; j4 += RANK_BLOCK) {
+        const int j = 4 * j4;
+        uint4 kk = {0u, 0u, 0u, 0u};
+        if (vec_ok && j + 3 < L) {
+            const float4 sc = *(const float4*)(score + j);
+            const uint32_t m = mask ? *(const uint32_t*)(mask + j) : 0u;
+            kk.x = (m & 0x000000ffu) ? one_key : f2key(sc.x);
+            kk.y = (m & 0x0000ff00u) ? one_key : f2key(sc.y);
+            kk.z = (m & 0x00ff0000u) ? one_key : f2key(sc.z);
+            kk.w = (m & 0xff000000u) ? one_key : f2key(sc.w);
+        } else {
+            uint32_t e[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j + u < L) e[u] = (mask && mask[j + u]) ? one_key : f2key(score[j + u]);
+            kk = uint4{e[0], e[1], e[2], e[3]};
+        }
+        ((uint4*)rk_keys)[j4] = kk;
+    }
+    __syncthreads();
+    const int t = tid % RANK_TOK;
+    const int q = __builtin_amdgcn_readfirstlane(tid / RANK_TOK);   // wave index: uniform, loop bounds are scalar
+    const int i = i0 + t;
+    const uint32_t ki = (i < L) ? rk_keys[i] : 0xffffffffu;
+    const int per = (n4 + RANK_SEG - 1) / RANK_SEG;
+    const int j4b = q * per, j4e = min(n4, j4b + per);
+    const int own4b = i0 / 4, own4e = own4b + RANK_TOK / 4;
+    int cnt = 0;
+    const uint4* k4 = (const uint4*)rk_keys;
+    // Keys before the workgroup's own token range count on '>=' (ties: lower index first) = '> ki - 1', keys
+    // after it on '>'; the own range is handled exactly below.  No real key is 0, so ki - 1 cannot wrap.
+    auto count_range = [&](int b, int e, uint32_t thr) {
+#pragma unroll 4
+        for (int j4 = b; j4 < e; ++j4) {
+            const uint4 kk = k4[j4];        // same address in every lane: LDS broadcast
+            cnt += (kk.x > thr) + (kk.y > thr) + (kk.z > thr) + (kk.w > thr);
+        }
+    };
+    count_range(j4b, min(j4e, own4b), ki - 1u);
+    count_range(max(j4b, own4e), j4e, ki);
+    {   // own range [i0, i0 + RANK_TOK): wave q takes keys i0 + 4q .. i0 + 4q + 3 (RANK_SEG * 4 == RANK_TOK)
+        static_assert(RANK_SEG * 4 == RANK_TOK, "own-range split");
+        const int j = i0 + 4 * q;
+        const uint4 kk = k4[j >> 2];        // padding keys (j >= L) are 0: never counted
+        cnt += (kk.x > ki || (kk.x == ki && j < i)) + (kk.y > ki || (kk.y == ki && j + 1 < i)) +
+               (kk.z > ki || (kk.z == ki && j + 2 < i)) + (kk.w > ki || (kk.w == ki && j + 3 < i));
+    }
+    part[q * RANK_TOK + t] = cnt;
+    __syncthreads();
+    if (tid < WAVE) {  // first wave: lane t owns token i0 + t
+        bool kept = false;
+        long long tm = 0x7fffffffffffffffLL;
+        if (i < L) {
+            int rank = 0;
+#pragma unroll
+            for (int sg = 0; sg < RANK_SEG; ++sg) rank += part[sg * RANK_TOK + tid];
+            kept = rank < keep;
+            sel[i] = kept;
+            if (ki == one_key && mask && mask[i]) score[i] = 1.0f;  // masked_fill_ is in place (:274)
+            if (kept && pos && reforge) tm = pos[i];
+        }
+        const unsigned long long b = __ballot(kept);
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long t2 = __shfl_xor(tm, o, WAVE);
+            tm = min(tm, t2);
+        }
+        if (tid == 0) {
+            blk_cnt[blockIdx.x] = (int32_t)__popcll(b);
+            blk_tmin[blockIdx.x] = tm;  // min_temp_id partial (:293)
+        }
+    }
+}
+
+// ordered emit: one workgroup per 256 tokens.  The number of kept tokens before its range and min_temp_id
+// come from the rank kernel's per-workgroup records (RANK_TOK tokens each).
+__global__ __launch_bounds__(256) void pivotkv_emit_kernel(const uint8_t* __restrict__ sel,
+                                                           const int32_t* __restrict__ blk_cnt,
+                                                           const int64_t* __restrict__ blk_tmin, int L, int keep,
+                                                           const int64_t* __restrict__ pos, int P, int reforge,
+                                                           int64_t* __restrict__ keep_idx, int32_t* __restrict__ rank,
+                                                           int64_t* __restrict__ pos_out, int64_t pos_ld) {
+    __shared__ int wtot[4];
+    __shared__ int wsum[4];
+    __shared__ long long wmin[4];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+    const int b0 = blockIdx.x * 256;
+    const bool rf = pos && reforge;
+    const int nb = (L + RANK_TOK - 1) / RANK_TOK, nb_before = b0 / RANK_TOK;
+    const int i = b0 + tid;
+    const int mine = (i < L) ? (int)sel[i] : 0;
+    const long long t0 = (mine && pos) ? (long long)pos[i] : 0;
+    int before = 0;
+    long long mn = 0x7fffffffffffffffLL;
+    for (int b = tid; b < nb; b += 256) {
+        before += (b < nb_before) ? blk_cnt[b] : 0;
+        if (rf) mn = min(mn, (long long)blk_tmin[b]);
+    }
+    // wave scan of the own flags + wave sums of `before` / min of mn, then combine across the 4 waves
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int t = __shfl_up(inc, o, WAVE);
+        if (lane >= o) inc += t;
+    }
+    before = wave_sum_i(before);
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long t = __shfl_xor(mn, o, WAVE);
+        mn = min(mn, t);
+    }
+    if (lane == WAVE - 1) wtot[wid] = inc;
+    if (lane == 0) { wsum[wid] = before; wmin[wid] = mn; }
+    __syncthreads();
+    int r = wsum[0] + wsum[1] + wsum[2] + wsum[3] + inc - mine;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wid) r += wtot[w];
+    mn = min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3]));
+    if (i >= L) return;
+    if (!mine) {
+        if (rank) rank[i] = -1;
+        return;
+    }
+    keep_idx[r] = i;  // topk(keep).sort()  (:276-277)
+    if (rank) rank[i] = r;
+    if (pos) {
+        // row 0: gathered id, rescaled when reforging: int64 -> float32 multiply -> truncation (:293-295)
+        const float ratio = (float)((double)keep / (double)L);  // comp_ratio = keep_len / k_len (:294)
+        pos_out[r] = rf ? mn + (long long)((float)(t0 - mn) * ratio) : t0;
+        for (int p = 1; p < P; ++p) pos_out[(size_t)p * pos_ld + r] = pos[(size_t)p * L + i];  // :283-288
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -377,6 +537,167 @@ __global__ __launch_bounds__(256) void commit_rows_kernel(const char* __restrict
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Chunk-batched cache maintenance.  `PivotKVCache.update` only has to hand the layer's attention the
+// uncompressed [prefix | chunk] view (longvideo_cache.py:238) and to decide which rows survive; the
+// gather / re-rotation / compaction of ALL layers of a chunk is flushed in two launches from
+// `after_forward` (the hook the reference calls after every video chunk, qwen2_vl.py:715-716):
+//   append_kernel          per update: K and V rows of the chunk -> cache tail (pure streaming copy)
+//   evict_batched_kernel   per flush : every pending (layer, chunk) unit in one launch (blockIdx.y = unit)
+//   commit_batched_kernel  per flush : staged rows -> head of the tail, every unit in one launch
+// A single unit is 6.5 MB of traffic (a 10 us launch is ramp-dominated); 28 layers per launch keep every
+// CU streaming.
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void append_kernel(const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
+                                                     const char* __restrict__ v, int64_t v_sh, int64_t v_sl, int Hkv,
+                                                     int L, int D, char* __restrict__ k_tail,
+                                                     char* __restrict__ v_tail, int64_t tail_sh) {
+    using R = Row16<DT>;
+    constexpr int VE = R::VE;
+    constexpr int ES = 16 / VE;
+    constexpr int U = 4;                // 16-byte chunks per thread per tensor, all loads before the stores
+    const int cpr = D / VE;             // 16-byte chunks per row
+    const size_t total = (size_t)Hkv * L * cpr;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; id < total; id += U * stride) {
+        u32x4 kk[U], vv[U];
+        size_t dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = id + u * stride;
+            const size_t ic = i < total ? i : id;
+            const int c = (int)(ic % cpr);
+            const size_t hl = ic / cpr;
+            const int l = (int)(hl % L), h = (int)(hl / L);
+            kk[u] = *(const u32x4*)(k + ((size_t)h * k_sh + (size_t)l * k_sl + (size_t)c * VE) * ES);
+            vv[u] = *(const u32x4*)(v + ((size_t)h * v_sh + (size_t)l * v_sl + (size_t)c * VE) * ES);
+            dst[u] = ((size_t)h * tail_sh + (size_t)l * D + (size_t)c * VE) * ES;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (id + u * stride < total) {
+                *(u32x4*)(k_tail + dst[u]) = kk[u];
+                *(u32x4*)(v_tail + dst[u]) = vv[u];
+            }
+        }
+    }
+}
+
+struct EvictUnits {
+    rtk_evict_unit u[RTK_EVICT_MAX_UNITS];
+};
+
+// One thread owns, for ONE kept row r of a unit, the 16-byte chunk c of the first half of the row and its
+// rotation partner in the second half, and walks the KV heads with it: the row's cos/sin (reforge) are
+// loaded once and reused by every head, and all of a head group's loads are issued before its stores.
+template <int DT, int HU>
+__global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, int Hkv, int D, int keep, int P) {
+    using R = Row16<DT>;
+    constexpr int VE = R::VE;
+    constexpr int ES = 16 / VE;
+    const rtk_evict_unit& un = units.u[blockIdx.y];
+    const int h2 = D / 2;
+    const int lpr = h2 / VE;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    // position ids of the kept tokens -> the layer's position cache (longvideo_cache.py:308-309)
+    if (un.pos_dst && id < P * keep) {
+        const int p = id / keep, r = id - p * keep;
+        un.pos_dst[(size_t)p * un.pos_dst_stride + r] = un.pos_src[(size_t)p * un.pos_src_stride + r];
+    }
+    const int r = id / lpr;
+    if (r >= keep) return;
+    const int d = (id - r * lpr) * VE;
+    const int l = (int)un.keep_idx[r];
+    const bool reforge = un.cos_new != nullptr;
+    float c1[VE], s1[VE], c2[VE], s2[VE];
+    if (reforge) {
+        const float* cr = un.cos_new + (size_t)r * D;
+        const float* sr = un.sin_new + (size_t)r * D;
+#pragma unroll
+        for (int e = 0; e < VE; e += 4) {
+            *(float4*)(c1 + e) = *(const float4*)(cr + d + e);
+            *(float4*)(s1 + e) = *(const float4*)(sr + d + e);
+            *(float4*)(c2 + e) = *(const float4*)(cr + d + h2 + e);
+            *(float4*)(s2 + e) = *(const float4*)(sr + d + h2 + e);
+        }
+    }
+    const char* ks = (const char*)un.k_src;
+    const char* vs = (const char*)un.v_src;
+    char* kd = (char*)un.k_dst;
+    char* vd = (char*)un.v_dst;
+    for (int hb = 0; hb < Hkv; hb += HU) {
+        u32x4 k_lo[HU], k_hi[HU], v_lo[HU], v_hi[HU];
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int h = min(hb + u, Hkv - 1);
+            const char* kr = ks + ((size_t)h * un.k_src_stride_h + (size_t)l * D) * ES;
+            const char* vr = vs + ((size_t)h * un.v_src_stride_h + (size_t)l * D) * ES;
+            k_lo[u] = *(const u32x4*)(kr + (size_t)d * ES);
+            k_hi[u] = *(const u32x4*)(kr + (size_t)(d + h2) * ES);
+            v_lo[u] = *(const u32x4*)(vr + (size_t)d * ES);
+            v_hi[u] = *(const u32x4*)(vr + (size_t)(d + h2) * ES);
+        }
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int h = hb + u;
+            if (h >= Hkv) break;
+            char* ko = kd + ((size_t)h * un.k_dst_stride_h + (size_t)r * D) * ES;
+            char* vo = vd + ((size_t)h * un.v_dst_stride_h + (size_t)r * D) * ES;
+            if (reforge) {  // kept K = un-rotated row rotated forward at its new position (:297-306)
+                float x1[VE], x2[VE], o1[VE], o2[VE];
+                R::unpack(k_lo[u], x1);
+                R::unpack(k_hi[u], x2);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    // (k*cos) + (rotate_half(k)*sin), one rounding per torch op, no fma contraction
+                    o1[e] = R::rnd(__fadd_rn(R::rnd(__fmul_rn(x1[e], c1[e])), R::rnd(__fmul_rn(-x2[e], s1[e]))));
+                    o2[e] = R::rnd(__fadd_rn(R::rnd(__fmul_rn(x2[e], c2[e])), R::rnd(__fmul_rn(x1[e], s2[e]))));
+                }
+                *(u32x4*)(ko + (size_t)d * ES) = R::pack(o1);
+                *(u32x4*)(ko + (size_t)(d + h2) * ES) = R::pack(o2);
+            } else {        // torch.gather(key_states, 2, keep)  (:279)
+                *(u32x4*)(ko + (size_t)d * ES) = k_lo[u];
+                *(u32x4*)(ko + (size_t)(d + h2) * ES) = k_hi[u];
+            }
+            *(u32x4*)(vo + (size_t)d * ES) = v_lo[u];  // torch.gather(value_states, 2, keep)  (:280)
+            *(u32x4*)(vo + (size_t)(d + h2) * ES) = v_hi[u];
+        }
+    }
+}
+
+struct CopyUnits {
+    rtk_copy_unit u[RTK_COPY_MAX_UNITS];
+};
+
+// dst[h][0:rows] = src[h][0:rows] for every unit (blockIdx.y); each head's row block is contiguous
+__global__ __launch_bounds__(256) void commit_batched_kernel(CopyUnits units, int H, size_t row_block_bytes) {
+    const rtk_copy_unit& un = units.u[blockIdx.y];
+    const char* src = (const char*)un.src;
+    char* dst = (char*)un.dst;
+    const size_t vec_per_head = row_block_bytes / 16;
+    const size_t total = (size_t)H * vec_per_head;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    constexpr int U = 4;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += U * stride) {
+        u32x4 t[U];
+        size_t o[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = id + u * stride;
+            const size_t ic = i < total ? i : id;
+            const size_t h = ic / vec_per_head, j = ic % vec_per_head;
+            t[u] = *(const u32x4*)(src + h * un.src_stride_h_bytes + j * 16);
+            o[u] = h * un.dst_stride_h_bytes + j * 16;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (id + u * stride < total) *(u32x4*)(dst + o[u]) = t[u];
+    }
+}
+
 }  // namespace rtk
 
 using namespace rtk;
@@ -411,24 +732,62 @@ extern "C" int rtk_pivotkv_commit(const void* k_stage, const void* v_stage, int6
     return RTK_OK;
 }
 
+static size_t sel_ws_layout(int L, size_t* cnt_off, size_t* tmin_off) {
+    const size_t nb = ((size_t)L + RANK_TOK - 1) / RANK_TOK;
+    const size_t c = ((size_t)L + 255) & ~(size_t)255;
+    const size_t t = c + ((nb * 4 + 255) & ~(size_t)255);
+    if (cnt_off) *cnt_off = c;
+    if (tmin_off) *tmin_off = t;
+    return t + ((nb * 8 + 255) & ~(size_t)255);
+}
+extern "C" size_t rtk_pivotkv_select_workspace_bytes(int L) { return L > 0 ? sel_ws_layout(L, nullptr, nullptr) : 0; }
+
 extern "C" int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep, const int64_t* pos, int P,
                                   int reforge, int64_t* keep_idx, int32_t* rank, int64_t* pos_out,
+                                  int64_t pos_out_stride, void* workspace, size_t workspace_bytes,
                                   rtk_stream_t stream) {
-    RTK_CHECK_ARG(score && keep_idx && rank, "rtk_pivotkv_select: NULL pointer");
+    RTK_CHECK_ARG(score && keep_idx, "rtk_pivotkv_select: NULL pointer");
     RTK_CHECK_ARG(L >= 1 && keep >= 1 && keep <= L, "rtk_pivotkv_select: keep=%d out of range for L=%d", keep, L);
     RTK_CHECK_ARG((pos == nullptr) == (pos_out == nullptr), "rtk_pivotkv_select: pos and pos_out go together");
     RTK_CHECK_ARG(!pos || P == 1 || P == 3, "rtk_pivotkv_select: P must be 1 or 3, got %d", P);
+    RTK_CHECK_ARG(!pos || pos_out_stride >= keep, "rtk_pivotkv_select: pos_out_stride %lld < keep %d",
+                  (long long)pos_out_stride, keep);
     hipStream_t st = (hipStream_t)stream;
+    const size_t lds = ((size_t)((L + RANK_TOK - 1) / RANK_TOK) * RANK_TOK + RANK_BLOCK) * sizeof(uint32_t);
+    if (workspace && workspace_bytes >= rtk_pivotkv_select_workspace_bytes(L) && ((uintptr_t)workspace & 255) == 0 &&
+        lds <= 160 * 1024 && L >= 512) {
+        // chip-wide path: rank by counting (every CU), then ordered emit
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)pivotkv_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        size_t cnt_off, tmin_off;
+        (void)sel_ws_layout(L, &cnt_off, &tmin_off);
+        uint8_t* sel = (uint8_t*)workspace;
+        int32_t* blk_cnt = (int32_t*)((char*)workspace + cnt_off);
+        int64_t* blk_tmin = (int64_t*)((char*)workspace + tmin_off);
+        const int vec_ok = (((uintptr_t)score & 15) == 0 && ((uintptr_t)mask & 3) == 0) ? 1 : 0;
+        RTK_LAUNCH(KID_PSEL, pivotkv_rank_kernel, dim3((L + RANK_TOK - 1) / RANK_TOK), dim3(RANK_BLOCK), lds, st, score, mask, L,
+                   keep, pos, reforge, sel, blk_cnt, blk_tmin, vec_ok);
+        RTK_LAUNCH_CHECK("pivotkv_rank_kernel");
+        RTK_LAUNCH(KID_PEMIT, pivotkv_emit_kernel, dim3((L + 255) / 256), dim3(256), 0, st, (const uint8_t*)sel,
+                   (const int32_t*)blk_cnt, (const int64_t*)blk_tmin, L, keep, pos, P, reforge, keep_idx, rank, pos_out,
+                   pos_out_stride);
+        RTK_LAUNCH_CHECK("pivotkv_emit_kernel");
+        return RTK_OK;
+    }
+    RTK_CHECK_ARG(rank, "rtk_pivotkv_select: the one-workgroup path needs the rank buffer");
 #define RTK_PSEL_FAST(E)                                                                                          \
     RTK_LAUNCH(KID_PSEL, pivotkv_select_fast_kernel<E>, dim3(1), dim3(PSEL_BLOCK), 0, st, score, mask, L, keep, pos, \
-               P, reforge, keep_idx, rank, pos_out)
+               P, reforge, keep_idx, rank, pos_out, pos_out_stride)
     const int per = (L + PSEL_BLOCK - 1) / PSEL_BLOCK;
     if (per <= 2) RTK_PSEL_FAST(2);
     else if (per <= 8) RTK_PSEL_FAST(8);
     else if (per <= 32) RTK_PSEL_FAST(32);
     else
         RTK_LAUNCH(KID_PSEL, pivotkv_select_kernel, dim3(1), dim3(PSEL_BLOCK), 0, st, score, mask, L, keep, pos, P,
-                   reforge, keep_idx, rank, pos_out);
+                   reforge, keep_idx, rank, pos_out, pos_out_stride);
 #undef RTK_PSEL_FAST
     RTK_LAUNCH_CHECK("pivotkv_select_kernel");
     return RTK_OK;
@@ -495,5 +854,108 @@ extern "C" int rtk_copy_rows(const void* src, int64_t src_stride_h, void* dst, i
     RTK_LAUNCH(KID_COPY, copy_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)src,
                        (int64_t)(src_stride_h * es), (char*)dst, (int64_t)(dst_stride_h * es), H, blk);
     RTK_LAUNCH_CHECK("copy_rows_kernel");
+    return RTK_OK;
+}
+
+extern "C" int rtk_pivotkv_append(const void* k, int64_t k_stride_h, int64_t k_stride_l, const void* v,
+                                  int64_t v_stride_h, int64_t v_stride_l, int Hkv, int L, int D, int dtype,
+                                  void* k_tail, void* v_tail, int64_t tail_stride_h, rtk_stream_t stream) {
+    RTK_CHECK_ARG(k && v && k_tail && v_tail, "rtk_pivotkv_append: NULL pointer");
+    RTK_CHECK_ARG(Hkv >= 1 && L >= 1 && D >= 1, "rtk_pivotkv_append: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_append: unsupported dtype %d", dtype);
+    const int ve = dtype == RTK_BF16 ? 8 : 4;
+    const int es = dtype == RTK_BF16 ? 2 : 4;
+    const bool aligned = D % ve == 0 && (k_stride_h * es) % 16 == 0 && (k_stride_l * es) % 16 == 0 &&
+                         (v_stride_h * es) % 16 == 0 && (v_stride_l * es) % 16 == 0 && (tail_stride_h * es) % 16 == 0 &&
+                         (((uintptr_t)k | (uintptr_t)v | (uintptr_t)k_tail | (uintptr_t)v_tail) & 15) == 0;
+    if (!aligned) {
+        set_error("rtk_pivotkv_append: pointers, strides and head_dim rows must be 16-byte aligned");
+        return RTK_EUNSUPPORTED;
+    }
+    const size_t chunks = (size_t)Hkv * L * (D / ve);
+    const unsigned grid = (unsigned)std::min<size_t>((chunks + 4 * 256 - 1) / (4 * 256), 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RTK_BF16)
+        RTK_LAUNCH(KID_APPEND, append_kernel<RTK_BF16>, dim3(grid), dim3(256), 0, st, (const char*)k, k_stride_h,
+                   k_stride_l, (const char*)v, v_stride_h, v_stride_l, Hkv, L, D, (char*)k_tail, (char*)v_tail,
+                   tail_stride_h);
+    else
+        RTK_LAUNCH(KID_APPEND, append_kernel<RTK_F32>, dim3(grid), dim3(256), 0, st, (const char*)k, k_stride_h,
+                   k_stride_l, (const char*)v, v_stride_h, v_stride_l, Hkv, L, D, (char*)k_tail, (char*)v_tail,
+                   tail_stride_h);
+    RTK_LAUNCH_CHECK("append_kernel");
+    return RTK_OK;
+}
+
+extern "C" int rtk_pivotkv_evict_batched(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P,
+                                         int dtype, rtk_stream_t stream) {
+    RTK_CHECK_ARG(units && n_units >= 1, "rtk_pivotkv_evict_batched: no units");
+    RTK_CHECK_ARG(Hkv >= 1 && keep >= 1 && D >= 2, "rtk_pivotkv_evict_batched: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_evict_batched: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(P == 0 || P == 1 || P == 3, "rtk_pivotkv_evict_batched: P must be 0, 1 or 3, got %d", P);
+    const int ve = dtype == RTK_BF16 ? 8 : 4;
+    const int es = dtype == RTK_BF16 ? 2 : 4;
+    if (D % (2 * ve) != 0) {
+        set_error("rtk_pivotkv_evict_batched: head_dim %d must be a multiple of %d for this dtype", D, 2 * ve);
+        return RTK_EUNSUPPORTED;
+    }
+    for (int i = 0; i < n_units; ++i) {
+        const rtk_evict_unit& u = units[i];
+        RTK_CHECK_ARG(u.k_src && u.v_src && u.keep_idx && u.k_dst && u.v_dst, "rtk_pivotkv_evict_batched: unit %d: NULL pointer", i);
+        RTK_CHECK_ARG((u.cos_new == nullptr) == (u.sin_new == nullptr), "rtk_pivotkv_evict_batched: unit %d: cos_new and sin_new go together", i);
+        RTK_CHECK_ARG((u.pos_dst == nullptr) || (u.pos_src != nullptr && P > 0), "rtk_pivotkv_evict_batched: unit %d: pos_dst needs pos_src and P", i);
+        const bool aligned = (u.k_src_stride_h * es) % 16 == 0 && (u.v_src_stride_h * es) % 16 == 0 &&
+                             (u.k_dst_stride_h * es) % 16 == 0 && (u.v_dst_stride_h * es) % 16 == 0 &&
+                             (((uintptr_t)u.k_src | (uintptr_t)u.v_src | (uintptr_t)u.k_dst | (uintptr_t)u.v_dst |
+                               (uintptr_t)u.cos_new | (uintptr_t)u.sin_new) & 15) == 0;
+        if (!aligned) {
+            set_error("rtk_pivotkv_evict_batched: unit %d: pointers and strides must be 16-byte aligned", i);
+            return RTK_EUNSUPPORTED;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int threads = std::max(keep * (D / 2 / ve), P * keep);
+    const unsigned gx = (unsigned)((threads + 255) / 256);
+    for (int b = 0; b < n_units; b += RTK_EVICT_MAX_UNITS) {
+        const int n = std::min(RTK_EVICT_MAX_UNITS, n_units - b);
+        EvictUnits eu;
+        for (int i = 0; i < n; ++i) eu.u[i] = units[b + i];
+        for (int i = n; i < RTK_EVICT_MAX_UNITS; ++i) eu.u[i] = units[b];
+        if (dtype == RTK_BF16)
+            RTK_LAUNCH(KID_EVICTB, (evict_batched_kernel<RTK_BF16, 4>), dim3(gx, n), dim3(256), 0, st, eu, Hkv, D, keep, P);
+        else
+            RTK_LAUNCH(KID_EVICTB, (evict_batched_kernel<RTK_F32, 2>), dim3(gx, n), dim3(256), 0, st, eu, Hkv, D, keep, P);
+        RTK_LAUNCH_CHECK("evict_batched_kernel");
+    }
+    return RTK_OK;
+}
+
+extern "C" int rtk_pivotkv_commit_batched(const rtk_copy_unit* units, int n_units, int H, int rows, int D, int dtype,
+                                          rtk_stream_t stream) {
+    RTK_CHECK_ARG(units && n_units >= 1, "rtk_pivotkv_commit_batched: no units");
+    RTK_CHECK_ARG(H >= 1 && rows >= 0 && D >= 1, "rtk_pivotkv_commit_batched: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_commit_batched: unsupported dtype %d", dtype);
+    if (rows == 0) return RTK_OK;
+    const size_t es = dtype == RTK_BF16 ? 2 : 4;
+    const size_t blk = (size_t)rows * D * es;
+    for (int i = 0; i < n_units; ++i) {
+        const rtk_copy_unit& u = units[i];
+        RTK_CHECK_ARG(u.src && u.dst, "rtk_pivotkv_commit_batched: unit %d: NULL pointer", i);
+        if (blk % 16 || u.src_stride_h_bytes % 16 || u.dst_stride_h_bytes % 16 || (((uintptr_t)u.src | (uintptr_t)u.dst) & 15)) {
+            set_error("rtk_pivotkv_commit_batched: unit %d: blocks must be 16-byte aligned", i);
+            return RTK_EUNSUPPORTED;
+        }
+    }
+    const size_t total = (size_t)H * (blk / 16);
+    const unsigned gx = (unsigned)std::min<size_t>((total + 4 * 256 - 1) / (4 * 256), 1024);
+    hipStream_t st = (hipStream_t)stream;
+    for (int b = 0; b < n_units; b += RTK_COPY_MAX_UNITS) {
+        const int n = std::min(RTK_COPY_MAX_UNITS, n_units - b);
+        CopyUnits cu;
+        for (int i = 0; i < n; ++i) cu.u[i] = units[b + i];
+        for (int i = n; i < RTK_COPY_MAX_UNITS; ++i) cu.u[i] = units[b];
+        RTK_LAUNCH(KID_COMMITB, commit_batched_kernel, dim3(gx, n), dim3(256), 0, st, cu, H, blk);
+        RTK_LAUNCH_CHECK("commit_batched_kernel");
+    }
     return RTK_OK;
 }

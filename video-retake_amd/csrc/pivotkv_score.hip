@@ -16,6 +16,10 @@
 // reduction over the streamed operand is lane-local over the 16 accumulator registers plus one
 // cross-half shuffle.  The streamed operand goes HBM/L2 -> registers -> XOR-swizzled LDS tile
 // (conflict-free ds_read_b128) with the next tile's global loads in flight during the MFMAs.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include "common.cuh"
@@ -75,14 +79,26 @@ template <> struct Vec16<RTK_BF16> {
     }
 };
 
-constexpr int UNROT_HEADS = 4;
+constexpr int UNROT_HEADS = 7;
 
-template <int DT>
+// bf16 pairs through the hardware converter (v_cvt_pk_bf16_f32: round to nearest even, like c10::BFloat16)
+using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+// DIV: 0 = no division (attention_scaling^2 == 1), 1 = multiply by the reciprocal (bf16 only, the host has
+// verified EXHAUSTIVELY over all 65536 bf16 inputs that bf16(x * rcp) == bf16(x / a2) for this a2), 2 = IEEE
+template <int DT, int DIV>
 __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __restrict__ q, int64_t q_sh, int64_t q_sl,
                                                                 const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
                                                                 int Hq, int Hkv, int L, int D,
                                                                 const float* __restrict__ cosv,
-                                                                const float* __restrict__ sinv, float a2,
+                                                                const float* __restrict__ sinv, float a2, float rcp_a2,
                                                                 char* __restrict__ q_out, char* __restrict__ k_out) {
     using V = Vec16<DT>;
     constexpr int VE = V::VE;
@@ -129,22 +145,49 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
             *(u32x4*)(orow + (size_t)(d + h2) * ES) = hi[u];
             continue;
         }
-        float x1[VE], x2[VE], o1[VE], o2[VE];
-        V::unpack(lo[u], x1);
-        V::unpack(hi[u], x2);
+        // rotate_half(x)[d] = -x2, rotate_half(x)[d+h2] = x1   (longvideo_cache.py:28-32)
+        // x~ = ((x*cos) - (rotate_half(x)*sin)) / a^2, one rounding per torch op (:76-78)
+        if constexpr (DT == RTK_BF16) {
+            const uint32_t wl[4] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w}, wh[4] = {hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+            uint32_t r1[4], r2[4];
 #pragma unroll
-        for (int e = 0; e < VE; ++e) {
-            // rotate_half(x)[d] = -x2, rotate_half(x)[d+h2] = x1   (longvideo_cache.py:28-32)
-            if (DT == RTK_BF16) {
-                o1[e] = rbf(rbf(rbf(x1[e] * c1[e]) - rbf(-x2[e] * s1[e])) / a2);
-                o2[e] = rbf(rbf(rbf(x2[e] * c2[e]) - rbf(x1[e] * s2[e])) / a2);
-            } else {
-                o1[e] = __fdiv_rn(__fsub_rn(__fmul_rn(x1[e], c1[e]), __fmul_rn(-x2[e], s1[e])), a2);
-                o2[e] = __fdiv_rn(__fsub_rn(__fmul_rn(x2[e], c2[e]), __fmul_rn(x1[e], s2[e])), a2);
+            for (int w = 0; w < 4; ++w) {
+                const float x1a = bf_lo(wl[w]), x1b = bf_hi(wl[w]), x2a = bf_lo(wh[w]), x2b = bf_hi(wh[w]);
+                const int e = 2 * w;
+                const uint32_t p1 = pack2_bf16(x1a * c1[e], x1b * c1[e + 1]);          // x1*cos
+                const uint32_t n1 = pack2_bf16(x2a * s1[e], x2b * s1[e + 1]);          // -(rotate_half(x)*sin) = x2*sin
+                const uint32_t p2 = pack2_bf16(x2a * c2[e], x2b * c2[e + 1]);          // x2*cos
+                const uint32_t n2 = pack2_bf16(x1a * s2[e], x1b * s2[e + 1]);          // rotate_half(x)*sin = x1*sin
+                uint32_t t1 = pack2_bf16(bf_lo(p1) + bf_lo(n1), bf_hi(p1) + bf_hi(n1));
+                uint32_t t2 = pack2_bf16(bf_lo(p2) - bf_lo(n2), bf_hi(p2) - bf_hi(n2));
+                if constexpr (DIV == 1) {
+                    t1 = pack2_bf16(bf_lo(t1) * rcp_a2, bf_hi(t1) * rcp_a2);
+                    t2 = pack2_bf16(bf_lo(t2) * rcp_a2, bf_hi(t2) * rcp_a2);
+                } else if constexpr (DIV == 2) {
+                    t1 = pack2_bf16(__fdiv_rn(bf_lo(t1), a2), __fdiv_rn(bf_hi(t1), a2));
+                    t2 = pack2_bf16(__fdiv_rn(bf_lo(t2), a2), __fdiv_rn(bf_hi(t2), a2));
+                }
+                r1[w] = t1;
+                r2[w] = t2;
             }
+            *(u32x4*)(orow + (size_t)d * ES) = u32x4{r1[0], r1[1], r1[2], r1[3]};
+            *(u32x4*)(orow + (size_t)(d + h2) * ES) = u32x4{r2[0], r2[1], r2[2], r2[3]};
+        } else {
+            float x1[VE], x2[VE], o1[VE], o2[VE];
+            V::unpack(lo[u], x1);
+            V::unpack(hi[u], x2);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                o1[e] = __fsub_rn(__fmul_rn(x1[e], c1[e]), __fmul_rn(-x2[e], s1[e]));
+                o2[e] = __fsub_rn(__fmul_rn(x2[e], c2[e]), __fmul_rn(x1[e], s2[e]));
+                if constexpr (DIV != 0) {
+                    o1[e] = __fdiv_rn(o1[e], a2);
+                    o2[e] = __fdiv_rn(o2[e], a2);
+                }
+            }
+            *(u32x4*)(orow + (size_t)d * ES) = V::pack(o1);
+            *(u32x4*)(orow + (size_t)(d + h2) * ES) = V::pack(o2);
         }
-        *(u32x4*)(orow + (size_t)d * ES) = V::pack(o1);
-        *(u32x4*)(orow + (size_t)(d + h2) * ES) = V::pack(o2);
     }
 }
 
@@ -828,14 +871,17 @@ __global__ __launch_bounds__(256) void score_pass2_generic(const void* __restric
 }
 
 // finalize: score[j] = mean_g( (sum_split partial[g,split,j]) / G )      (longvideo_cache.py:269-270)
-// fixed summation order; loads are issued eight at a time so the kernel is not latency-serialised
-__global__ __launch_bounds__(64) void score_finalize_kernel(const float* __restrict__ partial, int Hkv, int RS, int G,
-                                                            int L, float* __restrict__ score) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= L) return;
-    float tot = 0.f;
-    for (int g = 0; g < Hkv; ++g) {
-        const float* p = partial + (size_t)g * RS * L + j;
+// Fixed summation order (bit-reproducible).  A workgroup owns 64 keys; its four waves take the KV groups
+// g = wave, wave + 4, ... so that up to 4 x 8 loads per key are in flight, then wave 0 adds the per-group means
+// in group order.
+__global__ __launch_bounds__(256) void score_finalize_kernel(const float* __restrict__ partial, int Hkv, int RS, int G,
+                                                             int L, float* __restrict__ score) {
+    extern __shared__ float fin_gs[];  // [Hkv][64]
+    const int jl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jl;
+    const int jc = min(j, L - 1);
+    for (int g = part; g < Hkv; g += 4) {
+        const float* p = partial + (size_t)g * RS * L + jc;
         float gs = 0.f;
         int r = 0;
         for (; r + 8 <= RS; r += 8) {
@@ -846,9 +892,14 @@ __global__ __launch_bounds__(64) void score_finalize_kernel(const float* __restr
             for (int u = 0; u < 8; ++u) gs += v[u];
         }
         for (; r < RS; ++r) gs += p[(size_t)r * L];
-        tot += gs / (float)G;
+        fin_gs[g * 64 + jl] = gs / (float)G;
     }
-    score[j] = tot / (float)Hkv;
+    __syncthreads();
+    if (part == 0 && j < L) {
+        float tot = 0.f;
+        for (int g = 0; g < Hkv; ++g) tot += fin_gs[g * 64 + jl];
+        score[j] = tot / (float)Hkv;
+    }
 }
 
 // Work decomposition.  Both passes are cut into >= ~3000 workgroups (about 4 rounds over 256 CUs x 3
@@ -869,6 +920,38 @@ static int pick_splits(int tiles_fixed, int heads, int stream_tiles, int cap, in
         if ((Hkv * eff) % NXCD == 0) return t;
     }
     return s;
+}
+
+// bf16(x * (1/a2)) == bf16(x / a2) for EVERY finite bf16 x?  (x is bf16-valued in the un-rotate chain, so the
+// check is exhaustive: 65536 cases, cached per a2.)  True for the YaRN factor-4 scaling 1.1386^2.
+static bool bf16_rcp_is_exact(float a2) {
+    static std::mutex mu;
+    static std::map<uint32_t, bool> cache;
+    uint32_t key;
+    memcpy(&key, &a2, 4);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    auto to_bf = [](float f) -> uint16_t {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    };
+    const volatile float rcp = 1.0f / a2;
+    bool ok = std::isfinite(rcp) && a2 != 0.0f;
+    for (uint32_t b = 0; ok && b < 65536; ++b) {
+        const uint32_t u = b << 16;
+        float x;
+        memcpy(&x, &u, 4);
+        if (!std::isfinite(x)) continue;
+        const volatile float qd = x / a2, qm = x * rcp;   // volatile: no fused / extended-precision evaluation
+        // flush-to-zero differences between host and device do not matter: both sides would round tiny values the same
+        if (to_bf(qd) != to_bf(qm)) ok = false;
+    }
+    cache[key] = ok;
+    return ok;
 }
 
 struct ScoreWs {
@@ -927,8 +1010,16 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         if (vec_ok) {
             const int threads = L * (D / 2 / VE);
             const int groups = (Hq + UNROT_HEADS - 1) / UNROT_HEADS + (Hkv + UNROT_HEADS - 1) / UNROT_HEADS;
-            RTK_LAUNCH(KID_UNROT, unrotate_pack_vec_kernel<DT>, dim3((threads + 255) / 256, groups), dim3(256), 0, st,
-                       (const char*)q, qsh, qsl, (const char*)k, ksh, ksl, Hq, Hkv, L, D, cosv, sinv, a2, qt, kt);
+            const dim3 grid((threads + 255) / 256, groups);
+            const int div = (!cosv || a2 == 1.0f) ? 0 : ((DT == RTK_BF16 && bf16_rcp_is_exact(a2)) ? 1 : 2);
+            const float rcp = 1.0f / a2;
+#define RTK_UNROT(DIV)                                                                                             \
+    RTK_LAUNCH(KID_UNROT, (unrotate_pack_vec_kernel<DT, DIV>), grid, dim3(256), 0, st, (const char*)q, qsh, qsl,     \
+               (const char*)k, ksh, ksl, Hq, Hkv, L, D, cosv, sinv, a2, rcp, qt, kt)
+            if (div == 0) RTK_UNROT(0);
+            else if (div == 1) RTK_UNROT(1);
+            else RTK_UNROT(2);
+#undef RTK_UNROT
         } else {
             const size_t nq = (size_t)Hq * L * (D / 2), nk = (size_t)Hkv * L * (D / 2);
             RTK_LAUNCH(KID_UNROT, unrotate_pack_kernel<DT>, dim3((unsigned)std::min<size_t>((nq + 255) / 256, 8192)),
@@ -973,7 +1064,8 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                            (const void*)qt, (const void*)kt, lse, Hq, Hkv, L, D, part);
         RTK_LAUNCH_CHECK("score_generic");
     }
-    RTK_LAUNCH(KID_FINALIZE, score_finalize_kernel, dim3((L + 63) / 64), dim3(64), 0, st, part, Hkv, rs_n, G, L, score);
+    RTK_LAUNCH(KID_FINALIZE, score_finalize_kernel, dim3((L + 63) / 64), dim3(256), (size_t)Hkv * 64 * sizeof(float), st, part,
+               Hkv, rs_n, G, L, score);
     RTK_LAUNCH_CHECK("score_finalize_kernel");
     return RTK_OK;
 }

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void rope_merge_kernel(const void* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void rope_table_kernel(const int64_t* __restrict__ pos, int L, int D,
+__global__ __launch_bounds__(256) void rope_table_kernel(const int64_t* __restrict__ pos, int64_t pos_ld, int L, int D,
                                                          const float* __restrict__ inv_freq, float scaling,
                                                          RowSel rs, int round_bf16, float* __restrict__ cos_out,
                                                          float* __restrict__ sin_out) {
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void rope_table_kernel(const int64_t* __restri
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int d = (int)(i % D);
         const size_t l = i / D;
-        const float p = (float)pos[(size_t)rs.row[d] * L + l];
+        const float p = (float)pos[(size_t)rs.row[d] * pos_ld + l];
         const float ang = p * inv_freq[d < h2 ? d : d - h2];
         float s, c;
         sincosf(ang, &s, &c);
@@ -113,9 +113,43 @@ __global__ __launch_bounds__(256) void rope_shift_kernel(void* __restrict__ kv, 
     }
 }
 
+
+// Temporal-id continuity fix of the attention patch (qwen2_vl.py:68-73), on the device: the whole row is
+// shifted so that its first id follows the last id stored for the layer.  One workgroup: the first id is
+// read by everyone before anyone writes.
+__global__ __launch_bounds__(1024) void position_shift_kernel(int64_t* __restrict__ t, int n,
+                                                             const int64_t* __restrict__ prev) {
+    constexpr int E = 8;  // ids per thread per sweep, all loaded before the first id is overwritten
+    const long long p = prev ? (long long)prev[0] : -1ll;
+    const long long delta = p + 1 - (long long)t[0];
+    for (int base = 0; base < n; base += E * 1024) {
+        long long v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = base + e * 1024 + (int)threadIdx.x;
+            v[e] = i < n ? (long long)t[i] : 0;
+        }
+        if (base == 0) __syncthreads();  // everybody has read t[0]
+        if (delta != 0) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = base + e * 1024 + (int)threadIdx.x;
+                if (i < n) t[i] = v[e] + delta;
+            }
+        }
+    }
+}
+
 }  // namespace rtk
 
 using namespace rtk;
+
+extern "C" int rtk_position_shift(int64_t* temporal_ids, int n, const int64_t* prev_dev, rtk_stream_t stream) {
+    RTK_CHECK_ARG(temporal_ids && n >= 1, "rtk_position_shift: NULL pointer or empty row");
+    RTK_LAUNCH(KID_SHIFT, position_shift_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, temporal_ids, n, prev_dev);
+    RTK_LAUNCH_CHECK("position_shift_kernel");
+    return RTK_OK;
+}
 
 extern "C" int rtk_rope_shift(void* k, int64_t stride_h, int H, int n, int D, int dtype, const int64_t* delta_dev,
                               const float* inv_freq, int P, const int* sections_host, int nsec, rtk_stream_t stream) {
@@ -158,17 +192,19 @@ extern "C" int rtk_rope_merge(const void* cos_in, const void* sin_in, int P, int
     return RTK_OK;
 }
 
-extern "C" int rtk_rope_table(const int64_t* pos, int P, int L, const float* inv_freq, int D, float attention_scaling,
+extern "C" int rtk_rope_table(const int64_t* pos, int64_t pos_stride, int P, int L, const float* inv_freq, int D,
+                              float attention_scaling,
                               const int* sections_host, int nsec, int round_bf16, float* cos_out, float* sin_out,
                               rtk_stream_t stream) {
     RTK_CHECK_ARG(pos && inv_freq && cos_out && sin_out, "rtk_rope_table: NULL pointer");
     RTK_CHECK_ARG(L >= 1 && D >= 2, "rtk_rope_table: bad shape L=%d D=%d", L, D);
+    RTK_CHECK_ARG(pos_stride >= L, "rtk_rope_table: pos_stride %lld < L %d", (long long)pos_stride, L);
     RowSel rs;
     int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_rope_table");
     if (rc) return rc;
     const unsigned grid = (unsigned)std::min<size_t>(((size_t)L * D + 255) / 256, 4096);
-    RTK_LAUNCH(KID_ROPE, rope_table_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pos, L, D, inv_freq,
-                       attention_scaling, rs, round_bf16, cos_out, sin_out);
+    RTK_LAUNCH(KID_ROPE, rope_table_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pos, pos_stride, L, D,
+               inv_freq, attention_scaling, rs, round_bf16, cos_out, sin_out);
     RTK_LAUNCH_CHECK("rope_table_kernel");
     return RTK_OK;
 }

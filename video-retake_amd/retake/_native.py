@@ -13,12 +13,26 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 RTK_F32, RTK_BF16 = 0, 1
 RTK_EINVAL, RTK_EUNSUPPORTED, RTK_EWORKSPACE, RTK_EHIP, RTK_EREFCRASH = -1, -2, -3, -4, -5
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+
+class EvictUnit(C.Structure):
+    """rtk_evict_unit (include/retake_hip.h)."""
+    _fields_ = [("k_src", _vp), ("k_src_stride_h", _i64), ("v_src", _vp), ("v_src_stride_h", _i64),
+                ("keep_idx", _vp), ("cos_new", _vp), ("sin_new", _vp),
+                ("k_dst", _vp), ("k_dst_stride_h", _i64), ("v_dst", _vp), ("v_dst_stride_h", _i64),
+                ("pos_src", _vp), ("pos_src_stride", _i64), ("pos_dst", _vp), ("pos_dst_stride", _i64)]
+
+
+class CopyUnit(C.Structure):
+    """rtk_copy_unit (include/retake_hip.h)."""
+    _fields_ = [("src", _vp), ("src_stride_h_bytes", _i64), ("dst", _vp), ("dst_stride_h_bytes", _i64)]
+
 
 _SIGNATURES = {
     "rtk_version": (C.c_int, []),
@@ -28,16 +42,21 @@ _SIGNATURES = {
     "rtk_dpselect_select": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rtk_gather_frames": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "rtk_rope_merge": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
-    "rtk_rope_table": (C.c_int, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _vp, _vp, _vp]),
+    "rtk_rope_table": (C.c_int, [_vp, _i64, _i, _i, _vp, _i, _f, _vp, _i, _i, _vp, _vp, _vp]),
     "rtk_rope_shift": (C.c_int, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "rtk_pivotkv_score_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "rtk_pivotkv_score": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp,
                                     _vp, _sz, _vp]),
-    "rtk_pivotkv_select": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "rtk_pivotkv_select_workspace_bytes": (C.c_size_t, [_i]),
+    "rtk_pivotkv_select": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rtk_pivotkv_evict": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp,
                                     _vp, _i64, _vp, _vp, _i64, _vp]),
     "rtk_copy_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "rtk_pivotkv_commit": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "rtk_pivotkv_append": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    "rtk_pivotkv_evict_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rtk_pivotkv_commit_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "rtk_position_shift": (C.c_int, [_vp, _i, _vp, _vp]),
     "rtk_profile_enable": (C.c_int, [_i]),
     "rtk_profile_enable_mask": (C.c_int, [C.c_uint]),
     "rtk_profile_collect": (C.c_int, []),

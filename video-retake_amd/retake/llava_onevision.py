@@ -65,11 +65,15 @@ def retake_Qwen2Attention_forward(self, hidden_states, position_embeddings, atte
     position_ids = None
     if past_key_value is not None and getattr(past_key_value, "pos_embed_reforge", False):
         position_ids = kwargs.get("position_ids")
-        prev_tempo_idx = past_key_value.get_prev_temporal_idx(self.layer_idx)
-        cur_tempo_idx = position_ids[0, 0]
-        if prev_tempo_idx + 1 != cur_tempo_idx:
-            position_ids = position_ids.clone()
-            position_ids[0, :] += prev_tempo_idx + 1 - cur_tempo_idx
+        if position_ids.is_cuda and hasattr(past_key_value, "shift_temporal_ids_"):
+            # same rule on the device, no host sync (a zero shift leaves the clone equal to the ids)
+            position_ids = past_key_value.shift_temporal_ids_(position_ids.clone(), self.layer_idx)
+        else:
+            prev_tempo_idx = past_key_value.get_prev_temporal_idx(self.layer_idx)
+            cur_tempo_idx = position_ids[0, 0]
+            if prev_tempo_idx + 1 != cur_tempo_idx:
+                position_ids = position_ids.clone()
+                position_ids[0, :] += prev_tempo_idx + 1 - cur_tempo_idx
         position_embeddings = None  # must be recomputed from the shifted ids
     if position_embeddings is None:
         cos, sin = self.rotary_emb(value_states, position_ids)

@@ -8,12 +8,20 @@ keys/values of the layer); scoring, selection and the eviction scan run as HIP k
     rtk_pivotkv_select                mask override, top-k, id gather + rescale    (:272-295)
     rtk_pivotkv_evict                 append + gather + re-rotate + compaction     (:238, :278-318)
 
+    rtk_pivotkv_append                chunk -> pre-allocated cache tail            (:238)
+    rtk_pivotkv_evict_batched /       gather + re-rotate + compaction of EVERY layer of the chunk,
+    rtk_pivotkv_commit_batched        two launches per chunk                       (:278-318)
+
 Memory layout (differs from the reference on purpose): each layer owns ONE pre-allocated
-[1, Hkv, capacity, D] key and value buffer.  A chunk is appended at the tail (that view is what
-`update` returns to the layer's attention), the kept rows are staged and committed over the tail's
-head once the layer's attention has consumed the view (next `update` of the layer, `after_forward`,
-or any access to `key_cache` / `value_cache`).  This removes the reference's two O(cache) torch.cat
-rebuilds per (layer, chunk).
+[1, Hkv, capacity, D] key and value buffer and one [P, capacity] position-id buffer.  `update` appends
+the chunk at the tail (that view is what it returns to the layer's attention), scores it and records
+which rows survive in the layer's slot of a per-chunk batch.  The eviction itself — gather of the kept
+rows, re-rotation of the kept keys at their new ids, compaction over the head of the tail, position
+bookkeeping — is deferred until the view has been consumed and then flushed for ALL pending layers at
+once (`after_forward`, which the reference calls after every video chunk; or the next `update` of a
+pending layer; or any access to `key_cache` / `value_cache` / `position_cache`).  This removes the
+reference's two O(cache) torch.cat rebuilds per (layer, chunk) and turns 28 launch-bound evictions
+into one bandwidth-bound launch.
 """
 from __future__ import annotations
 
@@ -140,18 +148,19 @@ DynamicCache = _HFDynamicCache if _hf_dynamic_cache_is_legacy() else _ListDynami
 
 
 class _LayerStore:
-    """One layer's pre-allocated K/V buffers [1, Hkv, cap, D] plus the staged kept rows."""
+    """One layer's pre-allocated K/V buffers [1, Hkv, cap, D] and position ids [P, cap]."""
 
-    __slots__ = ("k", "v", "length", "pending", "k_stage", "v_stage", "pending_keep", "pending_event", "pending_pos")
+    __slots__ = ("k", "v", "length", "pending", "pending_keep", "pending_event", "pos", "pos_len", "pos_ndim")
 
     def __init__(self):
         self.k = self.v = None
         self.length = 0          # committed tokens
         self.pending = 0         # uncompressed chunk tokens sitting at [length, length+pending)
-        self.k_stage = self.v_stage = None
         self.pending_keep = 0
-        self.pending_event = None  # side-stream completion of the staged rows (overlap_streams > 0)
-        self.pending_pos = None    # compressed position ids not yet appended to position_cache
+        self.pending_event = None  # worker-stream completion of this layer's scoring (overlap_streams > 0)
+        self.pos = None          # int64 [P, cap]: position ids of the cached tokens (pos_embed_reforge)
+        self.pos_len = 0
+        self.pos_ndim = 0        # 3: ids are [3, 1, n] (M-RoPE), 2: [1, n]
 
 
 class _Side:
@@ -162,8 +171,31 @@ class _Side:
         self.ws: Dict[str, torch.Tensor] = {}
 
 
+class _Batch:
+    """Per-chunk batch of pending evictions: slot = layer index.  All units share the chunk geometry."""
+
+    def __init__(self, key, slots, Hkv, L, D, keep, P, reforge, dtype, device):
+        self.key, self.slots, self.keep, self.P, self.reforge = key, slots, keep, P, reforge
+        self.Hkv, self.L, self.D, self.dtype, self.device = Hkv, L, D, dtype, device
+        self.keep_idx = torch.empty((slots, keep), dtype=torch.int64, device=device)
+        self.pos_new = torch.empty((P, slots, keep), dtype=torch.int64, device=device) if P else None
+        self.v_stage = torch.empty((slots, Hkv, keep, D), dtype=dtype, device=device)
+        if reforge:  # kept K is re-rotated from the un-rotated copy straight into the cache: no K staging
+            self.k_unrot = torch.empty((slots, Hkv, L, D), dtype=dtype, device=device)
+            self.cos_new = torch.empty((slots * keep, D), dtype=torch.float32, device=device)
+            self.sin_new = torch.empty((slots * keep, D), dtype=torch.float32, device=device)
+            self.k_stage = None
+        else:
+            self.k_unrot = self.cos_new = self.sin_new = None
+            self.k_stage = torch.empty((slots, Hkv, keep, D), dtype=dtype, device=device)
+        self.pending: List[int] = []
+        self.rotary_emb_fn = None
+        self.mrope_section = None
+        self.x_like = None
+
+
 class _CacheView:
-    """List-like view handed out as `key_cache` / `value_cache`: indexing commits pending compaction
+    """List-like view handed out as `key_cache` / `value_cache`: indexing flushes pending compaction
     first, so readers always see the compacted cache exactly like the reference's lists."""
 
     def __init__(self, owner: "PivotKVCache", which: str):
@@ -180,7 +212,8 @@ class _CacheView:
         st = self._o._layers[i]
         if st.k is None:
             return []
-        self._o._commit(i)
+        if st.pending:
+            self._o._flush()
         buf = st.k if self._w == "k" else st.v
         return buf[:, :, :st.length]
 
@@ -203,6 +236,8 @@ class PivotKVCache(DynamicCache):
 
     def __init__(self, config) -> None:
         self._layers: List[_LayerStore] = []
+        self._batch: Optional[_Batch] = None
+        self._pos_layers = 0
         self._kview = _CacheView(self, "k")
         self._vview = _CacheView(self, "v")
         super().__init__()
@@ -225,17 +260,17 @@ class PivotKVCache(DynamicCache):
         # MI355X build option: compute cos/sin tables in a HIP kernel from rotary_emb.inv_freq instead of
         # calling the rotary module (valid for the default / YaRN inv_freq*position rotary modules)
         self.native_rope = bool(kv_compression_kwargs.get("native_rope", False))
-        # MI355X build option: run scoring / selection / eviction of each update on one of N worker HIP
-        # streams.  Only the tail append stays on the caller's stream (it is all the layer's attention
-        # needs); the staged rows are committed after waiting for the worker's event.  Independent
-        # updates then overlap on the GPU (the one-workgroup select kernel hides under MFMA kernels).
+        # MI355X build option: run scoring / selection of each update on one of N worker HIP streams.  Only
+        # the tail append stays on the caller's stream (it is all the layer's attention needs); the flush
+        # waits for the workers' events.  Independent updates then overlap on the GPU.
         self.overlap_streams = int(kv_compression_kwargs.get("overlap_streams", 0))
         self._sides: List[_Side] = []
         self._side_rr = 0
-        self._position_cache: List[torch.Tensor] = []
+        self._pos_layers = 0          # len(position_cache) of the reference (skipped layers are padded with [])
         self.num_evicted_tokens: List[int] = []
         self.keypatches_mask_chunk = None
         self._ws: Dict[str, torch.Tensor] = {}
+        self._batch: Optional[_Batch] = None
         self._warned = False
 
     # ---- list views --------------------------------------------------------------------------
@@ -245,6 +280,7 @@ class PivotKVCache(DynamicCache):
 
     @key_cache.setter
     def key_cache(self, value):  # the base class assigns [] in __init__
+        self._flush()
         self._layers = []
         for v in value:
             self._kview.append(v)
@@ -263,7 +299,8 @@ class PivotKVCache(DynamicCache):
 
     def _adopt(self, i: int, which: str, value):
         st = self._layers[i]
-        self._commit(i)
+        if st.pending:
+            self._flush()
         if isinstance(value, list) and len(value) == 0:
             st.k = st.v = None
             st.length = 0
@@ -290,25 +327,51 @@ class PivotKVCache(DynamicCache):
         for i in range(len(self)):
             yield self[i]
 
+    # ---- position ids of the cached tokens (reference :143, :179-215) -----------------------------
+    def _pos_view(self, st: _LayerStore):
+        v = st.pos[:, :st.pos_len]
+        return v.unsqueeze(1) if st.pos_ndim == 3 else v
+
     @property
     def position_cache(self):
-        """Per-layer position ids of the cached tokens (reference :143).  Reading it flushes deferred work."""
-        for i in range(len(self._layers)):
-            if self._layers[i].pending_pos is not None:
-                self._commit(i)
-        return self._position_cache
+        """Per-layer position ids of the cached tokens (reference :143): a list of [3, 1, n] / [1, n] views
+        of the layers' id buffers, [] for skipped layers.  Reading it flushes deferred work."""
+        self._flush()
+        out = []
+        for i in range(self._pos_layers):
+            st = self._layers[i] if i < len(self._layers) else None
+            out.append([] if st is None or st.pos is None else self._pos_view(st))
+        return out
 
     @position_cache.setter
     def position_cache(self, value):
-        self._position_cache = value
+        self._flush()
+        self._pos_layers = len(value)
+        for i, t in enumerate(value):
+            st = self._store(i)
+            if isinstance(t, list) and len(t) == 0:
+                st.pos, st.pos_len, st.pos_ndim = None, 0, 0
+            else:
+                st.pos_ndim = t.ndim
+                st.pos = t.reshape(t.shape[0], t.shape[-1]).contiguous()
+                st.pos_len = t.shape[-1]
+
+    def _pos_reserve(self, st: _LayerStore, P: int, ndim: int, more: int, device):
+        need = st.pos_len + more
+        if st.pos is not None and st.pos.shape[1] >= need:
+            return
+        cap = max(need, 2 * (st.pos.shape[1] if st.pos is not None else 0), 4096)
+        buf = torch.empty((P, cap), dtype=torch.int64, device=device)
+        if st.pos is not None and st.pos_len:
+            buf[:, :st.pos_len].copy_(st.pos[:, :st.pos_len])
+        st.pos, st.pos_ndim = buf, ndim
 
     # ---- hooks (reference :146-150): after_forward is where deferred compaction is flushed -------
     def before_forward(self, **kwargs):
         pass
 
     def after_forward(self, **kwargs):
-        for i in range(len(self._layers)):
-            self._commit(i)
+        self._flush()
 
     # ---- bookkeeping lists (reference :152-215) ------------------------------------------------
     def update_num_evicted_tokens(self, num_tokens: int, layer_idx: int):
@@ -322,25 +385,52 @@ class PivotKVCache(DynamicCache):
 
     def update_position_ids(self, position_ids: torch.Tensor, layer_idx: int):
         """position_cache[layer] = cat(prev, position_ids, dim=-1), padding skipped layers with []
-        (longvideo_cache.py:179-209)."""
-        pc = self._position_cache
-        if len(pc) <= layer_idx:
-            pc.extend([[] for _ in range(layer_idx - len(pc))])
-            pc.append(position_ids)
-        elif len(pc[layer_idx]) == 0:
-            pc[layer_idx] = position_ids
-        else:
-            pc[layer_idx] = torch.cat([pc[layer_idx], position_ids], dim=-1)
-        return pc[layer_idx]
+        (longvideo_cache.py:179-209).  The ids are appended to the layer's pre-allocated id buffer."""
+        st = self._store(layer_idx)
+        if st.pending:
+            self._flush()
+        n = position_ids.shape[-1]
+        P = position_ids.shape[0]
+        self._pos_reserve(st, P, position_ids.ndim, n, position_ids.device)
+        st.pos[:, st.pos_len:st.pos_len + n].copy_(position_ids.reshape(P, n))
+        st.pos_len += n
+        self._pos_layers = max(self._pos_layers, layer_idx + 1)
+        return self._pos_view(st)
 
     def get_prev_temporal_idx(self, layer_idx: int):
         """Last temporal id stored for the layer, -1 if none (longvideo_cache.py:211-215)."""
-        if len(self._layers) > layer_idx and self._layers[layer_idx].pending_pos is not None:
-            self._commit(layer_idx)  # ids of the previous chunk are still on a worker stream
-        if len(self._position_cache) <= layer_idx:
+        if layer_idx >= self._pos_layers and not (len(self._layers) > layer_idx and self._layers[layer_idx].pending):
             return -1
-        cache_layer = self._position_cache[layer_idx]
-        return cache_layer[0, 0, -1] if cache_layer.ndim == 3 else cache_layer[0, -1]
+        st = self._layers[layer_idx]
+        if st.pending:
+            self._flush()  # the ids of the previous chunk are still in the batch
+        if layer_idx >= self._pos_layers or st.pos is None or st.pos_len == 0:
+            return -1
+        return st.pos[0, st.pos_len - 1]
+
+    def shift_temporal_ids_(self, position_ids: torch.Tensor, layer_idx: int):
+        """The attention patch's continuity fix (qwen2_vl.py:68-73, llava_onevision.py:68-72) on the device:
+        position_ids[0, 0, :] (or [0, :]) += prev + 1 - its first element, in place, where prev is the last
+        temporal id cached for the layer.  Same result as the reference's compare-then-shift, without the
+        host round trip of the comparison."""
+        if not self.pos_embed_reforge:
+            return position_ids
+        nv.require_device(position_ids)
+        row = position_ids[0, 0] if position_ids.ndim == 3 else position_ids[0]
+        if position_ids.dtype != torch.int64 or row.stride(-1) != 1:
+            prev = self.get_prev_temporal_idx(layer_idx)
+            row += prev + 1 - row[0].clone()
+            return position_ids
+        prev_ptr = None
+        if len(self._layers) > layer_idx:
+            st = self._layers[layer_idx]
+            if st.pending:
+                self._flush()
+            if layer_idx < self._pos_layers and st.pos is not None and st.pos_len:
+                prev_ptr = C.c_void_p(st.pos.data_ptr() + 8 * (st.pos_len - 1))
+        with torch.cuda.device(position_ids.device):
+            nv.check(nv.lib.rtk_position_shift(nv.ptr(row), row.shape[0], prev_ptr, nv.stream()), "rtk_position_shift")
+        return position_ids
 
     # ---- storage -------------------------------------------------------------------------------
     def _store(self, layer_idx: int) -> _LayerStore:
@@ -352,7 +442,8 @@ class PivotKVCache(DynamicCache):
         """Make room for `tokens` more rows after the committed length of the layer."""
         st = self._store(layer_idx)
         need = st.length + tokens
-        if st.k is not None and st.k.shape[2] >= need and st.k.is_contiguous():
+        if st.k is not None and st.k.shape[2] >= need and st.k.is_contiguous() and st.v.is_contiguous() \
+                and st.v.shape[2] == st.k.shape[2]:
             return st
         cap = max(need, 2 * (st.k.shape[2] if st.k is not None else 0), 1024)
         shape = (1, like.shape[1], cap, like.shape[3])
@@ -363,32 +454,6 @@ class PivotKVCache(DynamicCache):
             nvv[:, :, :st.length].copy_(st.v[:, :, :st.length])
         st.k, st.v = nk, nvv
         return st
-
-    def _commit(self, layer_idx: int):
-        """Move the staged kept rows over the head of the uncompressed tail (reference :313-318)."""
-        st = self._layers[layer_idx]
-        if not st.pending:
-            return
-        keep, H, D = st.pending_keep, st.k.shape[1], st.k.shape[3]
-        cap = st.k.shape[2]
-        off = st.length * D * st.k.element_size()
-        with torch.cuda.device(st.k.device):
-            if st.pending_event is not None:  # staged rows were produced on a worker stream
-                torch.cuda.current_stream().wait_event(st.pending_event)
-                st.pending_event = None
-            if st.pending_pos is not None:
-                st.pending_pos.record_stream(torch.cuda.current_stream())
-                self.update_position_ids(st.pending_pos, layer_idx)
-                st.pending_pos = None
-            s = nv.stream()
-            dt = nv.dtype_code(st.k)
-            sst = st.k_stage.shape[2] * D  # staging head stride (its capacity may exceed this chunk's keep)
-            nv.check(nv.lib.rtk_pivotkv_commit(nv.ptr(st.k_stage), nv.ptr(st.v_stage), sst,
-                                               C.c_void_p(st.k.data_ptr() + off), C.c_void_p(st.v.data_ptr() + off),
-                                               cap * D, H, keep, D, dt, s), "rtk_pivotkv_commit")
-        st.length += keep
-        st.pending = 0
-        st.pending_keep = 0
 
     def _next_side(self, device) -> Optional[_Side]:
         if self.overlap_streams <= 0:
@@ -410,27 +475,25 @@ class PivotKVCache(DynamicCache):
             ws[name] = t
         return t[:n].view(*shape)
 
-    def _rope_tables(self, name, rotary_emb_fn, x_like, position_ids, mrope_section, n, D, ws=None):
-        """fp32 [n, D] cos/sin tables of `position_ids`, section-merged (reference :249 + :68-74)."""
+    def _rope_tables(self, cos_t, sin_t, rotary_emb_fn, x_like, pos2d, pos_ld, ndim, mrope_section, n, D):
+        """fp32 [n, D] cos/sin tables of the ids pos2d [P, n] (row stride pos_ld), section-merged
+        (reference :249 / :298 + :68-74), written into cos_t / sin_t."""
         dev = x_like.device
-        cos_t = self._buf(name + "_cos", (n, D), torch.float32, dev, ws)
-        sin_t = self._buf(name + "_sin", (n, D), torch.float32, dev, ws)
-        P = 3 if position_ids.ndim == 3 else 1
+        P = pos2d.shape[0]
         sec = (C.c_int * len(mrope_section))(*mrope_section) if mrope_section else None
         nsec = len(mrope_section) if mrope_section else 0
         s = nv.stream()
         if self.native_rope and hasattr(rotary_emb_fn, "inv_freq"):
-            pos = position_ids.reshape(P, n)
-            if not pos.is_contiguous():
-                pos = pos.contiguous()
             inv = rotary_emb_fn.inv_freq
             if inv.device != dev or inv.dtype != torch.float32 or not inv.is_contiguous():
                 inv = inv.to(device=dev, dtype=torch.float32).contiguous()
-            nv.check(nv.lib.rtk_rope_table(nv.ptr(pos), P, n, nv.ptr(inv), D, float(rotary_emb_fn.attention_scaling),
-                                           sec, nsec, int(x_like.dtype == torch.bfloat16), nv.ptr(cos_t), nv.ptr(sin_t),
-                                           s), "rtk_rope_table")
-            return cos_t, sin_t
-        cos, sin = rotary_emb_fn(x_like, position_ids)  # third-party module, exactly as the reference calls it
+            nv.check(nv.lib.rtk_rope_table(nv.ptr(pos2d), pos_ld, P, n, nv.ptr(inv), D,
+                                           float(rotary_emb_fn.attention_scaling), sec, nsec,
+                                           int(x_like.dtype == torch.bfloat16), nv.ptr(cos_t), nv.ptr(sin_t), s),
+                     "rtk_rope_table")
+            return
+        ids = pos2d.unsqueeze(1) if ndim == 3 else pos2d
+        cos, sin = rotary_emb_fn(x_like, ids)  # third-party module, exactly as the reference calls it
         cos = cos.reshape(P, n, D)
         sin = sin.reshape(P, n, D)
         if not cos.is_contiguous():
@@ -439,7 +502,89 @@ class PivotKVCache(DynamicCache):
             sin = sin.contiguous()
         nv.check(nv.lib.rtk_rope_merge(nv.ptr(cos), nv.ptr(sin), P, n, D, nv.dtype_code(cos), sec, nsec, nv.ptr(cos_t),
                                        nv.ptr(sin_t), s), "rtk_rope_merge")
-        return cos_t, sin_t
+
+    # ---- deferred eviction -----------------------------------------------------------------------
+    def _get_batch(self, layer_idx, Hkv, L, D, keep, P, dtype, device) -> _Batch:
+        key = (Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device)
+        b = self._batch
+        if b is not None and b.key == key and layer_idx < b.slots:
+            return b
+        self._flush()
+        slots = max(int(self.num_hidden_layers), layer_idx + 1, b.slots if b is not None and b.key == key else 0)
+        self._batch = None  # release the old buffers before allocating the new ones
+        self._batch = _Batch(key, slots, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device)
+        return self._batch
+
+    def _flush(self):
+        """Evict every pending (layer, chunk) unit: one batched gather / re-rotate launch and one batched
+        commit launch (reference :278-318 for all layers of the chunk)."""
+        b = self._batch
+        if b is None or not b.pending:
+            return
+        layers, b.pending = b.pending, []
+        keep, D, Hkv, P = b.keep, b.D, b.Hkv, b.P
+        es = b.v_stage.element_size()
+        dt = nv.RTK_BF16 if b.dtype == torch.bfloat16 else nv.RTK_F32
+        with torch.cuda.device(b.device):
+            main = torch.cuda.current_stream()
+            for l in layers:
+                st = self._layers[l]
+                if st.pending_event is not None:  # scored on a worker stream
+                    main.wait_event(st.pending_event)
+                    st.pending_event = None
+            lo, hi = min(layers), max(layers)
+            if b.reforge:  # tables of the NEW ids of every pending slot in one go (reference :298)
+                n = (hi - lo + 1) * keep
+                if self.native_rope and hasattr(b.rotary_emb_fn, "inv_freq"):
+                    pos2d, ld = b.pos_new[:, lo], b.slots * keep   # id row p of slots lo..hi is contiguous
+                else:
+                    pos2d, ld = b.pos_new[:, lo:hi + 1].reshape(P, n), n  # a copy when the slot range is partial
+                self._rope_tables(b.cos_new[lo * keep:], b.sin_new[lo * keep:], b.rotary_emb_fn, b.x_like, pos2d, ld,
+                                  3 if P == 3 else 2, b.mrope_section, n, D)
+            units = (nv.EvictUnit * len(layers))()
+            copies = (nv.CopyUnit * (len(layers) * (1 if b.reforge else 2)))()
+            nc = 0
+            for i, l in enumerate(layers):
+                st = self._layers[l]
+                cap = st.k.shape[2]
+                tail = st.length * D * es
+                u = units[i]
+                if b.reforge:
+                    u.k_src, u.k_src_stride_h = b.k_unrot[l].data_ptr(), b.L * D
+                    u.cos_new = b.cos_new.data_ptr() + l * keep * D * 4
+                    u.sin_new = b.sin_new.data_ptr() + l * keep * D * 4
+                    u.k_dst, u.k_dst_stride_h = st.k.data_ptr() + tail, cap * D  # straight into the cache
+                else:
+                    u.k_src, u.k_src_stride_h = st.k.data_ptr() + tail, cap * D
+                    u.cos_new = u.sin_new = None
+                    u.k_dst, u.k_dst_stride_h = b.k_stage[l].data_ptr(), keep * D
+                    copies[nc].src, copies[nc].src_stride_h_bytes = b.k_stage[l].data_ptr(), keep * D * es
+                    copies[nc].dst, copies[nc].dst_stride_h_bytes = st.k.data_ptr() + tail, cap * D * es
+                    nc += 1
+                u.v_src, u.v_src_stride_h = st.v.data_ptr() + tail, cap * D
+                u.v_dst, u.v_dst_stride_h = b.v_stage[l].data_ptr(), keep * D
+                copies[nc].src, copies[nc].src_stride_h_bytes = b.v_stage[l].data_ptr(), keep * D * es
+                copies[nc].dst, copies[nc].dst_stride_h_bytes = st.v.data_ptr() + tail, cap * D * es
+                nc += 1
+                u.keep_idx = b.keep_idx[l].data_ptr()
+                if b.reforge and P:  # bookkeeping (reference :308-309)
+                    self._pos_reserve(st, P, 3 if P == 3 else 2, keep, b.device)
+                    u.pos_src, u.pos_src_stride = b.pos_new.data_ptr() + l * keep * 8, b.slots * keep
+                    u.pos_dst, u.pos_dst_stride = st.pos.data_ptr() + st.pos_len * 8, st.pos.shape[1]
+                else:
+                    u.pos_src = u.pos_dst = None
+            s = nv.stream()
+            nv.check(nv.lib.rtk_pivotkv_evict_batched(units, len(layers), Hkv, D, keep, P if b.reforge else 0, dt, s),
+                     "rtk_pivotkv_evict_batched")
+            nv.check(nv.lib.rtk_pivotkv_commit_batched(copies, nc, Hkv, keep, D, dt, s), "rtk_pivotkv_commit_batched")
+        for l in layers:
+            st = self._layers[l]
+            st.length += keep
+            st.pending = 0
+            st.pending_keep = 0
+            if b.reforge and P:
+                st.pos_len += keep
+                self._pos_layers = max(self._pos_layers, l + 1)
 
     # ---- the hot path ---------------------------------------------------------------------------
     def update(
@@ -468,12 +613,12 @@ class PivotKVCache(DynamicCache):
 
         # 1) append: the next layer's hidden states see the uncompressed chunk (reference :238)
         n_new = key_states.shape[2]
-        if len(self._layers) > layer_idx and self._layers[layer_idx].k is not None:
-            self._commit(layer_idx)
-        st = self.reserve(layer_idx, n_new, key_states)
-        P0 = st.length
+        if len(self._layers) > layer_idx and self._layers[layer_idx].pending:
+            self._flush()
 
         if not self.kvcache_compression:  # text prefill / decode (reference :319-321)
+            st = self.reserve(layer_idx, n_new, key_states)
+            P0 = st.length
             st.k[:, :, P0:P0 + n_new].copy_(key_states)
             st.v[:, :, P0:P0 + n_new].copy_(value_states)
             st.length += n_new
@@ -494,6 +639,7 @@ class PivotKVCache(DynamicCache):
             if t.stride(-1) != 1:
                 raise ValueError("q/k/v must be contiguous along head_dim")
         keep_len = max(1, int(self.compression_ratio * q_len))  # evict new tokens only (reference :263)
+        reforge = bool(self.pos_embed_reforge)
 
         mask = getattr(self, "keypatches_mask_chunk", None)
         if mask is not None:
@@ -501,75 +647,70 @@ class PivotKVCache(DynamicCache):
             if mask.dtype != torch.bool or not mask.is_contiguous():
                 mask = mask.to(torch.bool).contiguous()
             assert mask.numel() == L, "keypatches_mask_chunk must have one entry per chunk token"
-        if st.k_stage is None or st.k_stage.shape[2] < keep_len or st.k_stage.dtype != key_states.dtype:
-            st.k_stage = torch.empty((1, Hkv, keep_len, D), dtype=key_states.dtype, device=dev)
-            st.v_stage = torch.empty((1, Hkv, keep_len, D), dtype=key_states.dtype, device=dev)
+        Pn = 0
+        if position_ids is not None:
+            nv.require_device(position_ids)
+            Pn = 3 if position_ids.ndim == 3 else 1
+        batch = self._get_batch(layer_idx, Hkv, L, D, keep_len, Pn, key_states.dtype, dev)
+        if batch.pending and (batch.rotary_emb_fn is not rotary_emb_fn or batch.mrope_section != mrope_section):
+            self._flush()
+        batch.rotary_emb_fn, batch.mrope_section = rotary_emb_fn, mrope_section
+        batch.x_like = value_states[:, :, :1]
+        st = self.reserve(layer_idx, n_new, key_states)
+        P0 = st.length
+        cap = st.k.shape[2]
+        esz = st.k.element_size()
 
-        def compress(ws, append_tail: bool):
-            """score -> select -> eviction scan on the CURRENT stream, scratch from `ws`."""
+        def compress(ws):
+            """score -> select on the CURRENT stream, scratch from `ws`; results land in the layer's batch slot."""
             s = nv.stream()
             cos_t = sin_t = None
-            if self.pos_embed_reforge:
-                cos_t, sin_t = self._rope_tables("old", rotary_emb_fn, value_states, position_ids, mrope_section, L, D,
-                                                 ws)
+            pos_in = None
+            if position_ids is not None:
+                pos_in = position_ids.reshape(Pn, L)
+                if not pos_in.is_contiguous():
+                    pos_in = pos_in.contiguous()
+            if reforge:
+                cos_t = self._buf("old_cos", (L, D), torch.float32, dev, ws)
+                sin_t = self._buf("old_sin", (L, D), torch.float32, dev, ws)
+                self._rope_tables(cos_t, sin_t, rotary_emb_fn, value_states, pos_in, L, position_ids.ndim, mrope_section,
+                                  L, D)
             # 2) score (reference :248-270)
             ws_bytes = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
             wsb = self._buf("score_ws", (ws_bytes + 256,), torch.uint8, dev, ws)
             ws_ptr = (wsb.data_ptr() + 255) & ~255
             score = self._buf("score", (L,), torch.float32, dev, ws)
-            k_unrot = self._buf("k_unrot", (Hkv, L, D), key_states.dtype, dev, ws)
+            k_unrot = batch.k_unrot[layer_idx] if reforge else None
             nv.check(nv.lib.rtk_pivotkv_score(
                 nv.ptr(query_states), query_states.stride(1), query_states.stride(2),
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
                 Hq, Hkv, L, D, dt, nv.ptr(cos_t), nv.ptr(sin_t),
-                float(getattr(rotary_emb_fn, "attention_scaling", 1.0)) if self.pos_embed_reforge else 1.0,
+                float(getattr(rotary_emb_fn, "attention_scaling", 1.0)) if reforge else 1.0,
                 nv.ptr(score), nv.ptr(k_unrot), C.c_void_p(ws_ptr), ws_bytes, s), "rtk_pivotkv_score")
             # 3) mask override + top-k + position ids (reference :272-295)
-            keep_idx = self._buf("keep_idx", (keep_len,), torch.int64, dev, ws)
+            keep_idx = batch.keep_idx[layer_idx]
             rank = self._buf("rank", (L,), torch.int32, dev, ws)
-            pos_in = pos_out = None
-            Pn = 0
-            if position_ids is not None:
-                Pn = 3 if position_ids.ndim == 3 else 1
-                pos_in = position_ids.reshape(Pn, L)
-                if not pos_in.is_contiguous():
-                    pos_in = pos_in.contiguous()
-                pos_out = torch.empty((Pn, keep_len), dtype=torch.int64, device=dev)  # becomes part of position_cache
+            pos_out = batch.pos_new[:, layer_idx] if pos_in is not None else None
+            sel_bytes = nv.lib.rtk_pivotkv_select_workspace_bytes(L)
+            sel_ws = self._buf("select_ws", (sel_bytes,), torch.uint8, dev, ws)
             nv.check(nv.lib.rtk_pivotkv_select(nv.ptr(score), nv.ptr(mask), L, keep_len, nv.ptr(pos_in), Pn,
-                                               int(bool(self.pos_embed_reforge)), nv.ptr(keep_idx), nv.ptr(rank),
-                                               nv.ptr(pos_out), s), "rtk_pivotkv_select")
-            cpos = None
-            if pos_out is not None:
-                cpos = pos_out.view(3, 1, keep_len) if Pn == 3 else pos_out.view(1, keep_len)
-            # 4) eviction scan: (append +) gather (+ re-rotate at the new ids) (reference :238, :278-306)
-            cos_n = sin_n = None
-            if self.pos_embed_reforge:
-                cos_n, sin_n = self._rope_tables("new", rotary_emb_fn, value_states[:, :, :1], cpos, mrope_section,
-                                                 keep_len, D, ws)
-            cap = st.k.shape[2]
-            esz = st.k.element_size()
-            k_tail = C.c_void_p(st.k.data_ptr() + P0 * D * esz) if append_tail else None
-            v_tail = C.c_void_p(st.v.data_ptr() + P0 * D * esz) if append_tail else None
-            nv.check(nv.lib.rtk_pivotkv_evict(
-                nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
-                nv.ptr(value_states), value_states.stride(1), value_states.stride(2),
-                nv.ptr(k_unrot), Hkv, L, D, dt, nv.ptr(keep_idx), keep_len, nv.ptr(cos_n), nv.ptr(sin_n),
-                k_tail, v_tail, cap * D, nv.ptr(st.k_stage), nv.ptr(st.v_stage), st.k_stage.shape[2] * D, s),
-                "rtk_pivotkv_evict")
-            self.last_keep_indices = keep_idx  # scratch views, valid until the worker's next update (diagnostics)
+                                               int(reforge), nv.ptr(keep_idx), nv.ptr(rank), nv.ptr(pos_out),
+                                               batch.slots * keep_len, nv.ptr(sel_ws), sel_bytes, s),
+                     "rtk_pivotkv_select")
+            self.last_keep_indices = keep_idx  # diagnostics: valid until the slot's next update
             self.last_scores = score
-            return cpos
 
         with torch.cuda.device(dev):
+            nv.check(nv.lib.rtk_pivotkv_append(
+                nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
+                nv.ptr(value_states), value_states.stride(1), value_states.stride(2), Hkv, L, D, dt,
+                C.c_void_p(st.k.data_ptr() + P0 * D * esz), C.c_void_p(st.v.data_ptr() + P0 * D * esz), cap * D,
+                nv.stream()), "rtk_pivotkv_append")
             side = self._next_side(dev)
             if side is None:
-                compressed_position_ids = compress(self._ws, append_tail=True)
-                if self.pos_embed_reforge:  # bookkeeping (reference :308-309)
-                    self.update_position_ids(compressed_position_ids, layer_idx)
+                compress(self._ws)
             else:
                 main = torch.cuda.current_stream()
-                st.k[:, :, P0:P0 + n_new].copy_(key_states)      # the append is all this layer's attention needs
-                st.v[:, :, P0:P0 + n_new].copy_(value_states)
                 ready = torch.cuda.Event()
                 ready.record(main)
                 for t in (query_states, key_states, value_states, position_ids, mask):
@@ -577,14 +718,14 @@ class PivotKVCache(DynamicCache):
                         t.record_stream(side.stream)
                 with torch.cuda.stream(side.stream):
                     side.stream.wait_event(ready)
-                    compressed_position_ids = compress(side.ws, append_tail=False)
+                    compress(side.ws)
                     done = torch.cuda.Event()
                     done.record(side.stream)
                 st.pending_event = done
-                st.pending_pos = compressed_position_ids if self.pos_embed_reforge else None
         self.update_num_evicted_tokens(k_len - keep_len, layer_idx)  # reference :310
         st.pending = n_new
         st.pending_keep = keep_len
+        batch.pending.append(layer_idx)
         return st.k[:, :, :P0 + n_new], st.v[:, :, :P0 + n_new]
 
 

@@ -44,10 +44,14 @@ def _qkv_and_cache_update(self, hidden_states, position_ids, past_key_value, cac
     # Position ids were reforged by the cache for earlier chunks: keep the temporal axis continuous
     # (reference :68-73).  In place, so later layers of this forward see the shifted ids too.
     if past_key_value is not None and getattr(past_key_value, "pos_embed_reforge", False):
-        prev_tempo_idx = past_key_value.get_prev_temporal_idx(self.layer_idx)
-        if prev_tempo_idx + 1 != position_ids[0, 0, 0]:
+        if position_ids.is_cuda and hasattr(past_key_value, "shift_temporal_ids_"):
             assert bsz == 1
-            position_ids[0, 0, :] += prev_tempo_idx + 1 - position_ids[0, 0, 0]
+            past_key_value.shift_temporal_ids_(position_ids, self.layer_idx)  # same rule on the device, no host sync
+        else:
+            prev_tempo_idx = past_key_value.get_prev_temporal_idx(self.layer_idx)
+            if prev_tempo_idx + 1 != position_ids[0, 0, 0]:
+                assert bsz == 1
+                position_ids[0, 0, :] += prev_tempo_idx + 1 - position_ids[0, 0, 0]
 
     # RoPE is computed inside the layer so that reforged ids take effect (reference :75-79)
     cos, sin = self.rotary_emb(value_states, position_ids)

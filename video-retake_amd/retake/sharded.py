@@ -223,13 +223,11 @@ def bench_main(args, rank: int, world: int, local_rank: int):
         for ci, c in enumerate(range(c0, c1)):
             cache.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
             cache.kvcache_compression = True
+            pos = pos_base[ci].clone()
             for layer in range(args.layers):
                 q, k, v = pool[call % len(pool)]
                 call += 1
-                pos = pos_base[ci]
-                prev = cache.get_prev_temporal_idx(layer)
-                pos = pos.clone()
-                pos[0, 0, :] += (prev + 1) - pos[0, 0, 0]   # block-local ids start at 0 (provisional)
+                cache.shift_temporal_ids_(pos, layer)       # block-local ids start at 0 (provisional)
                 cache.update(k, v, layer, {"query_states": q, "position_ids": pos, "rotary_emb": rotary,
                                            "mrope_section": B.MROPE})
             cache.after_forward()
