@@ -128,6 +128,22 @@ def run_video(frames, pool, masks, pos_base, rotary, layers, tdtype):
     return retained, cache
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel from the newest committed PMC profile (profiles/rNN_pmc_hbm_traffic.csv:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 per MI355X_MICROARCH.md).  bench.py
+    cannot collect counters itself; the profile is of the same kernels on the same shapes."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")))
+    if not files:
+        return None, None
+    for row in csv.DictReader(open(files[-1])):
+        if kernel_substr in row["kernel"] and row.get("hbm_total_MB"):
+            return float(row["hbm_total_MB"]) * 1e6, os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def cpu_baseline(args, frames_cpu_sample, n_updates):
     """Times the CPU oracle on a bounded sample and extrapolates to the full workload."""
     from oracle import oracle as orc
@@ -268,9 +284,10 @@ def main():
         dom = max(("score_pass1", "score_pass2"), key=lambda k: kern[k]["total_ms"])
         avg_s = kern[dom]["avg_us"] * 1e-6
         peak = MFMA_PEAK_TFLOPS[args.dtype]
+        traffic, src = pmc_traffic(dom) if args.dtype == "bf16" and T == 2048 else (None, None)
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": peak,
-                           "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / peak, "traffic": None,
-                           "algorithmic_flops_per_launch": flops}
+                           "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / peak, "traffic": traffic,
+                           "traffic_source": src, "algorithmic_flops_per_launch": flops}
         # HBM-bound kernels of the path, same convention (bytes the launch has to move / avg duration).
         # The eviction scan (16.3 MB algorithmic per (layer, chunk)) is three kernels here:
         #   append          per update: K,V rows read + written to the cache tail
@@ -290,8 +307,12 @@ def main():
                              ("dpselect_dis", "dpselect_dis", dp_bytes), ("gather_frames", "gather_frames", ga_bytes)):
             if key in kern:
                 gbs = b / (kern[key]["avg_us"] * 1e-6) / 1e9
+                tr = None
+                if args.dtype == "bf16" and T == 2048 and args.layers == LAYERS:
+                    tr = pmc_traffic({"append": "append_kernel", "evict_batched": "evict_batched_kernel",
+                                      "commit_batched": "commit_batched_kernel"}.get(name, "\0"))[0]
                 extra[name] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b}
+                               "frac": gbs / HBM_PEAK_GBS, "traffic": tr, "algorithmic_bytes_per_launch": b}
         if all(k in kern for k in ("append", "evict_batched", "commit_batched")):
             # the whole eviction scan of one (layer, chunk) unit against SURVEY's algorithmic byte count
             t_unit = (kern["append"]["avg_us"] + (kern["evict_batched"]["avg_us"] + kern["commit_batched"]["avg_us"])

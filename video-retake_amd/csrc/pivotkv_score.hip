@@ -17,6 +17,7 @@
 // cross-half shuffle.  The streamed operand goes HBM/L2 -> registers -> XOR-swizzled LDS tile
 // (conflict-free ds_read_b128) with the next tile's global loads in flight during the MFMAs.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass1_kernel(const char* __res
 #define RTK_TA(x, y)
 #define RTK_TS(x)
 #endif
-#define RTK_STEP1(JT, PAR, ISSUE, STORE) \
+#define RTK_STEP1(JT, PAR, ISSUE, STORE, MAYRAG) \
     { \
         constexpr int par = PAR; \
         const char* cur = smem + par * T::BYTES; \
@@ -539,7 +540,9 @@ _Pragma("unroll") \
         RTK_TA(acc0[0], acc1[0]) RTK_TM(1) \
 _Pragma("unroll") \
         for (int nb = 0; nb < NB; ++nb) { \
-            if ((JT) < nfull) rs[nb].template update<false>(acc0[nb], acc1[nb], 0, 0, hf, c2, sqrt_d); \
+            /* steady state: tiles are full by construction (a run-time test here gets if-converted into 64 */ \
+            /* v_cmp + v_cndmask per tile: 40 % more VALU issue in a kernel that is issue bound)            */ \
+            if (!(MAYRAG) || (JT) < nfull) rs[nb].template update<false>(acc0[nb], acc1[nb], 0, 0, hf, c2, sqrt_d); \
             else rs[nb].template update<true>(acc0[nb], acc1[nb], (JT) * TILE_ROWS, nkeys, hf, c2, sqrt_d); \
         } \
         RTK_TS(rs[0].sum) RTK_TM(2) \
@@ -553,16 +556,16 @@ _Pragma("unroll") \
     }
     int jt = 0;
     for (; jt + PF + 1 < ntiles; jt += 2) {  // steady state, two tiles per trip (parities are constants)
-        RTK_STEP1(jt, 0, true, true)
-        RTK_STEP1(jt + 1, 1, true, true)
+        RTK_STEP1(jt, 0, true, true, false)      // jt + 2 < ntiles here, and only the last tile can be ragged
+        RTK_STEP1(jt + 1, 1, true, true, false)
     }
     // tail: at most PF + 1 tiles; jt is even here, so the parities are known statically (a run-time parity
     // would make the compiler select between the two staging sets through memory)
 #define RTK_TAIL(PAR)                                              \
     if (jt < ntiles) {                                             \
-        if (jt + PF < ntiles) RTK_STEP1(jt, PAR, true, true)       \
-        else if (jt + 1 < ntiles) RTK_STEP1(jt, PAR, false, true)  \
-        else RTK_STEP1(jt, PAR, false, false)                      \
+        if (jt + PF < ntiles) RTK_STEP1(jt, PAR, true, true, true)       \
+        else if (jt + 1 < ntiles) RTK_STEP1(jt, PAR, false, true, true)  \
+        else RTK_STEP1(jt, PAR, false, false, true)                      \
         ++jt;                                                      \
     }
     RTK_TAIL(0)
@@ -584,6 +587,35 @@ _Pragma("unroll") \
         if (hf == 0 && i < L) lse_part[((size_t)ks * Hq + h) * L + i] = out;
     }
 }
+
+// online max / sum of one query row, one 32-key block at a time (bf16 path, log2 domain)
+struct RowStatB {  // online max / sum of one query row over the keys this lane sees (bf16 path, log2 domain)
+    float m, sum;
+    __device__ __forceinline__ void init() { m = -INFINITY; sum = 0.f; }
+    template <bool RAGGED>
+    __device__ __forceinline__ void update(f32x16& a, int j0, int j_end, int hf, float c2) {
+        if (RAGGED) {  // keys >= j_end do not exist
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (j0 + acc_row(r, hf) >= j_end) a[r] = -INFINITY;
+        }
+        const float mn = fmaxf(m, max16(a));
+        if (RAGGED && mn == -INFINITY) return;
+        const float nb = -mn * c2;
+        float add = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(fmaf(a[r], c2, nb));
+        sum = sum * __builtin_amdgcn_exp2f((m - mn) * c2) + add;
+        m = mn;
+    }
+    __device__ __forceinline__ float finish(float c2) const {
+        const float m2 = __shfl_xor(m, 32, WAVE), s2 = __shfl_xor(sum, 32, WAVE);
+        const float mm = fmaxf(m, m2);
+        if (mm == -INFINITY) return -INFINITY;
+        const float tot = sum * __builtin_amdgcn_exp2f((m - mm) * c2) + s2 * __builtin_amdgcn_exp2f((m2 - mm) * c2);
+        return mm * c2 + __builtin_amdgcn_logf(tot);  // v_log_f32 = log2
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // pass 2: partial[g,split,j] = sum_{h in g} sum_{i in split} exp(s_hij - lse[h,i])
@@ -796,6 +828,255 @@ _Pragma("unroll") \
         const int j = j0 + 32 * nb + (lane & 31);
         if (hf == 0 && j < L) partial[((size_t)g * RS + rs) * L + j] = col[nb];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2, LDS-DMA form (bf16, the production kernel): the decomposition of score_pass2_kernel without its in-wave
+// software pipeline (one 32-row block of logits live at a time: ~95 VGPRs -> 4 waves per SIMD), and the streamed
+// query tile goes HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds): no staging registers, no ds_write pass.  A wave's DMA instruction fills
+// 1 KiB of LDS linearly (lane * 16 B), so the XOR swizzle of the tile is applied to the SOURCE address:
+// LDS position p of row r receives chunk p ^ (r & 15), the same involution the fragment reads apply.
+// NB = 32-key register blocks per wave (NB = 2: every A fragment read from LDS feeds two MFMAs).
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass2_dma_kernel(
+    const char* __restrict__ q, const char* __restrict__ k, const float* __restrict__ lse, int Hq, int Hkv, int L,
+    int rows_per_split, int col_tiles, int RS, int xcd_remap, float* __restrict__ partial) {
+    constexpr int DT = RTK_BF16;
+    using M = MM<DT>;
+    using T = Tile<DT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lse_s = (float*)(smem + 2 * T::BYTES);  // [2][TILE_ROWS]
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), hf = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const int G = Hq / Hkv;
+    int bx, g, rs;
+    {
+        int grp;
+        if (xcd_remap) {
+            const int xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+            grp = xcd + NXCD * (slot / col_tiles);
+            bx = slot % col_tiles;
+        } else {
+            grp = blockIdx.x / col_tiles;
+            bx = blockIdx.x % col_tiles;
+        }
+        g = grp % Hkv;
+        rs = grp / Hkv;
+    }
+    const int j0 = bx * (REG_ROWS * NB) + wid * (32 * NB);
+    const char* kg = k + (size_t)g * L * HD * M::ESIZE;
+    const int ib = rs * rows_per_split, ie = min(L, ib + rows_per_split);
+    const int nrows = ie - ib;
+    const int tiles_per_head = (nrows + TILE_ROWS - 1) / TILE_ROWS;
+    const int ntiles = tiles_per_head * G;
+
+    int frag_off[M::NREG];
+    {
+        const int row = lane & 31;
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) frag_off[r] = row * T::ROWB + ((M::chunk_of(r, hf) ^ (row & 15)) * 16);
+    }
+    u32x4 kf[NB][M::NREG];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) load_reg_frag<DT>(kg, j0 + 32 * nb, L, lane, kf[nb]);
+    const float sqrt_d = sqrtf((float)HD);
+    const float c2 = 1.4426950408889634f / sqrt_d;
+    float col[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) col[nb] = 0.f;
+
+    // DMA addressing: piece P = 4u + wid (u = 0..3) covers tile rows 4P .. 4P+3; this lane fills position
+    // (lane & 15) of row 4P + (lane >> 4) with source chunk (lane & 15) ^ (row & 15)
+    const int drow = 4 * wid + (lane >> 4);                                        // row inside a 16-row group
+    const int dvoff = drow * T::ROWB + (((lane & 15) ^ (drow & 15)) * 16);          // + u * 16 rows via soffset
+    const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, Hq * L * HD * M::ESIZE, 0x00020000);
+    float lstA = 0.f;
+    int nt = 0;
+    const int last_row = Hq * L - 1;
+    int nrow0 = (g * G) * L + ib;
+    // issues the DMA of the cursor tile into LDS buffer `b`, fetches this thread's lse element, advances the cursor
+#define RTK_DMA_ISSUE(b)                                                                                  \
+    {                                                                                                     \
+        const int row_base = nrow0 + nt * TILE_ROWS;                                                      \
+        _Pragma("unroll")                                                                                 \
+        for (int u = 0; u < 4; ++u)                                                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                     \
+                qrsrc, (void __attribute__((address_space(3)))*)(smem + (b) * T::BYTES + (4 * u + wid) * 1024), 16, \
+                dvoff, (row_base + 16 * u) * T::ROWB, 0, 0);                                              \
+        const int r__ = nt * TILE_ROWS + (tid & (TILE_ROWS - 1));                                         \
+        lstA = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : INFINITY;                                \
+        const bool wrap__ = (nt + 1 == tiles_per_head);                                                   \
+        nt = wrap__ ? 0 : nt + 1;                                                                         \
+        nrow0 += wrap__ ? L : 0;                                                                          \
+    }
+#define RTK_DMA_STEP(BUF, ISSUE)                                                                          \
+    {                                                                                                     \
+        constexpr int buf = BUF;                                                                          \
+        const char* cur = smem + buf * T::BYTES;                                                          \
+        const float* lcur = lse_s + buf * TILE_ROWS;                                                      \
+        if constexpr (ISSUE) RTK_DMA_ISSUE(buf ^ 1)                                                       \
+        _Pragma("unroll")                                                                                 \
+        for (int blk = 0; blk < 2; ++blk) {                                                               \
+            u32x4 a[M::NREG];                                                                             \
+            float ls[16];                                                                                 \
+            _Pragma("unroll")                                                                             \
+            for (int r = 0; r < M::NREG; ++r) a[r] = *(const u32x4*)(cur + blk * 32 * T::ROWB + frag_off[r]); \
+            load_ls(ls, lcur, blk, hf);                                                                   \
+            f32x16 acc[NB];                                                                               \
+            _Pragma("unroll")                                                                             \
+            for (int nb = 0; nb < NB; ++nb) {                                                             \
+                acc[nb] = f32x16{0};                                                                      \
+                _Pragma("unroll")                                                                         \
+                for (int r = 0; r < M::NREG; ++r) M::mma(acc[nb], a[r], kf[nb][r]);                       \
+            }                                                                                             \
+            _Pragma("unroll")                                                                             \
+            for (int nb = 0; nb < NB; ++nb) {                                                             \
+                colsum_block<DT>(col[nb], acc[nb], ls, c2, sqrt_d);                                       \
+                asm volatile("" : "+v"(col[nb]) : : "memory");                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                        \
+            }                                                                                             \
+        }                                                                                                 \
+        if constexpr (ISSUE) {                                                                            \
+            if (tid < TILE_ROWS) lse_s[(buf ^ 1) * TILE_ROWS + tid] = lstA;                               \
+        }                                                                                                 \
+        __syncthreads(); /* drains the DMA (vmcnt(0)) and the LDS reads of this tile */                   \
+    }
+    RTK_DMA_ISSUE(0)
+    if (tid < TILE_ROWS) lse_s[tid] = lstA;
+    __syncthreads();
+    int it = 0;
+    for (; it + 2 < ntiles; it += 2) {
+        RTK_DMA_STEP(0, true)
+        RTK_DMA_STEP(1, true)
+    }
+    if (it < ntiles) {
+        if (it + 1 < ntiles) RTK_DMA_STEP(0, true)
+        else RTK_DMA_STEP(0, false)
+        ++it;
+    }
+    if (it < ntiles) {
+        RTK_DMA_STEP(1, false)
+        ++it;
+    }
+#undef RTK_DMA_STEP
+#undef RTK_DMA_ISSUE
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const float c = col[nb] + __shfl_xor(col[nb], 32, WAVE);
+        const int j = j0 + 32 * nb + (lane & 31);
+        if (hf == 0 && j < L) partial[((size_t)g * RS + rs) * L + j] = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1, LDS-DMA form (bf16): same decomposition as score_pass1_kernel (32 query rows per wave in
+// registers, 64-key tiles streamed), with the key tile DMA'd straight into the swizzled LDS image and one
+// 32-key block in flight per wave (~100 VGPRs -> 4 waves per SIMD).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SC_BLOCK, 4) void score_pass1_dma_kernel(const char* __restrict__ q,
+                                                                      const char* __restrict__ k, int Hq, int Hkv, int L,
+                                                                      int keys_per_split, int row_tiles, int xcd_remap,
+                                                                      float* __restrict__ lse_part) {
+    constexpr int DT = RTK_BF16;
+    using M = MM<DT>;
+    using T = Tile<DT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), hf = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const int G = Hq / Hkv;
+    int bx, h, ks;
+    {
+        const int per_group = row_tiles * G;
+        int grp, w;
+        if (xcd_remap) {
+            const int xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+            grp = xcd + NXCD * (slot / per_group);
+            w = slot % per_group;
+        } else {
+            grp = blockIdx.x / per_group;
+            w = blockIdx.x % per_group;
+        }
+        ks = grp / Hkv;
+        h = (grp % Hkv) * G + w / row_tiles;
+        bx = w % row_tiles;
+    }
+    const int g = h / G;
+    const int i0 = bx * REG_ROWS + wid * 32;
+    const int jb = ks * keys_per_split, je = min(L, jb + keys_per_split);
+    const int nkeys = je - jb;
+    const int nfull = nkeys / TILE_ROWS;
+    const int ntiles = (nkeys + TILE_ROWS - 1) / TILE_ROWS;
+    u32x4 qf[M::NREG];
+    load_reg_frag<DT>(q + (size_t)h * L * HD * M::ESIZE, i0, L, lane, qf);
+    int frag_off[M::NREG];
+    {
+        const int row = lane & 31;
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) frag_off[r] = row * T::ROWB + ((M::chunk_of(r, hf) ^ (row & 15)) * 16);
+    }
+    const float c2 = 1.4426950408889634f / sqrtf((float)HD);
+    RowStatB rs;
+    rs.init();
+    const int drow = 4 * wid + (lane >> 4);
+    const int dvoff = drow * T::ROWB + (((lane & 15) ^ (drow & 15)) * 16);
+    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(k + (size_t)g * L * HD * M::ESIZE), 0, L * HD * M::ESIZE, 0x00020000);
+#define RTK_DMA1_ISSUE(t, b)                                                                              \
+    {                                                                                                     \
+        _Pragma("unroll")                                                                                 \
+        for (int u = 0; u < 4; ++u)                                                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                     \
+                krsrc, (void __attribute__((address_space(3)))*)(smem + (b) * T::BYTES + (4 * u + wid) * 1024), 16, \
+                dvoff, (jb + (t) * TILE_ROWS + 16 * u) * T::ROWB, 0, 0);                                  \
+    }
+#define RTK_DMA1_STEP(JT, BUF, ISSUE, RAG)                                                                \
+    {                                                                                                     \
+        constexpr int buf = BUF;                                                                          \
+        const char* cur = smem + buf * T::BYTES;                                                          \
+        if constexpr (ISSUE) RTK_DMA1_ISSUE((JT) + 1, buf ^ 1)                                            \
+        _Pragma("unroll")                                                                                 \
+        for (int blk = 0; blk < 2; ++blk) {                                                               \
+            u32x4 a[M::NREG];                                                                             \
+            _Pragma("unroll")                                                                             \
+            for (int r = 0; r < M::NREG; ++r) a[r] = *(const u32x4*)(cur + blk * 32 * T::ROWB + frag_off[r]); \
+            f32x16 acc = f32x16{0};                                                                       \
+            _Pragma("unroll")                                                                             \
+            for (int r = 0; r < M::NREG; ++r) M::mma(acc, a[r], qf[r]);                                   \
+            rs.update<RAG>(acc, (JT) * TILE_ROWS + 32 * blk, nkeys, hf, c2);                              \
+            asm volatile("" : "+v"(rs.sum), "+v"(rs.m) : : "memory");                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+        }                                                                                                 \
+        __syncthreads(); /* drains the DMA (vmcnt(0)) and the LDS reads of this tile */                   \
+    }
+    RTK_DMA1_ISSUE(0, 0)
+    __syncthreads();
+    int jt = 0;
+    for (; jt + 2 < nfull; jt += 2) {   // both tiles full, and a tile jt + 2 exists
+        RTK_DMA1_STEP(jt, 0, true, false)
+        RTK_DMA1_STEP(jt + 1, 1, true, false)
+    }
+    // at most three tiles left (jt even => buffer parity static); only the last one can be ragged
+#define RTK_DMA1_TAIL(PAR)                                                     \
+    if (jt < ntiles) {                                                         \
+        if (jt + 1 < ntiles) {                                                 \
+            if (jt < nfull) RTK_DMA1_STEP(jt, PAR, true, false)                \
+            else RTK_DMA1_STEP(jt, PAR, true, true)                            \
+        } else {                                                               \
+            if (jt < nfull) RTK_DMA1_STEP(jt, PAR, false, false)               \
+            else RTK_DMA1_STEP(jt, PAR, false, true)                           \
+        }                                                                      \
+        ++jt;                                                                  \
+    }
+    RTK_DMA1_TAIL(0)
+    RTK_DMA1_TAIL(1)
+    RTK_DMA1_TAIL(0)
+#undef RTK_DMA1_TAIL
+#undef RTK_DMA1_STEP
+#undef RTK_DMA1_ISSUE
+    const float out = rs.finish(c2);
+    const int i = i0 + (lane & 31);
+    if (hf == 0 && i < L) lse_part[((size_t)ks * Hq + h) * L + i] = out;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1044,18 +1325,37 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         const int jt = (L + REG_ROWS * NBR - 1) / (REG_ROWS * NBR);
         auto per_split = [](int n, int parts) { return (((n + parts - 1) / parts + TILE_ROWS - 1) / TILE_ROWS) * TILE_ROWS; };
         const int kps = per_split(L, w.KS), rps = per_split(L, w.RS);
-        const int ks_n = (L + kps - 1) / kps;  // non-empty splits only
+        const int ks_n4 = (L + kps - 1) / kps;  // non-empty splits only
         rs_n = (L + rps - 1) / rps;
-        RTK_LAUNCH(KID_PASS1, (score_pass1_kernel<DT, NBR>), dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
-                   (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse);
+        const int ks_n = ks_n4;
+        // bf16 production kernels: LDS-DMA forms.  RTK_SCORE_LEGACY=1 selects the register-staged kernels (A/B only).
+        static const bool legacy = [] { const char* e = getenv("RTK_SCORE_LEGACY"); return e && atoi(e) != 0; }();
+        const bool dma = (DT == RTK_BF16) && !legacy;
+        static bool dma_attr = false;
+        if (dma && !dma_attr) {
+            (void)hipFuncSetAttribute((const void*)score_pass1_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+            (void)hipFuncSetAttribute((const void*)score_pass2_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+            dma_attr = true;
+        }
+        if (dma)
+            RTK_LAUNCH(KID_PASS1, score_pass1_dma_kernel, dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
+                       (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse);
+        else
+            RTK_LAUNCH(KID_PASS1, (score_pass1_kernel<DT, NBR>), dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
+                       (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse);
         RTK_LAUNCH_CHECK("score_pass1_kernel");
         if (ks_n > 1) {
             const size_t n = (size_t)Hq * L;
             RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<DT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lse, n, ks_n);
         }
-        RTK_LAUNCH(KID_PASS2, (score_pass2_kernel<DT, NBR>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
-                   (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
-                   (int)((Hkv * rs_n) % NXCD == 0), part);
+        if (dma)
+            RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<1>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
+                       (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
+                       (int)((Hkv * rs_n) % NXCD == 0), part);
+        else
+            RTK_LAUNCH(KID_PASS2, (score_pass2_kernel<DT, NBR>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
+                       (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
+                       (int)((Hkv * rs_n) % NXCD == 0), part);
         RTK_LAUNCH_CHECK("score_pass2_kernel");
     } else {
         RTK_LAUNCH(KID_PASS1, score_pass1_generic<DT>, dim3(L, Hq), dim3(256), D * sizeof(float), st, (const void*)qt,
