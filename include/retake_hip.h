@@ -75,6 +75,26 @@ int rtk_gather_frames(const void* x, int T, int N, int C, int dtype, const int64
                       void* out, rtk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * MA-LLM / MA-LLM-hard merges — replaces retake/visual_compression.py:5-47 and :50-83 (one merge step;
+ * the caller loops until the target frame count is reached, qwen2_vl.py:402-410)
+ * ------------------------------------------------------------------------------------------- */
+
+/* :19 / :63  F.cosine_similarity(mb[:, :-1], mb[:, 1:], dim=-1): x [T,N,C] -> cos_out [T-1,N] fp32 holding
+ * the value in the INPUT dtype (RTK_BF16: the reference's bf16 rounding chain). */
+int rtk_adjacent_cosine(const void* x, int T, int N, int C, int dtype, float* cos_out, rtk_stream_t stream);
+
+/* :20-24 / :64-67  idx[n] = first arg-max over t of cos[t,n]; sync != 0: arg-max of the patch-mean row
+ * (rounded to bf16 when round_bf16 != 0), written to every n.  cos [T1,N] fp32, idx [N] int64. */
+int rtk_mallm_argmax(const float* cos, int T1, int N, int sync, int round_bf16, int64_t* idx, rtk_stream_t stream);
+
+/* :26-46 / :69-82  the merge: x [T,N,C], sizes [T,N] (dtype of x; soft merge only) -> out [T-1,N,C],
+ * sizes_out [T-1,N].  hard == 0: out[t] = (x[d]*s[d]) / s[d] with d = t + (t > idx), and at t = idx the
+ * size-weighted mean of frames idx and idx+1, one rounding per torch op; hard != 0: out[t] = x[t + (t >= idx)]
+ * (sizes / sizes_out may be NULL). */
+int rtk_mallm_merge(const void* x, const void* sizes, const int64_t* idx, int T, int N, int C, int dtype,
+                    int hard, void* out, void* sizes_out, rtk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * RoPE tables — replaces longvideo_cache.py:68-74 (M-RoPE section merge) and, optionally, the
  * rotary_emb_fn(...) calls at :249 and :298 when the rotary module is the standard
  * inv_freq/attention_scaling kind.

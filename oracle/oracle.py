@@ -34,7 +34,7 @@ def lib():
         _lib = C.CDLL(_SO)
         for name in ("orc_dpselect_dis_f32", "orc_dpselect_dis_bf16", "orc_topk_sorted", "orc_dpselect_select",
                      "orc_gather_frames", "orc_mrope_merge", "orc_rope_apply", "orc_pivotkv_score",
-                     "orc_pivotkv_select", "orc_gather_rows", "orc_pivotkv_positions", "orc_num_threads"):
+                     "orc_pivotkv_select", "orc_gather_rows", "orc_pivotkv_positions", "orc_num_threads", "orc_mallm_step"):
             getattr(_lib, name).restype = C.c_int
         _lib.orc_rope_apply.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_double, C.c_void_p]
@@ -52,6 +52,37 @@ def _p(a: np.ndarray):
 def _chk(rc: int, what: str):
     if rc != 0:
         raise RuntimeError(f"oracle {what} failed rc={rc}")
+
+
+# ---------------------------------------------------------------------------------------------
+# MA-LLM merges
+# ---------------------------------------------------------------------------------------------
+def mallm_step(x: np.ndarray, sizes, sync: bool, hard: bool):
+    """One merge step (visual_compression.py:5-83).  x [T,N,C] float32 or uint16 (bf16 bits); sizes [T,N] same
+    dtype (ignored for hard).  Returns (out [T-1,N,C], sizes_out [T-1,N] or None, idx [N])."""
+    x = np.ascontiguousarray(x)
+    T, N, Cc = x.shape
+    is_bf16 = x.dtype == np.uint16
+    out = np.empty((T - 1, N, Cc), dtype=x.dtype)
+    so = None if hard else np.empty((T - 1, N), dtype=x.dtype)
+    idx = np.empty((N,), dtype=np.int64)
+    sz = None if hard else np.ascontiguousarray(sizes, dtype=x.dtype)
+    _chk(lib().orc_mallm_step(_p(x), None if hard else _p(sz), int(is_bf16), T, N, Cc, int(bool(sync)), int(bool(hard)),
+                              _p(out), None if hard else _p(so), _p(idx)), "mallm_step")
+    return out, so, idx
+
+
+def mallm_compress(x: np.ndarray, tgt: int, sync: bool, hard: bool):
+    """The loop of qwen2_vl.py:402-410: merge until tgt frames are left.  Returns (bank, sizes, idx per step)."""
+    x = np.ascontiguousarray(x)
+    one = np.uint16(0x3F80) if x.dtype == np.uint16 else np.float32(1.0)
+    sizes = np.full(x.shape[:2], one, dtype=x.dtype)
+    steps = []
+    while x.shape[0] > tgt:
+        x, sizes_new, idx = mallm_step(x, sizes, sync, hard)
+        sizes = sizes_new if sizes_new is not None else sizes[:-1]
+        steps.append(idx)
+    return x, (None if hard else sizes), np.stack(steps) if steps else np.zeros((0, x.shape[1]), np.int64)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -505,6 +505,57 @@ def gen_glue(outdir):
     print("glue_qwen2vl: segments", seg, "chunk", rec["chunk_size"], "ids", ids.shape, "->", out[0].shape)
 
 
+
+# --------------------------------------------------------------------------------------
+# MA-LLM / MA-LLM-hard merges (visual_compression.py:5-83, driven as qwen2_vl.py:402-410 does)
+# --------------------------------------------------------------------------------------
+def gen_mallm(vc, outdir):
+    import torch.nn.functional as F
+
+    # (name, seed, T, N, C, tgt, sync, hard, dtype)
+    cases = [
+        ("mallm_soft_async_16x6x32_t9", 11, 16, 6, 32, 9, False, False, "fp32"),
+        ("mallm_soft_sync_16x6x32_t9", 12, 16, 6, 32, 9, True, False, "fp32"),
+        ("mallm_hard_async_16x6x32_t9", 13, 16, 6, 32, 9, False, True, "fp32"),
+        ("mallm_hard_sync_16x6x32_t9", 14, 16, 6, 32, 9, True, True, "fp32"),
+        ("mallm_soft_async_40x9x72_t22", 15, 40, 9, 72, 22, False, False, "fp32"),
+        ("mallm_soft_async_12x5x64_t1", 16, 12, 5, 64, 1, False, False, "fp32"),
+        ("mallm_soft_async_16x6x32_t11_bf16", 17, 16, 6, 32, 11, False, False, "bf16"),
+        ("mallm_hard_async_16x6x32_t11_bf16", 18, 16, 6, 32, 11, False, True, "bf16"),
+    ]
+    for name, seed, T, N, C, tgt, sync, hard, dtype in cases:
+        x = synth.frames_video(seed, T, N, C)
+        xt = torch.from_numpy(x)
+        if dtype == "bf16":
+            xt = xt.bfloat16()
+        bank = xt.clone()
+        size = torch.ones_like(bank[:, :, :, 0])
+        steps_idx, margins = [], []
+        while bank.shape[1] > tgt:
+            sim = F.cosine_similarity(bank[:, :-1, :], bank[:, 1:, :], dim=-1)        # what the reference computes
+            sim64 = F.cosine_similarity(bank.double()[:, :-1, :], bank.double()[:, 1:, :], dim=-1)
+            if sync:
+                sim = sim.mean(-1, keepdim=True).expand(-1, -1, N)
+                sim64 = sim64.mean(-1, keepdim=True).expand(-1, -1, N)
+            steps_idx.append(torch.max(sim, dim=1).indices[0].numpy().copy())
+            if sim64.shape[1] > 1:
+                top2 = torch.topk(sim64[0], 2, dim=0).values
+                margins.append(float((top2[0] - top2[1]).min()))
+            if hard:
+                bank = vc.memory_bank_compress_MALLM_hard(bank, sync=sync)
+            else:
+                bank, size = vc.memory_bank_compress_MALLM(bank, size, sync=sync)
+        margin = min(margins) if margins else np.inf
+        if dtype == "fp32":
+            assert margin > FRAGILE, (name, margin)
+        out = bank.float().numpy() if dtype == "fp32" else bank.view(torch.int16).numpy().view(np.uint16)
+        rec = dict(x=x if dtype == "fp32" else xt.view(torch.int16).numpy().view(np.uint16), dtype=dtype, T=T, N=N, C=C,
+                   tgt=tgt, sync=sync, hard=hard, out=out, steps_idx=np.stack(steps_idx).astype(np.int64), margin=margin,
+                   size=(size.float().numpy() if not hard else np.zeros((0,), np.float32)))
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), **rec)
+        print(name, "steps", len(steps_idx), "margin %.3g" % margin, "out", out.shape)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -516,6 +567,8 @@ def main():
         gen_pivotkv(lc, HERE)
     if args.only in (None, "glue"):
         gen_glue(HERE)
+    if args.only in (None, "mallm"):
+        gen_mallm(vc, HERE)
 
 
 if __name__ == "__main__":

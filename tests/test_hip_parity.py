@@ -143,6 +143,77 @@ def test_dpselect_window5_vs_oracle():
 
 
 # ---------------------------------------------------------------------------------------------------
+# MA-LLM / MA-LLM-hard merges (visual_compression.py:5-83), driven like qwen2_vl.py:402-410
+# ---------------------------------------------------------------------------------------------------
+def _mallm_loop(xt, tgt, sync, hard):
+    import retake.visual_compression as vc
+
+    bank = xt
+    size = torch.ones_like(bank[:, :, :, 0])
+    while bank.shape[1] > tgt:
+        if hard:
+            bank = vc.memory_bank_compress_MALLM_hard(bank, sync=sync)
+        else:
+            bank, size = vc.memory_bank_compress_MALLM(bank, size, sync=sync)
+    return bank, size
+
+
+@pytest.mark.parametrize("name", gu.names("mallm_"))
+def test_mallm_golden(name):
+    g = gu.load(name)
+    bf16 = str(g["dtype"]) == "bf16"
+    x = g["x"]
+    xt = torch.from_numpy(x.view(np.int16)).to(dev()).view(torch.bfloat16) if bf16 else torch.from_numpy(x).to(dev())
+    bank, size = _mallm_loop(xt, int(g["tgt"]), bool(g["sync"]), bool(g["hard"]))
+    assert bank.shape == tuple(g["out"].shape) and bank.dtype == xt.dtype
+    if not bf16:
+        out = bank.cpu().numpy()
+        if bool(g["hard"]):
+            np.testing.assert_array_equal(out, g["out"])             # pure frame copies: the same pairs were merged
+        else:
+            assert np.abs(out - g["out"]).max() <= 1e-5
+            np.testing.assert_array_equal(size.cpu().numpy(), g["size"])
+    else:
+        a = bank.float().cpu().numpy()
+        b = (g["out"].astype(np.uint32) << 16).view(np.float32)
+        assert np.abs(a - b).max() <= 2 ** -6 and (a != b).mean() < 0.02
+
+
+@pytest.mark.parametrize("T,N,C,sync,hard,bf16", [(9, 3, 33, False, False, False), (20, 7, 1280, True, False, False),
+                                                  (6, 1, 8, False, True, False), (14, 5, 96, False, False, True),
+                                                  (33, 4, 4100, True, True, True)])
+def test_mallm_step_vs_oracle(T, N, C, sync, hard, bf16):
+    """One merge step on odd shapes (generic cosine kernel, C beyond the register path, N = 1) against the oracle."""
+    import retake.visual_compression as vc
+
+    x = synth.frames_video(50 + T + C, T, N, C)[0]
+    sizes = np.random.default_rng(T).integers(1, 12, size=(T, N)).astype(np.float32)
+    xt, st = torch.from_numpy(x).to(dev()), torch.from_numpy(sizes).to(dev())
+    if bf16:
+        xt, st = xt.bfloat16(), st.bfloat16()
+        xo = xt.view(torch.int16).cpu().numpy().view(np.uint16)
+        so = st.view(torch.int16).cpu().numpy().view(np.uint16)
+    else:
+        xo, so = x, sizes
+    o_out, o_sizes, o_idx = orc.mallm_step(xo, so, sync, hard)
+    if hard:
+        out, sz = vc.memory_bank_compress_MALLM_hard(xt[None], sync=sync), None
+    else:
+        out, sz = vc.memory_bank_compress_MALLM(xt[None], st[None], sync=sync)
+    got = out[0].view(torch.int16).cpu().numpy().view(np.uint16) if bf16 else out[0].cpu().numpy()
+    # the merged pair can only differ from the oracle's where its own top-2 similarity gap is at noise level
+    same_pairs = np.array_equal(got[:, :, 0] if hard else got.shape, o_out[:, :, 0] if hard else o_out.shape)
+    if bf16:
+        a = (got.astype(np.uint32) << 16).view(np.float32)
+        b = (o_out.astype(np.uint32) << 16).view(np.float32)
+        assert (a != b).mean() < 0.02 or not same_pairs
+    else:
+        assert np.abs(got - o_out).max() <= 1e-5
+        if not hard:
+            np.testing.assert_array_equal(sz[0].cpu().numpy(), o_sizes)
+
+
+# ---------------------------------------------------------------------------------------------------
 # PivotKV
 # ---------------------------------------------------------------------------------------------------
 def _make_cache(g, native_rope=False, overlap_streams=0):

@@ -155,3 +155,26 @@ def test_position_rescale_float32_truncation():
     t = pos[0, idx]
     want = t.min() + ((t - t.min()).astype(np.float32) * np.float32(keep / L)).astype(np.int64)
     np.testing.assert_array_equal(out[0], want)
+
+
+# ---------------------------------------------------------------------------------------------------
+# MA-LLM / MA-LLM-hard merges (visual_compression.py:5-83)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", gu.names("mallm_"))
+def test_mallm_matches_reference(name):
+    g = gu.load(name)
+    x = g["x"][0]
+    bank, sizes, steps = orc.mallm_compress(x, int(g["tgt"]), bool(g["sync"]), bool(g["hard"]))
+    np.testing.assert_array_equal(steps, g["steps_idx"])            # the merged pair of every step, bit-exact
+    ref = g["out"][0]
+    if str(g["dtype"]) == "fp32":
+        if bool(g["hard"]):
+            np.testing.assert_array_equal(bank, ref)                # pure copies
+        else:
+            assert np.abs(bank - ref).max() <= 1e-5
+            np.testing.assert_array_equal(sizes, g["size"][0])
+    else:
+        a = (bank.astype(np.uint32) << 16).view(np.float32)
+        b = (ref.astype(np.uint32) << 16).view(np.float32)
+        assert np.abs(a - b).max() <= 2 ** -6                       # at most a bf16 ulp on values of O(1)
+        assert (a != b).mean() < 0.02

@@ -33,7 +33,7 @@ template <> struct Elem<RTK_BF16> {
 // VPL = 16-byte vectors per lane; a row has nvec = C / PER_VEC vectors, lane owns vec k*64+lane.
 template <int DT, int VPL>
 __global__ __launch_bounds__(256) void dis_kernel(const typename Elem<DT>::vec_t* __restrict__ x, int T, int N,
-                                                  int nvec, int strip, float* __restrict__ dis) {
+                                                  int nvec, int strip, int emit_cos, float* __restrict__ dis) {
     using E = Elem<DT>;
     constexpr int PV = E::PER_VEC;
     constexpr int NE = VPL * PV;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void dis_kernel(const typename Elem<DT>::vec_t
     };
 
     if (t0 == 0) {
-        if (lane == 0) dis[n] = 1.0f;  // torch.ones_like(dis[:1])   (:103-106)
+        if (lane == 0 && !emit_cos) dis[n] = 1.0f;  // torch.ones_like(dis[:1])   (:103-106)
         load_row(0);
     } else {
         load_row(t0 - 1);  // halo
@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256) void dis_kernel(const typename Elem<DT>::vec_t
         }
         dot = wave_sum(dot);
         if (DT == RTK_BF16) dot = rbf(dot);
-        if (lane == 0) dis[(size_t)t * N + n] = 1.0f - dot;
+        if (lane == 0) {
+            if (emit_cos) dis[(size_t)(t - 1) * N + n] = dot;  // MA-LLM: the similarity itself, [T-1, N]
+            else dis[(size_t)t * N + n] = 1.0f - dot;
+        }
 #pragma unroll
         for (int e = 0; e < NE; ++e) prevn[e] = cur[e];
     }
@@ -115,13 +118,13 @@ __global__ __launch_bounds__(256) void dis_kernel(const typename Elem<DT>::vec_t
 // Generic fallback: any C (scalar loads, two passes over each row through L2).  One wave per (t,n).
 template <int DT>
 __global__ __launch_bounds__(256) void dis_kernel_generic(const void* __restrict__ xv, int T, int N, int C,
-                                                          float* __restrict__ dis) {
+                                                          int emit_cos, float* __restrict__ dis) {
     const int lane = threadIdx.x & (WAVE - 1);
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     if (wave >= (size_t)T * N) return;
     const int t = (int)(wave / N), n = (int)(wave % N);
     if (t == 0) {
-        if (lane == 0) dis[n] = 1.0f;
+        if (lane == 0 && !emit_cos) dis[n] = 1.0f;
         return;
     }
     auto ld = [&](size_t off) -> float {
@@ -148,7 +151,10 @@ __global__ __launch_bounds__(256) void dis_kernel_generic(const void* __restrict
         for (int c = lane; c < C; c += WAVE) dot = fmaf(ld(a0 + c) / na, ld(b0 + c) / nb, dot);
         dot = wave_sum(dot);
     }
-    if (lane == 0) dis[(size_t)t * N + n] = 1.0f - dot;
+    if (lane == 0) {
+        if (emit_cos) dis[(size_t)(t - 1) * N + n] = dot;
+        else dis[(size_t)t * N + n] = 1.0f - dot;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -263,6 +269,104 @@ __global__ __launch_bounds__(256) void gather_rows_bytes_kernel(const uint8_t* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MA-LLM / MA-LLM-hard (visual_compression.py:5-83): one merge step = adjacent cosine (dis_kernel in
+// cosine mode) -> arg-max frame pair per patch position -> merge + shift into a [T-1,N,C] bank.
+// ------------------------------------------------------------------------------------------------
+// idx[n] = first arg-max over t of sim[t,n]; sync: of the patch-mean row, the same for every n (:20-24)
+__global__ __launch_bounds__(256) void mallm_argmax_kernel(const float* __restrict__ cosv, int T1, int N, int sync,
+                                                           int round_bf16, int64_t* __restrict__ idx) {
+    extern __shared__ float mrow[];  // sync: [T1] patch means
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+    const int n = blockIdx.x;
+    if (sync) {
+        for (int t = wid; t < T1; t += 4) {  // similarity_matrix.mean(-1): fp32 accumulate, one rounding
+            float s = 0.f;
+            for (int j = lane; j < N; j += WAVE) s += cosv[(size_t)t * N + j];
+            s = wave_sum(s);
+            if (lane == 0) {
+                float m = s / (float)N;
+                mrow[t] = round_bf16 ? rbf(m) : m;
+            }
+        }
+        __syncthreads();
+    }
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int t = tid; t < T1; t += 256) {
+        const float v = sync ? mrow[t] : cosv[(size_t)t * N + n];
+        if (v > best || (v == best && t < bidx) || bidx == 0x7fffffff) {
+            best = v;
+            bidx = t;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(best, o, WAVE);
+        const int i2 = __shfl_xor(bidx, o, WAVE);
+        if (i2 != 0x7fffffff && (bidx == 0x7fffffff || v2 > best || (v2 == best && i2 < bidx))) {
+            best = v2;
+            bidx = i2;
+        }
+    }
+    if (lane == 0) { bv[wid] = best; bi[wid] = bidx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bi[w] != 0x7fffffff && (bi[0] == 0x7fffffff || bv[w] > bv[0] || (bv[w] == bv[0] && bi[w] < bi[0]))) {
+                bv[0] = bv[w];
+                bi[0] = bi[w];
+            }
+        if (sync) for (int j = 0; j < N; ++j) idx[j] = bi[0];
+        else idx[n] = bi[0];
+    }
+}
+
+// out[t,n,:] for the T-1 output frames; one thread per element (the op is a streaming copy with at most two
+// source rows per output row).  Soft merge keeps the reference's op order and roundings (:35-45):
+//   (x[d]*s[d]) / s[d]   and at the merged slot   ((x[i]*s[i]) + (x[i+1]*s[i+1])) / (s[i] + s[i+1])
+template <int DT>
+__global__ __launch_bounds__(256) void mallm_merge_kernel(const void* __restrict__ xv, const void* __restrict__ sv,
+                                                          const int64_t* __restrict__ idx, int T, int N, int C, int hard,
+                                                          void* __restrict__ outv, void* __restrict__ sov) {
+    const size_t total = (size_t)(T - 1) * N * C;
+    auto ldx = [&](size_t i) -> float { return DT == RTK_BF16 ? bf2f(((const uint16_t*)xv)[i]) : ((const float*)xv)[i]; };
+    auto lds = [&](size_t i) -> float { return DT == RTK_BF16 ? bf2f(((const uint16_t*)sv)[i]) : ((const float*)sv)[i]; };
+    auto rnd = [&](float v) -> float { return DT == RTK_BF16 ? rbf(v) : v; };
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const size_t tn = e / C;
+        const int n = (int)(tn % N), t = (int)(tn / N);
+        const int ix = (int)idx[n];
+        float o;
+        if (hard) {
+            const int d = t + (t >= ix);
+            if (DT == RTK_BF16) ((uint16_t*)outv)[e] = ((const uint16_t*)xv)[((size_t)d * N + n) * C + c];
+            else ((float*)outv)[e] = ((const float*)xv)[((size_t)d * N + n) * C + c];
+            continue;
+        }
+        const int d = t + (t > ix);
+        const float sd = lds((size_t)d * N + n);
+        const float xd = ldx(((size_t)d * N + n) * C + c);
+        float den = sd;
+        if (t != ix) {
+            o = rnd(__fdiv_rn(rnd(__fmul_rn(xd, sd)), sd));
+        } else {
+            const float ss = lds((size_t)(ix + 1) * N + n);
+            const float xs = ldx(((size_t)(ix + 1) * N + n) * C + c);
+            den = rnd(__fadd_rn(sd, ss));
+            o = rnd(__fdiv_rn(rnd(__fadd_rn(rnd(__fmul_rn(xd, sd)), rnd(__fmul_rn(xs, ss)))), den));
+        }
+        if (DT == RTK_BF16) ((uint16_t*)outv)[e] = f2bf(o);
+        else ((float*)outv)[e] = o;
+        if (c == 0) {
+            if (DT == RTK_BF16) ((uint16_t*)sov)[tn] = f2bf(den);
+            else ((float*)sov)[tn] = den;
+        }
+    }
+}
+
 }  // namespace rtk
 
 using namespace rtk;
@@ -271,7 +375,7 @@ using namespace rtk;
 // C ABI
 // ------------------------------------------------------------------------------------------------
 template <int DT>
-static int launch_dis(const void* x, int T, int N, int C, float* dis, hipStream_t st) {
+static int launch_dis(const void* x, int T, int N, int C, int emit_cos, float* dis, hipStream_t st) {
     constexpr int PV = Elem<DT>::PER_VEC;
     using vec_t = typename Elem<DT>::vec_t;
     const bool vec_ok = (C % PV == 0) && (((uintptr_t)x & 15) == 0);
@@ -280,7 +384,7 @@ static int launch_dis(const void* x, int T, int N, int C, float* dis, hipStream_
     if (!vec_ok || vpl > 16) {
         const size_t waves = (size_t)T * N;
         const unsigned grid = (unsigned)((waves * WAVE + 255) / 256);
-        RTK_LAUNCH(KID_DIS, dis_kernel_generic<DT>, dim3(grid), dim3(256), 0, st, x, T, N, C, dis);
+        RTK_LAUNCH(KID_DIS, dis_kernel_generic<DT>, dim3(grid), dim3(256), 0, st, x, T, N, C, emit_cos, dis);
         RTK_LAUNCH_CHECK("dis_kernel_generic");
         return RTK_OK;
     }
@@ -291,7 +395,7 @@ static int launch_dis(const void* x, int T, int N, int C, float* dis, hipStream_
     const unsigned grid = (unsigned)((waves * WAVE + 255) / 256);
     const vec_t* xv = (const vec_t*)x;
 #define RTK_DIS_CASE(V)                                                                                  \
-    RTK_LAUNCH(KID_DIS, (dis_kernel<DT, V>), dim3(grid), dim3(256), 0, st, xv, T, N, nvec, strip, dis); \
+    RTK_LAUNCH(KID_DIS, (dis_kernel<DT, V>), dim3(grid), dim3(256), 0, st, xv, T, N, nvec, strip, emit_cos, dis); \
     break;
     switch (vpl) {
         case 1: RTK_DIS_CASE(1)
@@ -315,10 +419,54 @@ extern "C" int rtk_dpselect_dis(const void* x, int T, int N, int C, int dtype, f
     RTK_CHECK_ARG(x && dis, "rtk_dpselect_dis: NULL pointer");
     RTK_CHECK_ARG(T >= 1 && N >= 1 && C >= 1, "rtk_dpselect_dis: bad shape T=%d N=%d C=%d", T, N, C);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == RTK_F32) return launch_dis<RTK_F32>(x, T, N, C, dis, st);
-    if (dtype == RTK_BF16) return launch_dis<RTK_BF16>(x, T, N, C, dis, st);
+    if (dtype == RTK_F32) return launch_dis<RTK_F32>(x, T, N, C, 0, dis, st);
+    if (dtype == RTK_BF16) return launch_dis<RTK_BF16>(x, T, N, C, 0, dis, st);
     set_error("rtk_dpselect_dis: unsupported dtype %d", dtype);
     return RTK_EINVAL;
+}
+
+extern "C" int rtk_adjacent_cosine(const void* x, int T, int N, int C, int dtype, float* cos_out, rtk_stream_t stream) {
+    RTK_CHECK_ARG(x && cos_out, "rtk_adjacent_cosine: NULL pointer");
+    RTK_CHECK_ARG(T >= 2 && N >= 1 && C >= 1, "rtk_adjacent_cosine: bad shape T=%d N=%d C=%d", T, N, C);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RTK_F32) return launch_dis<RTK_F32>(x, T, N, C, 1, cos_out, st);
+    if (dtype == RTK_BF16) return launch_dis<RTK_BF16>(x, T, N, C, 1, cos_out, st);
+    set_error("rtk_adjacent_cosine: unsupported dtype %d", dtype);
+    return RTK_EINVAL;
+}
+
+extern "C" int rtk_mallm_argmax(const float* cosv, int T1, int N, int sync, int round_bf16, int64_t* idx,
+                                rtk_stream_t stream) {
+    RTK_CHECK_ARG(cosv && idx, "rtk_mallm_argmax: NULL pointer");
+    RTK_CHECK_ARG(T1 >= 1 && N >= 1, "rtk_mallm_argmax: bad shape T1=%d N=%d", T1, N);
+    const size_t lds = sync ? (size_t)T1 * sizeof(float) : 0;
+    if (lds > 64 * 1024) {
+        set_error("rtk_mallm_argmax: %d frames exceed the sync path's LDS row", T1);
+        return RTK_EUNSUPPORTED;
+    }
+    RTK_LAUNCH(KID_DPSEL, mallm_argmax_kernel, dim3(sync ? 1 : N), dim3(256), lds, (hipStream_t)stream, cosv, T1, N, sync,
+               round_bf16, idx);
+    RTK_LAUNCH_CHECK("mallm_argmax_kernel");
+    return RTK_OK;
+}
+
+extern "C" int rtk_mallm_merge(const void* x, const void* sizes, const int64_t* idx, int T, int N, int C, int dtype,
+                               int hard, void* out, void* sizes_out, rtk_stream_t stream) {
+    RTK_CHECK_ARG(x && idx && out, "rtk_mallm_merge: NULL pointer");
+    RTK_CHECK_ARG(hard || (sizes && sizes_out), "rtk_mallm_merge: the soft merge needs sizes and sizes_out");
+    RTK_CHECK_ARG(T >= 2 && N >= 1 && C >= 1, "rtk_mallm_merge: bad shape T=%d N=%d C=%d", T, N, C);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_mallm_merge: unsupported dtype %d", dtype);
+    const size_t total = (size_t)(T - 1) * N * C;
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65535u * 16u);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RTK_BF16)
+        RTK_LAUNCH(KID_GATHER, mallm_merge_kernel<RTK_BF16>, dim3(grid), dim3(256), 0, st, x, sizes, idx, T, N, C, hard, out,
+                   sizes_out);
+    else
+        RTK_LAUNCH(KID_GATHER, mallm_merge_kernel<RTK_F32>, dim3(grid), dim3(256), 0, st, x, sizes, idx, T, N, C, hard, out,
+                   sizes_out);
+    RTK_LAUNCH_CHECK("mallm_merge_kernel");
+    return RTK_OK;
 }
 
 extern "C" int rtk_dpselect_select(const float* dis, int T, int N, int tgt, int window, int sync, int64_t* idx,

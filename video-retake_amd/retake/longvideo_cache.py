@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import sys
 from typing import Any, Dict, List, Optional, Tuple
 
 import torch
@@ -37,6 +38,15 @@ try:  # the HF classes are third-party; they only matter for isinstance checks i
     from transformers.cache_utils import DynamicCache as _HFDynamicCache
 except Exception:  # noqa: BLE001
     _HFDynamicCache = None
+
+_WARNED = set()
+
+
+def _warn_once(msg: str):
+    if msg not in _WARNED:
+        _WARNED.add(msg)
+        print(msg, file=sys.stderr)
+
 
 __all__ = ["repeat_kv", "rotate_half", "apply_multimodal_rotary_pos_emb", "apply_rotary_pos_emb", "PivotKVCache",
            "build_kvcache", "DynamicCache"]
@@ -603,9 +613,9 @@ class PivotKVCache(DynamicCache):
             key_states_output, value_states_output: the layer's UNCOMPRESSED keys/values
             ([prefix | whole current chunk]) for this layer's self attention (reference :217-323).
         """
-        if not self._warned:
+        if not self._warned:  # the reference's logger.warning_once (:232): a log line on stderr, once per process
             self._warned = True
-            print("Enable PivotKVCache compression: length after compression %.2f" % (self.compression_ratio))
+            _warn_once("Enable PivotKVCache compression: length after compression %.2f" % (self.compression_ratio))
         cache_kwargs = cache_kwargs if cache_kwargs is not None else {}
         position_ids = cache_kwargs.pop("position_ids", None)
         nv.require_device(key_states, value_states)

@@ -5,6 +5,8 @@
     rtk_dpselect_dis     adjacent-frame cosine distance          (:100-106)
     rtk_dpselect_select  peaks + bonus + top-k + sorted indices  (:108-135 / :142-169)
     rtk_gather_frames    frame gather                            (:138 / :173)
+`memory_bank_compress_MALLM` / `memory_bank_compress_MALLM_hard` (:5-83) are one merge step each, like the
+reference's: rtk_adjacent_cosine -> rtk_mallm_argmax -> rtk_mallm_merge.
 """
 from __future__ import annotations
 
@@ -63,10 +65,43 @@ def memory_bank_compress_keyframe(memory_bank: torch.Tensor, tgt_mem_len: int, w
     return out, mask.flatten()
 
 
-def memory_bank_compress_MALLM(memory_bank, compression_size, sync: bool = False):
-    # SURVEY §8(f) rank 4 ("next"): used by no shipped config (all use compression_method "Keyframe").
-    raise NotImplementedError("compression_method 'MA-LLM' is not implemented in the MI355X build yet")
+def _mallm_step(memory_bank: torch.Tensor, compression_size, sync: bool, hard: bool):
+    if memory_bank.ndim != 4:
+        raise ValueError(f"memory_bank must be [B,T,N,C], got {tuple(memory_bank.shape)}")
+    nv.require_device(memory_bank)
+    B, T, N, Cc = memory_bank.shape
+    dev, dt = memory_bank.device, nv.dtype_code(memory_bank)
+    out = torch.empty((B, T - 1, N, Cc), dtype=memory_bank.dtype, device=dev)
+    sizes_out = None if hard else torch.empty((B, T - 1, N), dtype=memory_bank.dtype, device=dev)
+    with torch.cuda.device(dev):
+        st = nv.stream()
+        cosv = torch.empty((T - 1, N), dtype=torch.float32, device=dev)
+        idx = torch.empty((N,), dtype=torch.int64, device=dev)
+        for b in range(B):  # the reference's ops are batched over B; the callers pass B = 1
+            x = memory_bank[b]
+            if not x.is_contiguous():
+                x = x.contiguous()
+            sz = None
+            if not hard:
+                sz = compression_size[b].to(memory_bank.dtype)
+                if not sz.is_contiguous():
+                    sz = sz.contiguous()
+            nv.check(nv.lib.rtk_adjacent_cosine(nv.ptr(x), T, N, Cc, dt, nv.ptr(cosv), st), "rtk_adjacent_cosine")
+            nv.check(nv.lib.rtk_mallm_argmax(nv.ptr(cosv), T - 1, N, int(bool(sync)), int(dt == nv.RTK_BF16),
+                                             nv.ptr(idx), st), "rtk_mallm_argmax")
+            nv.check(nv.lib.rtk_mallm_merge(nv.ptr(x), nv.ptr(sz), nv.ptr(idx), T, N, Cc, dt, int(hard), nv.ptr(out[b]),
+                                            None if hard else nv.ptr(sizes_out[b]), st), "rtk_mallm_merge")
+    return out, sizes_out
 
 
-def memory_bank_compress_MALLM_hard(memory_bank, sync: bool = False):
-    raise NotImplementedError("compression_method 'MA-LLM-hard' is not implemented in the MI355X build yet")
+def memory_bank_compress_MALLM(memory_bank: torch.Tensor, compression_size: torch.Tensor, sync: bool = False) -> tuple:
+    """MA-LLM merge step (reference: visual_compression.py:5-47): the most similar adjacent frame pair of every
+    patch position (of the patch mean when `sync`) is merged into its first frame, weighted by how many frames
+    each already holds.  Returns (compressed_memory_bank [B,T-1,N,C], compressed_size [B,T-1,N])."""
+    return _mallm_step(memory_bank, compression_size, sync, hard=False)
+
+
+def memory_bank_compress_MALLM_hard(memory_bank: torch.Tensor, sync: bool = False) -> torch.Tensor:
+    """MA-LLM-hard merge step (reference: visual_compression.py:50-83): the first frame of the most similar
+    adjacent pair is replaced by the second.  Returns compressed_memory_bank [B,T-1,N,C]."""
+    return _mallm_step(memory_bank, None, sync, hard=True)[0]
