@@ -144,6 +144,19 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
+def score_roofline(kern, dtype, L, T):
+    """roofline object of the dominant kernel (one of the two score passes): algorithmic flops of one Q K^T per
+    launch / average launch duration from the HIP events, against the dense MFMA peak."""
+    flops = 2.0 * Hq * L * L * D
+    dom = max(("score_pass1", "score_pass2"), key=lambda k: kern[k]["total_ms"])
+    avg_s = kern[dom]["avg_us"] * 1e-6
+    peak = MFMA_PEAK_TFLOPS[dtype]
+    traffic, src = pmc_traffic(dom) if dtype == "bf16" and L == FRAMES_PER_CHUNK * N_PATCH else (None, None)
+    return {"kernel": dom, "bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": peak, "unit": "TFLOP/s",
+            "frac": flops / avg_s / 1e12 / peak, "traffic": traffic, "traffic_source": src,
+            "algorithmic_flops_per_launch": flops}
+
+
 def cpu_baseline(args, frames_cpu_sample, n_updates):
     """Times the CPU oracle on a bounded sample and extrapolates to the full workload."""
     from oracle import oracle as orc
@@ -280,14 +293,7 @@ def main():
         out["kernels_timed_region"] = timed
         for k, v in timed.items():
             kern[k] = v
-        flops = 2.0 * Hq * L * L * D                     # one Q K^T per launch
-        dom = max(("score_pass1", "score_pass2"), key=lambda k: kern[k]["total_ms"])
-        avg_s = kern[dom]["avg_us"] * 1e-6
-        peak = MFMA_PEAK_TFLOPS[args.dtype]
-        traffic, src = pmc_traffic(dom) if args.dtype == "bf16" and T == 2048 else (None, None)
-        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": peak,
-                           "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / peak, "traffic": traffic,
-                           "traffic_source": src, "algorithmic_flops_per_launch": flops}
+        out["roofline"] = score_roofline(kern, args.dtype, L, T)
         # HBM-bound kernels of the path, same convention (bytes the launch has to move / avg duration).
         # The eviction scan (16.3 MB algorithmic per (layer, chunk)) is three kernels here:
         #   append          per update: K,V rows read + written to the cache tail

@@ -145,6 +145,20 @@ int rtk_pivotkv_score(const void* q, int64_t q_stride_h, int64_t q_stride_l,
                       float* score, void* k_unrot, void* workspace, size_t workspace_bytes,
                       rtk_stream_t stream);
 
+/* The same computation cut into its three stream-ordered stages, so that a caller can put the two big
+ * matrix kernels of consecutive updates back to back on one stream while the small pre / post kernels of the
+ * neighbouring updates run on other streams (PivotKVCache pipeline_streams): same arguments, same workspace.
+ *   RTK_SCORE_PREPARE   un-rotate + pack q~ (workspace) and k~ (k_unrot or workspace)
+ *   RTK_SCORE_PASSES    pass 1, lse combine, pass 2 (reads q~/k~, writes the column partials)
+ *   RTK_SCORE_FINALIZE  fixed-order reduction of the partials -> score */
+enum rtk_score_stage { RTK_SCORE_PREPARE = 1, RTK_SCORE_PASSES = 2, RTK_SCORE_FINALIZE = 4 };
+int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64_t q_stride_l,
+                             const void* k, int64_t k_stride_h, int64_t k_stride_l,
+                             int Hq, int Hkv, int L, int D, int dtype,
+                             const float* cos, const float* sin, float attention_scaling,
+                             float* score, void* k_unrot, void* workspace, size_t workspace_bytes,
+                             int stages, rtk_stream_t stream);
+
 /* P6-P7, P9-P10  longvideo_cache.py:272-277, :283-295.
  *   score [L] fp32: entries with mask != 0 are overwritten with 1.0 IN PLACE (masked_fill_, :274);
  *   mask may be NULL.

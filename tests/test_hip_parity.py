@@ -416,9 +416,10 @@ def test_pivotkv_bf16_tracks_fp32_oracle():
     assert torch.equal(kept_v[0, :, :, :].cpu(), vb[0][:, torch.from_numpy(idx)])
 
 
+@pytest.mark.parametrize("streams", [0, 2])
 @pytest.mark.parametrize("reforge", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_pivotkv_batched_flush_equals_per_layer_flush(reforge, dtype):
+def test_pivotkv_batched_flush_equals_per_layer_flush(reforge, dtype, streams):
     """Deferred eviction: 3 layers x 3 chunks flushed once per chunk from after_forward (one batched launch
     for all layers) must leave exactly the cache that flushing after every single update leaves."""
     import retake.longvideo_cache as lc
@@ -428,12 +429,12 @@ def test_pivotkv_batched_flush_equals_per_layer_flush(reforge, dtype):
     inv_f = synth.inv_freq(D)
     rot = synth.RotaryStub(inv_f, synth.YARN_FACTOR4_ATTENTION_SCALING, device=dev())
 
-    def cfg():
+    def cfg(streams=0):
         return types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=layers, num_attention_heads=Hq,
                                      num_key_value_heads=Hkv,
                                      longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
                                          "compression_ratio": 0.25, "compression_method": "pivotkv",
-                                         "pos_embed_reforge": reforge}})
+                                         "pos_embed_reforge": reforge, "overlap_streams": streams}})
 
     def run(cache, eager):
         for c in range(n_chunks):
@@ -454,7 +455,7 @@ def test_pivotkv_batched_flush_equals_per_layer_flush(reforge, dtype):
             cache.after_forward()
         return cache
 
-    a = run(lc.build_kvcache(cfg()), eager=False)
+    a = run(lc.build_kvcache(cfg(streams)), eager=False)    # the shared ids tensor is shifted in place per layer
     b = run(lc.build_kvcache(cfg()), eager=True)
     keep = L // 4
     for l in range(layers):

@@ -21,7 +21,9 @@ def main():
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--streams", type=int, default=0)
     a = ap.parse_args()
+    B.OVERLAP_STREAMS = a.streams
     dev = torch.device("cuda:0")
     td = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     g = torch.Generator(device=dev).manual_seed(0)

@@ -1275,13 +1275,13 @@ extern "C" size_t rtk_pivotkv_score_workspace_bytes(int Hq, int Hkv, int L, int 
 template <int DT>
 static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, int64_t ksh, int64_t ksl, int Hq,
                       int Hkv, int L, int D, const float* cosv, const float* sinv, float a, float* score,
-                      void* k_unrot, char* ws, const ScoreWs& w, hipStream_t st) {
+                      void* k_unrot, char* ws, const ScoreWs& w, int stages, hipStream_t st) {
     char* qt = ws + w.q_off;
     char* kt = k_unrot ? (char*)k_unrot : ws + w.k_off;
     float* lse = (float*)(ws + w.lse_off);
     float* part = (float*)(ws + w.part_off);
     const float a2 = (float)((double)a * (double)a);  // python float ** 2, then an fp32 tensor / scalar
-    {
+    if (stages & RTK_SCORE_PREPARE) {
         constexpr int VE = Vec16<DT>::VE;
         const int es = 16 / VE;
         const bool vec_ok = (D % (2 * VE) == 0) && ((qsh * es) % 16 == 0) && ((qsl * es) % 16 == 0) &&
@@ -1337,49 +1337,55 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
             (void)hipFuncSetAttribute((const void*)score_pass2_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
             dma_attr = true;
         }
-        if (dma)
-            RTK_LAUNCH(KID_PASS1, score_pass1_dma_kernel, dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
-                       (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse);
-        else
-            RTK_LAUNCH(KID_PASS1, (score_pass1_kernel<DT, NBR>), dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
-                       (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse);
-        RTK_LAUNCH_CHECK("score_pass1_kernel");
-        if (ks_n > 1) {
-            const size_t n = (size_t)Hq * L;
-            RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<DT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lse, n, ks_n);
+        if (stages & RTK_SCORE_PASSES) {
+            if (dma)
+                RTK_LAUNCH(KID_PASS1, score_pass1_dma_kernel, dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
+                           (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse);
+            else
+                RTK_LAUNCH(KID_PASS1, (score_pass1_kernel<DT, NBR>), dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
+                           (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse);
+            RTK_LAUNCH_CHECK("score_pass1_kernel");
+            if (ks_n > 1) {
+                const size_t n = (size_t)Hq * L;
+                RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<DT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lse, n, ks_n);
+            }
+            if (dma)
+                RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<1>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
+                           (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
+                           (int)((Hkv * rs_n) % NXCD == 0), part);
+            else
+                RTK_LAUNCH(KID_PASS2, (score_pass2_kernel<DT, NBR>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
+                           (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
+                           (int)((Hkv * rs_n) % NXCD == 0), part);
+            RTK_LAUNCH_CHECK("score_pass2_kernel");
         }
-        if (dma)
-            RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<1>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
-                       (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
-                       (int)((Hkv * rs_n) % NXCD == 0), part);
-        else
-            RTK_LAUNCH(KID_PASS2, (score_pass2_kernel<DT, NBR>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
-                       (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
-                       (int)((Hkv * rs_n) % NXCD == 0), part);
-        RTK_LAUNCH_CHECK("score_pass2_kernel");
-    } else {
+    } else if (stages & RTK_SCORE_PASSES) {
         RTK_LAUNCH(KID_PASS1, score_pass1_generic<DT>, dim3(L, Hq), dim3(256), D * sizeof(float), st, (const void*)qt,
                            (const void*)kt, Hq, Hkv, L, D, lse);
         RTK_LAUNCH(KID_PASS2, score_pass2_generic<DT>, dim3((L + 255) / 256, Hkv), dim3(256), D * sizeof(float), st,
                            (const void*)qt, (const void*)kt, lse, Hq, Hkv, L, D, part);
         RTK_LAUNCH_CHECK("score_generic");
     }
-    RTK_LAUNCH(KID_FINALIZE, score_finalize_kernel, dim3((L + 63) / 64), dim3(256), (size_t)Hkv * 64 * sizeof(float), st, part,
-               Hkv, rs_n, G, L, score);
-    RTK_LAUNCH_CHECK("score_finalize_kernel");
+    if (stages & RTK_SCORE_FINALIZE) {
+        RTK_LAUNCH(KID_FINALIZE, score_finalize_kernel, dim3((L + 63) / 64), dim3(256), (size_t)Hkv * 64 * sizeof(float), st,
+                   part, Hkv, rs_n, G, L, score);
+        RTK_LAUNCH_CHECK("score_finalize_kernel");
+    }
     return RTK_OK;
 }
 
-extern "C" int rtk_pivotkv_score(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k,
-                                 int64_t k_stride_h, int64_t k_stride_l, int Hq, int Hkv, int L, int D, int dtype,
-                                 const float* cosv, const float* sinv, float attention_scaling, float* score,
-                                 void* k_unrot, void* workspace, size_t workspace_bytes, rtk_stream_t stream) {
+extern "C" int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k,
+                                        int64_t k_stride_h, int64_t k_stride_l, int Hq, int Hkv, int L, int D, int dtype,
+                                        const float* cosv, const float* sinv, float attention_scaling, float* score,
+                                        void* k_unrot, void* workspace, size_t workspace_bytes, int stages,
+                                        rtk_stream_t stream) {
     RTK_CHECK_ARG(q && k && score && workspace, "rtk_pivotkv_score: NULL pointer");
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0, "rtk_pivotkv_score: Hq=%d must be a multiple of Hkv=%d", Hq, Hkv);
     RTK_CHECK_ARG(L >= 1 && D >= 2 && D % 2 == 0, "rtk_pivotkv_score: bad shape L=%d D=%d", L, D);
     RTK_CHECK_ARG((cosv == nullptr) == (sinv == nullptr), "rtk_pivotkv_score: cos and sin must both be given or both NULL");
     RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_score: unsupported dtype %d", dtype);
     RTK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "rtk_pivotkv_score: workspace must be 256-byte aligned");
+    RTK_CHECK_ARG(stages > 0 && stages <= 7, "rtk_pivotkv_score: stages mask %d out of range", stages);
     const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
     if (workspace_bytes < w.total) {
         set_error("rtk_pivotkv_score: workspace %zu < required %zu bytes", workspace_bytes, w.total);
@@ -1388,7 +1394,16 @@ extern "C" int rtk_pivotkv_score(const void* q, int64_t q_stride_h, int64_t q_st
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RTK_BF16)
         return score_impl<RTK_BF16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, cosv, sinv,
-                                    attention_scaling, score, k_unrot, (char*)workspace, w, st);
+                                    attention_scaling, score, k_unrot, (char*)workspace, w, stages, st);
     return score_impl<RTK_F32>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, cosv, sinv,
-                               attention_scaling, score, k_unrot, (char*)workspace, w, st);
+                               attention_scaling, score, k_unrot, (char*)workspace, w, stages, st);
+}
+
+extern "C" int rtk_pivotkv_score(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k,
+                                 int64_t k_stride_h, int64_t k_stride_l, int Hq, int Hkv, int L, int D, int dtype,
+                                 const float* cosv, const float* sinv, float attention_scaling, float* score,
+                                 void* k_unrot, void* workspace, size_t workspace_bytes, rtk_stream_t stream) {
+    return rtk_pivotkv_score_stages(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, dtype, cosv, sinv,
+                                    attention_scaling, score, k_unrot, workspace, workspace_bytes,
+                                    RTK_SCORE_PREPARE | RTK_SCORE_PASSES | RTK_SCORE_FINALIZE, stream);
 }

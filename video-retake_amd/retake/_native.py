@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libr
 ABI_VERSION = 2
 
 RTK_F32, RTK_BF16 = 0, 1
+SCORE_PREPARE, SCORE_PASSES, SCORE_FINALIZE = 1, 2, 4
 RTK_EINVAL, RTK_EUNSUPPORTED, RTK_EWORKSPACE, RTK_EHIP, RTK_EREFCRASH = -1, -2, -3, -4, -5
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -50,6 +51,8 @@ _SIGNATURES = {
     "rtk_pivotkv_score_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "rtk_pivotkv_score": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp,
                                     _vp, _sz, _vp]),
+    "rtk_pivotkv_score_stages": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp,
+                                           _vp, _sz, _i, _vp]),
     "rtk_pivotkv_select_workspace_bytes": (C.c_size_t, [_i]),
     "rtk_pivotkv_select": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rtk_pivotkv_evict": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp,

@@ -671,44 +671,58 @@ class PivotKVCache(DynamicCache):
         cap = st.k.shape[2]
         esz = st.k.element_size()
 
-        def compress(ws):
-            """score -> select on the CURRENT stream, scratch from `ws`; results land in the layer's batch slot."""
-            s = nv.stream()
-            cos_t = sin_t = None
-            pos_in = None
-            if position_ids is not None:
-                pos_in = position_ids.reshape(Pn, L)
-                if not pos_in.is_contiguous():
-                    pos_in = pos_in.contiguous()
+        a_scale = float(getattr(rotary_emb_fn, "attention_scaling", 1.0)) if reforge else 1.0
+        ws_bytes = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
+        sel_bytes = nv.lib.rtk_pivotkv_select_workspace_bytes(L)
+        keep_idx = batch.keep_idx[layer_idx]
+        shared = {}   # values handed from one stage to the next
+
+        def score_stage(ws, stages):
+            wsb = self._buf("score_ws", (ws_bytes + 256,), torch.uint8, dev, ws)
+            ws_ptr = (wsb.data_ptr() + 255) & ~255
+            score = self._buf("score", (L,), torch.float32, dev, ws)
+            k_unrot = batch.k_unrot[layer_idx] if reforge else None
+            nv.check(nv.lib.rtk_pivotkv_score_stages(
+                nv.ptr(query_states), query_states.stride(1), query_states.stride(2),
+                nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
+                Hq, Hkv, L, D, dt, nv.ptr(shared.get("cos")), nv.ptr(shared.get("sin")), a_scale,
+                nv.ptr(score), nv.ptr(k_unrot), C.c_void_p(ws_ptr), ws_bytes, stages, nv.stream()), "rtk_pivotkv_score")
+            return score
+
+        def stage_pre(ws, pos_in):
+            """RoPE tables of the chunk's ids + un-rotate / pack (reference :248-259), on the CURRENT stream."""
             if reforge:
                 cos_t = self._buf("old_cos", (L, D), torch.float32, dev, ws)
                 sin_t = self._buf("old_sin", (L, D), torch.float32, dev, ws)
                 self._rope_tables(cos_t, sin_t, rotary_emb_fn, value_states, pos_in, L, position_ids.ndim, mrope_section,
                                   L, D)
-            # 2) score (reference :248-270)
-            ws_bytes = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
-            wsb = self._buf("score_ws", (ws_bytes + 256,), torch.uint8, dev, ws)
-            ws_ptr = (wsb.data_ptr() + 255) & ~255
-            score = self._buf("score", (L,), torch.float32, dev, ws)
-            k_unrot = batch.k_unrot[layer_idx] if reforge else None
-            nv.check(nv.lib.rtk_pivotkv_score(
-                nv.ptr(query_states), query_states.stride(1), query_states.stride(2),
-                nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
-                Hq, Hkv, L, D, dt, nv.ptr(cos_t), nv.ptr(sin_t),
-                float(getattr(rotary_emb_fn, "attention_scaling", 1.0)) if reforge else 1.0,
-                nv.ptr(score), nv.ptr(k_unrot), C.c_void_p(ws_ptr), ws_bytes, s), "rtk_pivotkv_score")
-            # 3) mask override + top-k + position ids (reference :272-295)
-            keep_idx = batch.keep_idx[layer_idx]
+                shared["cos"], shared["sin"] = cos_t, sin_t
+            score_stage(ws, nv.SCORE_PREPARE)
+
+        def stage_big(ws):
+            """the two matrix passes (reference :260-268)"""
+            score_stage(ws, nv.SCORE_PASSES)
+
+        def stage_post(ws, pos_in):
+            """column-mass reduction, mask override + top-k + position ids (reference :269-295)"""
+            score = score_stage(ws, nv.SCORE_FINALIZE)
             rank = self._buf("rank", (L,), torch.int32, dev, ws)
             pos_out = batch.pos_new[:, layer_idx] if pos_in is not None else None
-            sel_bytes = nv.lib.rtk_pivotkv_select_workspace_bytes(L)
             sel_ws = self._buf("select_ws", (sel_bytes,), torch.uint8, dev, ws)
             nv.check(nv.lib.rtk_pivotkv_select(nv.ptr(score), nv.ptr(mask), L, keep_len, nv.ptr(pos_in), Pn,
                                                int(reforge), nv.ptr(keep_idx), nv.ptr(rank), nv.ptr(pos_out),
-                                               batch.slots * keep_len, nv.ptr(sel_ws), sel_bytes, s),
+                                               batch.slots * keep_len, nv.ptr(sel_ws), sel_bytes, nv.stream()),
                      "rtk_pivotkv_select")
             self.last_keep_indices = keep_idx  # diagnostics: valid until the slot's next update
             self.last_scores = score
+
+        def pos_2d(snapshot: bool):
+            if position_ids is None:
+                return None
+            p2 = position_ids.reshape(Pn, L)
+            # worker streams read the ids later than the caller's stream runs on: the attention patch shifts the
+            # SAME ids tensor in place for the next layer (qwen2_vl.py:73), so they get a private copy
+            return p2.clone() if snapshot else (p2 if p2.is_contiguous() else p2.contiguous())
 
         with torch.cuda.device(dev):
             nv.check(nv.lib.rtk_pivotkv_append(
@@ -718,17 +732,23 @@ class PivotKVCache(DynamicCache):
                 nv.stream()), "rtk_pivotkv_append")
             side = self._next_side(dev)
             if side is None:
-                compress(self._ws)
+                pos_in = pos_2d(False)
+                stage_pre(self._ws, pos_in)
+                stage_big(self._ws)
+                stage_post(self._ws, pos_in)
             else:
                 main = torch.cuda.current_stream()
+                pos_in = pos_2d(True)
                 ready = torch.cuda.Event()
                 ready.record(main)
-                for t in (query_states, key_states, value_states, position_ids, mask):
+                for t in (query_states, key_states, value_states, pos_in, mask):
                     if t is not None:
                         t.record_stream(side.stream)
                 with torch.cuda.stream(side.stream):
                     side.stream.wait_event(ready)
-                    compress(side.ws)
+                    stage_pre(side.ws, pos_in)
+                    stage_big(side.ws)
+                    stage_post(side.ws, pos_in)
                     done = torch.cuda.Event()
                     done.record(side.stream)
                 st.pending_event = done

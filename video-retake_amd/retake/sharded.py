@@ -236,6 +236,9 @@ def bench_main(args, rank: int, world: int, local_rank: int):
 
     for _ in range(args.warmup):
         step()
+    ids = nv.profile_kernel_ids()   # HIP events around the dominant kernels, on their launch stream, in the timed region
+    nv.check(nv.lib.rtk_profile_reset(), "profile_reset")
+    nv.check(nv.lib.rtk_profile_enable_mask((1 << ids["score_pass1"]) | (1 << ids["score_pass2"])), "profile_enable")
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -251,6 +254,8 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     tot = torch.tensor([float(retained)], dtype=torch.float64, device=dev)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt = float(dt.item())
+    nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
+    kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in nv.profile_read().items()}
     if rank == 0:
         out = {
             "metric": "frames/sec through DPSelect+PivotKV @2048 frames; retained-KV-tokens/sec",
@@ -264,6 +269,8 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                                    f"all-gather over RCCL (BASELINE configs[3])",
                        "frames": T, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L,
                        "parallelism": f"chunk-sharded x{world}", "assembled_cache_tokens": int(keys[0].shape[2])},
+            "kernels_timed_region_rank0": kern,
+            "roofline": B.score_roofline(kern, args.dtype, L, T),
         }
         print(json.dumps(out))
     dist.barrier()
