@@ -302,13 +302,18 @@ def main():
         #   commit_batched  per chunk : staged V rows read + written, all units in one launch
         keep = int(RATIO * L)
         ap_bytes = 2 * 2 * Hkv * L * D * es
+        prep_bytes = (2 * Hq + 5 * Hkv) * L * D * es        # q: read + q~; k: read + k~ + tail; v: read + tail
         evu_bytes = 2 * 2 * Hkv * keep * D * es + 2 * keep * D * 4 + 8 * keep + 2 * 8 * 3 * keep
         cmu_bytes = 2 * Hkv * keep * D * es
         ev_bytes = 5 * L + 2 * Hkv * L * D * es + 2 * Hkv * keep * D * es + 8 * 3 * (L + keep)
         dp_bytes = T * N_PATCH * C_EMB * es + 4 * T * N_PATCH
         ga_bytes = 2 * T * N_PATCH * C_EMB * es
         extra = {}
-        for name, key, b in (("append", "append", ap_bytes), ("evict_batched", "evict_batched", evu_bytes * args.layers),
+        fused = "append" not in kern   # native-RoPE path: tables + un-rotate + append are ONE kernel (unrotate_pack)
+        for name, key, b in (("append", "append", ap_bytes),
+                             ("prepare_fused" if fused else "unrotate", "unrotate_pack",
+                              prep_bytes if fused else 2 * (Hq + Hkv) * L * D * es),
+                             ("evict_batched", "evict_batched", evu_bytes * args.layers),
                              ("commit_batched", "commit_batched", cmu_bytes * args.layers),
                              ("dpselect_dis", "dpselect_dis", dp_bytes), ("gather_frames", "gather_frames", ga_bytes)):
             if key in kern:
@@ -316,13 +321,16 @@ def main():
                 tr = None
                 if args.dtype == "bf16" and T == 2048 and args.layers == LAYERS:
                     tr = pmc_traffic({"append": "append_kernel", "evict_batched": "evict_batched_kernel",
-                                      "commit_batched": "commit_batched_kernel"}.get(name, "\0"))[0]
+                                      "commit_batched": "commit_batched_kernel",
+                                      "prepare_fused": "prepare_native_kernel"}.get(name, "\0"))[0]
                 extra[name] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": gbs / HBM_PEAK_GBS, "traffic": tr, "algorithmic_bytes_per_launch": b}
-        if all(k in kern for k in ("append", "evict_batched", "commit_batched")):
-            # the whole eviction scan of one (layer, chunk) unit against SURVEY's algorithmic byte count
-            t_unit = (kern["append"]["avg_us"] + (kern["evict_batched"]["avg_us"] + kern["commit_batched"]["avg_us"])
-                      / args.layers) * 1e-6
+        if all(k in kern for k in ("evict_batched", "commit_batched")) and ("append" in kern or fused):
+            # the whole eviction scan of one (layer, chunk) unit against SURVEY's algorithmic byte count: the tail
+            # append (its own kernel, or its byte share of the fused prepare kernel) + 1/layers of the two batched
+            # launches
+            t_app = kern["append"]["avg_us"] if not fused else kern["unrotate_pack"]["avg_us"] * ap_bytes / prep_bytes
+            t_unit = (t_app + (kern["evict_batched"]["avg_us"] + kern["commit_batched"]["avg_us"]) / args.layers) * 1e-6
             gbs = ev_bytes / t_unit / 1e9
             extra["eviction_scan_per_unit"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                "frac": gbs / HBM_PEAK_GBS, "traffic": None,

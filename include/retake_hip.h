@@ -159,6 +159,20 @@ int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64_t q_stride
                              float* score, void* k_unrot, void* workspace, size_t workspace_bytes,
                              int stages, rtk_stream_t stream);
 
+/* Fused form of {rtk_rope_table, RTK_SCORE_PREPARE, rtk_pivotkv_append} for the standard inv_freq rotary
+ * modules (longvideo_cache.py:238, :248-259): one pass over the chunk's q, k, v that builds each token's
+ * cos/sin in registers (same arithmetic and rounding as rtk_rope_table), writes q~ into `workspace` (where
+ * rtk_pivotkv_score_stages(RTK_SCORE_PASSES) expects it) and k~ into k_unrot, and appends k and v to the cache
+ * tail.  Needs 16-byte aligned pointers / strides; returns RTK_EUNSUPPORTED otherwise (use the three calls). */
+int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_stride_l,
+                        const void* k, int64_t k_stride_h, int64_t k_stride_l,
+                        const void* v, int64_t v_stride_h, int64_t v_stride_l,
+                        int Hq, int Hkv, int L, int D, int dtype,
+                        const int64_t* pos, int64_t pos_stride, int P, const float* inv_freq, float attention_scaling,
+                        const int* sections_host, int nsec, int round_bf16,
+                        void* k_unrot, void* workspace, size_t workspace_bytes,
+                        void* k_tail, void* v_tail, int64_t tail_stride_h, rtk_stream_t stream);
+
 /* P6-P7, P9-P10  longvideo_cache.py:272-277, :283-295.
  *   score [L] fp32: entries with mask != 0 are overwritten with 1.0 IN PLACE (masked_fill_, :274);
  *   mask may be NULL.

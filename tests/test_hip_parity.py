@@ -524,6 +524,60 @@ def test_select_chipwide_equals_one_workgroup_and_oracle(L, keep, P, reforge, ti
         np.testing.assert_array_equal(pa[:, :keep], g)
 
 
+def test_fused_prepare_equals_separate_kernels():
+    """rtk_pivotkv_prepare (tables in registers + un-rotate + append, one launch) against the three separate
+    kernels on the same strided HF-layout inputs: q~, k~ and both cache tails must be bit-identical."""
+    import ctypes as C
+
+    import bench as B
+    import retake._native as nv
+
+    Hq, Hkv, D, L = 28, 4, 128, 1000
+    g = torch.Generator(device=dev()).manual_seed(21)
+    for dtype in (torch.bfloat16, torch.float32):
+        q = (1.7 * torch.randn((1, L, Hq, D), generator=g, device=dev())).to(dtype).transpose(1, 2)
+        k = (1.7 * torch.randn((1, L, Hkv, D), generator=g, device=dev())).to(dtype).transpose(1, 2)
+        v = (1.7 * torch.randn((1, L, Hkv, D), generator=g, device=dev())).to(dtype).transpose(1, 2)
+        pos = torch.stack([torch.arange(L, device=dev()) // 50 + 1000, torch.arange(L, device=dev()) % 14,
+                           torch.arange(L, device=dev()) % 7]).contiguous()
+        rot = B.Rotary(dev())
+        dt = nv.dtype_code(q)
+        es = q.element_size()
+        wsb = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
+        sec = (C.c_int * 3)(*B.MROPE)
+        res = []
+        for fused in (True, False):
+            ws = torch.zeros(wsb, dtype=torch.uint8, device=dev())
+            kun = torch.zeros((Hkv, L, D), dtype=dtype, device=dev())
+            kt = torch.zeros((1, Hkv, L + 9, D), dtype=dtype, device=dev())
+            vt = torch.zeros_like(kt)
+            if fused:
+                nv.check(nv.lib.rtk_pivotkv_prepare(
+                    nv.ptr(q), q.stride(1), q.stride(2), nv.ptr(k), k.stride(1), k.stride(2), nv.ptr(v), v.stride(1),
+                    v.stride(2), Hq, Hkv, L, D, dt, nv.ptr(pos), L, 3, nv.ptr(rot.inv_freq), B.A_SCALE, sec, 3,
+                    int(dtype == torch.bfloat16), nv.ptr(kun), nv.ptr(ws), wsb, C.c_void_p(kt.data_ptr() + 5 * D * es),
+                    C.c_void_p(vt.data_ptr() + 5 * D * es), (L + 9) * D, nv.stream()), "prepare")
+            else:
+                cos = torch.empty((L, D), dtype=torch.float32, device=dev())
+                sin = torch.empty_like(cos)
+                score = torch.empty(L, dtype=torch.float32, device=dev())
+                nv.check(nv.lib.rtk_rope_table(nv.ptr(pos), L, 3, L, nv.ptr(rot.inv_freq), D, B.A_SCALE, sec, 3,
+                                               int(dtype == torch.bfloat16), nv.ptr(cos), nv.ptr(sin), nv.stream()), "table")
+                nv.check(nv.lib.rtk_pivotkv_score_stages(
+                    nv.ptr(q), q.stride(1), q.stride(2), nv.ptr(k), k.stride(1), k.stride(2), Hq, Hkv, L, D, dt,
+                    nv.ptr(cos), nv.ptr(sin), B.A_SCALE, nv.ptr(score), nv.ptr(kun), nv.ptr(ws), wsb, nv.SCORE_PREPARE,
+                    nv.stream()), "unrotate")
+                nv.check(nv.lib.rtk_pivotkv_append(nv.ptr(k), k.stride(1), k.stride(2), nv.ptr(v), v.stride(1), v.stride(2),
+                                                   Hkv, L, D, dt, C.c_void_p(kt.data_ptr() + 5 * D * es),
+                                                   C.c_void_p(vt.data_ptr() + 5 * D * es), (L + 9) * D, nv.stream()), "append")
+            torch.cuda.synchronize()
+            res.append((ws[: Hq * L * D * es].clone(), kun, kt, vt))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+        assert torch.equal(res[0][2][:, :, 5:5 + L], k) and torch.equal(res[0][3][:, :, 5:5 + L], v)
+        assert int(res[0][2][:, :, :5].abs().sum()) == 0 and int(res[0][2][:, :, 5 + L:].abs().sum()) == 0
+
+
 def test_evict_batched_abi_vs_torch_gather():
     """rtk_pivotkv_append / rtk_pivotkv_evict_batched / rtk_pivotkv_commit_batched straight through the C ABI:
     5 units, no reforge -> K and V rows must be byte-identical to torch.gather; ids copied."""

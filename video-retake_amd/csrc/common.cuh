@@ -55,6 +55,38 @@ void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 }  // namespace rtk
 
+// ---- M-RoPE channel -> position-row selection (longvideo_cache.py:68-74), shared by rope.hip and the fused prepare kernel
+namespace rtk {
+struct RowSel {
+    uint8_t row[256];  // which of the P position rows (t/h/w) feeds channel d
+};
+
+inline int make_rowsel(RowSel& rs, int P, int D, const int* sections, int nsec, const char* who) {
+    if (D > 256 || (D & 1)) {
+        set_error("%s: head_dim %d unsupported (must be even and <= 256)", who, D);
+        return RTK_EUNSUPPORTED;
+    }
+    for (int d = 0; d < D; ++d) rs.row[d] = 0;
+    if (P == 1) return RTK_OK;
+    if (P != 3 || !sections || nsec < 1) {
+        set_error("%s: P=%d needs mrope sections", who, P);
+        return RTK_EINVAL;
+    }
+    int tot = 0;
+    for (int i = 0; i < nsec; ++i) tot += sections[i];
+    if (2 * tot != D) {
+        set_error("%s: sum(mrope_section)*2 = %d != head_dim %d", who, 2 * tot, D);
+        return RTK_EINVAL;
+    }
+    int d = 0;
+    for (int rep = 0; rep < 2; ++rep)
+        for (int i = 0; i < nsec; ++i)
+            for (int c = 0; c < sections[i]; ++c, ++d) rs.row[d] = (uint8_t)((rep * nsec + i) % 3);
+    return RTK_OK;
+}
+
+}  // namespace rtk
+
 // ---- optional per-kernel HIP-event timing (rtk_profile_*), used by bench.py ------------------------
 namespace rtk {
 enum KernelId {

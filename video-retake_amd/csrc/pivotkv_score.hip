@@ -192,6 +192,153 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused prepare (native RoPE tables only): one pass over the chunk's q, k, v that
+//   builds the token's cos/sin chunk in registers (what rope_table_kernel writes to HBM: same sincosf, same
+//   scaling, same bf16 rounding), un-rotates q and k with it (same arithmetic as unrotate_pack_vec_kernel),
+//   and appends k and v to the cache tail (what append_kernel does) — k is read once instead of twice and
+//   three launches become one.  One thread = one token x one 16-byte chunk pair; blockIdx.y splits the heads
+//   in two: y = 0 the first half of the q heads + k (k~ and the k tail), y = 1 the second half + the v tail.
+// ------------------------------------------------------------------------------------------------
+template <int DT, int DIV>
+__global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restrict__ q, int64_t q_sh, int64_t q_sl,
+                                                            const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
+                                                            const char* __restrict__ v, int64_t v_sh, int64_t v_sl,
+                                                            int Hq, int Hkv, int L, int D,
+                                                            const int64_t* __restrict__ pos, int64_t pos_ld,
+                                                            const float* __restrict__ inv_freq, float scaling, RowSel rs,
+                                                            int round_bf16, float a2, float rcp_a2,
+                                                            char* __restrict__ q_out, char* __restrict__ k_out,
+                                                            char* __restrict__ k_tail, char* __restrict__ v_tail,
+                                                            int64_t tail_sh) {
+    using V = Vec16<DT>;
+    constexpr int VE = V::VE;
+    constexpr int ES = 16 / VE;
+    const int h2 = D / 2, lpr = h2 / VE;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= L * lpr) return;
+    const int l = id / lpr, d = (id - l * lpr) * VE;
+    float c1[VE], s1[VE], c2[VE], s2[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {   // rope_table_kernel's arithmetic for channels d + e and d + e + h2
+        const float f = inv_freq[d + e];
+        const int r1 = rs.row[d + e], r2 = rs.row[d + e + h2];
+        const float p1 = (float)pos[(size_t)r1 * pos_ld + l];
+        float sn, cs;
+        sincosf(p1 * f, &sn, &cs);
+        cs *= scaling;
+        sn *= scaling;
+        if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
+        c1[e] = cs;
+        s1[e] = sn;
+        if (r2 != r1) {
+            const float p2 = (float)pos[(size_t)r2 * pos_ld + l];
+            sincosf(p2 * f, &sn, &cs);
+            cs *= scaling;
+            sn *= scaling;
+            if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
+        }
+        c2[e] = cs;
+        s2[e] = sn;
+    }
+    // x~ = ((x*cos) - (rotate_half(x)*sin)) / a^2 for one head's chunk pair, one rounding per torch op (:76-78)
+    auto unrot = [&](const u32x4& lo, const u32x4& hi, u32x4& olo, u32x4& ohi) {
+        if constexpr (DT == RTK_BF16) {
+            const uint32_t wl[4] = {lo.x, lo.y, lo.z, lo.w}, wh[4] = {hi.x, hi.y, hi.z, hi.w};
+            uint32_t r1[4], r2[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float x1a = bf_lo(wl[w]), x1b = bf_hi(wl[w]), x2a = bf_lo(wh[w]), x2b = bf_hi(wh[w]);
+                const int e = 2 * w;
+                const uint32_t p1 = pack2_bf16(x1a * c1[e], x1b * c1[e + 1]);
+                const uint32_t n1 = pack2_bf16(x2a * s1[e], x2b * s1[e + 1]);
+                const uint32_t p2 = pack2_bf16(x2a * c2[e], x2b * c2[e + 1]);
+                const uint32_t n2 = pack2_bf16(x1a * s2[e], x1b * s2[e + 1]);
+                uint32_t t1 = pack2_bf16(bf_lo(p1) + bf_lo(n1), bf_hi(p1) + bf_hi(n1));
+                uint32_t t2 = pack2_bf16(bf_lo(p2) - bf_lo(n2), bf_hi(p2) - bf_hi(n2));
+                if constexpr (DIV == 1) {
+                    t1 = pack2_bf16(bf_lo(t1) * rcp_a2, bf_hi(t1) * rcp_a2);
+                    t2 = pack2_bf16(bf_lo(t2) * rcp_a2, bf_hi(t2) * rcp_a2);
+                } else if constexpr (DIV == 2) {
+                    t1 = pack2_bf16(__fdiv_rn(bf_lo(t1), a2), __fdiv_rn(bf_hi(t1), a2));
+                    t2 = pack2_bf16(__fdiv_rn(bf_lo(t2), a2), __fdiv_rn(bf_hi(t2), a2));
+                }
+                r1[w] = t1;
+                r2[w] = t2;
+            }
+            olo = u32x4{r1[0], r1[1], r1[2], r1[3]};
+            ohi = u32x4{r2[0], r2[1], r2[2], r2[3]};
+        } else {
+            float x1[VE], x2[VE], o1[VE], o2[VE];
+            V::unpack(lo, x1);
+            V::unpack(hi, x2);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                o1[e] = __fsub_rn(__fmul_rn(x1[e], c1[e]), __fmul_rn(-x2[e], s1[e]));
+                o2[e] = __fsub_rn(__fmul_rn(x2[e], c2[e]), __fmul_rn(x1[e], s2[e]));
+                if constexpr (DIV != 0) {
+                    o1[e] = __fdiv_rn(o1[e], a2);
+                    o2[e] = __fdiv_rn(o2[e], a2);
+                }
+            }
+            olo = V::pack(o1);
+            ohi = V::pack(o2);
+        }
+    };
+    constexpr int HU = 7;   // heads per batch: all loads of a batch are issued before its arithmetic and stores
+    const int qhalf = (Hq + 1) / 2;
+    const int qb = blockIdx.y == 0 ? 0 : qhalf, qe = blockIdx.y == 0 ? qhalf : Hq;
+    for (int hb = qb; hb < qe; hb += HU) {
+        u32x4 lo[HU], hi[HU];
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int h = min(hb + u, qe - 1);
+            const char* row = q + ((size_t)h * q_sh + (size_t)l * q_sl) * ES;
+            lo[u] = *(const u32x4*)(row + (size_t)d * ES);
+            hi[u] = *(const u32x4*)(row + (size_t)(d + h2) * ES);
+        }
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int h = hb + u;
+            if (h >= qe) break;
+            u32x4 olo, ohi;
+            unrot(lo[u], hi[u], olo, ohi);
+            char* orow = q_out + ((size_t)h * L + l) * D * ES;
+            *(u32x4*)(orow + (size_t)d * ES) = olo;
+            *(u32x4*)(orow + (size_t)(d + h2) * ES) = ohi;
+        }
+    }
+    // the KV heads: y = 0 takes k (k~ for the scoring / eviction + the rotated rows for the tail), y = 1 takes v
+    const char* src = blockIdx.y == 0 ? k : v;
+    const int64_t sh = blockIdx.y == 0 ? k_sh : v_sh, sl = blockIdx.y == 0 ? k_sl : v_sl;
+    char* tail = blockIdx.y == 0 ? k_tail : v_tail;
+    for (int hb = 0; hb < Hkv; hb += 4) {
+        u32x4 lo[4], hi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int h = min(hb + u, Hkv - 1);
+            const char* row = src + ((size_t)h * sh + (size_t)l * sl) * ES;
+            lo[u] = *(const u32x4*)(row + (size_t)d * ES);
+            hi[u] = *(const u32x4*)(row + (size_t)(d + h2) * ES);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int h = hb + u;
+            if (h >= Hkv) break;
+            char* trow = tail + ((size_t)h * tail_sh + (size_t)l * D) * ES;
+            *(u32x4*)(trow + (size_t)d * ES) = lo[u];
+            *(u32x4*)(trow + (size_t)(d + h2) * ES) = hi[u];
+            if (blockIdx.y == 0) {
+                u32x4 olo, ohi;
+                unrot(lo[u], hi[u], olo, ohi);
+                char* orow = k_out + ((size_t)h * L + l) * D * ES;
+                *(u32x4*)(orow + (size_t)d * ES) = olo;
+                *(u32x4*)(orow + (size_t)(d + h2) * ES) = ohi;
+            }
+        }
+    }
+}
+
 // scalar fallback (any even head_dim, any alignment)
 template <int DT>
 __global__ __launch_bounds__(256) void unrotate_pack_kernel(const void* __restrict__ xv, int64_t stride_h,
@@ -1406,4 +1553,67 @@ extern "C" int rtk_pivotkv_score(const void* q, int64_t q_stride_h, int64_t q_st
     return rtk_pivotkv_score_stages(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, dtype, cosv, sinv,
                                     attention_scaling, score, k_unrot, workspace, workspace_bytes,
                                     RTK_SCORE_PREPARE | RTK_SCORE_PASSES | RTK_SCORE_FINALIZE, stream);
+}
+
+template <int DT>
+static int prepare_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, int64_t ksh, int64_t ksl, const void* v,
+                        int64_t vsh, int64_t vsl, int Hq, int Hkv, int L, int D, const int64_t* pos, int64_t pos_stride,
+                        const float* inv_freq, float a, const RowSel& rs, int round_bf16, char* qt, char* kt, void* k_tail,
+                        void* v_tail, int64_t tail_sh, hipStream_t st) {
+    constexpr int VE = Vec16<DT>::VE;
+    const float a2 = (float)((double)a * (double)a);
+    const int div = (a2 == 1.0f) ? 0 : ((DT == RTK_BF16 && bf16_rcp_is_exact(a2)) ? 1 : 2);
+    const float rcp = 1.0f / a2;
+    const int threads = L * (D / 2 / VE);
+    const dim3 grid((threads + 63) / 64, 2);
+#define RTK_PREP(DIV)                                                                                               \
+    RTK_LAUNCH(KID_UNROT, (prepare_native_kernel<DT, DIV>), grid, dim3(64), 0, st, (const char*)q, qsh, qsl,          \
+               (const char*)k, ksh, ksl, (const char*)v, vsh, vsl, Hq, Hkv, L, D, pos, pos_stride, inv_freq, a, rs,  \
+               round_bf16, a2, rcp, qt, kt, (char*)k_tail, (char*)v_tail, tail_sh)
+    if (div == 0) RTK_PREP(0);
+    else if (div == 1) RTK_PREP(1);
+    else RTK_PREP(2);
+#undef RTK_PREP
+    RTK_LAUNCH_CHECK("prepare_native_kernel");
+    return RTK_OK;
+}
+
+extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k,
+                                   int64_t k_stride_h, int64_t k_stride_l, const void* v, int64_t v_stride_h,
+                                   int64_t v_stride_l, int Hq, int Hkv, int L, int D, int dtype, const int64_t* pos,
+                                   int64_t pos_stride, int P, const float* inv_freq, float attention_scaling,
+                                   const int* sections_host, int nsec, int round_bf16, void* k_unrot, void* workspace,
+                                   size_t workspace_bytes, void* k_tail, void* v_tail, int64_t tail_stride_h,
+                                   rtk_stream_t stream) {
+    RTK_CHECK_ARG(q && k && v && pos && inv_freq && k_unrot && workspace && k_tail && v_tail, "rtk_pivotkv_prepare: NULL pointer");
+    RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && L >= 1 && D >= 2, "rtk_pivotkv_prepare: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_prepare: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(pos_stride >= L, "rtk_pivotkv_prepare: pos_stride %lld < L %d", (long long)pos_stride, L);
+    RTK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "rtk_pivotkv_prepare: workspace must be 256-byte aligned");
+    const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
+    if (workspace_bytes < w.total) {
+        set_error("rtk_pivotkv_prepare: workspace %zu < required %zu bytes", workspace_bytes, w.total);
+        return RTK_EWORKSPACE;
+    }
+    const int ve = dtype == RTK_BF16 ? 8 : 4, es = dtype == RTK_BF16 ? 2 : 4;
+    const bool ok = (D % (2 * ve) == 0) && D <= 256 && (q_stride_h * es) % 16 == 0 && (q_stride_l * es) % 16 == 0 &&
+                    (k_stride_h * es) % 16 == 0 && (k_stride_l * es) % 16 == 0 && (v_stride_h * es) % 16 == 0 &&
+                    (v_stride_l * es) % 16 == 0 && (tail_stride_h * es) % 16 == 0 &&
+                    (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)k_unrot | (uintptr_t)k_tail | (uintptr_t)v_tail) & 15) == 0;
+    if (!ok) {
+        set_error("rtk_pivotkv_prepare: needs 16-byte aligned pointers / strides and head_dim a multiple of %d", 2 * ve);
+        return RTK_EUNSUPPORTED;   // callers fall back to rtk_rope_table + rtk_pivotkv_score + rtk_pivotkv_append
+    }
+    RowSel rs;
+    int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_pivotkv_prepare");
+    if (rc) return rc;
+    char* qt = (char*)workspace + w.q_off;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RTK_BF16)
+        return prepare_impl<RTK_BF16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv,
+                                      L, D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot,
+                                      k_tail, v_tail, tail_stride_h, st);
+    return prepare_impl<RTK_F32>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv, L,
+                                 D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot, k_tail,
+                                 v_tail, tail_stride_h, st);
 }

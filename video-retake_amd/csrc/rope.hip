@@ -5,34 +5,6 @@
 
 namespace rtk {
 
-struct RowSel {
-    uint8_t row[256];  // which of the P position rows (t/h/w) feeds channel d
-};
-
-static int make_rowsel(RowSel& rs, int P, int D, const int* sections, int nsec, const char* who) {
-    if (D > 256 || (D & 1)) {
-        set_error("%s: head_dim %d unsupported (must be even and <= 256)", who, D);
-        return RTK_EUNSUPPORTED;
-    }
-    for (int d = 0; d < D; ++d) rs.row[d] = 0;
-    if (P == 1) return RTK_OK;
-    if (P != 3 || !sections || nsec < 1) {
-        set_error("%s: P=%d needs mrope sections", who, P);
-        return RTK_EINVAL;
-    }
-    int tot = 0;
-    for (int i = 0; i < nsec; ++i) tot += sections[i];
-    if (2 * tot != D) {
-        set_error("%s: sum(mrope_section)*2 = %d != head_dim %d", who, 2 * tot, D);
-        return RTK_EINVAL;
-    }
-    int d = 0;
-    for (int rep = 0; rep < 2; ++rep)
-        for (int i = 0; i < nsec; ++i)
-            for (int c = 0; c < sections[i]; ++c, ++d) rs.row[d] = (uint8_t)((rep * nsec + i) % 3);
-    return RTK_OK;
-}
-
 template <int DT>
 __global__ __launch_bounds__(256) void rope_merge_kernel(const void* __restrict__ cin, const void* __restrict__ sin_,
                                                          int L, int D, RowSel rs, float* __restrict__ cos_out,

@@ -53,6 +53,8 @@ _SIGNATURES = {
                                     _vp, _sz, _vp]),
     "rtk_pivotkv_score_stages": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp,
                                            _vp, _sz, _i, _vp]),
+    "rtk_pivotkv_prepare": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i,
+                                      _vp, _f, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _i64, _vp]),
     "rtk_pivotkv_select_workspace_bytes": (C.c_size_t, [_i]),
     "rtk_pivotkv_select": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rtk_pivotkv_evict": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp,

@@ -724,19 +724,49 @@ class PivotKVCache(DynamicCache):
             # SAME ids tensor in place for the next layer (qwen2_vl.py:73), so they get a private copy
             return p2.clone() if snapshot else (p2 if p2.is_contiguous() else p2.contiguous())
 
-        with torch.cuda.device(dev):
+        k_tail = C.c_void_p(st.k.data_ptr() + P0 * D * esz)
+        v_tail = C.c_void_p(st.v.data_ptr() + P0 * D * esz)
+
+        def append_tail():   # reference :238 — the uncompressed view this layer's attention reads
             nv.check(nv.lib.rtk_pivotkv_append(
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
                 nv.ptr(value_states), value_states.stride(1), value_states.stride(2), Hkv, L, D, dt,
-                C.c_void_p(st.k.data_ptr() + P0 * D * esz), C.c_void_p(st.v.data_ptr() + P0 * D * esz), cap * D,
-                nv.stream()), "rtk_pivotkv_append")
+                k_tail, v_tail, cap * D, nv.stream()), "rtk_pivotkv_append")
+
+        def fused_prepare(ws, pos_in) -> bool:
+            """append + native RoPE tables + un-rotate in ONE launch (k read once); False if the shape needs the
+            separate kernels."""
+            if not (reforge and self.native_rope and hasattr(rotary_emb_fn, "inv_freq") and pos_in is not None):
+                return False
+            inv = rotary_emb_fn.inv_freq
+            if inv.device != dev or inv.dtype != torch.float32 or not inv.is_contiguous():
+                inv = inv.to(device=dev, dtype=torch.float32).contiguous()
+            wsb = self._buf("score_ws", (ws_bytes + 256,), torch.uint8, dev, ws)
+            ws_ptr = (wsb.data_ptr() + 255) & ~255
+            sec = (C.c_int * len(mrope_section))(*mrope_section) if mrope_section else None
+            rc = nv.lib.rtk_pivotkv_prepare(
+                nv.ptr(query_states), query_states.stride(1), query_states.stride(2),
+                nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
+                nv.ptr(value_states), value_states.stride(1), value_states.stride(2),
+                Hq, Hkv, L, D, dt, nv.ptr(pos_in), L, Pn, nv.ptr(inv), a_scale, sec,
+                len(mrope_section) if mrope_section else 0, int(key_states.dtype == torch.bfloat16),
+                nv.ptr(batch.k_unrot[layer_idx]), C.c_void_p(ws_ptr), ws_bytes, k_tail, v_tail, cap * D, nv.stream())
+            if rc == nv.RTK_EUNSUPPORTED:
+                return False
+            nv.check(rc, "rtk_pivotkv_prepare")
+            return True
+
+        with torch.cuda.device(dev):
             side = self._next_side(dev)
             if side is None:
                 pos_in = pos_2d(False)
-                stage_pre(self._ws, pos_in)
+                if not fused_prepare(self._ws, pos_in):
+                    append_tail()
+                    stage_pre(self._ws, pos_in)
                 stage_big(self._ws)
                 stage_post(self._ws, pos_in)
             else:
+                append_tail()   # on the caller's stream: all this layer's attention needs
                 main = torch.cuda.current_stream()
                 pos_in = pos_2d(True)
                 ready = torch.cuda.Event()
