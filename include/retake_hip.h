@@ -157,7 +157,7 @@ int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64_t q_stride
                              int Hq, int Hkv, int L, int D, int dtype,
                              const float* cos, const float* sin, float attention_scaling,
                              float* score, void* k_unrot, void* workspace, size_t workspace_bytes,
-                             int stages, rtk_stream_t stream);
+                             int stages, float* partial_out /* NULL = inside workspace */, rtk_stream_t stream);
 
 /* Fused form of {rtk_rope_table, RTK_SCORE_PREPARE, rtk_pivotkv_append} for the standard inv_freq rotary
  * modules (longvideo_cache.py:238, :248-259): one pass over the chunk's q, k, v that builds each token's
@@ -171,7 +171,9 @@ int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_stride_l,
                         const int64_t* pos, int64_t pos_stride, int P, const float* inv_freq, float attention_scaling,
                         const int* sections_host, int nsec, int round_bf16,
                         void* k_unrot, void* workspace, size_t workspace_bytes,
-                        void* k_tail, void* v_tail, int64_t tail_stride_h, rtk_stream_t stream);
+                        void* k_tail, void* v_tail, int64_t tail_stride_h,
+                        int64_t* pos_copy /* optional [P, L]: private copy of the ids for a deferred selection */,
+                        rtk_stream_t stream);
 
 /* P6-P7, P9-P10  longvideo_cache.py:272-277, :283-295.
  *   score [L] fp32: entries with mask != 0 are overwritten with 1.0 IN PLACE (masked_fill_, :274);
@@ -191,6 +193,28 @@ int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep,
                        const int64_t* pos, int P, int reforge,
                        int64_t* keep_idx, int32_t* rank, int64_t* pos_out, int64_t pos_out_stride,
                        void* workspace, size_t workspace_bytes, rtk_stream_t stream);
+
+/* The selection of n (layer, chunk) units in the same three launches (finalize of the column partials ->
+ * rank -> emit): what PivotKVCache runs from after_forward for all layers of a chunk.  Units share L, keep, P
+ * and the partial layout (Hkv, RS, G as reported by rtk_pivotkv_score_partials).  Chip-wide path only
+ * (RTK_EUNSUPPORTED for L < 512: call rtk_pivotkv_select per unit).  `units` is a HOST array. */
+typedef struct rtk_select_unit {
+    const float* partial;   /* column partials [Hkv, RS, L] written by RTK_SCORE_PASSES (partial_out), or NULL: score is final */
+    float* score;           /* [L] fp32 (written from the partials, masked entries overwritten with 1.0) */
+    const uint8_t* mask;    /* [L] key-patch mask or NULL */
+    const int64_t* pos;     /* [P, L] position ids (row stride L) or NULL */
+    int64_t* keep_idx;      /* [keep] */
+    int32_t* rank;          /* [L] or NULL */
+    int64_t* pos_out;       /* rows at pos_out + p*pos_out_stride, or NULL */
+    void* workspace;        /* rtk_pivotkv_select_workspace_bytes(L), 256-byte aligned */
+} rtk_select_unit;
+#define RTK_SELECT_MAX_UNITS 28
+int rtk_pivotkv_select_batched(const rtk_select_unit* units, int n_units, int Hkv, int RS, int G, int L,
+                               int keep, int P, int reforge, int64_t pos_out_stride, rtk_stream_t stream);
+
+/* Layout of the column partials rtk_pivotkv_score_stages(RTK_SCORE_PASSES) produces for these sizes: returns the
+ * number of floats (Hkv * RS * L) and writes RS (row splits actually used) to *rs_out. */
+size_t rtk_pivotkv_score_partials(int Hq, int Hkv, int L, int D, int dtype, int* rs_out);
 
 /* P1, P8, P11, P13  longvideo_cache.py:238, :278-280, :297-306, :313-318 — the eviction scan.
  * One launch over the chunk's K and V rows:

@@ -552,11 +552,13 @@ def test_fused_prepare_equals_separate_kernels():
             kt = torch.zeros((1, Hkv, L + 9, D), dtype=dtype, device=dev())
             vt = torch.zeros_like(kt)
             if fused:
+                pos_copy = torch.zeros_like(pos)
                 nv.check(nv.lib.rtk_pivotkv_prepare(
                     nv.ptr(q), q.stride(1), q.stride(2), nv.ptr(k), k.stride(1), k.stride(2), nv.ptr(v), v.stride(1),
                     v.stride(2), Hq, Hkv, L, D, dt, nv.ptr(pos), L, 3, nv.ptr(rot.inv_freq), B.A_SCALE, sec, 3,
                     int(dtype == torch.bfloat16), nv.ptr(kun), nv.ptr(ws), wsb, C.c_void_p(kt.data_ptr() + 5 * D * es),
-                    C.c_void_p(vt.data_ptr() + 5 * D * es), (L + 9) * D, nv.stream()), "prepare")
+                    C.c_void_p(vt.data_ptr() + 5 * D * es), (L + 9) * D, nv.ptr(pos_copy), nv.stream()), "prepare")
+                assert torch.equal(pos_copy, pos)
             else:
                 cos = torch.empty((L, D), dtype=torch.float32, device=dev())
                 sin = torch.empty_like(cos)
@@ -566,7 +568,7 @@ def test_fused_prepare_equals_separate_kernels():
                 nv.check(nv.lib.rtk_pivotkv_score_stages(
                     nv.ptr(q), q.stride(1), q.stride(2), nv.ptr(k), k.stride(1), k.stride(2), Hq, Hkv, L, D, dt,
                     nv.ptr(cos), nv.ptr(sin), B.A_SCALE, nv.ptr(score), nv.ptr(kun), nv.ptr(ws), wsb, nv.SCORE_PREPARE,
-                    nv.stream()), "unrotate")
+                    None, nv.stream()), "unrotate")
                 nv.check(nv.lib.rtk_pivotkv_append(nv.ptr(k), k.stride(1), k.stride(2), nv.ptr(v), v.stride(1), v.stride(2),
                                                    Hkv, L, D, dt, C.c_void_p(kt.data_ptr() + 5 * D * es),
                                                    C.c_void_p(vt.data_ptr() + 5 * D * es), (L + 9) * D, nv.stream()), "append")
@@ -576,6 +578,48 @@ def test_fused_prepare_equals_separate_kernels():
             assert torch.equal(a, b)
         assert torch.equal(res[0][2][:, :, 5:5 + L], k) and torch.equal(res[0][3][:, :, 5:5 + L], v)
         assert int(res[0][2][:, :, :5].abs().sum()) == 0 and int(res[0][2][:, :, 5 + L:].abs().sum()) == 0
+
+
+def test_select_batched_equals_single_units():
+    """rtk_pivotkv_select_batched over 5 units (column partials -> finalize -> rank -> emit in three launches) must
+    equal finalizing on the host and selecting every unit on its own."""
+    import retake._native as nv
+
+    Hkv, RS, G, L, keep, P, n = 4, 3, 7, 1500, 400, 3, 5
+    g = torch.Generator(device=dev()).manual_seed(33)
+    units = (nv.SelectUnit * n)()
+    hold = []
+    wsb = nv.lib.rtk_pivotkv_select_workspace_bytes(L)
+    ld = n * keep
+    pos_new = torch.full((P, n, keep), -1, dtype=torch.int64, device=dev())
+    for i in range(n):
+        part = torch.rand((Hkv, RS, L), generator=g, device=dev()) * 2.0
+        mask = torch.rand(L, generator=g, device=dev()) < 0.25 if i % 2 == 0 else None
+        pos = torch.stack([torch.arange(L, device=dev()) // 100 + 40 + i, torch.arange(L, device=dev()) % 11,
+                           torch.arange(L, device=dev()) % 5]).contiguous()
+        score = torch.empty(L, dtype=torch.float32, device=dev())
+        keep_idx = torch.empty(keep, dtype=torch.int64, device=dev())
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+        u = units[i]
+        u.partial, u.score, u.mask, u.pos = part.data_ptr(), score.data_ptr(), (mask.data_ptr() if mask is not None else None), pos.data_ptr()
+        u.keep_idx, u.rank, u.pos_out, u.workspace = keep_idx.data_ptr(), None, pos_new.data_ptr() + i * keep * 8, ws.data_ptr()
+        hold.append((part, mask, pos, score, keep_idx, ws))
+    nv.check(nv.lib.rtk_pivotkv_select_batched(units, n, Hkv, RS, G, L, keep, P, 1, ld, nv.stream()), "select_batched")
+    torch.cuda.synchronize()
+    for i, (part, mask, pos, score, keep_idx, ws) in enumerate(hold):
+        ref = ((part.sum(1) / G).sum(0) / Hkv)
+        s1 = ref.clone()
+        k1 = torch.empty(keep, dtype=torch.int64, device=dev())
+        r1 = torch.empty(L, dtype=torch.int32, device=dev())
+        p1 = torch.empty((P, keep), dtype=torch.int64, device=dev())
+        ws1 = torch.empty(wsb, dtype=torch.uint8, device=dev())
+        nv.check(nv.lib.rtk_pivotkv_select(nv.ptr(s1), nv.ptr(mask), L, keep, nv.ptr(pos), P, 1, nv.ptr(k1), nv.ptr(r1),
+                                           nv.ptr(p1), keep, nv.ptr(ws1), wsb, nv.stream()), "select")
+        assert (score - s1).abs().max().item() <= 1e-6          # fixed-order finalize vs torch's sums
+        if torch.equal((score == s1), torch.ones_like(score, dtype=torch.bool)):
+            assert torch.equal(keep_idx, k1) and torch.equal(pos_new[:, i], p1)
+        else:   # a score differing in the last bit can only swap tokens at the threshold
+            assert len(set(keep_idx.tolist()) ^ set(k1.tolist())) <= 4
 
 
 def test_evict_batched_abi_vs_torch_gather():

@@ -251,11 +251,56 @@ constexpr int RANK_TOK = 64;           // tokens ranked per workgroup (one per l
 constexpr int RANK_SEG = 16;           // waves per workgroup, each scanning one segment of the keys
 constexpr int RANK_BLOCK = RANK_TOK * RANK_SEG;
 
-__global__ __launch_bounds__(RANK_BLOCK) void pivotkv_rank_kernel(float* __restrict__ score,
-                                                           const uint8_t* __restrict__ mask, int L, int keep,
-                                                           const int64_t* __restrict__ pos, int reforge,
-                                                           uint8_t* __restrict__ sel, int32_t* __restrict__ blk_cnt,
-                                                           int64_t* __restrict__ blk_tmin, int vec_ok) {
+struct SelUnits {
+    rtk_select_unit u[RTK_SELECT_MAX_UNITS];
+};
+// scratch layout inside a unit's workspace: sel [L] bytes | per-rank-workgroup counts | per-rank-workgroup minima
+__host__ __device__ inline size_t sel_ws_cnt_off(int L) { return ((size_t)L + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t sel_ws_tmin_off(int L) {
+    const size_t nb = ((size_t)L + 63) / 64;
+    return sel_ws_cnt_off(L) + ((nb * 4 + 255) & ~(size_t)255);
+}
+
+// score[j] = mean_g( (sum_split partial[g,split,j]) / G ) for every unit that still carries partials
+// (longvideo_cache.py:269-270): the deferred form of score_finalize_kernel, same fixed summation order.
+__global__ __launch_bounds__(256) void finalize_units_kernel(SelUnits units, int Hkv, int RS, int G, int L) {
+    extern __shared__ float fin_gs[];  // [Hkv][64]
+    const rtk_select_unit& un = units.u[blockIdx.y];
+    if (!un.partial) return;
+    const int jl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jl;
+    const int jc = min(j, L - 1);
+    for (int g = part; g < Hkv; g += 4) {
+        const float* p = un.partial + (size_t)g * RS * L + jc;
+        float gs = 0.f;
+        int r = 0;
+        for (; r + 8 <= RS; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(r + u) * L];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gs += v[u];
+        }
+        for (; r < RS; ++r) gs += p[(size_t)r * L];
+        fin_gs[g * 64 + jl] = gs / (float)G;
+    }
+    __syncthreads();
+    if (part == 0 && j < L) {
+        float tot = 0.f;
+        for (int g = 0; g < Hkv; ++g) tot += fin_gs[g * 64 + jl];
+        un.score[j] = tot / (float)Hkv;
+    }
+}
+
+__global__ __launch_bounds__(RANK_BLOCK) void pivotkv_rank_kernel(SelUnits units, int L, int keep, int reforge) {
+    const rtk_select_unit& un = units.u[blockIdx.y];
+    float* __restrict__ score = un.score;
+    const uint8_t* __restrict__ mask = un.mask;
+    const int64_t* __restrict__ pos = un.pos;
+    uint8_t* __restrict__ sel = (uint8_t*)un.workspace;
+    int32_t* __restrict__ blk_cnt = (int32_t*)((char*)un.workspace + sel_ws_cnt_off(L));
+    int64_t* __restrict__ blk_tmin = (int64_t*)((char*)un.workspace + sel_ws_tmin_off(L));
+    const int vec_ok = (((uintptr_t)score & 15) == 0 && ((uintptr_t)mask & 3) == 0) ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) uint32_t rk_keys[];  // [n4 * 4] keys (zero padded) + [RANK_SEG][RANK_TOK] counts
     const int tid = threadIdx.x;
     const int i0 = blockIdx.x * RANK_TOK;
@@ -340,12 +385,16 @@ __global__ __launch_bounds__(RANK_BLOCK) void pivotkv_rank_kernel(float* __restr
 
 // ordered emit: one workgroup per 256 tokens.  The number of kept tokens before its range and min_temp_id
 // come from the rank kernel's per-workgroup records (RANK_TOK tokens each).
-__global__ __launch_bounds__(256) void pivotkv_emit_kernel(const uint8_t* __restrict__ sel,
-                                                           const int32_t* __restrict__ blk_cnt,
-                                                           const int64_t* __restrict__ blk_tmin, int L, int keep,
-                                                           const int64_t* __restrict__ pos, int P, int reforge,
-                                                           int64_t* __restrict__ keep_idx, int32_t* __restrict__ rank,
-                                                           int64_t* __restrict__ pos_out, int64_t pos_ld) {
+__global__ __launch_bounds__(256) void pivotkv_emit_kernel(SelUnits units, int L, int keep, int P, int reforge,
+                                                           int64_t pos_ld) {
+    const rtk_select_unit& un = units.u[blockIdx.y];
+    const uint8_t* __restrict__ sel = (const uint8_t*)un.workspace;
+    const int32_t* __restrict__ blk_cnt = (const int32_t*)((const char*)un.workspace + sel_ws_cnt_off(L));
+    const int64_t* __restrict__ blk_tmin = (const int64_t*)((const char*)un.workspace + sel_ws_tmin_off(L));
+    const int64_t* __restrict__ pos = un.pos;
+    int64_t* __restrict__ keep_idx = un.keep_idx;
+    int32_t* __restrict__ rank = un.rank;
+    int64_t* __restrict__ pos_out = un.pos_out;
     __shared__ int wtot[4];
     __shared__ int wsum[4];
     __shared__ long long wmin[4];
@@ -732,15 +781,71 @@ extern "C" int rtk_pivotkv_commit(const void* k_stage, const void* v_stage, int6
     return RTK_OK;
 }
 
-static size_t sel_ws_layout(int L, size_t* cnt_off, size_t* tmin_off) {
+extern "C" size_t rtk_pivotkv_select_workspace_bytes(int L) {
+    if (L <= 0) return 0;
     const size_t nb = ((size_t)L + RANK_TOK - 1) / RANK_TOK;
-    const size_t c = ((size_t)L + 255) & ~(size_t)255;
-    const size_t t = c + ((nb * 4 + 255) & ~(size_t)255);
-    if (cnt_off) *cnt_off = c;
-    if (tmin_off) *tmin_off = t;
-    return t + ((nb * 8 + 255) & ~(size_t)255);
+    return sel_ws_tmin_off(L) + ((nb * 8 + 255) & ~(size_t)255);
 }
-extern "C" size_t rtk_pivotkv_select_workspace_bytes(int L) { return L > 0 ? sel_ws_layout(L, nullptr, nullptr) : 0; }
+
+static bool chipwide_ok(int L) {
+    const size_t lds = ((size_t)((L + RANK_TOK - 1) / RANK_TOK) * RANK_TOK + RANK_BLOCK) * sizeof(uint32_t);
+    return L >= 512 && lds <= 160 * 1024;
+}
+
+// finalize (units that carry partials) -> rank -> emit, every unit in the same three launches
+static int select_units(const rtk_select_unit* units, int n, int Hkv, int RS, int G, int L, int keep, int P, int reforge,
+                        int64_t pos_out_stride, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pivotkv_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const size_t lds = ((size_t)((L + RANK_TOK - 1) / RANK_TOK) * RANK_TOK + RANK_BLOCK) * sizeof(uint32_t);
+    for (int b = 0; b < n; b += RTK_SELECT_MAX_UNITS) {
+        const int m = std::min(RTK_SELECT_MAX_UNITS, n - b);
+        SelUnits su;
+        bool any_partial = false;
+        for (int i = 0; i < RTK_SELECT_MAX_UNITS; ++i) {
+            su.u[i] = units[b + std::min(i, m - 1)];
+            any_partial = any_partial || (i < m && su.u[i].partial != nullptr);
+        }
+        if (any_partial) {
+            RTK_LAUNCH(KID_FINALIZE, finalize_units_kernel, dim3((L + 63) / 64, m), dim3(256), (size_t)Hkv * 64 * sizeof(float),
+                       st, su, Hkv, RS, G, L);
+            RTK_LAUNCH_CHECK("finalize_units_kernel");
+        }
+        RTK_LAUNCH(KID_PSEL, pivotkv_rank_kernel, dim3((L + RANK_TOK - 1) / RANK_TOK, m), dim3(RANK_BLOCK), lds, st, su, L, keep,
+                   reforge);
+        RTK_LAUNCH_CHECK("pivotkv_rank_kernel");
+        RTK_LAUNCH(KID_PEMIT, pivotkv_emit_kernel, dim3((L + 255) / 256, m), dim3(256), 0, st, su, L, keep, P, reforge,
+                   pos_out_stride);
+        RTK_LAUNCH_CHECK("pivotkv_emit_kernel");
+    }
+    return RTK_OK;
+}
+
+extern "C" int rtk_pivotkv_select_batched(const rtk_select_unit* units, int n_units, int Hkv, int RS, int G, int L,
+                                          int keep, int P, int reforge, int64_t pos_out_stride, rtk_stream_t stream) {
+    RTK_CHECK_ARG(units && n_units >= 1, "rtk_pivotkv_select_batched: no units");
+    RTK_CHECK_ARG(L >= 1 && keep >= 1 && keep <= L, "rtk_pivotkv_select_batched: keep=%d out of range for L=%d", keep, L);
+    RTK_CHECK_ARG(P == 0 || P == 1 || P == 3, "rtk_pivotkv_select_batched: P must be 0, 1 or 3, got %d", P);
+    RTK_CHECK_ARG(P == 0 || pos_out_stride >= keep, "rtk_pivotkv_select_batched: pos_out_stride < keep");
+    bool partials = false;
+    for (int i = 0; i < n_units; ++i) {
+        const rtk_select_unit& u = units[i];
+        RTK_CHECK_ARG(u.score && u.keep_idx && u.workspace, "rtk_pivotkv_select_batched: unit %d: NULL pointer", i);
+        RTK_CHECK_ARG(((uintptr_t)u.workspace & 255) == 0, "rtk_pivotkv_select_batched: unit %d: workspace must be 256-byte aligned", i);
+        RTK_CHECK_ARG((u.pos == nullptr) == (u.pos_out == nullptr), "rtk_pivotkv_select_batched: unit %d: pos and pos_out go together", i);
+        RTK_CHECK_ARG((u.pos != nullptr) == (P > 0), "rtk_pivotkv_select_batched: unit %d: pos must be given iff P > 0", i);
+        partials = partials || u.partial;
+    }
+    RTK_CHECK_ARG(!partials || (Hkv >= 1 && RS >= 1 && G >= 1), "rtk_pivotkv_select_batched: partials need Hkv, RS, G");
+    if (!chipwide_ok(L)) {
+        set_error("rtk_pivotkv_select_batched: L=%d is outside the chip-wide selection path (use rtk_pivotkv_select)", L);
+        return RTK_EUNSUPPORTED;
+    }
+    return select_units(units, n_units, Hkv, RS, G, L, keep, P, reforge, pos_out_stride, (hipStream_t)stream);
+}
 
 extern "C" int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep, const int64_t* pos, int P,
                                   int reforge, int64_t* keep_idx, int32_t* rank, int64_t* pos_out,
@@ -753,29 +858,19 @@ extern "C" int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int 
     RTK_CHECK_ARG(!pos || pos_out_stride >= keep, "rtk_pivotkv_select: pos_out_stride %lld < keep %d",
                   (long long)pos_out_stride, keep);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = ((size_t)((L + RANK_TOK - 1) / RANK_TOK) * RANK_TOK + RANK_BLOCK) * sizeof(uint32_t);
     if (workspace && workspace_bytes >= rtk_pivotkv_select_workspace_bytes(L) && ((uintptr_t)workspace & 255) == 0 &&
-        lds <= 160 * 1024 && L >= 512) {
+        chipwide_ok(L)) {
         // chip-wide path: rank by counting (every CU), then ordered emit
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)pivotkv_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        size_t cnt_off, tmin_off;
-        (void)sel_ws_layout(L, &cnt_off, &tmin_off);
-        uint8_t* sel = (uint8_t*)workspace;
-        int32_t* blk_cnt = (int32_t*)((char*)workspace + cnt_off);
-        int64_t* blk_tmin = (int64_t*)((char*)workspace + tmin_off);
-        const int vec_ok = (((uintptr_t)score & 15) == 0 && ((uintptr_t)mask & 3) == 0) ? 1 : 0;
-        RTK_LAUNCH(KID_PSEL, pivotkv_rank_kernel, dim3((L + RANK_TOK - 1) / RANK_TOK), dim3(RANK_BLOCK), lds, st, score, mask, L,
-                   keep, pos, reforge, sel, blk_cnt, blk_tmin, vec_ok);
-        RTK_LAUNCH_CHECK("pivotkv_rank_kernel");
-        RTK_LAUNCH(KID_PEMIT, pivotkv_emit_kernel, dim3((L + 255) / 256), dim3(256), 0, st, (const uint8_t*)sel,
-                   (const int32_t*)blk_cnt, (const int64_t*)blk_tmin, L, keep, pos, P, reforge, keep_idx, rank, pos_out,
-                   pos_out_stride);
-        RTK_LAUNCH_CHECK("pivotkv_emit_kernel");
-        return RTK_OK;
+        rtk_select_unit u;
+        u.partial = nullptr;
+        u.score = score;
+        u.mask = mask;
+        u.pos = pos;
+        u.keep_idx = keep_idx;
+        u.rank = rank;
+        u.pos_out = pos_out;
+        u.workspace = workspace;
+        return select_units(&u, 1, 0, 0, 0, L, keep, pos ? P : 0, reforge, pos_out_stride, st);
     }
     RTK_CHECK_ARG(rank, "rtk_pivotkv_select: the one-workgroup path needs the rank buffer");
 #define RTK_PSEL_FAST(E)                                                                                          \

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
                                                             int round_bf16, float a2, float rcp_a2,
                                                             char* __restrict__ q_out, char* __restrict__ k_out,
                                                             char* __restrict__ k_tail, char* __restrict__ v_tail,
-                                                            int64_t tail_sh) {
+                                                            int64_t tail_sh, int P, int64_t* __restrict__ pos_copy) {
     using V = Vec16<DT>;
     constexpr int VE = V::VE;
     constexpr int ES = 16 / VE;
@@ -218,6 +218,8 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= L * lpr) return;
     const int l = id / lpr, d = (id - l * lpr) * VE;
+    if (pos_copy && blockIdx.y == 0 && d == 0)   // the ids the caller may shift in place before the deferred selection runs
+        for (int p = 0; p < P; ++p) pos_copy[(size_t)p * L + l] = pos[(size_t)p * pos_ld + l];
     float c1[VE], s1[VE], c2[VE], s2[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) {   // rope_table_kernel's arithmetic for channels d + e and d + e + h2
@@ -1422,11 +1424,11 @@ extern "C" size_t rtk_pivotkv_score_workspace_bytes(int Hq, int Hkv, int L, int 
 template <int DT>
 static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, int64_t ksh, int64_t ksl, int Hq,
                       int Hkv, int L, int D, const float* cosv, const float* sinv, float a, float* score,
-                      void* k_unrot, char* ws, const ScoreWs& w, int stages, hipStream_t st) {
+                      void* k_unrot, char* ws, const ScoreWs& w, int stages, float* partial_out, hipStream_t st) {
     char* qt = ws + w.q_off;
     char* kt = k_unrot ? (char*)k_unrot : ws + w.k_off;
     float* lse = (float*)(ws + w.lse_off);
-    float* part = (float*)(ws + w.part_off);
+    float* part = partial_out ? partial_out : (float*)(ws + w.part_off);
     const float a2 = (float)((double)a * (double)a);  // python float ** 2, then an fp32 tensor / scalar
     if (stages & RTK_SCORE_PREPARE) {
         constexpr int VE = Vec16<DT>::VE;
@@ -1521,11 +1523,23 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
     return RTK_OK;
 }
 
+extern "C" size_t rtk_pivotkv_score_partials(int Hq, int Hkv, int L, int D, int dtype, int* rs_out) {
+    if (Hq < 1 || Hkv < 1 || L < 1 || D < 1) return 0;
+    const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
+    int rs_n = 1;
+    if (D == HD) {   // the non-empty row splits score_impl launches
+        const int rps = ((((L + w.RS - 1) / w.RS) + TILE_ROWS - 1) / TILE_ROWS) * TILE_ROWS;
+        rs_n = (L + rps - 1) / rps;
+    }
+    if (rs_out) *rs_out = rs_n;
+    return (size_t)Hkv * rs_n * L;
+}
+
 extern "C" int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k,
                                         int64_t k_stride_h, int64_t k_stride_l, int Hq, int Hkv, int L, int D, int dtype,
                                         const float* cosv, const float* sinv, float attention_scaling, float* score,
                                         void* k_unrot, void* workspace, size_t workspace_bytes, int stages,
-                                        rtk_stream_t stream) {
+                                        float* partial_out, rtk_stream_t stream) {
     RTK_CHECK_ARG(q && k && score && workspace, "rtk_pivotkv_score: NULL pointer");
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0, "rtk_pivotkv_score: Hq=%d must be a multiple of Hkv=%d", Hq, Hkv);
     RTK_CHECK_ARG(L >= 1 && D >= 2 && D % 2 == 0, "rtk_pivotkv_score: bad shape L=%d D=%d", L, D);
@@ -1541,9 +1555,9 @@ extern "C" int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RTK_BF16)
         return score_impl<RTK_BF16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, cosv, sinv,
-                                    attention_scaling, score, k_unrot, (char*)workspace, w, stages, st);
+                                    attention_scaling, score, k_unrot, (char*)workspace, w, stages, partial_out, st);
     return score_impl<RTK_F32>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, cosv, sinv,
-                               attention_scaling, score, k_unrot, (char*)workspace, w, stages, st);
+                               attention_scaling, score, k_unrot, (char*)workspace, w, stages, partial_out, st);
 }
 
 extern "C" int rtk_pivotkv_score(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k,
@@ -1552,14 +1566,14 @@ extern "C" int rtk_pivotkv_score(const void* q, int64_t q_stride_h, int64_t q_st
                                  void* k_unrot, void* workspace, size_t workspace_bytes, rtk_stream_t stream) {
     return rtk_pivotkv_score_stages(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, dtype, cosv, sinv,
                                     attention_scaling, score, k_unrot, workspace, workspace_bytes,
-                                    RTK_SCORE_PREPARE | RTK_SCORE_PASSES | RTK_SCORE_FINALIZE, stream);
+                                    RTK_SCORE_PREPARE | RTK_SCORE_PASSES | RTK_SCORE_FINALIZE, nullptr, stream);
 }
 
 template <int DT>
 static int prepare_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, int64_t ksh, int64_t ksl, const void* v,
                         int64_t vsh, int64_t vsl, int Hq, int Hkv, int L, int D, const int64_t* pos, int64_t pos_stride,
                         const float* inv_freq, float a, const RowSel& rs, int round_bf16, char* qt, char* kt, void* k_tail,
-                        void* v_tail, int64_t tail_sh, hipStream_t st) {
+                        void* v_tail, int64_t tail_sh, int P, int64_t* pos_copy, hipStream_t st) {
     constexpr int VE = Vec16<DT>::VE;
     const float a2 = (float)((double)a * (double)a);
     const int div = (a2 == 1.0f) ? 0 : ((DT == RTK_BF16 && bf16_rcp_is_exact(a2)) ? 1 : 2);
@@ -1569,7 +1583,7 @@ static int prepare_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, 
 #define RTK_PREP(DIV)                                                                                               \
     RTK_LAUNCH(KID_UNROT, (prepare_native_kernel<DT, DIV>), grid, dim3(64), 0, st, (const char*)q, qsh, qsl,          \
                (const char*)k, ksh, ksl, (const char*)v, vsh, vsl, Hq, Hkv, L, D, pos, pos_stride, inv_freq, a, rs,  \
-               round_bf16, a2, rcp, qt, kt, (char*)k_tail, (char*)v_tail, tail_sh)
+               round_bf16, a2, rcp, qt, kt, (char*)k_tail, (char*)v_tail, tail_sh, P, pos_copy)
     if (div == 0) RTK_PREP(0);
     else if (div == 1) RTK_PREP(1);
     else RTK_PREP(2);
@@ -1584,7 +1598,7 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
                                    int64_t pos_stride, int P, const float* inv_freq, float attention_scaling,
                                    const int* sections_host, int nsec, int round_bf16, void* k_unrot, void* workspace,
                                    size_t workspace_bytes, void* k_tail, void* v_tail, int64_t tail_stride_h,
-                                   rtk_stream_t stream) {
+                                   int64_t* pos_copy, rtk_stream_t stream) {
     RTK_CHECK_ARG(q && k && v && pos && inv_freq && k_unrot && workspace && k_tail && v_tail, "rtk_pivotkv_prepare: NULL pointer");
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && L >= 1 && D >= 2, "rtk_pivotkv_prepare: bad shape");
     RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_prepare: unsupported dtype %d", dtype);
@@ -1612,8 +1626,8 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
     if (dtype == RTK_BF16)
         return prepare_impl<RTK_BF16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv,
                                       L, D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot,
-                                      k_tail, v_tail, tail_stride_h, st);
+                                      k_tail, v_tail, tail_stride_h, P, pos_copy, st);
     return prepare_impl<RTK_F32>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv, L,
                                  D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot, k_tail,
-                                 v_tail, tail_stride_h, st);
+                                 v_tail, tail_stride_h, P, pos_copy, st);
 }

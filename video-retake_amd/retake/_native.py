@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 RTK_F32, RTK_BF16 = 0, 1
 SCORE_PREPARE, SCORE_PASSES, SCORE_FINALIZE = 1, 2, 4
@@ -28,6 +28,12 @@ class EvictUnit(C.Structure):
                 ("keep_idx", _vp), ("cos_new", _vp), ("sin_new", _vp),
                 ("k_dst", _vp), ("k_dst_stride_h", _i64), ("v_dst", _vp), ("v_dst_stride_h", _i64),
                 ("pos_src", _vp), ("pos_src_stride", _i64), ("pos_dst", _vp), ("pos_dst_stride", _i64)]
+
+
+class SelectUnit(C.Structure):
+    """rtk_select_unit (include/retake_hip.h)."""
+    _fields_ = [("partial", _vp), ("score", _vp), ("mask", _vp), ("pos", _vp), ("keep_idx", _vp), ("rank", _vp),
+                ("pos_out", _vp), ("workspace", _vp)]
 
 
 class CopyUnit(C.Structure):
@@ -52,9 +58,11 @@ _SIGNATURES = {
     "rtk_pivotkv_score": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp,
                                     _vp, _sz, _vp]),
     "rtk_pivotkv_score_stages": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp,
-                                           _vp, _sz, _i, _vp]),
+                                           _vp, _sz, _i, _vp, _vp]),
+    "rtk_pivotkv_score_partials": (C.c_size_t, [_i, _i, _i, _i, _i, C.POINTER(C.c_int)]),
+    "rtk_pivotkv_select_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "rtk_pivotkv_prepare": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i,
-                                      _vp, _f, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _i64, _vp]),
+                                      _vp, _f, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _i64, _vp, _vp]),
     "rtk_pivotkv_select_workspace_bytes": (C.c_size_t, [_i]),
     "rtk_pivotkv_select": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rtk_pivotkv_evict": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp,

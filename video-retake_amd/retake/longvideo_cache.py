@@ -184,11 +184,25 @@ class _Side:
 class _Batch:
     """Per-chunk batch of pending evictions: slot = layer index.  All units share the chunk geometry."""
 
-    def __init__(self, key, slots, Hkv, L, D, keep, P, reforge, dtype, device):
+    def __init__(self, key, slots, Hq, Hkv, L, D, keep, P, reforge, dtype, device):
         self.key, self.slots, self.keep, self.P, self.reforge = key, slots, keep, P, reforge
         self.Hkv, self.L, self.D, self.dtype, self.device = Hkv, L, D, dtype, device
         self.keep_idx = torch.empty((slots, keep), dtype=torch.int64, device=device)
         self.pos_new = torch.empty((P, slots, keep), dtype=torch.int64, device=device) if P else None
+        # deferred selection (flushed for all layers at once): per-slot column partials of the scoring passes, the
+        # final score, a private copy of the chunk's position ids (the caller shifts its tensor in place for the next
+        # layer), the key-patch mask of the update and the selection scratch
+        self.rs_n = C.c_int(0)
+        self.part_floats = nv.lib.rtk_pivotkv_score_partials(Hq, Hkv, L, D, nv.RTK_BF16 if dtype == torch.bfloat16 else nv.RTK_F32,
+                                                             C.byref(self.rs_n))
+        self.partials = torch.empty((slots, self.part_floats), dtype=torch.float32, device=device)
+        self.score = torch.empty((slots, L), dtype=torch.float32, device=device)
+        self.pos_old = torch.empty((slots, P, L), dtype=torch.int64, device=device) if P else None
+        self.sel_bytes = nv.lib.rtk_pivotkv_select_workspace_bytes(L)
+        self.sel_ws = torch.empty((slots, self.sel_bytes), dtype=torch.uint8, device=device)
+        self.masks: Dict[int, Optional[torch.Tensor]] = {}
+        self.selected = set()      # layers whose selection already ran inside update (small chunks)
+        self.Hq = Hq
         self.v_stage = torch.empty((slots, Hkv, keep, D), dtype=dtype, device=device)
         if reforge:  # kept K is re-rotated from the un-rotated copy straight into the cache: no K staging
             self.k_unrot = torch.empty((slots, Hkv, L, D), dtype=dtype, device=device)
@@ -247,6 +261,7 @@ class PivotKVCache(DynamicCache):
     def __init__(self, config) -> None:
         self._layers: List[_LayerStore] = []
         self._batch: Optional[_Batch] = None
+        self._last_slot = None
         self._pos_layers = 0
         self._kview = _CacheView(self, "k")
         self._vview = _CacheView(self, "v")
@@ -282,6 +297,19 @@ class PivotKVCache(DynamicCache):
         self._ws: Dict[str, torch.Tensor] = {}
         self._batch: Optional[_Batch] = None
         self._warned = False
+
+    # ---- diagnostics of the most recent compressed update (the selection may still be deferred: flush first) ----
+    @property
+    def last_scores(self):
+        b, l = self._last_slot
+        self._flush()
+        return b.score[l]
+
+    @property
+    def last_keep_indices(self):
+        b, l = self._last_slot
+        self._flush()
+        return b.keep_idx[l]
 
     # ---- list views --------------------------------------------------------------------------
     @property
@@ -514,15 +542,15 @@ class PivotKVCache(DynamicCache):
                                        nv.ptr(sin_t), s), "rtk_rope_merge")
 
     # ---- deferred eviction -----------------------------------------------------------------------
-    def _get_batch(self, layer_idx, Hkv, L, D, keep, P, dtype, device) -> _Batch:
-        key = (Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device)
+    def _get_batch(self, layer_idx, Hq, Hkv, L, D, keep, P, dtype, device) -> _Batch:
+        key = (Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device)
         b = self._batch
         if b is not None and b.key == key and layer_idx < b.slots:
             return b
         self._flush()
         slots = max(int(self.num_hidden_layers), layer_idx + 1, b.slots if b is not None and b.key == key else 0)
         self._batch = None  # release the old buffers before allocating the new ones
-        self._batch = _Batch(key, slots, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device)
+        self._batch = _Batch(key, slots, Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device)
         return self._batch
 
     def _flush(self):
@@ -542,6 +570,25 @@ class PivotKVCache(DynamicCache):
                 if st.pending_event is not None:  # scored on a worker stream
                     main.wait_event(st.pending_event)
                     st.pending_event = None
+            todo = [l for l in layers if l not in b.selected]
+            if todo:  # mask override + top-k + id gather / rescale of every layer of the chunk (reference :269-295)
+                su = (nv.SelectUnit * len(todo))()
+                for i, l in enumerate(todo):
+                    u = su[i]
+                    u.partial = b.partials[l].data_ptr()
+                    u.score = b.score[l].data_ptr()
+                    m = b.masks.get(l)
+                    u.mask = m.data_ptr() if m is not None else None
+                    u.pos = b.pos_old[l].data_ptr() if P else None
+                    u.keep_idx = b.keep_idx[l].data_ptr()
+                    u.rank = None
+                    u.pos_out = (b.pos_new.data_ptr() + l * keep * 8) if P else None
+                    u.workspace = b.sel_ws[l].data_ptr()
+                nv.check(nv.lib.rtk_pivotkv_select_batched(su, len(todo), Hkv, b.rs_n.value, b.Hq // Hkv, b.L, keep, P,
+                                                           int(b.reforge), b.slots * keep, nv.stream()),
+                         "rtk_pivotkv_select_batched")
+            b.selected.clear()
+            b.masks.clear()
             lo, hi = min(layers), max(layers)
             if b.reforge:  # tables of the NEW ids of every pending slot in one go (reference :298)
                 n = (hi - lo + 1) * keep
@@ -661,7 +708,7 @@ class PivotKVCache(DynamicCache):
         if position_ids is not None:
             nv.require_device(position_ids)
             Pn = 3 if position_ids.ndim == 3 else 1
-        batch = self._get_batch(layer_idx, Hkv, L, D, keep_len, Pn, key_states.dtype, dev)
+        batch = self._get_batch(layer_idx, Hq, Hkv, L, D, keep_len, Pn, key_states.dtype, dev)
         if batch.pending and (batch.rotary_emb_fn is not rotary_emb_fn or batch.mrope_section != mrope_section):
             self._flush()
         batch.rotary_emb_fn, batch.mrope_section = rotary_emb_fn, mrope_section
@@ -677,16 +724,19 @@ class PivotKVCache(DynamicCache):
         keep_idx = batch.keep_idx[layer_idx]
         shared = {}   # values handed from one stage to the next
 
+        defer_select = L >= 512   # the chip-wide selection kernels; smaller chunks select inside update
+
         def score_stage(ws, stages):
             wsb = self._buf("score_ws", (ws_bytes + 256,), torch.uint8, dev, ws)
             ws_ptr = (wsb.data_ptr() + 255) & ~255
-            score = self._buf("score", (L,), torch.float32, dev, ws)
+            score = batch.score[layer_idx]
             k_unrot = batch.k_unrot[layer_idx] if reforge else None
             nv.check(nv.lib.rtk_pivotkv_score_stages(
                 nv.ptr(query_states), query_states.stride(1), query_states.stride(2),
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
                 Hq, Hkv, L, D, dt, nv.ptr(shared.get("cos")), nv.ptr(shared.get("sin")), a_scale,
-                nv.ptr(score), nv.ptr(k_unrot), C.c_void_p(ws_ptr), ws_bytes, stages, nv.stream()), "rtk_pivotkv_score")
+                nv.ptr(score), nv.ptr(k_unrot), C.c_void_p(ws_ptr), ws_bytes, stages, nv.ptr(batch.partials[layer_idx]),
+                nv.stream()), "rtk_pivotkv_score")
             return score
 
         def stage_pre(ws, pos_in):
@@ -704,7 +754,11 @@ class PivotKVCache(DynamicCache):
             score_stage(ws, nv.SCORE_PASSES)
 
         def stage_post(ws, pos_in):
-            """column-mass reduction, mask override + top-k + position ids (reference :269-295)"""
+            """small chunks only: column-mass reduction, mask override + top-k + position ids (reference :269-295)
+            right away; larger chunks leave this to the batched selection of the flush"""
+            if defer_select:
+                batch.masks[layer_idx] = mask
+                return
             score = score_stage(ws, nv.SCORE_FINALIZE)
             rank = self._buf("rank", (L,), torch.int32, dev, ws)
             pos_out = batch.pos_new[:, layer_idx] if pos_in is not None else None
@@ -713,8 +767,7 @@ class PivotKVCache(DynamicCache):
                                                int(reforge), nv.ptr(keep_idx), nv.ptr(rank), nv.ptr(pos_out),
                                                batch.slots * keep_len, nv.ptr(sel_ws), sel_bytes, nv.stream()),
                      "rtk_pivotkv_select")
-            self.last_keep_indices = keep_idx  # diagnostics: valid until the slot's next update
-            self.last_scores = score
+            batch.selected.add(layer_idx)
 
         def pos_2d(snapshot: bool):
             if position_ids is None:
@@ -750,7 +803,8 @@ class PivotKVCache(DynamicCache):
                 nv.ptr(value_states), value_states.stride(1), value_states.stride(2),
                 Hq, Hkv, L, D, dt, nv.ptr(pos_in), L, Pn, nv.ptr(inv), a_scale, sec,
                 len(mrope_section) if mrope_section else 0, int(key_states.dtype == torch.bfloat16),
-                nv.ptr(batch.k_unrot[layer_idx]), C.c_void_p(ws_ptr), ws_bytes, k_tail, v_tail, cap * D, nv.stream())
+                nv.ptr(batch.k_unrot[layer_idx]), C.c_void_p(ws_ptr), ws_bytes, k_tail, v_tail, cap * D,
+                nv.ptr(batch.pos_old[layer_idx]) if defer_select else None, nv.stream())
             if rc == nv.RTK_EUNSUPPORTED:
                 return False
             nv.check(rc, "rtk_pivotkv_prepare")
@@ -763,6 +817,8 @@ class PivotKVCache(DynamicCache):
                 if not fused_prepare(self._ws, pos_in):
                     append_tail()
                     stage_pre(self._ws, pos_in)
+                    if defer_select and pos_in is not None:
+                        batch.pos_old[layer_idx].copy_(pos_in)
                 stage_big(self._ws)
                 stage_post(self._ws, pos_in)
             else:
@@ -777,6 +833,8 @@ class PivotKVCache(DynamicCache):
                 with torch.cuda.stream(side.stream):
                     side.stream.wait_event(ready)
                     stage_pre(side.ws, pos_in)
+                    if defer_select and pos_in is not None:
+                        batch.pos_old[layer_idx].copy_(pos_in)
                     stage_big(side.ws)
                     stage_post(side.ws, pos_in)
                     done = torch.cuda.Event()
@@ -786,6 +844,7 @@ class PivotKVCache(DynamicCache):
         st.pending = n_new
         st.pending_keep = keep_len
         batch.pending.append(layer_idx)
+        self._last_slot = (batch, layer_idx)
         return st.k[:, :, :P0 + n_new], st.v[:, :, :P0 + n_new]
 
 
