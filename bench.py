@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=LAYERS)
     ap.add_argument("--pool", type=int, default=48, help="distinct resident (q,k,v) sets cycled over the calls")
     ap.add_argument("--streams", type=int, default=0, help="worker HIP streams per cache (0 = everything on one stream)")
-    ap.add_argument("--also-streams", type=int, default=3,
+    ap.add_argument("--also-streams", type=int, default=0,
                     help="after the contract measurement, time the same steps again with this many worker streams "
                          "(reported under 'overlap'; 0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -144,17 +144,21 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
-def score_roofline(kern, dtype, L, T):
-    """roofline object of the dominant kernel (one of the two score passes): algorithmic flops of one Q K^T per
-    launch / average launch duration from the HIP events, against the dense MFMA peak."""
-    flops = 2.0 * Hq * L * L * D
+def score_roofline(kern, dtype, L, T, n_updates):
+    """roofline object of the dominant kernel (one of the two score passes): algorithmic flops per launch (one
+    Q K^T per (layer, chunk) unit, SURVEY §8(d), times the units one launch processes — the cache batches all
+    layers of a chunk into one launch) / average launch duration from the HIP events, against the dense MFMA peak."""
     dom = max(("score_pass1", "score_pass2"), key=lambda k: kern[k]["total_ms"])
+    units_per_launch = n_updates / kern[dom]["launches"]
+    flops = 2.0 * Hq * L * L * D * units_per_launch
     avg_s = kern[dom]["avg_us"] * 1e-6
     peak = MFMA_PEAK_TFLOPS[dtype]
     traffic, src = pmc_traffic(dom) if dtype == "bf16" and L == FRAMES_PER_CHUNK * N_PATCH else (None, None)
+    if traffic is not None and "_u1_" in (src or ""):   # a per-unit profile: scale to the units of one launch
+        traffic *= units_per_launch
     return {"kernel": dom, "bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": peak, "unit": "TFLOP/s",
             "frac": flops / avg_s / 1e12 / peak, "traffic": traffic, "traffic_source": src,
-            "algorithmic_flops_per_launch": flops}
+            "units_per_launch": units_per_launch, "algorithmic_flops_per_launch": flops}
 
 
 def cpu_baseline(args, frames_cpu_sample, n_updates):
@@ -293,7 +297,7 @@ def main():
         out["kernels_timed_region"] = timed
         for k, v in timed.items():
             kern[k] = v
-        out["roofline"] = score_roofline(kern, args.dtype, L, T)
+        out["roofline"] = score_roofline(kern, args.dtype, L, T, n_chunks * args.layers * args.steps)
         # HBM-bound kernels of the path, same convention (bytes the launch has to move / avg duration).
         # The eviction scan (16.3 MB algorithmic per (layer, chunk)) is three kernels here:
         #   append          per update: K,V rows read + written to the cache tail

@@ -175,6 +175,15 @@ int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_stride_l,
                         int64_t* pos_copy /* optional [P, L]: private copy of the ids for a deferred selection */,
                         rtk_stream_t stream);
 
+/* RTK_SCORE_PASSES for n_units (layer, chunk) units in ONE launch per kernel (blockIdx.y = unit): the units'
+ * score workspaces (holding q~ from RTK_SCORE_PREPARE / rtk_pivotkv_prepare), their k~ buffers (k_unrot0 == NULL:
+ * inside the workspaces) and their partial outputs lie workspace_stride / k_unrot_stride bytes and
+ * partial_stride_floats floats apart.  bf16, head_dim 128 (RTK_EUNSUPPORTED otherwise: run the stage per unit).
+ * What PivotKVCache runs from after_forward for all layers of a chunk: 28x larger grids, no per-layer tails. */
+int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspace_stride, void* k_unrot0, size_t k_unrot_stride,
+                                     float* partial0, size_t partial_stride_floats, int n_units,
+                                     int Hq, int Hkv, int L, int D, int dtype, rtk_stream_t stream);
+
 /* P6-P7, P9-P10  longvideo_cache.py:272-277, :283-295.
  *   score [L] fp32: entries with mask != 0 are overwritten with 1.0 IN PLACE (masked_fill_, :274);
  *   mask may be NULL.

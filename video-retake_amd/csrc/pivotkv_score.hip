@@ -773,7 +773,9 @@ struct RowStatB {  // online max / sum of one query row over the keys this lane 
 // ------------------------------------------------------------------------------------------------
 // lse[h,i] = log sum_ks exp(lse_part[ks,h,i]), written over split 0 (one thread per row: no hazard)
 template <int DT>
-__global__ __launch_bounds__(256) void lse_combine_kernel(float* __restrict__ lse_part, size_t n, int KS) {
+__global__ __launch_bounds__(256) void lse_combine_kernel(float* __restrict__ lse_part, size_t n, int KS,
+                                                          size_t unit_floats) {
+    lse_part += blockIdx.y * unit_floats;   // blockIdx.y = unit of a batched launch
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     float v[8];
@@ -990,12 +992,17 @@ _Pragma("unroll") \
 template <int NB>
 __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass2_dma_kernel(
     const char* __restrict__ q, const char* __restrict__ k, const float* __restrict__ lse, int Hq, int Hkv, int L,
-    int rows_per_split, int col_tiles, int RS, int xcd_remap, float* __restrict__ partial) {
+    int rows_per_split, int col_tiles, int RS, int xcd_remap, float* __restrict__ partial, size_t q_unit_bytes,
+    size_t k_unit_bytes, size_t lse_unit_floats, size_t part_unit_floats) {
     constexpr int DT = RTK_BF16;
     using M = MM<DT>;
     using T = Tile<DT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lse_s = (float*)(smem + 2 * T::BYTES);  // [2][TILE_ROWS]
+    q += blockIdx.y * q_unit_bytes;           // blockIdx.y = unit of a batched launch
+    k += blockIdx.y * k_unit_bytes;
+    lse += blockIdx.y * lse_unit_floats;
+    partial += blockIdx.y * part_unit_floats;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), hf = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const int G = Hq / Hkv;
@@ -1126,11 +1133,16 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass2_dma_k
 __global__ __launch_bounds__(SC_BLOCK, 4) void score_pass1_dma_kernel(const char* __restrict__ q,
                                                                       const char* __restrict__ k, int Hq, int Hkv, int L,
                                                                       int keys_per_split, int row_tiles, int xcd_remap,
-                                                                      float* __restrict__ lse_part) {
+                                                                      float* __restrict__ lse_part, size_t q_unit_bytes,
+                                                                      size_t k_unit_bytes, size_t lse_unit_floats) {
     constexpr int DT = RTK_BF16;
     using M = MM<DT>;
     using T = Tile<DT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // blockIdx.y = (layer, chunk) unit of a batched launch: same shapes, operands one unit stride apart
+    q += blockIdx.y * q_unit_bytes;
+    k += blockIdx.y * k_unit_bytes;
+    lse_part += blockIdx.y * lse_unit_floats;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), hf = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const int G = Hq / Hkv;
@@ -1424,7 +1436,10 @@ extern "C" size_t rtk_pivotkv_score_workspace_bytes(int Hq, int Hkv, int L, int 
 template <int DT>
 static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, int64_t ksh, int64_t ksl, int Hq,
                       int Hkv, int L, int D, const float* cosv, const float* sinv, float a, float* score,
-                      void* k_unrot, char* ws, const ScoreWs& w, int stages, float* partial_out, hipStream_t st) {
+                      void* k_unrot, char* ws, const ScoreWs& w, int stages, float* partial_out, hipStream_t st,
+                      int n_units = 1, size_t ws_stride = 0, size_t k_stride = 0, size_t part_stride = 0) {
+    // n_units > 1 (RTK_SCORE_PASSES only): the same passes for n_units units whose workspaces / k~ / partials lie
+    // ws_stride / k_stride bytes and part_stride floats apart — one launch per kernel, blockIdx.y = unit
     char* qt = ws + w.q_off;
     char* kt = k_unrot ? (char*)k_unrot : ws + w.k_off;
     float* lse = (float*)(ws + w.lse_off);
@@ -1488,20 +1503,23 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         }
         if (stages & RTK_SCORE_PASSES) {
             if (dma)
-                RTK_LAUNCH(KID_PASS1, score_pass1_dma_kernel, dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
-                           (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse);
+                RTK_LAUNCH(KID_PASS1, score_pass1_dma_kernel, dim3(Hkv * ks_n * jt * G, n_units), dim3(SC_BLOCK), LDS1, st,
+                           (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse,
+                           ws_stride, k_stride, ws_stride / sizeof(float));
             else
                 RTK_LAUNCH(KID_PASS1, (score_pass1_kernel<DT, NBR>), dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
                            (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse);
             RTK_LAUNCH_CHECK("score_pass1_kernel");
             if (ks_n > 1) {
                 const size_t n = (size_t)Hq * L;
-                RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<DT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lse, n, ks_n);
+                RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<DT>, dim3((unsigned)((n + 255) / 256), n_units), dim3(256), 0, st, lse, n,
+                           ks_n, ws_stride / sizeof(float));
             }
             if (dma)
-                RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<1>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
+                RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<1>), dim3(Hkv * rs_n * jt, n_units), dim3(SC_BLOCK), LDS2, st,
                            (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
-                           (int)((Hkv * rs_n) % NXCD == 0), part);
+                           (int)((Hkv * rs_n) % NXCD == 0), part, ws_stride, k_stride, ws_stride / sizeof(float),
+                           part_stride);
             else
                 RTK_LAUNCH(KID_PASS2, (score_pass2_kernel<DT, NBR>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
                            (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
@@ -1521,6 +1539,31 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         RTK_LAUNCH_CHECK("score_finalize_kernel");
     }
     return RTK_OK;
+}
+
+extern "C" int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspace_stride, void* k_unrot0,
+                                                size_t k_unrot_stride, float* partial0, size_t partial_stride_floats,
+                                                int n_units, int Hq, int Hkv, int L, int D, int dtype,
+                                                rtk_stream_t stream) {
+    RTK_CHECK_ARG(workspace0 && partial0 && n_units >= 1, "rtk_pivotkv_score_passes_batched: NULL pointer or no units");
+    RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0 && L >= 1, "rtk_pivotkv_score_passes_batched: bad shape");
+    RTK_CHECK_ARG(((uintptr_t)workspace0 & 255) == 0 && workspace_stride % 256 == 0,
+                  "rtk_pivotkv_score_passes_batched: workspaces must be 256-byte aligned");
+    const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
+    RTK_CHECK_ARG(n_units == 1 || workspace_stride >= w.total, "rtk_pivotkv_score_passes_batched: workspace stride too small");
+    if (dtype != RTK_BF16 || D != HD) {
+        set_error("rtk_pivotkv_score_passes_batched: bf16 with head_dim %d only (call RTK_SCORE_PASSES per unit)", HD);
+        return RTK_EUNSUPPORTED;
+    }
+    static const bool legacy = [] { const char* e = getenv("RTK_SCORE_LEGACY"); return e && atoi(e) != 0; }();
+    if (legacy) {
+        set_error("rtk_pivotkv_score_passes_batched: RTK_SCORE_LEGACY selects the per-unit kernels");
+        return RTK_EUNSUPPORTED;
+    }
+    float dummy_score = 0.f;  // not touched by RTK_SCORE_PASSES
+    return score_impl<RTK_BF16>(workspace0, 0, 0, workspace0, 0, 0, Hq, Hkv, L, D, nullptr, nullptr, 1.0f, &dummy_score,
+                                k_unrot0, (char*)workspace0, w, RTK_SCORE_PASSES, partial0, (hipStream_t)stream, n_units,
+                                workspace_stride, k_unrot0 ? k_unrot_stride : workspace_stride, partial_stride_floats);
 }
 
 extern "C" size_t rtk_pivotkv_score_partials(int Hq, int Hkv, int L, int D, int dtype, int* rs_out) {

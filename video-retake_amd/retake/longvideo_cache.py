@@ -202,7 +202,16 @@ class _Batch:
         self.sel_ws = torch.empty((slots, self.sel_bytes), dtype=torch.uint8, device=device)
         self.masks: Dict[int, Optional[torch.Tensor]] = {}
         self.selected = set()      # layers whose selection already ran inside update (small chunks)
+        self.scored = set()        # layers whose matrix passes already ran inside update
         self.Hq = Hq
+        # one score workspace per slot (q~, lse partials): the matrix passes of all layers run in one launch each
+        dtc = nv.RTK_BF16 if dtype == torch.bfloat16 else nv.RTK_F32
+        self.ws_bytes = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dtc)
+        self.ws_stride = (self.ws_bytes + 255) & ~255
+        self.batched_passes = dtype == torch.bfloat16 and D == 128 and L >= 512
+        self.score_ws = torch.empty(slots * self.ws_stride + 256, dtype=torch.uint8, device=device) \
+            if self.batched_passes else None
+        self.score_ws_base = ((self.score_ws.data_ptr() + 255) & ~255) if self.batched_passes else 0
         self.v_stage = torch.empty((slots, Hkv, keep, D), dtype=dtype, device=device)
         if reforge:  # kept K is re-rotated from the un-rotated copy straight into the cache: no K staging
             self.k_unrot = torch.empty((slots, Hkv, L, D), dtype=dtype, device=device)
@@ -570,6 +579,20 @@ class PivotKVCache(DynamicCache):
                 if st.pending_event is not None:  # scored on a worker stream
                     main.wait_event(st.pending_event)
                     st.pending_event = None
+            unscored = sorted(l for l in layers if l not in b.scored)
+            i = 0
+            while i < len(unscored):  # the matrix passes of every run of consecutive slots in one launch each (:260-268)
+                j = i
+                while j + 1 < len(unscored) and unscored[j + 1] == unscored[j] + 1:
+                    j += 1
+                l0, n = unscored[i], j - i + 1
+                nv.check(nv.lib.rtk_pivotkv_score_passes_batched(
+                    C.c_void_p(b.score_ws_base + l0 * b.ws_stride), b.ws_stride,
+                    nv.ptr(b.k_unrot[l0]) if b.reforge else None, b.L * D * Hkv * es,
+                    nv.ptr(b.partials[l0]), b.part_floats, n, b.Hq, Hkv, b.L, D, dt, nv.stream()),
+                    "rtk_pivotkv_score_passes_batched")
+                i = j + 1
+            b.scored.clear()
             todo = [l for l in layers if l not in b.selected]
             if todo:  # mask override + top-k + id gather / rescale of every layer of the chunk (reference :269-295)
                 su = (nv.SelectUnit * len(todo))()
@@ -726,9 +749,14 @@ class PivotKVCache(DynamicCache):
 
         defer_select = L >= 512   # the chip-wide selection kernels; smaller chunks select inside update
 
-        def score_stage(ws, stages):
+        def ws_pointer(ws):
+            if batch.batched_passes:   # the slot's own workspace: q~ must survive until the batched passes of the flush
+                return batch.score_ws_base + layer_idx * batch.ws_stride
             wsb = self._buf("score_ws", (ws_bytes + 256,), torch.uint8, dev, ws)
-            ws_ptr = (wsb.data_ptr() + 255) & ~255
+            return (wsb.data_ptr() + 255) & ~255
+
+        def score_stage(ws, stages):
+            ws_ptr = ws_pointer(ws)
             score = batch.score[layer_idx]
             k_unrot = batch.k_unrot[layer_idx] if reforge else None
             nv.check(nv.lib.rtk_pivotkv_score_stages(
@@ -750,8 +778,12 @@ class PivotKVCache(DynamicCache):
             score_stage(ws, nv.SCORE_PREPARE)
 
         def stage_big(ws):
-            """the two matrix passes (reference :260-268)"""
+            """the two matrix passes (reference :260-268): deferred to the flush (all layers of the chunk in one
+            launch per kernel) whenever the batched form supports the shape"""
+            if batch.batched_passes:
+                return
             score_stage(ws, nv.SCORE_PASSES)
+            batch.scored.add(layer_idx)
 
         def stage_post(ws, pos_in):
             """small chunks only: column-mass reduction, mask override + top-k + position ids (reference :269-295)
@@ -794,8 +826,7 @@ class PivotKVCache(DynamicCache):
             inv = rotary_emb_fn.inv_freq
             if inv.device != dev or inv.dtype != torch.float32 or not inv.is_contiguous():
                 inv = inv.to(device=dev, dtype=torch.float32).contiguous()
-            wsb = self._buf("score_ws", (ws_bytes + 256,), torch.uint8, dev, ws)
-            ws_ptr = (wsb.data_ptr() + 255) & ~255
+            ws_ptr = ws_pointer(ws)
             sec = (C.c_int * len(mrope_section))(*mrope_section) if mrope_section else None
             rc = nv.lib.rtk_pivotkv_prepare(
                 nv.ptr(query_states), query_states.stride(1), query_states.stride(2),

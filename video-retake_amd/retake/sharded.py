@@ -270,7 +270,7 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                        "frames": T, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L,
                        "parallelism": f"chunk-sharded x{world}", "assembled_cache_tokens": int(keys[0].shape[2])},
             "kernels_timed_region_rank0": kern,
-            "roofline": B.score_roofline(kern, args.dtype, L, T),
+            "roofline": B.score_roofline(kern, args.dtype, L, T, (c1 - c0) * args.layers * args.steps),
         }
         print(json.dumps(out))
     dist.barrier()
