@@ -1408,6 +1408,9 @@ static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
     const int reg_tiles = (L + nbr - 1) / nbr, stream_tiles = (L + TILE_ROWS - 1) / TILE_ROWS;
     w.RS = (D == HD) ? pick_splits(reg_tiles, Hkv, stream_tiles, 32, Hkv) : 1;
     w.KS = (D == HD) ? pick_splits(reg_tiles, Hq, stream_tiles, 8, Hkv) : 1;
+    // bf16 production path: the chunk-batched launches bring their own parallelism (28 layers), so pass 1 prefers
+    // longer key streams per workgroup (measured: 2 splits -1.7 % over 4) and half the lse partials
+    if (D == HD && dtype == RTK_BF16) w.KS = std::min(w.KS, 2);
     w.q_off = 0;
     w.k_off = al((size_t)Hq * L * D * es);
     w.lse_off = w.k_off + al((size_t)Hkv * L * D * es);
