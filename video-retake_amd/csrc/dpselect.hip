@@ -30,13 +30,48 @@ template <> struct Elem<RTK_BF16> {
     }
 };
 
-// VPL = 16-byte vectors per lane; a row has nvec = C / PER_VEC vectors, lane owns vec k*64+lane.
+using bf16x2_dp = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2_dp = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ uint32_t pack2_bf16_dp(float lo, float hi) {   // v_cvt_pk_bf16_f32
+    const f32x2_dp v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_dp));
+}
+
+// acc + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs (v_dot2c_f32_bf16): products of bf16 are exact in fp32
+__device__ __forceinline__ float dot2_bf16_dp(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_dp, a), __builtin_bit_cast(bf16x2_dp, b), acc, false);
+}
+
+// Sum over the 64 lanes, returned wave-uniform (read from lane 63).  Six DPP adds on the VALU instead of six
+// ds_bpermute round trips through the LDS crossbar: xor-1 and xor-2 inside quads, the two mirrors for 8 and 16
+// lanes, then row_bcast:15 / row_bcast:31 carry the row sums up to the last row.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    // lanes of rows outside ROW_MASK, and lanes whose DPP source is invalid, add 0 (old = 0, bound_ctrl off)
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+    v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);   // row_mirror        -> every lane holds its 16-lane row sum
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// VPL = 16-byte vectors per lane; a row has nvec = C / PER_VEC vectors, lane owns vec k*64+lane.  One wave walks
+// `strip` (<= 64) consecutive frames of one patch position; the strip's results stay in a register (lane i holds
+// row i) and are stored once at the end, and every load in the loop is unconditional (clamped addresses) so that
+// the two rows in flight are tracked with counted waits rather than a full drain.
 template <int DT, int VPL>
 __global__ __launch_bounds__(256) void dis_kernel(const typename Elem<DT>::vec_t* __restrict__ x, int T, int N,
                                                   int nvec, int strip, int emit_cos, float* __restrict__ dis) {
     using E = Elem<DT>;
+    using vec_t = typename E::vec_t;
     constexpr int PV = E::PER_VEC;
     constexpr int NE = VPL * PV;
+    constexpr int KFULL = (VPL <= 6) ? VPL - 1 : VPL - 2;   // vectors below KFULL are full for every lane
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int nstrips = (T + strip - 1) / strip;
@@ -47,72 +82,115 @@ __global__ __launch_bounds__(256) void dis_kernel(const typename Elem<DT>::vec_t
     const int t1 = min(T, t0 + strip);
     const size_t row_vecs = (size_t)nvec;
     const size_t frame_vecs = (size_t)N * row_vecs;
+    const vec_t* xrow = x + (size_t)n * row_vecs;
 
-    typename E::vec_t raw[VPL];
-    float prevn[NE];
-    float cur[NE];
+    vec_t rawA[VPL], rawB[VPL];   // two rows in flight per wave
+    float nA[NE], nB[NE];         // normalised rows: odd steps in nA, even steps in nB (no copies between steps)
 
-    auto load_row = [&](int t) {
-        const typename E::vec_t* p = x + (size_t)t * frame_vecs + (size_t)n * row_vecs;
+    // rows beyond the strip are clamped to its last row (a harmless re-read of a line that is in flight anyway)
+    auto load_row = [&](vec_t* raw, int t) {
+        const vec_t* p = xrow + (size_t)min(t, t1 - 1) * frame_vecs;
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
             const int v = k * WAVE + lane;
-            if (v < nvec) raw[k] = p[v];
-            else raw[k] = typename E::vec_t{};
+            raw[k] = p[k < KFULL ? v : min(v, nvec - 1)];
         }
     };
     // normalise the row held in raw[] into cur[] (x / max(||x||, eps)), reference rounding for bf16
-    auto normalise = [&]() {
+    auto normalise = [&](vec_t* raw, float* cur) {
+#pragma unroll
+        for (int k = KFULL; k < VPL; ++k)
+            if (k * WAVE + lane >= nvec) raw[k] = vec_t{};   // lanes past the end of the row contribute zeros
 #pragma unroll
         for (int k = 0; k < VPL; ++k) E::unpack(raw[k], cur + k * PV);
         float ss = 0.f;
+        if constexpr (DT == RTK_BF16) {   // sum of squares straight from the packed words, two elements per instruction
 #pragma unroll
-        for (int e = 0; e < NE; ++e) ss = fmaf(cur[e], cur[e], ss);
-        ss = wave_sum(ss);
+            for (int k = 0; k < VPL; ++k) {
+                ss = dot2_bf16_dp(raw[k].x, raw[k].x, ss);
+                ss = dot2_bf16_dp(raw[k].y, raw[k].y, ss);
+                ss = dot2_bf16_dp(raw[k].z, raw[k].z, ss);
+                ss = dot2_bf16_dp(raw[k].w, raw[k].w, ss);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) ss = fmaf(cur[e], cur[e], ss);
+        }
+        ss = wave_sum_uniform(ss);
         float nrm = sqrtf(ss);
         if (DT == RTK_BF16) {
             nrm = rbf(nrm);
             nrm = fmaxf(nrm, rbf(1e-8f));
+            // bf16(fl32(x / nrm)) without a division per element: x and nrm are bf16 values, and the exact quotient
+            // of two 8-bit significands is never closer than 128 fp32 ulp to a bf16 rounding midpoint (unless it is
+            // exactly representable), while x * fl32(1/nrm) is within 2 fp32 ulp of it - so the reciprocal product
+            // rounds to the same bf16 as the reference's division, always (tools/bf16_quotient_check.py walks every
+            // significand pair, subnormal results included).  Only a norm so large that 1/nrm is subnormal takes
+            // the true division; the branch is wave-uniform.
+            if (__builtin_amdgcn_readfirstlane(__float_as_int(nrm)) > 0x7b800000 /* 2^120 */) {
 #pragma unroll
-            for (int e = 0; e < NE; ++e) cur[e] = rbf(cur[e] / nrm);
+                for (int e = 0; e < NE; ++e) cur[e] = __fdiv_rn(cur[e], nrm);
+            } else {
+                const float rn = __frcp_rn(nrm);
+#pragma unroll
+                for (int e = 0; e < NE; ++e) cur[e] *= rn;
+            }
+#pragma unroll
+            for (int e = 0; e < NE; e += 2) {   // hardware pack-convert = round to nearest even, like c10::BFloat16
+                const uint32_t pk = pack2_bf16_dp(cur[e], cur[e + 1]);
+                cur[e] = __uint_as_float(pk << 16);
+                cur[e + 1] = __uint_as_float(pk & 0xffff0000u);
+            }
         } else {
             nrm = fmaxf(nrm, 1e-8f);
 #pragma unroll
             for (int e = 0; e < NE; ++e) cur[e] = cur[e] / nrm;
         }
     };
-
-    if (t0 == 0) {
-        if (lane == 0 && !emit_cos) dis[n] = 1.0f;  // torch.ones_like(dis[:1])   (:103-106)
-        load_row(0);
-    } else {
-        load_row(t0 - 1);  // halo
-    }
-    normalise();
-#pragma unroll
-    for (int e = 0; e < NE; ++e) prevn[e] = cur[e];
-    const int tb = (t0 == 0) ? 1 : t0;
-    if (tb < t1) load_row(tb);
-    for (int t = tb; t < t1; ++t) {
-        normalise();
-        if (t + 1 < t1) load_row(t + 1);  // prefetch the next frame's row while reducing this one
+    const int tb = (t0 == 0) ? 1 : t0;   // first row this wave produces a distance for
+    float res = 1.0f;                    // lane i: result of row tb + i (or of row 0 for the lane that gets it)
+    // cos / distance of row t (in cur[]) against the previous row (prevn[])
+    auto emit = [&](int t, const float* prevn, const float* cur) {
         float dot = 0.f;
         if (DT == RTK_BF16) {
 #pragma unroll
-            for (int e = 0; e < NE; ++e) dot += rbf(prevn[e] * cur[e]);
+            for (int e = 0; e < NE; e += 2) {
+                const uint32_t pk = pack2_bf16_dp(prevn[e] * cur[e], prevn[e + 1] * cur[e + 1]);
+                dot = dot2_bf16_dp(pk, 0x3f803f80u, dot);   // + bf16(product) for both halves
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < NE; ++e) dot = fmaf(prevn[e], cur[e], dot);
         }
-        dot = wave_sum(dot);
+        dot = wave_sum_uniform(dot);
         if (DT == RTK_BF16) dot = rbf(dot);
-        if (lane == 0) {
-            if (emit_cos) dis[(size_t)(t - 1) * N + n] = dot;  // MA-LLM: the similarity itself, [T-1, N]
-            else dis[(size_t)t * N + n] = 1.0f - dot;
-        }
-#pragma unroll
-        for (int e = 0; e < NE; ++e) prevn[e] = cur[e];
+        if (lane == t - tb) res = emit_cos ? dot : 1.0f - dot;
+    };
+
+    load_row(rawA, t0 == 0 ? 0 : t0 - 1);   // first row, or the halo row of the previous strip
+    load_row(rawB, tb);
+    normalise(rawA, nA);
+    load_row(rawA, tb + 1);
+    // rows tb, tb+2, ... go through rawB -> nB, rows tb+1, tb+3, ... through rawA -> nA; a raw buffer is
+    // re-issued (two rows ahead) as soon as its row has been unpacked
+    int t = tb;
+    for (; t + 1 < t1; t += 2) {   // whole pairs only: the loads outstanding at the loop head are always B then A
+        normalise(rawB, nB);
+        load_row(rawB, t + 2);
+        emit(t, nA, nB);
+        normalise(rawA, nA);
+        load_row(rawA, t + 3);
+        emit(t + 1, nB, nA);
     }
+    if (t < t1) {
+        normalise(rawB, nB);
+        emit(t, nA, nB);
+    }
+    // one store per produced row: MA-LLM keeps the similarity itself in [T-1, N]; DPSelect keeps 1 - cos in
+    // [T, N] with torch.ones_like(dis[:1]) for frame 0   (visual_compression.py:103-106)
+    const int tr = tb + lane;
+    if (tr < t1) dis[(size_t)(emit_cos ? tr - 1 : tr) * N + n] = res;
+    if (t0 == 0 && lane == 0 && !emit_cos) dis[n] = 1.0f;
 }
 
 // Generic fallback: any C (scalar loads, two passes over each row through L2).  One wave per (t,n).
@@ -388,14 +466,31 @@ static int launch_dis(const void* x, int T, int N, int C, int emit_cos, float* d
         RTK_LAUNCH_CHECK("dis_kernel_generic");
         return RTK_OK;
     }
-    // strip length: long enough that the halo re-read is small, short enough to fill 256 CUs
-    int strip = 32;
-    while (strip > 4 && (size_t)N * ((T + strip - 1) / strip) < 8192) strip >>= 1;
-    const size_t waves = (size_t)N * ((T + strip - 1) / strip);
-    const unsigned grid = (unsigned)((waves * WAVE + 255) / 256);
+    // Strip length: the whole job should be ONE resident set of waves.  Every wave does the same work per row,
+    // so a second, partly filled round of workgroups costs as much as a full one (measured: 12.5k waves on 8k
+    // slots ran at 57 % VALU utilisation); with strips sized so that N * nstrips just fits the resident slots the
+    // halo re-read is 1/strip and no SIMD idles while others finish.  Small jobs fall back to strips of >= 4 rows.
     const vec_t* xv = (const vec_t*)x;
+    size_t slots = 8192;
 #define RTK_DIS_CASE(V)                                                                                  \
-    RTK_LAUNCH(KID_DIS, (dis_kernel<DT, V>), dim3(grid), dim3(256), 0, st, xv, T, N, nvec, strip, emit_cos, dis); \
+    {                                                                                                    \
+        static int resident = 0; /* waves of this instantiation the chip holds at once */               \
+        if (!resident) {                                                                                 \
+            int dev = 0, cus = 256, nb = 0;                                                              \
+            (void)hipGetDevice(&dev);                                                                    \
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);               \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dis_kernel<DT, V>, 256, 0) != hipSuccess || nb < 1) \
+                nb = 1;                                                                                  \
+            resident = nb * cus * 4;                                                                     \
+        }                                                                                                \
+        slots = (size_t)resident;                                                                        \
+        int nstr = (int)std::max<size_t>(1, std::min<size_t>(slots / (size_t)N, (size_t)(T + 3) / 4));      \
+        nstr = std::max(nstr, (T + 63) / 64); /* a strip's results live in one register: <= 64 rows */     \
+        const int strip = (T + nstr - 1) / nstr;                                                         \
+        const size_t waves = (size_t)N * ((T + strip - 1) / strip);                                      \
+        const unsigned grid = (unsigned)((waves * WAVE + 255) / 256);                                    \
+        RTK_LAUNCH(KID_DIS, (dis_kernel<DT, V>), dim3(grid), dim3(256), 0, st, xv, T, N, nvec, strip, emit_cos, dis); \
+    }                                                                                                    \
     break;
     switch (vpl) {
         case 1: RTK_DIS_CASE(1)
