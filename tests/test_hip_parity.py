@@ -761,6 +761,65 @@ def test_sharded_blocks_reproduce_sequential_cache():
         assert (k_all - seq.key_cache[l]).abs().max().item() <= 1e-5
 
 
+def _single_rank_group():
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        import os
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+
+
+@pytest.mark.parametrize("sync", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dpselect_sharded_ratio_below_one_matches_single_gpu(sync, dtype):
+    """World size 1 through the real collective path: select on the gathered distances, padded block,
+    all-gather, placement gather - must equal the unsharded call bit for bit."""
+    import retake.visual_compression as vc
+    from retake import sharded
+
+    _single_rank_group()
+    T, N, C, t = 48, 6, 256, 17
+    x = torch.from_numpy(synth.frames_video(321, T, N, C)).to(dev()).to(dtype)     # [1, T, N, C]
+    ref_out, ref_mask = vc.memory_bank_compress_keyframe(x, t, 3, sync=sync)
+    out, mask, idx, dis = sharded.dpselect_sharded(x, False, t, 3, sync=sync)
+    assert out.shape == (1, t, N, C) and torch.equal(out, ref_out) and torch.equal(mask, ref_mask)
+    # ratio 1.0 still returns the rank's own frames
+    out1, mask1, idx1, _ = sharded.dpselect_sharded(x, False, T, 3, sync=sync)
+    assert torch.equal(out1, x) and mask1.numel() == T * N
+
+
+@pytest.mark.parametrize("sync", [True, False])
+def test_dpselect_frame_exchange_emulated_ranks(sync):
+    """Four ranks emulated on one device, every gather through rtk_gather_frames: local kept frames -> padded
+    blocks (concatenated as the all-gather would) -> placement == the global gather of the unsharded call."""
+    import retake._native as nv
+    import retake.visual_compression as vc
+    from retake import sharded
+
+    T, N, C, t, world = 64, 5, 128, 23, 4
+    xb = torch.from_numpy(synth.frames_video(99, T, N, C)).to(dev()).bfloat16()    # [1, T, N, C]
+    ref_out, _, idx, _, _ = vc.dpselect_stages(xb, t, 3, sync)
+    x = xb[0]
+    T_own = T // world
+    _, cmax, local, place = sharded.plan_frame_exchange(idx, T_own, world)
+    st, dt = nv.stream(), nv.dtype_code(x)
+    blocks = torch.empty((world * cmax, N, C), dtype=x.dtype, device=dev())
+    for r in range(world):
+        own = x[r * T_own:(r + 1) * T_own].contiguous()
+        mine = local[r, :, 0].contiguous() if sync else local[r].contiguous()
+        blk = blocks[r * cmax:(r + 1) * cmax]
+        nv.check(nv.lib.rtk_gather_frames(nv.ptr(own), T_own, N, C, dt, nv.ptr(mine), cmax, int(sync), nv.ptr(blk), st),
+                 "rtk_gather_frames")
+    plc = place[:, 0].contiguous() if sync else place
+    out = torch.empty((1, t, N, C), dtype=x.dtype, device=dev())
+    nv.check(nv.lib.rtk_gather_frames(nv.ptr(blocks), world * cmax, N, C, dt, nv.ptr(plc), t, int(sync), nv.ptr(out), st),
+             "rtk_gather_frames")
+    assert torch.equal(out, ref_out)
+
+
 # ---------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties (the oracle is too slow / too big here)
 # ---------------------------------------------------------------------------------------------------

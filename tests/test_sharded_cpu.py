@@ -91,3 +91,82 @@ def test_block_offsets_reproduce_sequential_chain():
         for (a, b), d in zip(blocks, delta):
             prov = np.concatenate([[0], np.cumsum(spans[a:b])[:-1]])
             np.testing.assert_array_equal(prov + d, seq_start[a:b])
+
+
+# ---------------------------------------------------------------------------------------------------
+# DPSelect at ratio < 1 on sharded frames: the exchange plan (who sends which kept frame where)
+# ---------------------------------------------------------------------------------------------------
+def _random_selection(seed, T, N, t, sync):
+    g = torch.Generator().manual_seed(seed)
+    if sync:
+        return torch.sort(torch.randperm(T, generator=g)[:t]).values
+    return torch.stack([torch.sort(torch.randperm(T, generator=g)[:t]).values for _ in range(N)], 1)
+
+
+@pytest.mark.parametrize("sync", [True, False])
+@pytest.mark.parametrize("T,N,t,world", [(32, 5, 13, 4), (16, 3, 1, 2), (24, 4, 23, 8), (8, 2, 4, 1), (64, 7, 16, 8)])
+def test_frame_exchange_plan_reassembles_global_gather(T, N, t, world, sync):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "video-retake_amd"))
+    from retake.sharded import plan_frame_exchange
+
+    C = 3
+    x = torch.arange(T * N * C, dtype=torch.float32).reshape(T, N, C)
+    idx = _random_selection(7 * T + t, T, N, t, sync)
+    T_own = T // world
+    start, cmax, local, place = plan_frame_exchange(idx, T_own, world)
+    assert start.shape == (world + 1, 1 if sync else N) and int(start[-1].min()) == t
+    assert local.shape == (world, cmax, 1 if sync else N) and int(local.min()) >= 0 and int(local.max()) < T_own
+    # what each rank would send (local gather of its own frames), in rank order, then the placement gather
+    blocks = []
+    for r in range(world):
+        own = x[r * T_own:(r + 1) * T_own]
+        if sync:
+            blocks.append(own[local[r, :, 0]])
+        else:
+            blocks.append(torch.gather(own, 0, local[r][:, :, None].expand(-1, -1, C)))
+    cat = torch.cat(blocks, 0)
+    if sync:
+        out, ref = cat[place[:, 0]], x[idx]
+    else:
+        out = torch.gather(cat, 0, place[:, :, None].expand(-1, -1, C))
+        ref = torch.gather(x, 0, idx[:, :, None].expand(-1, -1, C))
+    assert torch.equal(out, ref)
+
+
+def test_frame_exchange_plan_handles_a_rank_with_nothing_kept():
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "video-retake_amd"))
+    from retake.sharded import plan_frame_exchange
+
+    idx = torch.tensor([0, 1, 2, 12, 13])            # ranks 1 and 2 of 4 (T_own 4) keep nothing
+    start, cmax, local, place = plan_frame_exchange(idx, 4, 4)
+    assert start[:, 0].tolist() == [0, 3, 3, 3, 5] and cmax == 3
+    assert place[:, 0].tolist() == [0, 1, 2, 9, 10]
+
+
+def _exchange(rank, world):
+    """Both ranks hold the same selection; each gathers its own kept frames, all-gathers the padded blocks and
+    places them - the torch indexing stands in for rtk_gather_frames, the collective is the real one."""
+    from retake import sharded
+
+    T, N, C, t = 12, 3, 2, 7
+    x = torch.arange(T * N * C, dtype=torch.float32).reshape(T, N, C)
+    idx = _random_selection(5, T, N, t, False)
+    T_own = T // world
+    _, cmax, local, place = sharded.plan_frame_exchange(idx, T_own, world)
+    own = x[rank * T_own:(rank + 1) * T_own]
+    block = torch.gather(own, 0, local[rank][:, :, None].expand(-1, -1, C)).contiguous()
+    blocks = sharded.all_gather_rows(block)
+    out = torch.gather(blocks, 0, place[:, :, None].expand(-1, -1, C))
+    ref = torch.gather(x, 0, idx[:, :, None].expand(-1, -1, C))
+    return bool(torch.equal(out, ref)), tuple(blocks.shape)
+
+
+def test_frame_exchange_over_gloo():
+    for ok, shape in _spawn("_exchange"):
+        assert ok and shape[1:] == (3, 2)

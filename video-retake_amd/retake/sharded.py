@@ -6,8 +6,10 @@ The video's frame chunks are split into contiguous blocks, one per rank:
   DPSelect   every rank computes the distance rows of its frames (one halo frame on the left), the
              [T, N] distance matrix is all-gathered (T*N*4 bytes, 1.6 MB at 2048x196), and the cheap
              stencil + top-k runs redundantly on every rank — deterministic, so all ranks hold the
-             same indices and key-patch mask.  (Frame gather: ratio 1.0, the shipped default, keeps
-             every frame in place; a ratio < 1 gather across ranks is not implemented yet.)
+             same indices and key-patch mask.  Frame gather: at ratio 1.0 (the shipped default) every
+             frame stays in place; at ratio < 1 a rank gathers the kept frames it owns into a padded
+             block, the blocks are all-gathered, and one more gather puts them in output order
+             (`plan_frame_exchange`: kept indices ascend, so a rank's frames are one run per patch).
   PivotKV    (chunk, layer) scoring only reads the chunk's own q/k (longvideo_cache.py:264), so a rank
              runs `PivotKVCache.update` on its chunks with PROVISIONAL temporal ids starting at 0.
              Selection and the id rescale are translation invariant; the only coupling between blocks
@@ -80,17 +82,49 @@ def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+def plan_frame_exchange(idx: torch.Tensor, T_own: int, world: int):
+    """Who sends which kept frame where (DPSelect at ratio < 1 on frames sharded `T_own` per rank).
+
+    idx: the global selection, [t] (sync) or [t, N] (per patch position), ascending along dim 0
+    (visual_compression.py:135,169).  Because it ascends, the kept frames of patch n that live on rank r are
+    the run j in [start[r, n], start[r+1, n]).  Returns
+      start  [world+1, N'] int64 (N' = 1 for sync),
+      cmax   int, the longest run (the padded block length every rank sends),
+      local  [world, cmax, N'] int64: rank r's local frame index for slot (jl, n); padding repeats a valid frame,
+      place  [t, N'] int64: row of the rank-ordered concatenation of the padded blocks that holds output (j, n).
+    Pure index arithmetic on idx's device; identical on every rank because idx is."""
+    i2 = idx if idx.ndim == 2 else idx[:, None]
+    t, n_pos = i2.shape
+    dev = i2.device
+    bounds = torch.arange(world + 1, device=dev, dtype=torch.int64) * T_own
+    start = torch.searchsorted(i2.t().contiguous(), bounds[None, :].expand(n_pos, -1).contiguous()).t().contiguous()
+    cmax = max(1, int((start[1:] - start[:-1]).max().item()))
+    jl = torch.arange(cmax, device=dev, dtype=torch.int64)[None, :, None]          # [1, cmax, 1]
+    j = start[:-1, None, :] + jl                                                     # [world, cmax, N']
+    valid = j < start[1:, None, :]
+    src = torch.gather(i2[None].expand(world, -1, -1), 1, j.clamp(max=t - 1))       # global frame per slot
+    r0 = torch.arange(world, device=dev, dtype=torch.int64)[:, None, None] * T_own
+    local = torch.where(valid, src - r0, torch.zeros_like(src)).clamp_(0, T_own - 1)
+    owner = torch.div(i2, T_own, rounding_mode="floor")                              # [t, N']
+    jj = torch.arange(t, device=dev, dtype=torch.int64)[:, None]
+    place = owner * cmax + (jj - torch.gather(start, 0, owner))
+    return start, cmax, local.contiguous(), place.contiguous()
+
+
 # ---------------------------------------------------------------------------------------------------
 # device path
 # ---------------------------------------------------------------------------------------------------
 def dpselect_sharded(frames_local: torch.Tensor, has_halo: bool, tgt_mem_len: int, window_size: int = 3,
                      sync: bool = False, group=None):
-    """frames_local [1, T_loc (+1 halo frame in front), N, C].  Returns (compressed_local, mask_flat_global,
-    idx_global, dis_global).  tgt_mem_len must equal the total frame count (ratio 1.0)."""
+    """frames_local [1, T_loc (+1 halo frame in front), N, C]; every rank holds the same number of own frames.
+    Returns (compressed, mask_flat_global, idx_global, dis_global).  At ratio 1.0 (tgt_mem_len == total frames)
+    `compressed` is the rank's own frames [1, T_loc, N, C]; at ratio < 1 it is the full compressed bank
+    [1, tgt_mem_len, N, C], assembled on every rank from one all-gather of the kept frames."""
     from . import _native as nv
 
     nv.require_device(frames_local)
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     x = frames_local[0].contiguous()
     Tl, N, Cc = x.shape
     dev = x.device
@@ -102,21 +136,36 @@ def dpselect_sharded(frames_local: torch.Tensor, has_halo: bool, tgt_mem_len: in
         own = dis_l[1:] if has_halo else dis_l      # the halo frame only feeds the first own row
         dis = all_gather_rows(own, group)
         T = dis.shape[0]
-        if tgt_mem_len != T:
-            raise NotImplementedError("sharded DPSelect: frame gather across ranks (ratio < 1) is not implemented")
-        idx = torch.empty((T,) if sync else (T, N), dtype=torch.int64, device=dev)
-        mask = torch.empty((T, N), dtype=torch.bool, device=dev)
+        t = int(tgt_mem_len)
+        if not 1 <= t <= T:
+            raise ValueError(f"sharded DPSelect: tgt_mem_len {t} outside [1, {T}]")
+        idx = torch.empty((t,) if sync else (t, N), dtype=torch.int64, device=dev)
+        mask = torch.empty((t, N), dtype=torch.bool, device=dev)   # key-patch mask of the kept frames
         keys = torch.empty((2, T) if sync else (N, T), dtype=torch.float32, device=dev)
-        nv.check(nv.lib.rtk_dpselect_select(nv.ptr(dis), T, N, T, int(window_size), int(bool(sync)), nv.ptr(idx),
+        nv.check(nv.lib.rtk_dpselect_select(nv.ptr(dis), T, N, t, int(window_size), int(bool(sync)), nv.ptr(idx),
                                             nv.ptr(mask), nv.ptr(keys), st), "rtk_dpselect_select")
-        # ratio 1.0: every frame is kept at its own index -> the local output is a copy of the own frames
-        own_x = x[1:] if has_halo else x
-        rank = dist.get_rank(group)
+        own_x = (x[1:] if has_halo else x).contiguous()
         T_own = own_x.shape[0]
-        idx_l = (idx[rank * T_own:(rank + 1) * T_own] - rank * T_own).contiguous()
-        out = torch.empty((1, T_own, N, Cc), dtype=x.dtype, device=dev)
-        nv.check(nv.lib.rtk_gather_frames(nv.ptr(own_x.contiguous()), T_own, N, Cc, dt, nv.ptr(idx_l), T_own,
-                                          int(bool(sync)), nv.ptr(out), st), "rtk_gather_frames")
+        if T_own * world != T:
+            raise ValueError("sharded DPSelect: ranks must hold equally many frames")
+        if t == T:
+            # ratio 1.0: every frame is kept at its own index -> the local output is a copy of the own frames
+            idx_l = (idx[rank * T_own:(rank + 1) * T_own] - rank * T_own).contiguous()
+            out = torch.empty((1, T_own, N, Cc), dtype=x.dtype, device=dev)
+            nv.check(nv.lib.rtk_gather_frames(nv.ptr(own_x), T_own, N, Cc, dt, nv.ptr(idx_l), T_own,
+                                              int(bool(sync)), nv.ptr(out), st), "rtk_gather_frames")
+            return out, mask.flatten(), idx, dis
+        # ratio < 1: own kept frames -> padded block -> all-gather -> output order
+        _, cmax, local, place = plan_frame_exchange(idx, T_own, world)
+        mine = local[rank, :, 0].contiguous() if sync else local[rank].contiguous()
+        block = torch.empty((cmax, N, Cc), dtype=x.dtype, device=dev)
+        nv.check(nv.lib.rtk_gather_frames(nv.ptr(own_x), T_own, N, Cc, dt, nv.ptr(mine), cmax, int(bool(sync)),
+                                          nv.ptr(block), st), "rtk_gather_frames")
+        blocks = all_gather_rows(block, group)                       # [world * cmax, N, C] in rank order
+        plc = place[:, 0].contiguous() if sync else place
+        out = torch.empty((1, t, N, Cc), dtype=x.dtype, device=dev)
+        nv.check(nv.lib.rtk_gather_frames(nv.ptr(blocks), world * cmax, N, Cc, dt, nv.ptr(plc), t, int(bool(sync)),
+                                          nv.ptr(out), st), "rtk_gather_frames")
     return out, mask.flatten(), idx, dis
 
 
