@@ -330,16 +330,28 @@ def main():
                 extra[name] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": gbs / HBM_PEAK_GBS, "traffic": tr, "algorithmic_bytes_per_launch": b}
         if all(k in kern for k in ("evict_batched", "commit_batched")) and ("append" in kern or fused):
-            # the whole eviction scan of one (layer, chunk) unit against SURVEY's algorithmic byte count: the tail
-            # append (its own kernel, or its byte share of the fused prepare kernel) + 1/layers of the two batched
-            # launches
-            t_app = kern["append"]["avg_us"] if not fused else kern["unrotate_pack"]["avg_us"] * ap_bytes / prep_bytes
-            t_unit = (t_app + (kern["evict_batched"]["avg_us"] + kern["commit_batched"]["avg_us"]) / args.layers) * 1e-6
-            gbs = ev_bytes / t_unit / 1e9
+            # SURVEY §8(d) "PivotKV eviction scan (P6-P13)": mask override + select + kept-row gather / re-rotation +
+            # id bookkeeping + compaction of one (layer, chunk) unit, against SURVEY's algorithmic byte count.  Every
+            # stage is one launch per chunk covering all layers, so a unit's share is 1/layers of each launch.
+            per_chunk = {"pivotkv_select": 1, "pivotkv_emit": 1, "rope_table": 2, "evict_batched": 1, "commit_batched": 1}
+            stages = {k: kern[k]["avg_us"] * n / args.layers for k, n in per_chunk.items() if k in kern}
+            t_scan = sum(stages.values()) * 1e-6
+            gbs = ev_bytes / t_scan / 1e9
             extra["eviction_scan_per_unit"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                                               "algorithmic_bytes_per_unit": ev_bytes, "us_per_unit": t_unit * 1e6,
-                                               "moved_bytes_per_unit": ap_bytes + evu_bytes + cmu_bytes}
+                                               "algorithmic_bytes_per_unit": ev_bytes, "us_per_unit": t_scan * 1e6,
+                                               "stages_us_per_unit": stages,
+                                               "moved_bytes_per_unit": evu_bytes + cmu_bytes}
+            # the same plus the tail append update() owes the layer's attention (reference :238, P1): its own kernel,
+            # or its byte share of the fused prepare kernel.  SURVEY's byte count has no term for it.
+            t_app = kern["append"]["avg_us"] if not fused else kern["unrotate_pack"]["avg_us"] * ap_bytes / prep_bytes
+            t_unit = t_scan + t_app * 1e-6
+            gbs = ev_bytes / t_unit / 1e9
+            extra["cache_update_per_unit"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                              "algorithmic_bytes_per_unit": ev_bytes, "us_per_unit": t_unit * 1e6,
+                                              "moved_bytes_per_unit": ap_bytes + evu_bytes + cmu_bytes,
+                                              "moved_GBps": (ap_bytes + evu_bytes + cmu_bytes) / t_unit / 1e9}
         out["roofline_hbm_kernels"] = extra
     if args.also_streams > 0 and args.streams == 0:
         # same workload with scoring / selection / eviction on worker HIP streams (PivotKVCache

@@ -33,6 +33,9 @@ for it in range(3):
     names = ["issue loads", "LDS reads + MFMAs", "softmax VALU", "LDS store", "barrier"]
     print("iter", it, "tiles sampled", tiles)
     tot = sum(v[:5])
+    if tot == 0:
+        print('   (score kernels of this build carry no phase counters)')
+        break
     for n, x in zip(names, v[:5]):
         print(f"   {n:20s} {x / tiles:9.1f} cycles/tile  ({100 * x / tot:5.1f} %)")
     print(f"   total per tile {tot / tiles:9.1f}")

@@ -88,13 +88,10 @@ __device__ unsigned long long g_sel_timing[8];
 #define RTK_ST(k)
 #endif
 template <int E>
-__global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* __restrict__ score,
-                                                                         const uint8_t* __restrict__ mask, int L,
-                                                                         int keep, const int64_t* __restrict__ pos,
-                                                                         int P, int reforge,
-                                                                         int64_t* __restrict__ keep_idx,
-                                                                         int32_t* __restrict__ rank,
-                                                                         int64_t* __restrict__ pos_out, int64_t pos_ld) {
+__device__ __forceinline__ void select_fast_body(float* __restrict__ score, const uint8_t* __restrict__ mask, int L,
+                                                 int keep, const int64_t* __restrict__ pos, int P, int reforge,
+                                                 int64_t* __restrict__ keep_idx, int32_t* __restrict__ rank,
+                                                 int64_t* __restrict__ pos_out, int64_t pos_ld) {
     __shared__ SelectSmem sm;
     __shared__ uint32_t wtot[PSEL_BLOCK / WAVE];
     __shared__ long long red[PSEL_BLOCK / WAVE];
@@ -103,21 +100,33 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* 
     const int base = tid * per;
     RTK_ST(0)
     uint32_t key[E];
-    long long t0[E];   // temporal ids of this thread's tokens (reforge): tmin and the rescale need no re-read
+    long long t0[E];   // temporal ids of this thread's tokens: tmin and the rescale need no re-read
+    long long p1[E], p2[E];   // rows 1 and 2 of the ids (M-RoPE h / w), loaded up front so the emit loop only stores
     const bool rf = pos && reforge;
+    {
+        // every load first (independent, in flight together), then the mask override stores
+        float sc[E];
+        uint8_t mk[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = base + e;
-        key[e] = 0;
-        t0[e] = 0;
-        if (e < per && i < L) {
-            float sc = score[i];
-            if (mask && mask[i]) {  // attn_weights.masked_fill_(mask, 1.)  (:274)
-                sc = 1.0f;
-                score[i] = sc;
+        for (int e = 0; e < E; ++e) {
+            const int i = min(base + e, L - 1);
+            sc[e] = score[i];
+            mk[e] = mask ? mask[i] : (uint8_t)0;
+            t0[e] = pos ? pos[i] : 0;
+            p1[e] = (pos && P > 1) ? pos[(size_t)L + i] : 0;
+            p2[e] = (pos && P > 2) ? pos[2 * (size_t)L + i] : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = base + e;
+            key[e] = 0;
+            if (e < per && i < L) {
+                if (mk[e]) {  // attn_weights.masked_fill_(mask, 1.)  (:274)
+                    sc[e] = 1.0f;
+                    score[i] = 1.0f;
+                }
+                key[e] = f2key(sc[e]);
             }
-            key[e] = f2key(sc);
-            if (rf) t0[e] = pos[i];
         }
     }
     auto valid = [&](int e) { return e < per && base + e < L; };
@@ -226,15 +235,27 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* 
             keep_idx[r] = i;  // topk(keep).sort()  (:276-277)
             if (pos) {
                 // row 0: gathered id, rescaled when reforging: int64 -> float32 multiply -> truncation (:293-295)
-                pos_out[r] = rf ? mn + (long long)((float)(t0[e] - mn) * ratio) : (long long)pos[i];
-                for (int p = 1; p < P; ++p) pos_out[(size_t)p * pos_ld + r] = pos[(size_t)p * L + i];  // :283-288
+                pos_out[r] = rf ? mn + (long long)((float)(t0[e] - mn) * ratio) : t0[e];
+                if (P > 1) pos_out[(size_t)pos_ld + r] = p1[e];      // :283-288
+                if (P > 2) pos_out[2 * (size_t)pos_ld + r] = p2[e];
             }
-            rank[i] = r++;
-        } else {
+            if (rank) rank[i] = r;
+            ++r;
+        } else if (rank) {
             rank[i] = -1;
         }
     }
     RTK_ST(4)
+}
+template <int E>
+__global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* __restrict__ score,
+                                                                         const uint8_t* __restrict__ mask, int L,
+                                                                         int keep, const int64_t* __restrict__ pos,
+                                                                         int P, int reforge,
+                                                                         int64_t* __restrict__ keep_idx,
+                                                                         int32_t* __restrict__ rank,
+                                                                         int64_t* __restrict__ pos_out, int64_t pos_ld) {
+    select_fast_body<E>(score, mask, L, keep, pos, P, reforge, keep_idx, rank, pos_out, pos_ld);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -254,6 +275,15 @@ constexpr int RANK_BLOCK = RANK_TOK * RANK_SEG;
 struct SelUnits {
     rtk_select_unit u[RTK_SELECT_MAX_UNITS];
 };
+// Batched launches (one unit per layer of a chunk): one workgroup per unit runs the register-resident radix
+// select above, all units side by side.  With >= 8 units in flight that beats spreading every unit over the
+// chip: the 28 selections of a chunk take one workgroup's latency instead of 28 x 98 ranking workgroups.
+template <int E>
+__global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_units_kernel(SelUnits units, int L, int keep, int P,
+                                                                          int reforge, int64_t pos_ld) {
+    const rtk_select_unit& u = units.u[blockIdx.x];
+    select_fast_body<E>(u.score, u.mask, L, keep, u.pos, P, reforge, u.keep_idx, u.rank, u.pos_out, pos_ld);
+}
 // scratch layout inside a unit's workspace: sel [L] bytes | per-rank-workgroup counts | per-rank-workgroup minima
 __host__ __device__ inline size_t sel_ws_cnt_off(int L) { return ((size_t)L + 255) & ~(size_t)255; }
 __host__ __device__ inline size_t sel_ws_tmin_off(int L) {
@@ -793,6 +823,7 @@ static bool chipwide_ok(int L) {
 }
 
 // finalize (units that carry partials) -> rank -> emit, every unit in the same three launches
+constexpr int UNITS_ONE_WG = 8;   // batched launches with at least this many units select one workgroup per unit
 static int select_units(const rtk_select_unit* units, int n, int Hkv, int RS, int G, int L, int keep, int P, int reforge,
                         int64_t pos_out_stride, hipStream_t st) {
     static bool attr_set = false;
@@ -813,6 +844,18 @@ static int select_units(const rtk_select_unit* units, int n, int Hkv, int RS, in
             RTK_LAUNCH(KID_FINALIZE, finalize_units_kernel, dim3((L + 63) / 64, m), dim3(256), (size_t)Hkv * 64 * sizeof(float),
                        st, su, Hkv, RS, G, L);
             RTK_LAUNCH_CHECK("finalize_units_kernel");
+        }
+        const int per = (L + PSEL_BLOCK - 1) / PSEL_BLOCK;
+        if (m >= UNITS_ONE_WG && per <= 8) {
+            if (per <= 2) {
+                RTK_LAUNCH(KID_PSEL, pivotkv_select_units_kernel<2>, dim3(m), dim3(PSEL_BLOCK), 0, st, su, L, keep, P, reforge,
+                           pos_out_stride);
+            } else {
+                RTK_LAUNCH(KID_PSEL, pivotkv_select_units_kernel<8>, dim3(m), dim3(PSEL_BLOCK), 0, st, su, L, keep, P, reforge,
+                           pos_out_stride);
+            }
+            RTK_LAUNCH_CHECK("pivotkv_select_units_kernel");
+            continue;
         }
         RTK_LAUNCH(KID_PSEL, pivotkv_rank_kernel, dim3((L + RANK_TOK - 1) / RANK_TOK, m), dim3(RANK_BLOCK), lds, st, su, L, keep,
                    reforge);
