@@ -220,6 +220,37 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
     const int l = id / lpr, d = (id - l * lpr) * VE;
     if (pos_copy && blockIdx.y == 0 && d == 0)   // the ids the caller may shift in place before the deferred selection runs
         for (int p = 0; p < P; ++p) pos_copy[(size_t)p * L + l] = pos[(size_t)p * pos_ld + l];
+    constexpr int HU = 7;   // heads per batch: all loads of a batch are issued before its arithmetic and stores
+    const int qhalf = (Hq + 1) / 2;
+    const int qb = blockIdx.y == 0 ? 0 : qhalf, qe = blockIdx.y == 0 ? qhalf : Hq;
+    // the KV heads: y = 0 takes k (k~ for the scoring / eviction + the rotated rows for the tail), y = 1 takes v
+    const char* src = blockIdx.y == 0 ? k : v;
+    const int64_t sh = blockIdx.y == 0 ? k_sh : v_sh, sl = blockIdx.y == 0 ? k_sl : v_sl;
+    char* tail = blockIdx.y == 0 ? k_tail : v_tail;
+    // Software pipeline over head batches: the rows of batch b+1 (after the last query batch: the first KV batch)
+    // are requested before batch b is un-rotated and stored, and the first batch before the table arithmetic
+    // (sincosf is a few hundred instructions per value) - with ~1.5 waves per SIMD nothing else hides a round trip.
+    u32x4 lo[HU], hi[HU], lon[HU], hin[HU];
+    auto load_q = [&](u32x4* a, u32x4* b, int hb) {
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int h = min(hb + u, qe - 1);
+            const char* row = q + ((size_t)h * q_sh + (size_t)l * q_sl) * ES;
+            a[u] = *(const u32x4*)(row + (size_t)d * ES);
+            b[u] = *(const u32x4*)(row + (size_t)(d + h2) * ES);
+        }
+    };
+    auto load_kv = [&](u32x4* a, u32x4* b, int hb) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int h = min(hb + u, Hkv - 1);
+            const char* row = src + ((size_t)h * sh + (size_t)l * sl) * ES;
+            a[u] = *(const u32x4*)(row + (size_t)d * ES);
+            b[u] = *(const u32x4*)(row + (size_t)(d + h2) * ES);
+        }
+    };
+    if (qb < qe) load_q(lo, hi, qb);
+    else load_kv(lo, hi, 0);
     float c1[VE], s1[VE], c2[VE], s2[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) {   // rope_table_kernel's arithmetic for channels d + e and d + e + h2
@@ -287,18 +318,9 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
             ohi = V::pack(o2);
         }
     };
-    constexpr int HU = 7;   // heads per batch: all loads of a batch are issued before its arithmetic and stores
-    const int qhalf = (Hq + 1) / 2;
-    const int qb = blockIdx.y == 0 ? 0 : qhalf, qe = blockIdx.y == 0 ? qhalf : Hq;
     for (int hb = qb; hb < qe; hb += HU) {
-        u32x4 lo[HU], hi[HU];
-#pragma unroll
-        for (int u = 0; u < HU; ++u) {
-            const int h = min(hb + u, qe - 1);
-            const char* row = q + ((size_t)h * q_sh + (size_t)l * q_sl) * ES;
-            lo[u] = *(const u32x4*)(row + (size_t)d * ES);
-            hi[u] = *(const u32x4*)(row + (size_t)(d + h2) * ES);
-        }
+        if (hb + HU < qe) load_q(lon, hin, hb + HU);
+        else load_kv(lon, hin, 0);
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
             const int h = hb + u;
@@ -309,20 +331,14 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
             *(u32x4*)(orow + (size_t)d * ES) = olo;
             *(u32x4*)(orow + (size_t)(d + h2) * ES) = ohi;
         }
-    }
-    // the KV heads: y = 0 takes k (k~ for the scoring / eviction + the rotated rows for the tail), y = 1 takes v
-    const char* src = blockIdx.y == 0 ? k : v;
-    const int64_t sh = blockIdx.y == 0 ? k_sh : v_sh, sl = blockIdx.y == 0 ? k_sl : v_sl;
-    char* tail = blockIdx.y == 0 ? k_tail : v_tail;
-    for (int hb = 0; hb < Hkv; hb += 4) {
-        u32x4 lo[4], hi[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int h = min(hb + u, Hkv - 1);
-            const char* row = src + ((size_t)h * sh + (size_t)l * sl) * ES;
-            lo[u] = *(const u32x4*)(row + (size_t)d * ES);
-            hi[u] = *(const u32x4*)(row + (size_t)(d + h2) * ES);
+        for (int u = 0; u < HU; ++u) {
+            lo[u] = lon[u];
+            hi[u] = hin[u];
         }
+    }
+    for (int hb = 0; hb < Hkv; hb += 4) {
+        if (hb + 4 < Hkv) load_kv(lon, hin, hb + 4);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int h = hb + u;
@@ -337,6 +353,11 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
                 *(u32x4*)(orow + (size_t)d * ES) = olo;
                 *(u32x4*)(orow + (size_t)(d + h2) * ES) = ohi;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            lo[u] = lon[u];
+            hi[u] = hin[u];
         }
     }
 }
