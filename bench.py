@@ -307,7 +307,10 @@ def main():
         keep = int(RATIO * L)
         ap_bytes = 2 * 2 * Hkv * L * D * es
         prep_bytes = (2 * Hq + 5 * Hkv) * L * D * es        # q: read + q~; k: read + k~ + tail; v: read + tail
-        evu_bytes = 2 * 2 * Hkv * keep * D * es + 2 * keep * D * 4 + 8 * keep + 2 * 8 * 3 * keep
+        # kept K and V rows read + written, kept-index read, ids read + written; the fp32 cos/sin tables only when a
+        # separate launch wrote them (third-party rotary module) - with the native RoPE the kernel computes them
+        tables = "rope_table" in kern
+        evu_bytes = 2 * 2 * Hkv * keep * D * es + (2 * keep * D * 4 if tables else 0) + 8 * keep + 2 * 8 * 3 * keep
         cmu_bytes = 2 * Hkv * keep * D * es
         ev_bytes = 5 * L + 2 * Hkv * L * D * es + 2 * Hkv * keep * D * es + 8 * 3 * (L + keep)
         dp_bytes = T * N_PATCH * C_EMB * es + 4 * T * N_PATCH
@@ -333,7 +336,7 @@ def main():
             # SURVEY §8(d) "PivotKV eviction scan (P6-P13)": mask override + select + kept-row gather / re-rotation +
             # id bookkeeping + compaction of one (layer, chunk) unit, against SURVEY's algorithmic byte count.  Every
             # stage is one launch per chunk covering all layers, so a unit's share is 1/layers of each launch.
-            per_chunk = {"pivotkv_select": 1, "pivotkv_emit": 1, "rope_table": 2, "evict_batched": 1, "commit_batched": 1}
+            per_chunk = {"pivotkv_select": 1, "pivotkv_emit": 1, "rope_table": 1, "evict_batched": 1, "commit_batched": 1}
             stages = {k: kern[k]["avg_us"] * n / args.layers for k, n in per_chunk.items() if k in kern}
             t_scan = sum(stages.values()) * 1e-6
             gbs = ev_bytes / t_scan / 1e9

@@ -301,6 +301,15 @@ typedef struct rtk_evict_unit {
 int rtk_pivotkv_evict_batched(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P,
                               int dtype, rtk_stream_t stream);
 
+/* The same with the tables of the NEW ids computed in the kernel (reference :297-298: rotary_emb(compressed ids) and
+ * the M-RoPE section merge :68-74, i.e. rtk_rope_table's arithmetic: fp32 sincosf(id * inv_freq[d mod D/2]) *
+ * attention_scaling, rounded to bf16 when round_bf16): every unit needs pos_src (the kept rows' new ids, [P, keep])
+ * and cos_new = sin_new = NULL.  P = 1 (plain RoPE) or 3 (M-RoPE with `sections`).  Saves the table launch and
+ * 2 x keep x D x 4 bytes of write + read per unit. */
+int rtk_pivotkv_evict_batched_rope(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P,
+                                   int dtype, const float* inv_freq, float attention_scaling,
+                                   const int* sections_host, int nsec, int round_bf16, rtk_stream_t stream);
+
 typedef struct rtk_copy_unit {
     const void* src;
     int64_t src_stride_h_bytes;

@@ -670,6 +670,80 @@ def test_evict_batched_abi_vs_torch_gather():
         assert torch.equal(pos_dst[:, 7:7 + keep], pos_src) and int(pos_dst[:, :7].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("dtype,P,scaling", [(torch.bfloat16, 3, synth.YARN_FACTOR4_ATTENTION_SCALING), (torch.float32, 3, 1.0),
+                                             (torch.bfloat16, 1, 1.0)])
+def test_evict_batched_rope_equals_table_path(dtype, P, scaling):
+    """rtk_pivotkv_evict_batched_rope (cos/sin of the new ids computed in the eviction kernel) must write the very
+    bytes rtk_rope_table + rtk_pivotkv_evict_batched write - large temporal ids included."""
+    import ctypes as C
+
+    import retake._native as nv
+
+    Hkv, L, D, keep, n = 4, 300, 128, 77, 3
+    dt = nv.RTK_BF16 if dtype == torch.bfloat16 else nv.RTK_F32
+    g = torch.Generator(device=dev()).manual_seed(11)
+    inv = torch.from_numpy(synth.inv_freq(D)).to(dev())
+    sec = (C.c_int * 3)(16, 24, 24) if P == 3 else None
+    nsec = 3 if P == 3 else 0
+    outs = []
+    for native in (False, True):
+        units = (nv.EvictUnit * n)()
+        hold = []
+        for i in range(n):
+            gi = torch.Generator(device=dev()).manual_seed(100 + i)
+            ku = torch.randn((Hkv, L, D), generator=gi, device=dev()).to(dtype)       # un-rotated keys
+            v = torch.randn((Hkv, L, D), generator=gi, device=dev()).to(dtype)
+            idx = torch.sort(torch.randperm(L, generator=gi, device=dev())[:keep]).values
+            pos_new = torch.randint(0, 120000, (P, keep), generator=gi, device=dev())
+            kd = torch.zeros((Hkv, keep, D), dtype=dtype, device=dev())
+            vd = torch.zeros_like(kd)
+            pos_dst = torch.zeros((P, keep), dtype=torch.int64, device=dev())
+            cos_t = torch.empty((keep, D), dtype=torch.float32, device=dev())
+            sin_t = torch.empty_like(cos_t)
+            u = units[i]
+            u.k_src, u.k_src_stride_h, u.v_src, u.v_src_stride_h = ku.data_ptr(), L * D, v.data_ptr(), L * D
+            u.keep_idx = idx.data_ptr()
+            u.k_dst, u.k_dst_stride_h, u.v_dst, u.v_dst_stride_h = kd.data_ptr(), keep * D, vd.data_ptr(), keep * D
+            u.pos_src, u.pos_src_stride, u.pos_dst, u.pos_dst_stride = pos_new.data_ptr(), keep, pos_dst.data_ptr(), keep
+            if native:
+                u.cos_new = u.sin_new = None
+            else:
+                nv.check(nv.lib.rtk_rope_table(nv.ptr(pos_new), keep, P, keep, nv.ptr(inv), D, float(scaling), sec, nsec,
+                                               int(dtype == torch.bfloat16), nv.ptr(cos_t), nv.ptr(sin_t), nv.stream()),
+                         "rtk_rope_table")
+                u.cos_new, u.sin_new = cos_t.data_ptr(), sin_t.data_ptr()
+            hold.append((ku, v, idx, pos_new, kd, vd, pos_dst, cos_t, sin_t))
+        if native:
+            nv.check(nv.lib.rtk_pivotkv_evict_batched_rope(units, n, Hkv, D, keep, P, dt, nv.ptr(inv), float(scaling), sec,
+                                                           nsec, int(dtype == torch.bfloat16), nv.stream()), "evict_rope")
+        else:
+            nv.check(nv.lib.rtk_pivotkv_evict_batched(units, n, Hkv, D, keep, P, dt, nv.stream()), "evict_batched")
+        torch.cuda.synchronize()
+        outs.append([(h[4].clone(), h[5].clone(), h[6].clone()) for h in hold])
+    for (ka, va, pa), (kb, vb, pb) in zip(*outs):
+        assert torch.equal(ka, kb) and torch.equal(va, vb) and torch.equal(pa, pb)
+        assert float(ka.float().abs().sum()) > 0
+
+
+def test_evict_batched_rope_argument_errors():
+    import retake._native as nv
+
+    units = (nv.EvictUnit * 1)()
+    x = torch.zeros((4, 8, 128), dtype=torch.bfloat16, device=dev())
+    idx = torch.arange(4, device=dev())
+    u = units[0]
+    u.k_src, u.k_src_stride_h, u.v_src, u.v_src_stride_h = x.data_ptr(), 8 * 128, x.data_ptr(), 8 * 128
+    u.keep_idx = idx.data_ptr()
+    y = torch.zeros((4, 4, 128), dtype=torch.bfloat16, device=dev())
+    u.k_dst, u.k_dst_stride_h, u.v_dst, u.v_dst_stride_h = y.data_ptr(), 4 * 128, y.data_ptr(), 4 * 128
+    u.pos_src = u.pos_dst = None
+    inv = torch.ones(64, device=dev())
+    rc = nv.lib.rtk_pivotkv_evict_batched_rope(units, 1, 4, 128, 4, 1, nv.RTK_BF16, nv.ptr(inv), 1.0, None, 0, 1, nv.stream())
+    assert rc != 0 and b"pos_src" in nv.lib.rtk_last_error()
+    rc = nv.lib.rtk_pivotkv_evict_batched_rope(units, 1, 4, 128, 4, 1, nv.RTK_BF16, None, 1.0, None, 0, 1, nv.stream())
+    assert rc != 0
+
+
 # ---------------------------------------------------------------------------------------------------
 # glue: compress_video_tokens (DPSelect inside) against the reference golden
 # ---------------------------------------------------------------------------------------------------

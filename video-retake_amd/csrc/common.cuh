@@ -61,6 +61,55 @@ struct RowSel {
     uint8_t row[256];  // which of the P position rows (t/h/w) feeds channel d
 };
 
+// cos/sin of one token for channels d .. d+VE-1 (c1, s1) and d+h2 .. d+h2+VE-1 (c2, s2): rope_table_kernel's
+// arithmetic (fp32 id * inv_freq[channel mod h2], sincos, * attention_scaling, bf16 rounding on request).  The
+// token's P ids are passed in registers (pid[row]) and the row selectors come in two wide loads, so no load
+// depends on another one; d must be a multiple of VE (4 or 8).
+template <int VE>
+__device__ __forceinline__ void rope_chunk(const float* __restrict__ inv_freq, const RowSel& rs, int d, int h2,
+                                           const float (&pid)[3], float scaling, int round_bf16, float* c1, float* s1,
+                                           float* c2, float* s2) {
+    uint8_t ra[VE], rb[VE];
+    if constexpr (VE == 8) {
+        const uint64_t wa = *(const uint64_t*)(rs.row + d), wb = *(const uint64_t*)(rs.row + d + h2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ra[e] = (uint8_t)(wa >> (8 * e));
+            rb[e] = (uint8_t)(wb >> (8 * e));
+        }
+    } else {
+        const uint32_t wa = *(const uint32_t*)(rs.row + d), wb = *(const uint32_t*)(rs.row + d + h2);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            ra[e] = (uint8_t)(wa >> (8 * e));
+            rb[e] = (uint8_t)(wb >> (8 * e));
+        }
+    }
+    float f[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) f[e] = inv_freq[d + e];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        const float p1 = ra[e] == 0 ? pid[0] : (ra[e] == 1 ? pid[1] : pid[2]);
+        float sn, cs;
+        sincosf(p1 * f[e], &sn, &cs);
+        cs *= scaling;
+        sn *= scaling;
+        if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
+        c1[e] = cs;
+        s1[e] = sn;
+        if (rb[e] != ra[e]) {
+            const float p2 = rb[e] == 0 ? pid[0] : (rb[e] == 1 ? pid[1] : pid[2]);
+            sincosf(p2 * f[e], &sn, &cs);
+            cs *= scaling;
+            sn *= scaling;
+            if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
+        }
+        c2[e] = cs;
+        s2[e] = sn;
+    }
+}
+
 inline int make_rowsel(RowSel& rs, int P, int D, const int* sections, int nsec, const char* who) {
     if (D > 256 || (D & 1)) {
         set_error("%s: head_dim %d unsupported (must be even and <= 256)", who, D);

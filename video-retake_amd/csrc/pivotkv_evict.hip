@@ -672,8 +672,13 @@ struct EvictUnits {
 // One thread owns, for ONE kept row r of a unit, the 16-byte chunk c of the first half of the row and its
 // rotation partner in the second half, and walks the KV heads with it: the row's cos/sin (reforge) are
 // loaded once and reused by every head, and all of a head group's loads are issued before its stores.
-template <int DT, int HU>
-__global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, int Hkv, int D, int keep, int P) {
+// NATIVE: the cos/sin of the kept rows' NEW ids are computed here (rope_table_kernel's arithmetic on pos_src, 8 or 16
+// sincosf per thread, reused by all KV heads) instead of being read from fp32 tables another launch wrote:
+// one launch and 2 x keep x D x 4 bytes of write + read per unit less.
+template <int DT, int HU, bool NATIVE>
+__global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, int Hkv, int D, int keep, int P,
+                                                            const float* __restrict__ inv_freq, float scaling,
+                                                            RowSel rs, int round_bf16) {
     using R = Row16<DT>;
     constexpr int VE = R::VE;
     constexpr int ES = 16 / VE;
@@ -690,25 +695,13 @@ __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, in
     if (r >= keep) return;
     const int d = (id - r * lpr) * VE;
     const int l = (int)un.keep_idx[r];
-    const bool reforge = un.cos_new != nullptr;
-    float c1[VE], s1[VE], c2[VE], s2[VE];
-    if (reforge) {
-        const float* cr = un.cos_new + (size_t)r * D;
-        const float* sr = un.sin_new + (size_t)r * D;
-#pragma unroll
-        for (int e = 0; e < VE; e += 4) {
-            *(float4*)(c1 + e) = *(const float4*)(cr + d + e);
-            *(float4*)(s1 + e) = *(const float4*)(sr + d + e);
-            *(float4*)(c2 + e) = *(const float4*)(cr + d + h2 + e);
-            *(float4*)(s2 + e) = *(const float4*)(sr + d + h2 + e);
-        }
-    }
+    const bool reforge = NATIVE || un.cos_new != nullptr;
     const char* ks = (const char*)un.k_src;
     const char* vs = (const char*)un.v_src;
     char* kd = (char*)un.k_dst;
     char* vd = (char*)un.v_dst;
-    for (int hb = 0; hb < Hkv; hb += HU) {
-        u32x4 k_lo[HU], k_hi[HU], v_lo[HU], v_hi[HU];
+    u32x4 k_lo[HU], k_hi[HU], v_lo[HU], v_hi[HU];
+    auto load_batch = [&](int hb) {
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
             const int h = min(hb + u, Hkv - 1);
@@ -719,6 +712,27 @@ __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, in
             v_lo[u] = *(const u32x4*)(vr + (size_t)d * ES);
             v_hi[u] = *(const u32x4*)(vr + (size_t)(d + h2) * ES);
         }
+    };
+    load_batch(0);   // the rows are requested before the table arithmetic / table reads below
+    float c1[VE], s1[VE], c2[VE], s2[VE];
+    if (NATIVE) {
+        float pid[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pid[p] = (float)un.pos_src[(size_t)min(p, P - 1) * un.pos_src_stride + r];
+        rope_chunk<VE>(inv_freq, rs, d, h2, pid, scaling, round_bf16, c1, s1, c2, s2);
+    } else if (reforge) {
+        const float* cr = un.cos_new + (size_t)r * D;
+        const float* sr = un.sin_new + (size_t)r * D;
+#pragma unroll
+        for (int e = 0; e < VE; e += 4) {
+            *(float4*)(c1 + e) = *(const float4*)(cr + d + e);
+            *(float4*)(s1 + e) = *(const float4*)(sr + d + e);
+            *(float4*)(c2 + e) = *(const float4*)(cr + d + h2 + e);
+            *(float4*)(s2 + e) = *(const float4*)(sr + d + h2 + e);
+        }
+    }
+    for (int hb = 0; hb < Hkv; hb += HU) {
+        if (hb > 0) load_batch(hb);
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
             const int h = hb + u;
@@ -1025,8 +1039,13 @@ extern "C" int rtk_pivotkv_append(const void* k, int64_t k_stride_h, int64_t k_s
     return RTK_OK;
 }
 
-extern "C" int rtk_pivotkv_evict_batched(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P,
-                                         int dtype, rtk_stream_t stream) {
+static int evict_batched_impl(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P, int dtype,
+                              const float* inv_freq, float scaling, const RowSel* rsel, int round_bf16,
+                              rtk_stream_t stream) {
+    const bool native = inv_freq != nullptr;
+    RowSel rs;
+    if (rsel) rs = *rsel;
+    else for (int d = 0; d < 256; ++d) rs.row[d] = 0;
     RTK_CHECK_ARG(units && n_units >= 1, "rtk_pivotkv_evict_batched: no units");
     RTK_CHECK_ARG(Hkv >= 1 && keep >= 1 && D >= 2, "rtk_pivotkv_evict_batched: bad shape");
     RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_evict_batched: unsupported dtype %d", dtype);
@@ -1042,6 +1061,8 @@ extern "C" int rtk_pivotkv_evict_batched(const rtk_evict_unit* units, int n_unit
         RTK_CHECK_ARG(u.k_src && u.v_src && u.keep_idx && u.k_dst && u.v_dst, "rtk_pivotkv_evict_batched: unit %d: NULL pointer", i);
         RTK_CHECK_ARG((u.cos_new == nullptr) == (u.sin_new == nullptr), "rtk_pivotkv_evict_batched: unit %d: cos_new and sin_new go together", i);
         RTK_CHECK_ARG((u.pos_dst == nullptr) || (u.pos_src != nullptr && P > 0), "rtk_pivotkv_evict_batched: unit %d: pos_dst needs pos_src and P", i);
+        RTK_CHECK_ARG(!native || (u.pos_src != nullptr && P > 0 && u.cos_new == nullptr),
+                      "rtk_pivotkv_evict_batched_rope: unit %d: needs pos_src (the new ids), P > 0 and no tables", i);
         const bool aligned = (u.k_src_stride_h * es) % 16 == 0 && (u.v_src_stride_h * es) % 16 == 0 &&
                              (u.k_dst_stride_h * es) % 16 == 0 && (u.v_dst_stride_h * es) % 16 == 0 &&
                              (((uintptr_t)u.k_src | (uintptr_t)u.v_src | (uintptr_t)u.k_dst | (uintptr_t)u.v_dst |
@@ -1059,13 +1080,37 @@ extern "C" int rtk_pivotkv_evict_batched(const rtk_evict_unit* units, int n_unit
         EvictUnits eu;
         for (int i = 0; i < n; ++i) eu.u[i] = units[b + i];
         for (int i = n; i < RTK_EVICT_MAX_UNITS; ++i) eu.u[i] = units[b];
-        if (dtype == RTK_BF16)
-            RTK_LAUNCH(KID_EVICTB, (evict_batched_kernel<RTK_BF16, 4>), dim3(gx, n), dim3(256), 0, st, eu, Hkv, D, keep, P);
-        else
-            RTK_LAUNCH(KID_EVICTB, (evict_batched_kernel<RTK_F32, 2>), dim3(gx, n), dim3(256), 0, st, eu, Hkv, D, keep, P);
+#define RTK_EVB(DTV, HUV, NAT)                                                                                    \
+    RTK_LAUNCH(KID_EVICTB, (evict_batched_kernel<DTV, HUV, NAT>), dim3(gx, n), dim3(256), 0, st, eu, Hkv, D, keep, P, \
+               inv_freq, scaling, rs, round_bf16)
+        if (dtype == RTK_BF16) {
+            if (native) RTK_EVB(RTK_BF16, 4, true);
+            else RTK_EVB(RTK_BF16, 4, false);
+        } else {
+            if (native) RTK_EVB(RTK_F32, 2, true);
+            else RTK_EVB(RTK_F32, 2, false);
+        }
+#undef RTK_EVB
         RTK_LAUNCH_CHECK("evict_batched_kernel");
     }
     return RTK_OK;
+}
+
+extern "C" int rtk_pivotkv_evict_batched(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P,
+                                         int dtype, rtk_stream_t stream) {
+    return evict_batched_impl(units, n_units, Hkv, D, keep, P, dtype, nullptr, 0.f, nullptr, 0, stream);
+}
+
+extern "C" int rtk_pivotkv_evict_batched_rope(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P,
+                                              int dtype, const float* inv_freq, float attention_scaling,
+                                              const int* sections_host, int nsec, int round_bf16,
+                                              rtk_stream_t stream) {
+    RTK_CHECK_ARG(inv_freq, "rtk_pivotkv_evict_batched_rope: inv_freq is NULL");
+    RTK_CHECK_ARG(P == 1 || P == 3, "rtk_pivotkv_evict_batched_rope: P must be 1 or 3, got %d", P);
+    RowSel rs;
+    const int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_pivotkv_evict_batched_rope");
+    if (rc != RTK_OK) return rc;
+    return evict_batched_impl(units, n_units, Hkv, D, keep, P, dtype, inv_freq, attention_scaling, &rs, round_bf16, stream);
 }
 
 extern "C" int rtk_pivotkv_commit_batched(const rtk_copy_unit* units, int n_units, int H, int rows, int D, int dtype,

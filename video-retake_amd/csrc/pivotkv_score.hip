@@ -249,31 +249,13 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
             b[u] = *(const u32x4*)(row + (size_t)(d + h2) * ES);
         }
     };
+    float pid[3];   // the token's ids (t / h / w rows; a 1-D id fills all three)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pid[p] = (float)pos[(size_t)min(p, P - 1) * pos_ld + l];
     if (qb < qe) load_q(lo, hi, qb);
     else load_kv(lo, hi, 0);
     float c1[VE], s1[VE], c2[VE], s2[VE];
-#pragma unroll
-    for (int e = 0; e < VE; ++e) {   // rope_table_kernel's arithmetic for channels d + e and d + e + h2
-        const float f = inv_freq[d + e];
-        const int r1 = rs.row[d + e], r2 = rs.row[d + e + h2];
-        const float p1 = (float)pos[(size_t)r1 * pos_ld + l];
-        float sn, cs;
-        sincosf(p1 * f, &sn, &cs);
-        cs *= scaling;
-        sn *= scaling;
-        if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
-        c1[e] = cs;
-        s1[e] = sn;
-        if (r2 != r1) {
-            const float p2 = (float)pos[(size_t)r2 * pos_ld + l];
-            sincosf(p2 * f, &sn, &cs);
-            cs *= scaling;
-            sn *= scaling;
-            if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
-        }
-        c2[e] = cs;
-        s2[e] = sn;
-    }
+    rope_chunk<VE>(inv_freq, rs, d, h2, pid, scaling, round_bf16, c1, s1, c2, s2);
     // x~ = ((x*cos) - (rotate_half(x)*sin)) / a^2 for one head's chunk pair, one rounding per torch op (:76-78)
     auto unrot = [&](const u32x4& lo, const u32x4& hi, u32x4& olo, u32x4& ohi) {
         if constexpr (DT == RTK_BF16) {

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 RTK_F32, RTK_BF16 = 0, 1
 SCORE_PREPARE, SCORE_PASSES, SCORE_FINALIZE = 1, 2, 4
@@ -72,6 +72,7 @@ _SIGNATURES = {
     "rtk_pivotkv_commit": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "rtk_pivotkv_append": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "rtk_pivotkv_evict_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rtk_pivotkv_evict_batched_rope": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _i, _i, _vp]),
     "rtk_pivotkv_commit_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp]),
     "rtk_position_shift": (C.c_int, [_vp, _i, _vp, _vp]),
     "rtk_profile_enable": (C.c_int, [_i]),

@@ -613,12 +613,13 @@ class PivotKVCache(DynamicCache):
             b.selected.clear()
             b.masks.clear()
             lo, hi = min(layers), max(layers)
-            if b.reforge:  # tables of the NEW ids of every pending slot in one go (reference :298)
+            # reforge: K is re-rotated at the NEW ids (reference :297-306).  With the native RoPE the eviction kernel
+            # computes their cos/sin itself; a third-party rotary module is called once for every pending slot and its
+            # section-merged fp32 tables are handed over.
+            rope_in_kernel = bool(b.reforge and P and self.native_rope and hasattr(b.rotary_emb_fn, "inv_freq"))
+            if b.reforge and not rope_in_kernel:
                 n = (hi - lo + 1) * keep
-                if self.native_rope and hasattr(b.rotary_emb_fn, "inv_freq"):
-                    pos2d, ld = b.pos_new[:, lo], b.slots * keep   # id row p of slots lo..hi is contiguous
-                else:
-                    pos2d, ld = b.pos_new[:, lo:hi + 1].reshape(P, n), n  # a copy when the slot range is partial
+                pos2d, ld = b.pos_new[:, lo:hi + 1].reshape(P, n), n  # a copy when the slot range is partial
                 self._rope_tables(b.cos_new[lo * keep:], b.sin_new[lo * keep:], b.rotary_emb_fn, b.x_like, pos2d, ld,
                                   3 if P == 3 else 2, b.mrope_section, n, D)
             units = (nv.EvictUnit * len(layers))()
@@ -631,8 +632,11 @@ class PivotKVCache(DynamicCache):
                 u = units[i]
                 if b.reforge:
                     u.k_src, u.k_src_stride_h = b.k_unrot[l].data_ptr(), b.L * D
-                    u.cos_new = b.cos_new.data_ptr() + l * keep * D * 4
-                    u.sin_new = b.sin_new.data_ptr() + l * keep * D * 4
+                    if rope_in_kernel:
+                        u.cos_new = u.sin_new = None
+                    else:
+                        u.cos_new = b.cos_new.data_ptr() + l * keep * D * 4
+                        u.sin_new = b.sin_new.data_ptr() + l * keep * D * 4
                     u.k_dst, u.k_dst_stride_h = st.k.data_ptr() + tail, cap * D  # straight into the cache
                 else:
                     u.k_src, u.k_src_stride_h = st.k.data_ptr() + tail, cap * D
@@ -654,8 +658,20 @@ class PivotKVCache(DynamicCache):
                 else:
                     u.pos_src = u.pos_dst = None
             s = nv.stream()
-            nv.check(nv.lib.rtk_pivotkv_evict_batched(units, len(layers), Hkv, D, keep, P if b.reforge else 0, dt, s),
-                     "rtk_pivotkv_evict_batched")
+            if rope_in_kernel:
+                fn = b.rotary_emb_fn
+                inv = fn.inv_freq
+                if inv.device != b.device or inv.dtype != torch.float32 or not inv.is_contiguous():
+                    inv = inv.to(device=b.device, dtype=torch.float32).contiguous()
+                sec = (C.c_int * len(b.mrope_section))(*b.mrope_section) if b.mrope_section else None
+                nv.check(nv.lib.rtk_pivotkv_evict_batched_rope(units, len(layers), Hkv, D, keep, P, dt, nv.ptr(inv),
+                                                               float(fn.attention_scaling), sec,
+                                                               len(b.mrope_section) if b.mrope_section else 0,
+                                                               int(b.x_like.dtype == torch.bfloat16), s),
+                         "rtk_pivotkv_evict_batched_rope")
+            else:
+                nv.check(nv.lib.rtk_pivotkv_evict_batched(units, len(layers), Hkv, D, keep, P if b.reforge else 0, dt, s),
+                         "rtk_pivotkv_evict_batched")
             nv.check(nv.lib.rtk_pivotkv_commit_batched(copies, nc, Hkv, keep, D, dt, s), "rtk_pivotkv_commit_batched")
         for l in layers:
             st = self._layers[l]
