@@ -580,12 +580,15 @@ def test_fused_prepare_equals_separate_kernels():
         assert int(res[0][2][:, :, :5].abs().sum()) == 0 and int(res[0][2][:, :, 5 + L:].abs().sum()) == 0
 
 
-def test_select_batched_equals_single_units():
-    """rtk_pivotkv_select_batched over 5 units (column partials -> finalize -> rank -> emit in three launches) must
-    equal finalizing on the host and selecting every unit on its own."""
+@pytest.mark.parametrize("n,L,keep,P", [(5, 1500, 400, 3), (9, 1500, 400, 3), (28, 6272, 1568, 3), (12, 777, 31, 1),
+                                        (8, 2049, 2049, 3), (10, 5000, 1, 1)])
+def test_select_batched_equals_single_units(n, L, keep, P):
+    """rtk_pivotkv_select_batched (column partials -> finalize -> selection; fewer than 8 units: chip-wide rank +
+    emit, 8 or more: one radix-select workgroup per unit) must equal finalizing on the host and selecting every unit
+    on its own."""
     import retake._native as nv
 
-    Hkv, RS, G, L, keep, P, n = 4, 3, 7, 1500, 400, 3, 5
+    Hkv, RS, G = 4, 3, 7
     g = torch.Generator(device=dev()).manual_seed(33)
     units = (nv.SelectUnit * n)()
     hold = []
@@ -596,7 +599,7 @@ def test_select_batched_equals_single_units():
         part = torch.rand((Hkv, RS, L), generator=g, device=dev()) * 2.0
         mask = torch.rand(L, generator=g, device=dev()) < 0.25 if i % 2 == 0 else None
         pos = torch.stack([torch.arange(L, device=dev()) // 100 + 40 + i, torch.arange(L, device=dev()) % 11,
-                           torch.arange(L, device=dev()) % 5]).contiguous()
+                           torch.arange(L, device=dev()) % 5])[:P].contiguous()
         score = torch.empty(L, dtype=torch.float32, device=dev())
         keep_idx = torch.empty(keep, dtype=torch.int64, device=dev())
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
