@@ -120,6 +120,37 @@ def test_dpselect_odd_shapes_vs_oracle(T, N, C, tgt, sync):
         np.testing.assert_array_equal(out.cpu().numpy(), o_out)
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("T,N,C", [(2, 3, 64), (65, 4, 128), (129, 1, 1280), (200, 50, 1280), (3, 9000, 32),
+                                   (64, 130, 3584), (1000, 9, 8), (67, 33, 4096)])
+def test_dpselect_distance_strip_geometry_vs_oracle(T, N, C, bf16):
+    """The distance kernel's strip partition (strips of <= 64 frames sized from the resident wave slots, one halo row
+    per strip, results held in a register until the strip ends) on shapes that hit its corners: one strip per patch,
+    a last strip of one row, more patches than wave slots, channel counts from one vector per lane to 8."""
+    import retake._native as nv
+
+    x = synth.frames_video(4000 + T + N, T, N, C)[0]
+    if bf16:
+        xb = torch.from_numpy(x).bfloat16()
+        ref = orc.dpselect_dis(xb.view(torch.int16).numpy().view(np.uint16))
+        xt, dt = xb.to(dev()), nv.RTK_BF16
+    else:
+        ref = orc.dpselect_dis(x)
+        xt, dt = torch.from_numpy(x).to(dev()), nv.RTK_F32
+    dis = torch.full((T, N), -7.0, dtype=torch.float32, device=dev())
+    nv.check(nv.lib.rtk_dpselect_dis(nv.ptr(xt), T, N, C, dt, nv.ptr(dis), nv.stream()), "rtk_dpselect_dis")
+    d = np.abs(dis.cpu().numpy() - ref)
+    if bf16:   # same bar as the bf16 goldens: a different fp32 summation order may flip the last bf16 bit of a few sums
+        assert d.max() <= 2 ** -7 and (d > 0).mean() < 0.02
+    else:
+        assert d.max() < 2e-6
+    # the cosine form the MA-LLM merges use: [T-1, N], no leading row of ones
+    cosv = torch.full((T - 1, N), -7.0, dtype=torch.float32, device=dev())
+    nv.check(nv.lib.rtk_adjacent_cosine(nv.ptr(xt), T, N, C, dt, nv.ptr(cosv), nv.stream()), "rtk_adjacent_cosine")
+    dc = np.abs((1.0 - cosv.cpu().numpy()) - ref[1:])
+    assert dc.max() <= (2 ** -7 if bf16 else 2e-6)
+
+
 def _min_decision_gap(dis, tgt, sync):
     rows = dis.mean(1, keepdims=True).T if sync else dis.T
     gap = np.abs(np.diff(rows, axis=1)).min() if rows.shape[1] > 1 else np.inf
