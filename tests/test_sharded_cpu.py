@@ -170,3 +170,30 @@ def _exchange(rank, world):
 def test_frame_exchange_over_gloo():
     for ok, shape in _spawn("_exchange"):
         assert ok and shape[1:] == (3, 2)
+
+
+# ---------------------------------------------------------------------------------------------------
+# cache assembly: every layer in two collectives == three per-layer all-gathers + cat
+# ---------------------------------------------------------------------------------------------------
+def _assemble(rank, world):
+    from retake import sharded
+
+    layers, Hkv, n, D = 3, 2, 5, 4
+    g = torch.Generator().manual_seed(100 + rank)
+    keys = [torch.randn((1, Hkv, n, D), generator=g) for _ in range(layers)]
+    vals = [torch.randn((1, Hkv, n, D), generator=g) for _ in range(layers)]
+    ok = True
+    for pshape in ((3, 1, n), (1, n)):
+        pos = [torch.randint(0, 1000, pshape, generator=g) for _ in range(layers)]
+        ka, va, pa = sharded.all_gather_caches(keys, vals, pos)
+        for l in range(layers):
+            ok &= bool(torch.equal(ka[l], sharded.all_gather_cat(keys[l], 2)))
+            ok &= bool(torch.equal(va[l], sharded.all_gather_cat(vals[l], 2)))
+            ok &= bool(torch.equal(pa[l], sharded.all_gather_cat(pos[l], -1)))
+            ok &= tuple(ka[l].shape) == (1, Hkv, world * n, D) and tuple(pa[l].shape) == pshape[:-1] + (world * n,)
+    return ok
+
+
+def test_cache_assembly_two_collectives_equal_per_layer_gathers():
+    assert all(_spawn("_assemble"))
+    assert all(_spawn("_assemble", world=3))

@@ -20,7 +20,8 @@ The video's frame chunks are split into contiguous blocks, one per rank:
              kept K / V / ids so every rank holds the full compressed cache.
 
 No collective sits inside the scoring path; the exchanges are one small all-gather per video
-(distances), one tiny all-gather per video (offsets) and one all-gather per layer (cache assembly).
+(distances), one tiny all-gather per video (offsets) and two all-gathers per video for the cache assembly
+(K and V of every layer in one, the ids in the other).
 """
 from __future__ import annotations
 
@@ -28,6 +29,7 @@ import ctypes as C
 import json
 import math
 import os
+import sys
 import time
 from typing import List, Optional, Tuple
 
@@ -80,6 +82,44 @@ def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
         parts = list(out.chunk(world, dim=0))
         dist.all_gather(parts, local.contiguous(), group=group)
     return out
+
+
+def _all_gather_flat(send: torch.Tensor, group=None) -> torch.Tensor:
+    """send [...] -> [world, ...] in rank order, one collective."""
+    world = dist.get_world_size(group)
+    recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+    if send.is_cuda:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    else:  # gloo has no all_gather_into_tensor on every build
+        dist.all_gather(list(recv.unbind(0)), send, group=group)
+    return recv
+
+
+def all_gather_caches(keys: List[torch.Tensor], values: List[torch.Tensor], pos: List[torch.Tensor], group=None):
+    """Cache assembly for ALL layers with two collectives instead of three per layer (xGMI is point to point: few
+    large all-gathers use the links far better than 84 small ones, and each result needs one permute copy instead
+    of a per-tensor scatter + cat).
+
+    keys / values: per layer [1, Hkv, n, D]; pos: per layer [3, 1, n] or [1, n] int64; n and the shapes are the same
+    on every rank (every chunk keeps exactly `keep` tokens and the ranks hold equally many chunks).  Returns the
+    per-layer lists [1, Hkv, world*n, D] / [..., world*n] in rank order - views into one buffer per kind."""
+    world = dist.get_world_size(group)
+    n_layers = len(keys)
+    _, Hkv, n, D = keys[0].shape
+    send = torch.empty((2, n_layers, Hkv, n, D), dtype=keys[0].dtype, device=keys[0].device)
+    torch.stack([k[0] for k in keys], out=send[0])
+    torch.stack([v[0] for v in values], out=send[1])
+    recv = _all_gather_flat(send, group)                                        # [W, 2, layers, Hkv, n, D]
+    kv = recv.permute(1, 2, 3, 0, 4, 5).reshape(2, n_layers, Hkv, world * n, D)   # one copy: rank-major inside a head
+    pshape = tuple(pos[0].shape[:-1])
+    rows = 1
+    for d in pshape:
+        rows *= d
+    psend = torch.stack([p.reshape(rows, n) for p in pos])                      # [layers, rows, n]
+    precv = _all_gather_flat(psend, group)                                      # [W, layers, rows, n]
+    pall = precv.permute(1, 2, 0, 3).reshape(n_layers, rows, world * n)
+    return ([kv[0, l][None] for l in range(n_layers)], [kv[1, l][None] for l in range(n_layers)],
+            [pall[l].reshape(pshape + (world * n,)) for l in range(n_layers)])
 
 
 def plan_frame_exchange(idx: torch.Tensor, T_own: int, world: int):
@@ -211,14 +251,11 @@ class ShardedPivotKV:
                     pc[0] += delta[layer]
                 else:
                     pc += delta[layer]
-                if assemble:
-                    keys.append(all_gather_cat(k, 2, self.group))
-                    values.append(all_gather_cat(v, 2, self.group))
-                    pos.append(all_gather_cat(pc, -1, self.group))
-                else:
-                    keys.append(k)
-                    values.append(v)
-                    pos.append(pc)
+                keys.append(k)
+                values.append(v)
+                pos.append(pc)
+            if assemble:
+                keys, values, pos = all_gather_caches(keys, values, pos, self.group)
         return keys, values, pos
 
 
@@ -314,13 +351,21 @@ def bench_main(args, rank: int, world: int, local_rank: int):
             "retained_kv_tokens_per_s": float(tot.item()) / dt,
             "config": {"workload": f"Qwen2-VL-7B geometry, one {T}-frame synthetic video sharded by frame chunk over "
                                    f"{world} GPUs: DPSelect (distance rows all-gathered) + PivotKV 4x on "
-                                   f"{n_chunks} chunks x {args.layers} layers, L={L}; offsets + per-layer cache "
+                                   f"{n_chunks} chunks x {args.layers} layers, L={L}; offsets + whole-cache "
                                    f"all-gather over RCCL (BASELINE configs[3])",
                        "frames": T, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L,
                        "parallelism": f"chunk-sharded x{world}", "assembled_cache_tokens": int(keys[0].shape[2])},
             "kernels_timed_region_rank0": kern,
             "roofline": B.score_roofline(kern, args.dtype, L, T, (c1 - c0) * args.layers * args.steps),
         }
-        print(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to stdout through C stdio, which a pipe only sees at exit - after anything
+        # Python printed.  Flush it out first so that the JSON line is the last line of rank 0's stdout.
+        try:
+            C.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
