@@ -161,6 +161,26 @@ def score_roofline(kern, dtype, L, T, n_updates):
             "units_per_launch": units_per_launch, "algorithmic_flops_per_launch": flops}
 
 
+def hbm_achievable(dev):
+    """What a plain device-to-device copy reaches on this GPU, beside the nominal 8 TB/s every HBM roofline fraction
+    above is quoted against (state both): a 2 GiB buffer, far beyond L2 + MALL, timed with HIP events
+    outside the timed region; read + write bytes counted."""
+    n = 1 << 30   # bf16 elements: 2 GiB
+    src = torch.empty(n, dtype=torch.bfloat16, device=dev).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    gbs = 2 * n * 2 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    return {"copy_GBps": gbs, "frac_of_nominal": gbs / HBM_PEAK_GBS, "note": "torch copy_ of 2 GiB (read + write bytes)"}
+
+
 def cpu_baseline(args, frames_cpu_sample, n_updates):
     """Times the CPU oracle on a bounded sample and extrapolates to the full workload."""
     from oracle import oracle as orc
@@ -356,6 +376,7 @@ def main():
                                               "moved_bytes_per_unit": ap_bytes + evu_bytes + cmu_bytes,
                                               "moved_GBps": (ap_bytes + evu_bytes + cmu_bytes) / t_unit / 1e9}
         out["roofline_hbm_kernels"] = extra
+        out["hbm_achievable"] = hbm_achievable(frames.device)
     if args.also_streams > 0 and args.streams == 0:
         # same workload with scoring / selection / eviction on worker HIP streams (PivotKVCache
         # overlap_streams): kernels of independent updates overlap, so per-kernel event durations no longer
