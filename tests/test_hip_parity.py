@@ -965,6 +965,51 @@ def test_dpselect_full_size_properties(T, N, C, dtype):
     assert torch.equal(mask2, torch.gather(peaks.t(), 0, idx2))
 
 
+def test_pivotkv_full_size_invariants_plain_rope_2d_ids():
+    """BASELINE configs[4] geometry (LLaVA-Video: Qwen2 LLM, plain RoPE, ids [1, L]): 4 chunks of L = 6272 (bf16),
+    one layer.  Same invariants as the M-RoPE case: true top-k, V rows are copies, the reforged ids are dense and
+    monotone and continue the previous chunk's."""
+    import bench as B
+    import retake.longvideo_cache as lc
+
+    L = B.FRAMES_PER_CHUNK * B.N_PATCH
+    keep = int(B.RATIO * L)
+    g = torch.Generator(device=dev()).manual_seed(12)
+    cache = lc.build_kvcache(B.make_cache_config(1))
+    rot = B.Rotary(dev())
+    last_t = -1
+    for c in range(4):
+        q, k, v = ((1.7 * torch.randn((1, h, L, B.D), generator=g, device=dev())).bfloat16() for h in (B.Hq, B.Hkv, B.Hkv))
+        pos = (torch.arange(L, device=dev()) + 40 + c * L)[None].contiguous()     # [1, L] token positions
+        expect = pos.clone()
+        prev = cache.get_prev_temporal_idx(0)
+        expect[0, :] += (prev + 1) - expect[0, 0]                    # llava_onevision.py continuity rule
+        cache.shift_temporal_ids_(pos, 0)
+        assert torch.equal(pos, expect)
+        cache.keypatches_mask_chunk = None
+        cache.update(k, v, 0, {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": None})
+        cache.after_forward()
+        torch.cuda.synchronize()
+        idx = cache.last_keep_indices.clone()
+        score = cache.last_scores.clone()
+        assert abs(float(score.mean()) - 1.0) < 1e-4
+        assert bool((idx[1:] > idx[:-1]).all()) and idx.numel() == keep
+        rest = torch.ones(L, dtype=torch.bool, device=dev())
+        rest[idx] = False
+        assert float(score[rest].max()) <= float(score[idx].min())
+        vc_ = cache.value_cache[0]
+        assert vc_.shape[2] == (c + 1) * keep and torch.equal(vc_[0, :, c * keep:], v[0][:, idx])
+        pc = cache.position_cache[0]
+        assert pc.ndim == 2 and pc.shape == (1, (c + 1) * keep)
+        t_new = pc[0, c * keep:]
+        tmin = int(pos[0, idx].min())
+        ref_ids = tmin + ((pos[0, idx] - tmin).float() * float(keep / L)).long()   # reference :293-295
+        assert torch.equal(t_new, ref_ids)
+        assert int(t_new[0]) >= last_t + 1 and bool((t_new[1:] >= t_new[:-1]).all())
+        last_t = int(t_new[-1])
+    assert cache.num_evicted_tokens == [4 * (L - keep)]
+
+
 def test_pivotkv_full_size_invariants():
     """One layer, 8 chunks of L = 6272 (bf16): cache length, sorted kept indices, V rows are copies of the
     chunk's rows at those indices, temporal ids are dense and monotone after reforging, scores mean 1."""
