@@ -871,6 +871,51 @@ def test_sharded_blocks_reproduce_sequential_cache():
         assert (k_all - seq.key_cache[l]).abs().max().item() <= 1e-5
 
 
+def test_sharded_overlapped_assembly_equals_assembly_at_the_end():
+    """ShardedPivotKV.gather_chunk (one asynchronous all-gather per chunk, segments rotated to their temporal
+    position afterwards) must return the very cache finalize() assembles at the end - world size 1 through RCCL."""
+    import bench as B
+    from retake import sharded
+
+    _single_rank_group()
+    layers, n_chunks, gh, gw, gpc = 2, 3, 8, 8, 4
+    L = gpc * gh * gw
+    inv_f = synth.inv_freq(B.D)
+    rot = synth.RotaryStub(inv_f, B.A_SCALE, device=dev())
+    cfg = B.make_cache_config(layers)
+    cfg.longvideo_kwargs["kvcache_compression_kwargs"]["native_rope"] = False
+    data = {}
+    for c in range(n_chunks):
+        for l in range(layers):
+            q0, k0, v = synth.qkv_chunk(9000 + 10 * c + l, B.Hq, B.Hkv, L, B.D)
+            data[c, l] = tuple(torch.from_numpy(a).to(dev()).bfloat16() for a in (q0, k0, v))
+
+    def run(overlap):
+        sh = sharded.ShardedPivotKV(cfg, first_start=57)
+        cache = sh.cache
+        for c in range(n_chunks):
+            cache.keypatches_mask_chunk = None
+            cache.kvcache_compression = True
+            pos = torch.from_numpy(synth.mrope_position_ids(0, gpc, gh, gw, hw0=3)).to(dev())
+            for l in range(layers):
+                q0, k0, v = data[c, l]
+                cache.shift_temporal_ids_(pos, l)
+                q = synth.rope_forward(q0.float(), pos, rot, B.MROPE).bfloat16()
+                k = synth.rope_forward(k0.float(), pos, rot, B.MROPE).bfloat16()
+                cache.update(k, v, l, {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": B.MROPE})
+            cache.after_forward()
+            if overlap:
+                sh.gather_chunk()
+        return sh.finalize(torch.from_numpy(inv_f), B.MROPE, assemble=True)
+
+    ka, va, pa = run(False)
+    kb, vb, pb = run(True)
+    for l in range(layers):
+        assert ka[l].shape == kb[l].shape and torch.equal(ka[l], kb[l])
+        assert torch.equal(va[l], vb[l]) and torch.equal(pa[l], pb[l])
+        assert int(pa[l][0, 0, 0]) >= 57
+
+
 def _single_rank_group():
     import torch.distributed as dist
 

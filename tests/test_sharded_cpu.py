@@ -197,3 +197,42 @@ def _assemble(rank, world):
 def test_cache_assembly_two_collectives_equal_per_layer_gathers():
     assert all(_spawn("_assemble"))
     assert all(_spawn("_assemble", world=3))
+
+
+def _chunk_gather(rank, world):
+    """Per-chunk asynchronous gathers + finish == one gather of the concatenated blocks at the end."""
+    from retake import sharded
+
+    layers, Hkv, D, chunks = 2, 3, 4, 3
+    sizes = [5, 5, 2]                                   # rows kept per chunk (same on every rank)
+    g = torch.Generator().manual_seed(7 + rank)
+    cg = sharded.ChunkGather()
+    k_all = [[] for _ in range(layers)]
+    v_all = [[] for _ in range(layers)]
+    for c in range(chunks):
+        ks = [torch.randn((Hkv, sizes[c] + 3, D), generator=g)[:, 3:] for _ in range(layers)]     # strided views
+        vs = [torch.randn((Hkv, sizes[c], D), generator=g) for _ in range(layers)]
+        cg.start(ks, vs)
+        for l in range(layers):
+            k_all[l].append(ks[l])
+            v_all[l].append(vs[l])
+    assert cg.rows() == sum(sizes)
+    kv = cg.finish()
+    keys = [torch.cat(k_all[l], 1)[None] for l in range(layers)]
+    vals = [torch.cat(v_all[l], 1)[None] for l in range(layers)]
+    pos = [torch.zeros((1, sum(sizes)), dtype=torch.int64) for _ in range(layers)]
+    ka, va, _ = sharded.all_gather_caches(keys, vals, pos)
+    ok = tuple(kv.shape) == (2, layers, Hkv, world * sum(sizes), D)
+    for l in range(layers):
+        ok &= bool(torch.equal(kv[0, l][None], ka[l])) and bool(torch.equal(kv[1, l][None], va[l]))
+    # the offsets table every rank computes
+    last = torch.tensor([4 + rank, 9 - rank], dtype=torch.int64)
+    table = sharded.exchange_temporal_offsets(last, first_start=3, all_ranks=True)
+    mine = sharded.exchange_temporal_offsets(last, first_start=3)
+    ok &= bool(torch.equal(table[rank], mine)) and tuple(table.shape) == (world, 2) and table[0].tolist() == [3, 3]
+    return ok
+
+
+def test_chunk_gather_equals_gather_at_the_end():
+    assert all(_spawn("_chunk_gather"))
+    assert all(_spawn("_chunk_gather", world=3))

@@ -20,8 +20,9 @@ The video's frame chunks are split into contiguous blocks, one per rank:
              kept K / V / ids so every rank holds the full compressed cache.
 
 No collective sits inside the scoring path; the exchanges are one small all-gather per video
-(distances), one tiny all-gather per video (offsets) and two all-gathers per video for the cache assembly
-(K and V of every layer in one, the ids in the other).
+(distances), one tiny all-gather per video (offsets) and, for the cache assembly, either two all-gathers per
+video (K and V of every layer in one, the ids in the other) or - `gather_chunk` - one asynchronous all-gather per
+chunk that overlaps the next chunk's scoring, plus the ids at the end.
 """
 from __future__ import annotations
 
@@ -51,17 +52,20 @@ def shard_chunks(n_chunks: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def exchange_temporal_offsets(local_last: torch.Tensor, first_start: int = 0, group=None) -> torch.Tensor:
+def exchange_temporal_offsets(local_last: torch.Tensor, first_start: int = 0, group=None,
+                              all_ranks: bool = False) -> torch.Tensor:
     """local_last [layers] int64 = last PROVISIONAL temporal id of this rank's block per layer (block ids
     start at 0; -1 if the block kept nothing).  Returns delta [layers] int64 for this rank: the true start
-    of the block, i.e. first_start + sum over previous ranks of (last + 1)."""
+    of the block, i.e. first_start + sum over previous ranks of (last + 1); with all_ranks the whole
+    [world, layers] table (every rank computes the same one)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     gathered = [torch.empty_like(local_last) for _ in range(world)]
     dist.all_gather(gathered, local_last.contiguous(), group=group)
     spans = torch.stack(gathered) + 1                      # [world, layers]
     prefix = torch.cumsum(spans, dim=0) - spans            # exclusive
-    return prefix[rank] + first_start
+    table = (prefix + first_start).contiguous()
+    return table if all_ranks else table[rank]
 
 
 def all_gather_cat(t: torch.Tensor, dim: int, group=None) -> torch.Tensor:
@@ -111,6 +115,14 @@ def all_gather_caches(keys: List[torch.Tensor], values: List[torch.Tensor], pos:
     torch.stack([v[0] for v in values], out=send[1])
     recv = _all_gather_flat(send, group)                                        # [W, 2, layers, Hkv, n, D]
     kv = recv.permute(1, 2, 3, 0, 4, 5).reshape(2, n_layers, Hkv, world * n, D)   # one copy: rank-major inside a head
+    return ([kv[0, l][None] for l in range(n_layers)], [kv[1, l][None] for l in range(n_layers)],
+            all_gather_ids(pos, group))
+
+
+def all_gather_ids(pos: List[torch.Tensor], group=None) -> List[torch.Tensor]:
+    """Per-layer position ids [..., n] of every rank -> [..., world*n] in rank order, one collective."""
+    world = dist.get_world_size(group)
+    n_layers, n = len(pos), pos[0].shape[-1]
     pshape = tuple(pos[0].shape[:-1])
     rows = 1
     for d in pshape:
@@ -118,8 +130,57 @@ def all_gather_caches(keys: List[torch.Tensor], values: List[torch.Tensor], pos:
     psend = torch.stack([p.reshape(rows, n) for p in pos])                      # [layers, rows, n]
     precv = _all_gather_flat(psend, group)                                      # [W, layers, rows, n]
     pall = precv.permute(1, 2, 0, 3).reshape(n_layers, rows, world * n)
-    return ([kv[0, l][None] for l in range(n_layers)], [kv[1, l][None] for l in range(n_layers)],
-            [pall[l].reshape(pshape + (world * n,)) for l in range(n_layers)])
+    return [pall[l].reshape(pshape + (world * n,)) for l in range(n_layers)]
+
+
+class ChunkGather:
+    """Cache assembly overlapped with the compression of the following chunks: after each chunk's flush the rows it
+    kept in every layer go out in ONE asynchronous all-gather (RCCL runs it on its own stream beside the score
+    kernels of the next chunk); `finish` waits for the lot and lays the blocks out rank-major.  The rows travel at
+    their PROVISIONAL temporal position - the caller applies R(delta_r) to rank r's segment afterwards."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.items = []   # (work, recv [W, 2, layers, Hkv, n, D], send)
+
+    def start(self, k_new: List[torch.Tensor], v_new: List[torch.Tensor]):
+        """k_new / v_new: per layer [Hkv, n, D] (any strides), the rows one chunk added."""
+        n_layers = len(k_new)
+        Hkv, n, D = k_new[0].shape
+        send = torch.empty((2, n_layers, Hkv, n, D), dtype=k_new[0].dtype, device=k_new[0].device)
+        torch.stack(list(k_new), out=send[0])
+        torch.stack(list(v_new), out=send[1])
+        world = dist.get_world_size(self.group)
+        recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+        if send.is_cuda:
+            work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+        else:
+            work = dist.all_gather(list(recv.unbind(0)), send, group=self.group, async_op=True)
+        self.items.append((work, recv, send))
+
+    def rows(self) -> int:
+        return sum(it[2].shape[3] for it in self.items)
+
+    def drop(self):
+        for work, _, _ in self.items:
+            work.wait()
+        self.items = []
+
+    def finish(self) -> torch.Tensor:
+        """-> [2, layers, Hkv, world * rows, D]: rank-major, then chunk order, inside every head."""
+        for work, _, _ in self.items:
+            work.wait()
+        world, _, n_layers, Hkv, _, D = self.items[0][1].shape
+        total = self.rows()
+        out = torch.empty((2, n_layers, Hkv, world, total, D), dtype=self.items[0][1].dtype,
+                          device=self.items[0][1].device)
+        at = 0
+        for _, recv, _ in self.items:
+            n = recv.shape[4]
+            out[:, :, :, :, at:at + n] = recv.permute(1, 2, 3, 0, 4, 5)
+            at += n
+        self.items = []
+        return out.view(2, n_layers, Hkv, world * total, D)
 
 
 def plan_frame_exchange(idx: torch.Tensor, T_own: int, world: int):
@@ -218,9 +279,28 @@ class ShardedPivotKV:
         self.cache = PivotKVCache(config)
         self.group = group
         self.first_start = first_start
+        self._gather = None
+        self._seen: List[int] = []
 
     def update(self, key_states, value_states, layer_idx, cache_kwargs):
         return self.cache.update(key_states, value_states, layer_idx, cache_kwargs)
+
+    def gather_chunk(self):
+        """Optional, after `after_forward()` of a chunk: start the all-gather of the rows that chunk kept (all
+        layers, one collective) so that it overlaps the next chunk's scoring; `finalize(assemble=True)` then only
+        waits, rotates every rank's segment to its true temporal position and exchanges the ids."""
+        cache = self.cache
+        cache.after_forward()
+        kc, vc = cache.key_cache, cache.value_cache
+        if self._gather is None:
+            self._gather = ChunkGather(self.group)
+            self._seen = [0] * len(kc)
+        ks, vs = [], []
+        for layer in range(len(kc)):
+            ks.append(kc[layer][0, :, self._seen[layer]:])
+            vs.append(vc[layer][0, :, self._seen[layer]:])
+            self._seen[layer] = kc[layer].shape[2]
+        self._gather.start(ks, vs)
 
     def finalize(self, inv_freq: torch.Tensor, mrope_section: Optional[List[int]], assemble: bool = True):
         """Exchange offsets, rotate/shift this rank's block to its true temporal position, and optionally
@@ -232,7 +312,8 @@ class ShardedPivotKV:
         n_layers = len(cache.position_cache)
         dev = cache.position_cache[0].device
         last = torch.stack([pc.reshape(-1, pc.shape[-1])[0, -1] for pc in cache.position_cache])   # [layers]
-        delta = exchange_temporal_offsets(last, self.first_start, self.group)                      # [layers]
+        table = exchange_temporal_offsets(last, self.first_start, self.group, all_ranks=True)      # [world, layers]
+        delta = table[dist.get_rank(self.group)]                                                   # [layers]
         sec = (C.c_int * len(mrope_section))(*mrope_section) if mrope_section else None
         nsec = len(mrope_section) if mrope_section else 0
         keys, values, pos = [], [], []
@@ -254,7 +335,27 @@ class ShardedPivotKV:
                 keys.append(k)
                 values.append(v)
                 pos.append(pc)
-            if assemble:
+            g = self._gather
+            self._gather = None
+            if g is not None and (not assemble or g.rows() != keys[0].shape[2]):
+                g.drop()   # not every chunk went through gather_chunk: fall back to the gather at the end
+                g = None
+            if assemble and g is not None:
+                kv = g.finish()                                   # [2, layers, Hkv, world*n, D], provisional positions
+                world = table.shape[0]
+                seg = kv.shape[3] // world
+                for layer in range(n_layers):
+                    P = 3 if cache.position_cache[layer].ndim == 3 else 1
+                    for r in range(world):                        # rank r's segment -> its true temporal position
+                        part = kv[0, layer][:, r * seg:(r + 1) * seg]
+                        nv.check(nv.lib.rtk_rope_shift(C.c_void_p(part.data_ptr()), kv.shape[3] * kv.shape[4],
+                                                       kv.shape[2], seg, kv.shape[4], nv.dtype_code(kv),
+                                                       C.c_void_p(table.data_ptr() + (r * n_layers + layer) * 8),
+                                                       nv.ptr(inv), P, sec, nsec, st), "rtk_rope_shift")
+                keys = [kv[0, layer][None] for layer in range(n_layers)]
+                values = [kv[1, layer][None] for layer in range(n_layers)]
+                pos = all_gather_ids(pos, self.group)
+            elif assemble:
                 keys, values, pos = all_gather_caches(keys, values, pos, self.group)
         return keys, values, pos
 
@@ -317,6 +418,7 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                 cache.update(k, v, layer, {"query_states": q, "position_ids": pos, "rotary_emb": rotary,
                                            "mrope_section": B.MROPE})
             cache.after_forward()
+            sh.gather_chunk()   # this chunk's kept rows leave now, beside the next chunk's scoring
         keys, values, pos = sh.finalize(rotary.inv_freq, B.MROPE, assemble=True)
         return (c1 - c0) * args.layers * max(1, int(B.RATIO * L)), keys
 
