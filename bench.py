@@ -61,6 +61,7 @@ def parse():
                          "(reported under 'overlap'; 0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-self-check", action="store_true")
     ap.add_argument("--cpu-sample-updates", type=int, default=2)
     return ap.parse_args()
 
@@ -125,7 +126,31 @@ def run_video(frames, pool, masks, pos_base, rotary, layers, tdtype):
             cache.update(k, v, layer, kw)
         cache.after_forward()
         retained += layers * max(1, int(RATIO * L))
-    return retained, cache
+    return retained, cache, mask
+
+
+def self_check(cache, pool, mask, n_chunks, layers, rotary):
+    """Untimed, after the timed region: the last chunk's first / middle / last layer as left by the chunk-batched
+    launches (gridDim.y = layers) against one-unit launches of rtk_pivotkv_score + rtk_pivotkv_select on the same
+    inputs — score, kept indices and new ids bitwise — and the kept V rows against a torch gather.  Raises on mismatch,
+    so a run whose batched kernels mis-stride never prints a number."""
+    import unit_check as uc
+
+    L = FRAMES_PER_CHUNK * N_PATCH
+    keep = max(1, int(RATIO * L))
+    c = n_chunks - 1
+    lay = sorted({0, layers // 2, layers - 1})
+    inputs = {l: pool[(c * layers + l) % len(pool)][:2] for l in lay}
+    masks = {l: mask[c * L:(c + 1) * L] for l in lay}
+    res = uc.check_batch_against_units(cache, lay, inputs, masks, keep, rotary.inv_freq, A_SCALE, MROPE)
+    for l, _, idx in res:
+        v = pool[(c * layers + l) % len(pool)][2]
+        if not torch.equal(cache.value_cache[l][0, :, -keep:], v[0][:, idx]):
+            raise AssertionError(f"self-check: layer {l} kept V rows are not copies of the selected rows")
+        if cache.key_cache[l].shape[2] != n_chunks * keep:
+            raise AssertionError(f"self-check: layer {l} cache length {cache.key_cache[l].shape[2]} != {n_chunks * keep}")
+    return {"status": "ok", "chunk": c, "layers": lay,
+            "checked": "batched score / keep_idx / new ids == one-unit launches (bitwise); kept V rows == gather"}
 
 
 def pmc_traffic(kernel_substr):
@@ -271,7 +296,7 @@ def main():
     t0 = time.perf_counter()
     retained = 0
     for _ in range(args.steps):
-        r, cache = run_video(frames, pool, masks, pos_base, rotary, args.layers, tdtype)
+        r, cache, kp_mask = run_video(frames, pool, masks, pos_base, rotary, args.layers, tdtype)
         retained += r
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -279,6 +304,9 @@ def main():
     if use_events:
         nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
         prof = nv.profile_read()
+    check = self_check(cache, pool, kp_mask, n_chunks, args.layers, rotary) if not args.no_self_check else None
+    del cache
+    if use_events:
         # untimed: every kernel, 2 chunks' worth of frames / updates on one stream
         saved = OVERLAP_STREAMS
         OVERLAP_STREAMS = 0
@@ -310,6 +338,8 @@ def main():
                    "frames": T, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L, "keep": int(RATIO * L),
                    "input_pool_sets": len(pool), "worker_streams": args.streams, "parallelism": "1 GPU"},
     }
+    if check is not None:
+        out["self_check"] = check
     if prof:
         kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in prof_all.items()}
         out["kernels_untimed_single_stream"] = dict(kern)

@@ -452,12 +452,15 @@ def test_pivotkv_bf16_tracks_fp32_oracle():
 @pytest.mark.parametrize("streams", [0, 2])
 @pytest.mark.parametrize("reforge", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_pivotkv_batched_flush_equals_per_layer_flush(reforge, dtype, streams):
+@pytest.mark.parametrize("L", [320, 640])
+def test_pivotkv_batched_flush_equals_per_layer_flush(reforge, dtype, streams, L):
     """Deferred eviction: 3 layers x 3 chunks flushed once per chunk from after_forward (one batched launch
-    for all layers) must leave exactly the cache that flushing after every single update leaves."""
+    for all layers) must leave exactly the cache that flushing after every single update leaves.  L = 640 is over the
+    L >= 512 gate: the selection (and for bf16 the two matrix passes) of the three layers run as batched launches,
+    against one-unit launches of the same kernels in the eager cache."""
     import retake.longvideo_cache as lc
 
-    Hq, Hkv, D, L, layers, n_chunks = 28, 4, 128, 320, 3, 3
+    Hq, Hkv, D, layers, n_chunks = 28, 4, 128, 3, 3
     sec = [16, 24, 24]
     inv_f = synth.inv_freq(D)
     rot = synth.RotaryStub(inv_f, synth.YARN_FACTOR4_ATTENTION_SCALING, device=dev())
@@ -471,7 +474,7 @@ def test_pivotkv_batched_flush_equals_per_layer_flush(reforge, dtype, streams):
 
     def run(cache, eager):
         for c in range(n_chunks):
-            pos = torch.from_numpy(synth.mrope_position_ids(10 + 5 * c, 5, 8, 8, hw0=2)).to(dev())
+            pos = torch.from_numpy(synth.mrope_position_ids(10 + 5 * c, L // 64, 8, 8, hw0=2)).to(dev())
             cache.keypatches_mask_chunk = torch.from_numpy(np.random.default_rng(c).uniform(size=L) < 0.3).to(dev())
             cache.kvcache_compression = True
             for l in range(layers):
@@ -499,6 +502,114 @@ def test_pivotkv_batched_flush_equals_per_layer_flush(reforge, dtype, streams):
             assert torch.equal(a.position_cache[l], b.position_cache[l])
     assert a.num_evicted_tokens == b.num_evicted_tokens == [n_chunks * (L - keep)] * layers
     assert len(a.position_cache) == (layers if reforge else 0)
+
+
+def _bf16_tables_cpu(rot_cpu, pos3, sec, like):
+    """cos/sin [1,1,L,D] in the dtype of `like`, section-merged (reference :249 + :68-74), torch CPU."""
+    cos, sin = rot_cpu(like, pos3)
+    s2 = list(sec) * 2
+    cos = torch.cat([m[i % 3] for i, m in enumerate(cos.split(s2, dim=-1))], dim=-1).unsqueeze(1)
+    sin = torch.cat([m[i % 3] for i, m in enumerate(sin.split(s2, dim=-1))], dim=-1).unsqueeze(1)
+    return cos, sin
+
+
+def _rot_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+@pytest.mark.parametrize("L,layers,n_chunks", [(6272, 28, 2), (2304, 28, 2), (1024, 5, 3)])
+def test_pivotkv_benchmarked_batched_path_vs_units_and_oracle(L, layers, n_chunks):
+    """The configuration bench.py times: bf16, D 128, L >= 512, all layers of a chunk scored / selected / evicted by ONE
+    launch per kernel (gridDim.y = layers: rtk_pivotkv_score_passes_batched, rtk_pivotkv_select_batched,
+    rtk_pivotkv_evict_batched_rope), reforge + M-RoPE + native RoPE + key-patch mask, distinct q/k/v per layer,
+    `update` x layers + `after_forward` per chunk.
+      every layer, every chunk: score, kept indices and new ids BITWISE equal to one-unit launches
+                                (rtk_rope_table + rtk_pivotkv_score + rtk_pivotkv_select) on the same inputs;
+      first / middle / last layer of the last chunk: against the CPU oracle on the same bf16-valued inputs
+                                (un-rotation restated with torch bf16 ops like reference :248-259): scores <= 2e-5,
+                                kept indices margin-aware, V rows exact copies, ids by the reference's rescale rule,
+                                kept K within one bf16 ulp of the torch bf16 re-rotation (:297-306).
+    Reference: longvideo_cache.py:248-318."""
+    import retake.longvideo_cache as lc
+    import unit_check as uc
+
+    Hq, Hkv, D, ratio = 28, 4, 128, 0.25
+    sec = [16, 24, 24]
+    S = synth.YARN_FACTOR4_ATTENTION_SCALING
+    inv_f = synth.inv_freq(D)
+    rot = synth.RotaryStub(inv_f, S, device=dev())
+    rot_cpu = synth.RotaryStub(inv_f, S)
+    cfg = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=layers, num_attention_heads=Hq,
+                                num_key_value_heads=Hkv,
+                                longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
+                                    "compression_ratio": ratio, "compression_method": "pivotkv",
+                                    "pos_embed_reforge": True, "native_rope": True}})
+    cache = lc.build_kvcache(cfg)
+    keep = max(1, int(ratio * L))
+    gh, gw = (14, 14) if L == 6272 else ((9, 16) if L == 2304 else (8, 8))
+    ng = L // (gh * gw)
+    gen = torch.Generator(device=dev()).manual_seed(7000 + L)
+    check_layers = sorted({0, layers // 2, layers - 1})
+    for c in range(n_chunks):
+        pos = torch.from_numpy(synth.mrope_position_ids(40 + ng * c, ng, gh, gw, hw0=5)).to(dev())
+        mask = torch.rand(L, generator=gen, device=dev()) < 0.3
+        cache.keypatches_mask_chunk = mask
+        cache.kvcache_compression = True
+        inputs, vs, prev_len = {}, {}, cache.get_seq_length(0)
+        for l in range(layers):
+            cache.shift_temporal_ids_(pos, l)
+            q0 = 1.7 * torch.randn((1, Hq, L, D), generator=gen, device=dev())
+            k0 = 1.7 * torch.randn((1, Hkv, L, D), generator=gen, device=dev())
+            v = (1.7 * torch.randn((1, Hkv, L, D), generator=gen, device=dev())).bfloat16()
+            q = synth.rope_forward(q0, pos, rot, sec).bfloat16()
+            k = synth.rope_forward(k0, pos, rot, sec).bfloat16()
+            ko, vo = cache.update(k, v, l, {"query_states": q, "position_ids": pos, "rotary_emb": rot,
+                                            "mrope_section": list(sec)})
+            assert ko.shape[2] == prev_len + L and torch.equal(ko[:, :, -L:], k) and torch.equal(vo[:, :, -L:], v)
+            inputs[l], vs[l] = (q, k), v
+        assert cache._batch.batched_passes and len(cache._batch.pending) == layers
+        cache.after_forward()
+        uc.check_batch_against_units(cache, range(layers), inputs, {l: mask for l in range(layers)}, keep,
+                                     rot.inv_freq, S, sec)
+        if c + 1 < n_chunks:
+            continue
+        b = cache._batch
+        for l in check_layers:
+            q, k = (t.cpu() for t in inputs[l])
+            pos_l = b.pos_old[l].cpu().reshape(3, 1, L)
+            if c > 0:   # the continuity shift (qwen2_vl.py:68-73): first id = previous chunk's last kept id + 1
+                assert int(pos_l[0, 0, 0]) == int(cache.position_cache[l][0, 0, prev_len - 1]) + 1
+            cos, sin = _bf16_tables_cpu(rot_cpu, pos_l, sec, q)
+            a2 = S ** 2
+            qt = ((q * cos) - (_rot_half(q) * sin)) / a2          # reference :76-78, every op rounds to bf16
+            kt = ((k * cos) - (_rot_half(k) * sin)) / a2
+            so = orc.pivotkv_score(qt.float().numpy()[0], kt.float().numpy()[0])
+            so[mask.cpu().numpy()] = 1.0
+            score = b.score[l].cpu().numpy()
+            idx = b.keep_idx[l].cpu().numpy()
+            assert np.abs(score - so).max() < 2e-5
+            srt = np.sort(so)[::-1]
+            want = np.sort(np.lexsort((np.arange(L), -so.astype(np.float64)))[:keep])
+            diff = np.setxor1d(idx, want)
+            if diff.size:   # a disagreement is only acceptable within the score tolerance of the k-th boundary
+                assert np.abs(so[diff] - srt[keep - 1]).max() < 4e-5, (l, diff.size)
+            assert diff.size <= 8
+            # V rows: exact copies; ids: gather + temporal rescale (:283-295); K: bf16 re-rotation at the new ids
+            ti = torch.from_numpy(idx)
+            assert torch.equal(cache.value_cache[l][0, :, prev_len:].cpu(), vs[l][0].cpu()[:, ti])
+            g = pos_l[:, 0][:, ti].numpy().astype(np.int64)
+            tmin = g[0].min()
+            g[0] = tmin + ((g[0] - tmin).astype(np.float32) * np.float32(keep / L)).astype(np.int64)
+            np.testing.assert_array_equal(cache.position_cache[l][:, 0, prev_len:].cpu().numpy(), g)
+            cn, sn = _bf16_tables_cpu(rot_cpu, torch.from_numpy(g).reshape(3, 1, keep), sec, q)
+            kk = kt[:, :, ti]
+            kr = (kk * cn) + (_rot_half(kk) * sn)
+            got = cache.key_cache[l][:, :, prev_len:].cpu()
+            ne = got != kr
+            assert ne.float().mean().item() < 5e-3        # device sincosf vs torch's cos/sin: rare bf16 table flips
+            assert ((got.float() - kr.float()).abs() <= kr.float().abs() * 2.0 ** -7 + 1e-3).all()
+    assert cache.num_evicted_tokens == [n_chunks * (L - keep)] * layers
 
 
 @pytest.mark.parametrize("L,keep,P,reforge,ties", [(6272, 1568, 3, 1, False), (2304, 576, 1, 1, False),
