@@ -12,8 +12,12 @@
  * Conventions
  *   - every pointer is a DEVICE pointer on the current HIP device unless marked host;
  *   - the library never allocates or frees device memory: outputs and workspaces are caller-owned;
- *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
- *     re-entrant, and keeps no global mutable state besides the thread-local error string;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ *     re-entrant.  Process-wide state, all of it thread-safe: the thread-local error string; the opt-in
+ *     measurement hooks at the end of this header (off by default, mutex-guarded); a memo of which devices
+ *     have had the > 64 KiB dynamic-LDS opt-in applied to the score kernels (one atomic bit per device);
+ *     a mutex-guarded memo of exhaustive bf16 reciprocal checks keyed by attention_scaling^2.  No results
+ *     depend on any of it, and the library reads no environment variables;
  *   - return value 0 = success, negative = rtk_status; no C++ exception crosses the ABI;
  *   - dtype: RTK_F32 or RTK_BF16 for the frame / q / k / v payloads; scores, distances and RoPE
  *     tables are always fp32; indices are int64 and masks are 1 byte per element (torch.bool layout);

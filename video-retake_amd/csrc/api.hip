@@ -21,6 +21,7 @@ int hip_fail(hipError_t e, const char* what) {
 }  // namespace rtk
 
 // ---- per-kernel event timing ------------------------------------------------------------------------
+#include <atomic>
 #include <mutex>
 #include <vector>
 namespace rtk {
@@ -30,14 +31,14 @@ static const char* const kKernelNames[KID_COUNT] = {"dpselect_dis", "dpselect_se
                                                     "evict_batched", "commit_batched", "position_shift", "pivotkv_emit"};
 struct ProfRec { int kid; hipEvent_t a, b; };
 static std::mutex g_pm;
-static unsigned g_prof = 0;  // bit k set = time kernel id k
+static std::atomic<unsigned> g_prof{0};  // bit k set = time kernel id k
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 static double g_total_ms[KID_COUNT];
 static long long g_count[KID_COUNT];
 static thread_local hipEvent_t g_open = nullptr;
 
-bool profile_on(int kid) { return (g_prof >> kid) & 1u; }
+bool profile_on(int kid) { return (g_prof.load(std::memory_order_relaxed) >> kid) & 1u; }
 static hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;

@@ -81,12 +81,6 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, uint32_t* wtot /*[16]
     return before + inc - v;
 }
 
-#ifdef RTK_TIMING
-__device__ unsigned long long g_sel_timing[8];
-#define RTK_ST(k) if (tid == 0) { unsigned long long t__; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); g_sel_timing[k] = t__; }
-#else
-#define RTK_ST(k)
-#endif
 template <int E>
 __device__ __forceinline__ void select_fast_body(float* __restrict__ score, const uint8_t* __restrict__ mask, int L,
                                                  int keep, const int64_t* __restrict__ pos, int P, int reforge,
@@ -98,7 +92,6 @@ __device__ __forceinline__ void select_fast_body(float* __restrict__ score, cons
     const int tid = threadIdx.x;
     const int per = (L + PSEL_BLOCK - 1) / PSEL_BLOCK;  // <= E
     const int base = tid * per;
-    RTK_ST(0)
     uint32_t key[E];
     long long t0[E];   // temporal ids of this thread's tokens: tmin and the rescale need no re-read
     long long p1[E], p2[E];   // rows 1 and 2 of the ids (M-RoPE h / w), loaded up front so the emit loop only stores
@@ -130,7 +123,6 @@ __device__ __forceinline__ void select_fast_body(float* __restrict__ score, cons
         }
     }
     auto valid = [&](int e) { return e < per && base + e < L; };
-    RTK_ST(1)
     // exact k-th largest key: 4 radix passes of 8 bits over the register-resident keys
     uint32_t prefix = 0, pmask = 0;
     int kk = keep;
@@ -188,7 +180,6 @@ __device__ __forceinline__ void select_fast_body(float* __restrict__ score, cons
     }
     const uint32_t thr = prefix;
     const int need_eq = kk;
-    RTK_ST(2)
     int cnt_eq = 0, cnt_gt = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -226,7 +217,6 @@ __device__ __forceinline__ void select_fast_body(float* __restrict__ score, cons
         for (int w = 1; w < PSEL_BLOCK / WAVE; ++w) mn = min(mn, red[w]);
     }
     const float ratio = (float)((double)keep / (double)L);  // comp_ratio = keep_len / k_len (:294)
-    RTK_ST(3)
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         if (!valid(e)) continue;
@@ -245,7 +235,6 @@ __device__ __forceinline__ void select_fast_body(float* __restrict__ score, cons
             rank[i] = -1;
         }
     }
-    RTK_ST(4)
 }
 template <int E>
 __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* __restrict__ score,
@@ -794,13 +783,6 @@ __global__ __launch_bounds__(256) void commit_batched_kernel(CopyUnits units, in
 }  // namespace rtk
 
 using namespace rtk;
-
-#ifdef RTK_TIMING
-extern "C" int rtk_debug_read_select_timing(unsigned long long* out8) {
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(rtk::g_sel_timing), 64);
-    return 0;
-}
-#endif
 
 extern "C" int rtk_pivotkv_commit(const void* k_stage, const void* v_stage, int64_t stage_stride_h, void* k_dst,
                                   void* v_dst, int64_t dst_stride_h, int H, int rows, int D, int dtype,

@@ -16,6 +16,7 @@
 // reduction over the streamed operand is lane-local over the 16 accumulator registers plus one
 // cross-half shuffle.  The streamed operand goes HBM/L2 -> registers -> XOR-swizzled LDS tile
 // (conflict-free ds_read_b128) with the next tile's global loads in flight during the MFMAs.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -32,13 +33,6 @@
 #define SGB_TRANS 0x400
 
 namespace rtk {
-
-#ifdef RTK_TIMING  // instrumentation builds only (tools/variants.sh): per-phase wave cycles of score_pass1
-__device__ unsigned long long g_timing[8];
-#define RTK_T(var) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
-#else
-#define RTK_T(var)
-#endif
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -491,20 +485,10 @@ template <int DT> struct Pipe {
     }
     // explicit two-step form: fetch all A fragments of a block, then run the MFMAs on them
     __device__ __forceinline__ void read_frags(u32x4* a, const char* lds_tile, int blk) const {
-#ifdef RTK_ABLATE_LDSREAD  // ablation builds only: fragments stay whatever they were
-#pragma unroll
-        for (int r = 0; r < M::NREG; ++r) asm volatile("" : "+v"(a[r]));
-        return;
-#endif
 #pragma unroll
         for (int r = 0; r < M::NREG; ++r) a[r] = *(const u32x4*)(lds_tile + blk * 32 * T::ROWB + frag_off[r]);
     }
     __device__ __forceinline__ void mma_frags(f32x16& acc, const u32x4* a, const u32x4* rf) const {
-#ifdef RTK_ABLATE_MFMA  // ablation builds only: keep the operand traffic, skip the matrix pipe
-#pragma unroll
-        for (int r = 0; r < M::NREG; ++r) acc[r] += __uint_as_float(a[r].x) * __uint_as_float(rf[r].y);
-        return;
-#endif
 #pragma unroll
         for (int r = 0; r < M::NREG; ++r) M::mma(acc, a[r], rf[r]);
     }
@@ -584,15 +568,9 @@ struct RowStat {  // online max / sum of one query row, over the keys this lane 
 //        needs ~250 VGPRs (1-2 waves per SIMD): no gain over NB = 1 with 2-3 waves.
 //   PF = how many streamed tiles ahead the global loads run (register staging sets, counted vmcnt waits).
 //        PF = 2 did not help either: the kernels are bound by instruction issue, not by load latency.
-#ifndef RTK_NB_BF16
-#define RTK_NB_BF16 1
-#endif
-#ifndef RTK_PF_BF16
-#define RTK_PF_BF16 1
-#endif
 template <int DT> struct RegBlocks {
-    static constexpr int NB = (DT == RTK_BF16) ? RTK_NB_BF16 : 1;
-    static constexpr int PF = (DT == RTK_BF16) ? RTK_PF_BF16 : 1;
+    static constexpr int NB = 1;
+    static constexpr int PF = 1;
 };
 
 template <int DT, int NB>
@@ -658,17 +636,6 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass1_kernel(const char* __res
     // measured equal here).  Tile jt is computed from LDS buffer jt & 1 while the loads of tile jt + PF are
     // in flight; tile jt + 1 (loaded one step earlier when PF == 2) is written to the other buffer.
     // ISSUE / STORE are compile-time in the steady-state loop: no load sits inside a conditional there.
-#ifdef RTK_TIMING
-    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0, tnow = 0;
-    RTK_T(tprev);
-#define RTK_TM(k) { RTK_T(tnow); tacc[k] += tnow - tprev; tprev = tnow; }
-#define RTK_TA(x, y) asm volatile("" : "+v"(x), "+v"(y));
-#define RTK_TS(x) asm volatile("" : "+v"(x));
-#else
-#define RTK_TM(k)
-#define RTK_TA(x, y)
-#define RTK_TS(x)
-#endif
 #define RTK_STEP1(JT, PAR, ISSUE, STORE, MAYRAG) \
     { \
         constexpr int par = PAR; \
@@ -678,7 +645,6 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass1_kernel(const char* __res
             if constexpr (PF == 2 && par == 1) RTK_LOAD_TILE((JT) + PF, stB); \
             else RTK_LOAD_TILE((JT) + PF, stA); \
         } \
-        RTK_TM(0) \
         f32x16 acc0[NB], acc1[NB]; \
         { \
             u32x4 a[M::NREG]; \
@@ -689,7 +655,6 @@ _Pragma("unroll") \
 _Pragma("unroll") \
             for (int nb = 0; nb < NB; ++nb) { acc1[nb] = f32x16{0}; pp.mma_frags(acc1[nb], a, qf[nb]); } \
         } \
-        RTK_TA(acc0[0], acc1[0]) RTK_TM(1) \
 _Pragma("unroll") \
         for (int nb = 0; nb < NB; ++nb) { \
             /* steady state: tiles are full by construction (a run-time test here gets if-converted into 64 */ \
@@ -697,14 +662,11 @@ _Pragma("unroll") \
             if (!(MAYRAG) || (JT) < nfull) rs[nb].template update<false>(acc0[nb], acc1[nb], 0, 0, hf, c2, sqrt_d); \
             else rs[nb].template update<true>(acc0[nb], acc1[nb], (JT) * TILE_ROWS, nkeys, hf, c2, sqrt_d); \
         } \
-        RTK_TS(rs[0].sum) RTK_TM(2) \
         if constexpr (STORE) { \
             if constexpr (PF == 2 && par == 0) pp.store(nxt, stB); \
             else pp.store(nxt, stA); \
         } \
-        RTK_TM(3) \
         __syncthreads(); \
-        RTK_TM(4) \
     }
     int jt = 0;
     for (; jt + PF + 1 < ntiles; jt += 2) {  // steady state, two tiles per trip (parities are constants)
@@ -726,12 +688,6 @@ _Pragma("unroll") \
 #undef RTK_TAIL
 #undef RTK_STEP1
 #undef RTK_LOAD_TILE
-#ifdef RTK_TIMING
-    if (lane == 0 && blockIdx.x % 64 == 7)
-        for (int kk = 0; kk < 5; ++kk) atomicAdd(&g_timing[kk], tacc[kk]);
-    if (lane == 0 && blockIdx.x % 64 == 7) atomicAdd(&g_timing[7], (unsigned long long)ntiles);
-#endif
-
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const float out = rs[nb].finish(c2);
@@ -795,11 +751,6 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(float* __restrict__ ls
 // col += sum_r exp(acc[r]*scale - ls[r]) for one 32x32 block (16 values per lane)
 template <int DT>
 __device__ __forceinline__ void colsum_block(float& col, const f32x16& acc, const float* ls, float c2, float sqrt_d) {
-#ifdef RTK_ABLATE_SM  // ablation builds only (tools/variants.sh): keep the MFMAs alive, skip the softmax VALU
-    asm volatile("" ::"v"(acc));
-    col += ls[0];
-    return;
-#endif
     // scalar fma / exp2 / add per logit: v_pk_fma_f32 / v_pk_add_f32 were measured 5-7 % SLOWER here
     // (packed f32 ops cost extra issue slots beside MFMAs)
 #pragma unroll
@@ -1350,10 +1301,7 @@ __global__ __launch_bounds__(256) void score_finalize_kernel(const float* __rest
 // Work decomposition.  Both passes are cut into >= ~3000 workgroups (about 4 rounds over 256 CUs x 3
 // resident workgroups) so the last round's tail stays small; the splits depend on the shape only,
 // so results are deterministic.
-#ifndef RTK_TARGET_WGS
-#define RTK_TARGET_WGS 3072
-#endif
-constexpr int TARGET_WGS = RTK_TARGET_WGS;
+constexpr int TARGET_WGS = 3072;
 static int pick_splits(int tiles_fixed, int heads, int stream_tiles, int cap, int Hkv) {
     int s = (TARGET_WGS + tiles_fixed * heads - 1) / (tiles_fixed * heads);
     s = std::max(1, std::min(std::min(s, cap), stream_tiles));
@@ -1426,14 +1374,6 @@ static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
 
 using namespace rtk;
 
-#ifdef RTK_TIMING
-extern "C" int rtk_debug_read_timing(unsigned long long* out8, int reset) {
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(rtk::g_timing), 64);
-    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(rtk::g_timing), z, 64); }
-    return 0;
-}
-#endif
-
 extern "C" size_t rtk_pivotkv_score_workspace_bytes(int Hq, int Hkv, int L, int D, int dtype) {
     if (Hq < 1 || Hkv < 1 || L < 1 || D < 1) return 0;
     return score_ws(Hq, Hkv, L, D, dtype).total;
@@ -1486,11 +1426,21 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         constexpr int TILE_BYTES = Tile<DT>::BYTES;
         constexpr int NBR = RegBlocks<DT>::NB;
         constexpr int LDS1 = 2 * TILE_BYTES, LDS2 = 2 * TILE_BYTES + 2 * TILE_ROWS * (int)sizeof(float);
-        static bool attr_set = false;  // > 64 KiB of dynamic LDS (fp32 tiles) needs the opt-in once
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)score_pass1_kernel<DT, NBR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
-            (void)hipFuncSetAttribute((const void*)score_pass2_kernel<DT, NBR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-            attr_set = true;
+        // > 64 KiB of dynamic LDS (fp32 tiles) needs an opt-in per kernel AND per device: remembered in one atomic
+        // bit per (dtype, device) - racing first calls both opt in, which is harmless
+        static std::atomic<uint64_t> opted[2];
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        const uint64_t dev_bit = 1ull << (dev_id & 63);
+        if (!(opted[DT == RTK_BF16].load(std::memory_order_relaxed) & dev_bit)) {
+            if constexpr (DT == RTK_BF16) {
+                (void)hipFuncSetAttribute((const void*)score_pass1_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+                (void)hipFuncSetAttribute((const void*)score_pass2_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+            } else {
+                (void)hipFuncSetAttribute((const void*)score_pass1_kernel<DT, NBR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+                (void)hipFuncSetAttribute((const void*)score_pass2_kernel<DT, NBR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+            }
+            opted[DT == RTK_BF16].fetch_or(dev_bit, std::memory_order_relaxed);
         }
         const int jt = (L + REG_ROWS * NBR - 1) / (REG_ROWS * NBR);
         auto per_split = [](int n, int parts) { return (((n + parts - 1) / parts + TILE_ROWS - 1) / TILE_ROWS) * TILE_ROWS; };
@@ -1498,17 +1448,10 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         const int ks_n4 = (L + kps - 1) / kps;  // non-empty splits only
         rs_n = (L + rps - 1) / rps;
         const int ks_n = ks_n4;
-        // bf16 production kernels: LDS-DMA forms.  RTK_SCORE_LEGACY=1 selects the register-staged kernels (A/B only).
-        static const bool legacy = [] { const char* e = getenv("RTK_SCORE_LEGACY"); return e && atoi(e) != 0; }();
-        const bool dma = (DT == RTK_BF16) && !legacy;
-        static bool dma_attr = false;
-        if (dma && !dma_attr) {
-            (void)hipFuncSetAttribute((const void*)score_pass1_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
-            (void)hipFuncSetAttribute((const void*)score_pass2_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-            dma_attr = true;
-        }
+        // bf16: the LDS-DMA kernels; fp32 (parity dtype): the register-staged kernels
+        constexpr bool dma = (DT == RTK_BF16);
         if (stages & RTK_SCORE_PASSES) {
-            if (dma)
+            if constexpr (dma)
                 RTK_LAUNCH(KID_PASS1, score_pass1_dma_kernel, dim3(Hkv * ks_n * jt * G, n_units), dim3(SC_BLOCK), LDS1, st,
                            (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse,
                            ws_stride, k_stride, ws_stride / sizeof(float));
@@ -1521,7 +1464,7 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                 RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<DT>, dim3((unsigned)((n + 255) / 256), n_units), dim3(256), 0, st, lse, n,
                            ks_n, ws_stride / sizeof(float));
             }
-            if (dma)
+            if constexpr (dma)
                 RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<1>), dim3(Hkv * rs_n * jt, n_units), dim3(SC_BLOCK), LDS2, st,
                            (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
                            (int)((Hkv * rs_n) % NXCD == 0), part, ws_stride, k_stride, ws_stride / sizeof(float),
@@ -1559,11 +1502,6 @@ extern "C" int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspa
     RTK_CHECK_ARG(n_units == 1 || workspace_stride >= w.total, "rtk_pivotkv_score_passes_batched: workspace stride too small");
     if (dtype != RTK_BF16 || D != HD) {
         set_error("rtk_pivotkv_score_passes_batched: bf16 with head_dim %d only (call RTK_SCORE_PASSES per unit)", HD);
-        return RTK_EUNSUPPORTED;
-    }
-    static const bool legacy = [] { const char* e = getenv("RTK_SCORE_LEGACY"); return e && atoi(e) != 0; }();
-    if (legacy) {
-        set_error("rtk_pivotkv_score_passes_batched: RTK_SCORE_LEGACY selects the per-unit kernels");
         return RTK_EUNSUPPORTED;
     }
     float dummy_score = 0.f;  // not touched by RTK_SCORE_PASSES
