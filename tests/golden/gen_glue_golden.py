@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Golden vectors for the glue around the hot path, produced by driving the imported
+REFERENCE (/root/reference, read-only, build container only) with the stub modules of tests/glue_stubs.py:
+
+  glue_qwen2vl_forward_*.npz   retake_Qwen2VLForConditionalGeneration_forward (qwen2_vl.py:522-764): what the language
+                               model is handed per text segment / video chunk, cache flags and key-patch mask slices
+  glue_llava_forward_*.npz     retake_LlavaOnevisionForConditionalGeneration_forward (llava_onevision.py:306-583) incl.
+                               the t*side^2 -> t*pooled+1 key-patch mask truncation (:486) and the front trim (:261)
+  glue_llava.npz               compress_video_tokens / forge_input_chunks / segment_input_ids / get_chunk_size of LLaVA
+  glue_attention_qwen2vl.npz   retake_Qwen2VLAttention_forward (qwen2_vl.py:42-122) over text -> 2 video chunks -> text ->
+  glue_attention_llava.npz     decode with the reference PivotKVCache: outputs, shifted ids, final cache
+                               (retake_Qwen2Attention_forward, llava_onevision.py:59-141, likewise)
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_glue_golden.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import gen_golden as G  # noqa: E402
+import glue_stubs as gs  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def dpselect_margin(bank, tgt, sync):
+    """Smallest decision margin (fp64) of DPSelect on bank [1,T,N,C]: the fixture must not sit on a fragile decision."""
+    d32, d64 = G.dis_matrices(bank)
+    rows = d64.mean(1, keepdims=True).T if sync else d64.T
+    pm = G.peak_margins(rows)
+    pk = (rows > np.concatenate([np.full((rows.shape[0], 1), -np.inf), rows[:, :-1]], 1)) & \
+         (rows >= np.concatenate([rows[:, 1:], np.full((rows.shape[0], 1), -np.inf)], 1))
+    return min(pm, G.topk_margin(rows + 2.0 * pk, tgt))
+
+
+# --------------------------------------------------------------------------------------
+# model forwards
+# --------------------------------------------------------------------------------------
+def gen_qwen_forward(qv, outdir):
+    cases = {
+        "base": dict(cfg=dict(ratio=0.5), inp=dict(grid_t=24)),
+        "fcs_sync": dict(cfg=dict(ratio=1.0, sync=True, frame_chunk_size=5, chunk_frames=6), inp=dict(grid_t=16, seed=79)),
+        "dynamic": dict(cfg=dict(ratio=0.5, dynamic=40), inp=dict(grid_t=24, seed=80)),
+    }
+    for name, c in cases.items():
+        cfg = gs.qwen_config(**c["cfg"])
+        me = gs.make_qwen_model(qv, cfg)
+        kw = gs.qwen_inputs(**c["inp"])
+        T = int(kw["video_grid_thw"][0, 0])
+        emb = gs.StubVisual(24, 32)(kw["pixel_values_videos"], grid_thw=kw["video_grid_thw"]).reshape(1, T, -1, 32)
+        ratio = c["cfg"]["ratio"]
+        m = dpselect_margin(emb, max(1, round(ratio * T)), c["cfg"].get("sync", False))
+        assert m > G.FRAGILE, (name, m)
+        out = qv.retake_Qwen2VLForConditionalGeneration_forward(me, return_dict=False, **{k: v.clone() for k, v in kw.items()})
+        rec = gs.calls_to_record(me.model.calls, "call")
+        rec["logits"] = out[0].numpy()
+        rec["visual_calls"] = np.array(me.visual.calls, dtype=np.int64)
+        rec["kv_ratio_after"] = float(cfg.longvideo_kwargs["kvcache_compression_kwargs"]["compression_ratio"])
+        rec["cache_ratio"] = float(out[1].compression_ratio)
+        rec["cache_class"] = type(out[1]).__name__
+        rec["margin"] = m
+        np.savez_compressed(os.path.join(outdir, f"glue_qwen2vl_forward_{name}.npz"), **rec)
+        print(f"glue_qwen2vl_forward_{name}: {len(me.model.calls)} model calls, visual calls {me.visual.calls}, "
+              f"kv ratio {rec['kv_ratio_after']:.4f}, margin {m:.2e}")
+
+
+def gen_llava(lo, outdir):
+    cases = {
+        "base": dict(cfg=dict(ratio=0.5), inp=dict(T=12)),
+        "fcs_sync": dict(cfg=dict(ratio=1.0, sync=True, frame_chunk_size=5, chunk_frames=3), inp=dict(T=10, seed=81)),
+        "dynamic_odd": dict(cfg=dict(ratio=0.5, dynamic=30, side=5), inp=dict(T=8, side=5, seed=82)),
+    }
+    for name, c in cases.items():
+        cfg = gs.llava_config(**c["cfg"])
+        kw, bank = gs.llava_inputs(**c["inp"])
+        me = gs.make_llava_model(lo, cfg, bank)
+        T = bank.shape[0]
+        m = dpselect_margin(bank[None], max(1, round(c["cfg"]["ratio"] * T)), c["cfg"].get("sync", False))
+        assert m > G.FRAGILE, (name, m)
+        out = lo.retake_LlavaOnevisionForConditionalGeneration_forward(me, return_dict=False,
+                                                                      **{k: v.clone() for k, v in kw.items()})
+        rec = gs.calls_to_record(me.language_model.calls, "call")
+        rec["logits"] = out[0].numpy()
+        rec["tower_calls"] = np.array(me.vision_tower.calls, dtype=np.int64)
+        rec["kv_ratio_after"] = float(cfg.longvideo_kwargs["kvcache_compression_kwargs"]["compression_ratio"])
+        rec["cache_ratio"] = float(out[1].compression_ratio)
+        rec["margin"] = m
+        np.savez_compressed(os.path.join(outdir, f"glue_llava_forward_{name}.npz"), **rec)
+        n_mask = sum(int(cc["mask"].sum()) for cc in me.language_model.calls if cc["mask"] is not None)
+        print(f"glue_llava_forward_{name}: {len(me.language_model.calls)} LM calls, tower calls {me.vision_tower.calls}, "
+              f"mask bits seen {n_mask}, margin {m:.2e}")
+
+    # function level (llava_onevision.py:144-303)
+    cfg = gs.llava_config(ratio=0.5)
+    kw, bank = gs.llava_inputs(T=12)
+    me = gs.make_llava_model(lo, cfg, bank)
+    rec = {}
+    seg = me.segment_input_ids(kw["input_ids"])
+    rec["seg_s"], rec["seg_e"] = np.array([int(s) for s, _, _ in seg]), np.array([int(e) for _, e, _ in seg])
+    rec["seg_t"] = np.array([t for _, _, t in seg])
+    rec["chunk_size"] = me.get_chunk_size(cfg, kw["pixel_values_videos"])
+    out = me.compress_video_tokens(input_ids=kw["input_ids"].clone(), attention_mask=kw["attention_mask"].clone(),
+                                   selected_video_feature=bank.clone(), position_ids=kw["position_ids"].clone(),
+                                   cache_position=kw["cache_position"].clone(), labels=None)
+    for n, o in zip(["ids", "am", "feat", "pos", "cp"], out[:5]):
+        rec["cvt_" + n] = o.numpy()
+    rec["cvt_tgt"] = int(out[5])
+    rec["cvt_mask"] = out[6].numpy()
+    S = kw["input_ids"].shape[1]
+    ie = torch.arange(S * 2, dtype=torch.float32).reshape(1, S, 2)
+    o = me.forge_input_chunks(5, 17, seg, kw["position_ids"], kw["cache_position"], kw["attention_mask"], None, ie)
+    for n, t in zip(["pos", "cp", "am", "ie"], o[:4]):
+        rec["fic_" + n] = t.numpy()
+    rec["fic_prompt_length_is_none"] = o[4] is None
+    cfg.longvideo_kwargs["kvcache_compression_kwargs"]["prompt_guided_compression"] = True
+    o = me.forge_input_chunks(5, 17, seg, kw["position_ids"] + 100, kw["cache_position"], kw["attention_mask"], None, ie)
+    for n, t in zip(["pos", "cp", "am", "ie"], o[:4]):
+        rec["ficp_" + n] = t.numpy()
+    rec["ficp_prompt_length"] = int(o[4])
+    np.savez_compressed(os.path.join(outdir, "glue_llava.npz"), **rec)
+    print("glue_llava: segments", seg, "chunk", rec["chunk_size"], "ids", S, "->", out[0].shape[1], "tgt", out[5])
+
+
+# --------------------------------------------------------------------------------------
+# attention prologue + cache over a realistic call sequence
+# --------------------------------------------------------------------------------------
+def attention_scenario(lc, forward, llava, seed):
+    """text(5) -> video chunk (32) -> video chunk (32) -> text(3) -> decode(1), two layers sharing one reference
+    PivotKVCache (reforge on, ratio 0.5).  Returns the record or None when a top-k decision is fragile."""
+    hidden, heads, kvh, D = 64, 4, 2, 16
+    S = 1.1386
+    layers = [gs.StubAttention(l, hidden, heads, kvh, None if llava else (2, 3, 3), S, seed=seed) for l in range(2)]
+    cfg = G.make_config(heads, kvh, D, 2, 0.5, True, llava=llava)
+    cache = lc.PivotKVCache(cfg)
+    g = torch.Generator().manual_seed(seed)
+    rec = {"llava": llava, "seed": seed, "attention_scaling": S}
+    for l, a in enumerate(layers):
+        for i, w in enumerate(a.weights()):
+            rec[f"w{l}_{i}"] = w
+    # uncompressed numbering of the prompt: 5 text, 2 x 32 video tokens (2 grids of 4x4 each), 3 text, 1 decode
+    steps = [("text", 5), ("video", 32), ("video", 32), ("text", 3), ("decode", 1)]
+    captured = []
+    orig_topk = torch.Tensor.topk
+
+    def spy(self, *a, **k):
+        captured.append(self.detach().clone())
+        return orig_topk(self, *a, **k)
+
+    total = 0
+    t_next = 0
+    for si, (kind, n) in enumerate(steps):
+        x = torch.randn(1, n, hidden, generator=g)
+        if kind == "video":
+            if llava:
+                pos = (torch.arange(n) + total)[None]
+            else:
+                pos = torch.from_numpy(gs.synth.mrope_position_ids(t_next, 2, 4, 4, hw0=t_next))
+            t_next += 2 if not llava else 0
+            cache.kvcache_compression = True
+            cache.keypatches_mask_chunk = torch.rand(n, generator=g) < 0.3
+        else:
+            base = total if llava else t_next
+            pos = (torch.arange(n) + base)[None] if llava else (torch.arange(n) + base)[None, None].repeat(3, 1, 1)
+            t_next += n if not llava else 0
+            cache.kvcache_compression = False
+            cache.keypatches_mask_chunk = None
+        total += n
+        mask4 = gs.causal_mask(n, total)
+        cp = torch.arange(total - n, total)
+        rec[f"s{si}_x"], rec[f"s{si}_pos_in"], rec[f"s{si}_mask4"] = x.numpy(), pos.numpy().copy(), mask4.numpy()
+        rec[f"s{si}_kpmask"] = cache.keypatches_mask_chunk.numpy() if cache.keypatches_mask_chunk is not None else np.zeros(0, bool)
+        rec[f"s{si}_kind"] = kind
+        pos_shared = pos.clone()       # HF hands the same ids tensor to every layer of the forward
+        for l, att in enumerate(layers):
+            torch.Tensor.topk = spy
+            try:
+                with torch.no_grad():
+                    if llava:
+                        o = forward(att, x, None, mask4, cache, cp, position_ids=pos_shared)
+                    else:
+                        o = forward(att, x, mask4, pos_shared, cache, False, True, cp)
+            finally:
+                torch.Tensor.topk = orig_topk
+            rec[f"s{si}_l{l}_out"] = o[0].numpy()
+            rec[f"s{si}_l{l}_pos_after"] = pos_shared.numpy().copy()
+            if kind == "video":
+                sc = captured.pop().numpy().astype(np.float64)
+                srt = -np.sort(-sc)
+                keep = max(1, int(0.5 * n))
+                if srt[keep - 1] - srt[keep] < 1e-4:
+                    return None
+        if hasattr(cache, "after_forward"):
+            cache.after_forward()
+    for l in range(2):
+        rec[f"cache_k{l}"] = cache.key_cache[l].numpy()
+        rec[f"cache_v{l}"] = cache.value_cache[l].numpy()
+        rec[f"cache_pos{l}"] = cache.position_cache[l].numpy()
+    rec["num_evicted"] = np.array(cache.num_evicted_tokens, dtype=np.int64)
+    rec["n_steps"] = len(steps)
+    return rec
+
+
+def gen_attention(lc, qv, lo, outdir):
+    for name, fwd, llava in (("qwen2vl", qv.retake_Qwen2VLAttention_forward, False),
+                             ("llava", lo.retake_Qwen2Attention_forward, True)):
+        for attempt in range(50):
+            rec = attention_scenario(lc, fwd, llava, 300 + attempt)
+            if rec is not None:
+                break
+            print(f"  [attention_{name}] seed {300 + attempt}: fragile -> reseed")
+        else:
+            raise RuntimeError(name)
+        np.savez_compressed(os.path.join(outdir, f"glue_attention_{name}.npz"), **rec)
+        print(f"glue_attention_{name}: seed {rec['seed']}, cache lengths {[rec[f'cache_k{l}'].shape[2] for l in range(2)]}, "
+              f"evicted {rec['num_evicted'].tolist()}")
+
+
+def main():
+    vc, lc = G.import_reference()
+    qv = G.import_reference_glue()
+    import importlib
+
+    lo = importlib.import_module("retake.llava_onevision")
+    assert lo.__file__.startswith(G.REF)
+    lo.eager_attention_forward = gs.eager_attention_forward_448   # the 4.48 function the reference was written against
+    gen_qwen_forward(qv, HERE)
+    gen_llava(lo, HERE)
+    gen_attention(lc, qv, lo, HERE)
+
+
+if __name__ == "__main__":
+    main()

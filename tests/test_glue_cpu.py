@@ -184,6 +184,119 @@ def test_patch_rebinds_hf_classes():
                 setattr(m.Qwen2VLForConditionalGeneration, k, v)
 
 
+# ---------------------------------------------------------------------------------------------------
+# model forwards driven with stub modules against goldens recorded from the reference (tests/golden/gen_glue_golden.py).
+# On CPU the DPSelect call inside compress_video_tokens is served by the CPU oracle (the product has no CPU path);
+# tests/test_hip_parity.py runs the same scenarios with the HIP kernels on the GPU.
+# ---------------------------------------------------------------------------------------------------
+def _oracle_keyframe(memory_bank, tgt_mem_len, window_size=3, sync=True):
+    from oracle import oracle as orc
+
+    out, mask, _, _ = orc.dpselect(memory_bank.numpy(), tgt_mem_len, window_size, sync)
+    return torch.from_numpy(out), torch.from_numpy(mask)
+
+
+QWEN_FWD = {"base": (dict(ratio=0.5), dict(grid_t=24)),
+            "fcs_sync": (dict(ratio=1.0, sync=True, frame_chunk_size=5, chunk_frames=6), dict(grid_t=16, seed=79)),
+            "dynamic": (dict(ratio=0.5, dynamic=40), dict(grid_t=24, seed=80))}
+LLAVA_FWD = {"base": (dict(ratio=0.5), dict(T=12)),
+             "fcs_sync": (dict(ratio=1.0, sync=True, frame_chunk_size=5, chunk_frames=3), dict(T=10, seed=81)),
+             "dynamic_odd": (dict(ratio=0.5, dynamic=30, side=5), dict(T=8, side=5, seed=82))}
+
+
+def run_qwen_forward(name, device="cpu"):
+    import glue_stubs as gs
+    import retake.qwen2_vl as q
+
+    ck, ik = QWEN_FWD[name]
+    cfg = gs.qwen_config(**ck)
+    me = gs.make_qwen_model(q, cfg)
+    kw = gs.qwen_inputs(device=device, **ik)
+    out = q.retake_Qwen2VLForConditionalGeneration_forward(me, return_dict=False, **kw)
+    g = gu.load("glue_qwen2vl_forward_" + name)
+    gs.assert_calls_equal(me.model.calls, g, "call", emb_tol=0.0 if device == "cpu" else 1e-6)
+    np.testing.assert_allclose(out[0].cpu().numpy(), g["logits"], rtol=0, atol=0.0 if device == "cpu" else 1e-6)
+    np.testing.assert_array_equal(np.array(me.visual.calls, dtype=np.int64).reshape(g["visual_calls"].shape), g["visual_calls"])
+    # dynamic ratio is written back into the shared config dict and captured by the cache at construction (P0b)
+    assert cfg.longvideo_kwargs["kvcache_compression_kwargs"]["compression_ratio"] == float(g["kv_ratio_after"])
+    assert out[1].compression_ratio == float(g["cache_ratio"]) and type(out[1]).__name__ == str(g["cache_class"])
+    assert out[1].kvcache_compression is False and out[1].keypatches_mask_chunk is None   # off for decoding
+
+
+def run_llava_forward(name, device="cpu"):
+    import glue_stubs as gs
+    import retake.llava_onevision as lo
+
+    ck, ik = LLAVA_FWD[name]
+    cfg = gs.llava_config(**ck)
+    kw, bank = gs.llava_inputs(device=device, **ik)
+    me = gs.make_llava_model(lo, cfg, bank.to(device))
+    me.image_newline = me.image_newline.to(device)
+    out = lo.retake_LlavaOnevisionForConditionalGeneration_forward(me, return_dict=False, **kw)
+    g = gu.load("glue_llava_forward_" + name)
+    gs.assert_calls_equal(me.language_model.calls, g, "call", emb_tol=0.0 if device == "cpu" else 1e-6)
+    np.testing.assert_allclose(out[0].cpu().numpy(), g["logits"], rtol=0, atol=0.0 if device == "cpu" else 1e-6)
+    np.testing.assert_array_equal(np.array(me.vision_tower.calls, dtype=np.int64), g["tower_calls"])
+    assert cfg.longvideo_kwargs["kvcache_compression_kwargs"]["compression_ratio"] == float(g["kv_ratio_after"])
+    assert out[1].compression_ratio == float(g["cache_ratio"])
+
+
+@pytest.mark.parametrize("name", sorted(QWEN_FWD))
+def test_qwen2vl_forward_driver_matches_reference(name, monkeypatch):
+    """G6 (qwen2_vl.py:522-764): per text segment / video chunk the language model must be handed exactly the tensors,
+    cache flags and key-patch mask slices the reference hands it (frame-chunked vision tower, dynamic ratio included)."""
+    import retake.qwen2_vl as q
+
+    monkeypatch.setattr(q, "memory_bank_compress_keyframe", _oracle_keyframe)
+    run_qwen_forward(name)
+
+
+@pytest.mark.parametrize("name", sorted(LLAVA_FWD))
+def test_llava_forward_driver_matches_reference(name, monkeypatch):
+    """G6 for LLaVA-Video (llava_onevision.py:306-583): front trim of the attention mask (:261), the t*side^2 ->
+    t*pooled+1 key-patch mask truncation (:486), the dropped image_newline slot, 2-D ids."""
+    import retake.qwen2_vl as q
+
+    monkeypatch.setattr(q, "memory_bank_compress_keyframe", _oracle_keyframe)
+    run_llava_forward(name)
+
+
+def test_llava_glue_functions_match_reference(monkeypatch):
+    """G2-G5 LLaVA twins (llava_onevision.py:144-303) against the reference's outputs."""
+    import glue_stubs as gs
+    import retake.llava_onevision as lo
+    import retake.qwen2_vl as q
+
+    monkeypatch.setattr(q, "memory_bank_compress_keyframe", _oracle_keyframe)
+    g = gu.load("glue_llava")
+    cfg = gs.llava_config(ratio=0.5)
+    kw, bank = gs.llava_inputs(T=12)
+    me = gs.make_llava_model(lo, cfg, bank)
+    seg = me.segment_input_ids(kw["input_ids"])
+    assert [int(s) for s, _, _ in seg] == g["seg_s"].tolist() and [int(e) for _, e, _ in seg] == g["seg_e"].tolist()
+    assert [t for _, _, t in seg] == g["seg_t"].tolist()
+    assert me.get_chunk_size(cfg, kw["pixel_values_videos"]) == int(g["chunk_size"])
+    out = me.compress_video_tokens(input_ids=kw["input_ids"].clone(), attention_mask=kw["attention_mask"].clone(),
+                                   selected_video_feature=bank.clone(), position_ids=kw["position_ids"].clone(),
+                                   cache_position=kw["cache_position"].clone(), labels=None)
+    for n, o in zip(["ids", "am", "feat", "pos", "cp"], out[:5]):
+        np.testing.assert_array_equal(o.numpy(), g["cvt_" + n], err_msg=n)
+    assert int(out[5]) == int(g["cvt_tgt"])
+    np.testing.assert_array_equal(out[6].numpy(), g["cvt_mask"])
+    assert g["cvt_am"][0, 0] == 1 and kw["attention_mask"][0, 0] == 0      # the fixture does tell front from back trim
+    S = kw["input_ids"].shape[1]
+    ie = torch.arange(S * 2, dtype=torch.float32).reshape(1, S, 2)
+    o = me.forge_input_chunks(5, 17, seg, kw["position_ids"], kw["cache_position"], kw["attention_mask"], None, ie)
+    for n, t in zip(["pos", "cp", "am", "ie"], o[:4]):
+        np.testing.assert_array_equal(t.numpy(), g["fic_" + n])
+    assert o[4] is None
+    cfg.longvideo_kwargs["kvcache_compression_kwargs"]["prompt_guided_compression"] = True
+    o = me.forge_input_chunks(5, 17, seg, kw["position_ids"] + 100, kw["cache_position"], kw["attention_mask"], None, ie)
+    for n, t in zip(["pos", "cp", "am", "ie"], o[:4]):
+        np.testing.assert_array_equal(t.numpy(), g["ficp_" + n])
+    assert int(o[4]) == int(g["ficp_prompt_length"])
+
+
 class _StubAttention(torch.nn.Module):
     def __init__(self, hidden=64, heads=4, kv_heads=2):
         super().__init__()

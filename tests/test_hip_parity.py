@@ -1207,3 +1207,78 @@ def test_pivotkv_full_size_invariants():
         assert torch.equal(pc[1:, 0, c * keep:], pos[1:, 0][:, idx])             # h / w ids untouched
         last_t = int(t_new[-1])
     assert cache.num_evicted_tokens == [8 * (L - keep)]
+
+
+# ---------------------------------------------------------------------------------------------------
+# glue on the device: the reference-recorded model-forward scenarios with the HIP DPSelect inside, and the patched
+# attention forwards over text -> video chunks -> text -> decode with the HIP PivotKV cache
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["base", "fcs_sync", "dynamic"])
+def test_qwen2vl_forward_driver_on_gpu(name):
+    import test_glue_cpu as tg
+
+    tg.run_qwen_forward(name, device=dev())
+
+
+@pytest.mark.parametrize("name", ["base", "fcs_sync", "dynamic_odd"])
+def test_llava_forward_driver_on_gpu(name):
+    import test_glue_cpu as tg
+
+    tg.run_llava_forward(name, device=dev())
+
+
+@pytest.mark.parametrize("model", ["qwen2vl", "llava"])
+def test_attention_patch_with_pivotkv_cache_matches_reference(model):
+    """G1 (qwen2_vl.py:42-122 / llava_onevision.py:59-141) + P1-P15: two patched attention layers sharing one HIP
+    PivotKVCache through text(5) -> video chunk(32) -> video chunk(32) -> text(3) -> decode(1), against the reference's
+    attention outputs, the ids after the continuity shift (in place for Qwen2-VL, cloned for LLaVA) and the final
+    compressed cache / position cache / eviction counters recorded with the reference's own PivotKVCache."""
+    import glue_stubs as gs
+    import retake.llava_onevision as lo
+    import retake.longvideo_cache as lc
+    import retake.qwen2_vl as q
+
+    g = gu.load("glue_attention_" + model)
+    llava = bool(g["llava"])
+    S = float(g["attention_scaling"])
+    layers = [gs.StubAttention(l, 64, 4, 2, None if llava else (2, 3, 3), S,
+                               weights=[g[f"w{l}_{i}"] for i in range(7)]).to_device(dev()).eval() for l in range(2)]
+    llm = types.SimpleNamespace(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2)
+    kw = {"kvcache_compression": True, "kvcache_compression_kwargs": {"compression_ratio": 0.5,
+                                                                      "compression_method": "pivotkv",
+                                                                      "pos_embed_reforge": True}}
+    if llava:
+        cfg = types.SimpleNamespace(text_config=llm, longvideo_kwargs=kw)
+    else:
+        llm.longvideo_kwargs = kw
+        cfg = llm
+    cache = lc.build_kvcache(cfg)
+    total = 0
+    worst = 0.0
+    for si in range(int(g["n_steps"])):
+        kind = str(g[f"s{si}_kind"])
+        x = torch.from_numpy(g[f"s{si}_x"]).to(dev())
+        n = x.shape[1]
+        total += n
+        mask4 = torch.from_numpy(g[f"s{si}_mask4"]).to(dev())
+        cp = torch.arange(total - n, total, device=dev())
+        cache.kvcache_compression = kind == "video"
+        cache.keypatches_mask_chunk = torch.from_numpy(g[f"s{si}_kpmask"]).to(dev()) if kind == "video" else None
+        pos_shared = torch.from_numpy(g[f"s{si}_pos_in"]).to(dev())
+        for l, att in enumerate(layers):
+            with torch.no_grad():
+                if llava:
+                    o = lo.retake_Qwen2Attention_forward(att, x, None, mask4, cache, cp, position_ids=pos_shared)
+                else:
+                    o = q.retake_Qwen2VLAttention_forward(att, x, mask4, pos_shared, cache, False, True, cp)
+            ref = g[f"s{si}_l{l}_out"]
+            err = np.abs(o[0].cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+            worst = max(worst, err)
+            assert err < 2e-5, (si, l, err)     # fp32 projections on rocBLAS vs the reference's CPU matmuls
+            np.testing.assert_array_equal(pos_shared.cpu().numpy(), g[f"s{si}_l{l}_pos_after"])
+        cache.after_forward()
+    for l in range(2):
+        assert np.abs(cache.key_cache[l].cpu().numpy() - g[f"cache_k{l}"]).max() <= 1e-5
+        assert np.abs(cache.value_cache[l].cpu().numpy() - g[f"cache_v{l}"]).max() <= 1e-5
+        np.testing.assert_array_equal(cache.position_cache[l].cpu().numpy(), g[f"cache_pos{l}"])
+    assert cache.num_evicted_tokens == g["num_evicted"].tolist()

@@ -94,6 +94,11 @@ def retake_Qwen2Attention_forward(self, hidden_states, position_embeddings, atte
     if self.config._attn_implementation != "eager":
         if not (self.config._attn_implementation == "sdpa" and kwargs.get("output_attentions", False)):
             attention_interface = ALL_ATTENTION_FUNCTIONS[self.config._attn_implementation]
+    if attention_mask is not None and attention_mask.ndim == 4 and attention_mask.shape[-1] != key_states.shape[-2]:
+        # the compressed cache is shorter than the mask HF built from the uncompressed prompt: transformers 4.48's
+        # attention functions slice the mask to the key length themselves (what the reference relies on), later
+        # versions do not - slicing here gives the 4.48 behaviour on both
+        attention_mask = attention_mask[:, :, :, : key_states.shape[-2]]
     attn_output, attn_weights = attention_interface(
         self, query_states, key_states, value_states, attention_mask,
         dropout=0.0 if not self.training else self.attention_dropout, scaling=self.scaling,
