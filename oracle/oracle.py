@@ -34,10 +34,12 @@ def lib():
         _lib = C.CDLL(_SO)
         for name in ("orc_dpselect_dis_f32", "orc_dpselect_dis_bf16", "orc_topk_sorted", "orc_dpselect_select",
                      "orc_gather_frames", "orc_mrope_merge", "orc_rope_apply", "orc_pivotkv_score",
-                     "orc_pivotkv_select", "orc_gather_rows", "orc_pivotkv_positions", "orc_num_threads", "orc_mallm_step"):
+                     "orc_pivotkv_select", "orc_gather_rows", "orc_pivotkv_positions", "orc_num_threads", "orc_mallm_step",
+                     "orc_rope_apply_bf16", "orc_pivotkv_score_bf16"):
             getattr(_lib, name).restype = C.c_int
         _lib.orc_rope_apply.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_double, C.c_void_p]
+        _lib.orc_rope_apply_bf16.argtypes = _lib.orc_rope_apply.argtypes
     return _lib
 
 
@@ -148,16 +150,40 @@ def mrope_merge(cs3: np.ndarray, sections) -> np.ndarray:
     return out
 
 
-def rope_apply(x: np.ndarray, cos: np.ndarray, sin: np.ndarray, reverse: bool, attention_scaling: float = 1.0):
-    """x [H,L,D], cos/sin [L,D] -> rotated / un-rotated copy (longvideo_cache.py:76-81)."""
+def rope_apply(x: np.ndarray, cos: np.ndarray, sin: np.ndarray, reverse: bool, attention_scaling: float = 1.0,
+               bf16: bool = False):
+    """x [H,L,D], cos/sin [L,D] -> rotated / un-rotated copy (longvideo_cache.py:76-81).  bf16: the arrays hold bf16
+    values and every torch op of the formula rounds to bf16 (the reference on a bf16 model)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     H, L, D = x.shape
     cos = np.ascontiguousarray(cos, dtype=np.float32)
     sin = np.ascontiguousarray(sin, dtype=np.float32)
     out = np.empty_like(x)
-    _chk(lib().orc_rope_apply(_p(x), H, L, D, _p(cos), _p(sin), int(reverse), float(attention_scaling), _p(out)),
-         "rope_apply")
+    fn = lib().orc_rope_apply_bf16 if bf16 else lib().orc_rope_apply
+    _chk(fn(_p(x), H, L, D, _p(cos), _p(sin), int(reverse), float(attention_scaling), _p(out)), "rope_apply")
     return out
+
+
+def bf16_round(a: np.ndarray) -> np.ndarray:
+    """fp32 -> nearest bf16 value (ties to even), returned as fp32."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(b).astype(np.uint32) << 16).view(np.float32)
+
+
+def pivotkv_score_bf16(q: np.ndarray, k: np.ndarray) -> np.ndarray:
+    """The score in the reference's bf16 semantics (longvideo_cache.py:264-270 on bf16 tensors): q [Hq,L,D], k
+    [Hkv,L,D] fp32 arrays of bf16 values -> score [L] fp32 array of bf16 values."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    k = np.ascontiguousarray(k, dtype=np.float32)
+    Hq, L, D = q.shape
+    score = np.empty(L, dtype=np.float32)
+    _chk(lib().orc_pivotkv_score_bf16(_p(q), _p(k), Hq, k.shape[0], L, D, _p(score)), "score_bf16")
+    return score
 
 
 def pivotkv_score(q: np.ndarray, k: np.ndarray) -> np.ndarray:
@@ -208,7 +234,11 @@ class OraclePivotKV:
     """
 
     def __init__(self, num_heads: int, num_kv_heads: int, head_dim: int, compression_ratio: float,
-                 pos_embed_reforge: bool = False):
+                 pos_embed_reforge: bool = False, bf16: bool = False, score_rounding: str = "reference"):
+        """bf16: inputs are fp32 arrays of bf16 values and the RoPE steps round per torch op like the reference on a
+        bf16 model; score_rounding 'reference' = the reference's bf16 score chain, 'fp32' = exact products with fp32
+        accumulation and fp32 softmax / sums (what the HIP default computes for bf16 inputs)."""
+        self.bf16, self.score_rounding = bf16, score_rounding
         self.Hq, self.Hkv, self.D = num_heads, num_kv_heads, head_dim
         self.compression_ratio = compression_ratio
         self.pos_embed_reforge = pos_embed_reforge
@@ -242,7 +272,8 @@ class OraclePivotKV:
     def _tables(self, rotary, x, pos, mrope_section):
         import torch
 
-        cos, sin = rotary(torch.from_numpy(x), torch.from_numpy(pos))
+        xt = torch.from_numpy(x)
+        cos, sin = rotary(xt.bfloat16() if self.bf16 else xt, torch.from_numpy(pos))   # tables in the model dtype
         cos, sin = cos.float().numpy(), sin.float().numpy()
         if mrope_section:
             return mrope_merge(cos[:, 0], mrope_section), mrope_merge(sin[:, 0], mrope_section)
@@ -274,10 +305,13 @@ class OraclePivotKV:
         if self.pos_embed_reforge:  # :248-259
             cos, sin = self._tables(rotary, v, position_ids, mrope_section)
             a = rotary.attention_scaling
-            qs = rope_apply(qs, cos, sin, True, a)
-            ks = rope_apply(ks, cos, sin, True, a)
+            qs = rope_apply(qs, cos, sin, True, a, bf16=self.bf16)
+            ks = rope_apply(ks, cos, sin, True, a, bf16=self.bf16)
         keep = max(1, int(self.compression_ratio * L))  # :263
-        score = pivotkv_score(qs, ks)  # :264-270
+        if self.bf16 and self.score_rounding == "reference":
+            score = pivotkv_score_bf16(qs, ks)
+        else:
+            score = pivotkv_score(qs, ks)  # :264-270
         idx = pivotkv_select(score, self.keypatches_mask_chunk, keep)  # :272-277
         kk = gather_rows(ks, idx)  # :278-280
         vv = gather_rows(v[0], idx)
@@ -287,7 +321,7 @@ class OraclePivotKV:
         newpos_t = newpos.reshape((3, 1, keep) if position_ids.ndim == 3 else (1, keep))
         if self.pos_embed_reforge:  # :297-306
             cos, sin = self._tables(rotary, vv[None], newpos_t, mrope_section)
-            kk = rope_apply(kk, cos, sin, False)
+            kk = rope_apply(kk, cos, sin, False, bf16=self.bf16)
             self._upd_pos(newpos_t, layer)  # :308-309
         self._upd_evicted(k_len - keep, layer)  # :310
         self.key_cache[layer] = np.concatenate([k_out[:, :, :-L], kk[None]], axis=2)  # :313-318

@@ -556,6 +556,102 @@ def gen_mallm(vc, outdir):
         print(name, "steps", len(steps_idx), "margin %.3g" % margin, "out", out.shape)
 
 
+# --------------------------------------------------------------------------------------
+# PivotKV in the production dtype: the reference run in bf16 (longvideo_cache.py:260-270 rounds the logits, the
+# probabilities, the per-head column sums and both means to bf16)
+# --------------------------------------------------------------------------------------
+def bf16_bits(t: torch.Tensor) -> np.ndarray:
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def gen_pivotkv_bf16(lc, outdir):
+    S = synth.YARN_FACTOR4_ATTENTION_SCALING
+    # name, gh, gw, grids per chunk, chunks, ratio, mask rate, seed, raw
+    cases = [("bf16_qwen_L256", 8, 8, 4, 2, 0.25, 0.3, 211, True),
+             ("bf16_qwen_L1568", 14, 14, 8, 1, 0.25, 0.3, 212, False),
+             ("bf16_qwen_L6272", 14, 14, 32, 1, 0.25, 0.3, 213, False)]
+    Hq, Hkv, D, mrope = 28, 4, 128, [16, 24, 24]
+    for (name, gh, gw, gpc, nch, ratio, mrate, seed, raw) in cases:
+        L = gpc * gh * gw
+        inv_f = synth.inv_freq(D, 1e6)
+        rotary = synth.RotaryStub(inv_f, S)
+        cache = lc.PivotKVCache(make_config(Hq, Hkv, D, 1, ratio, True))
+        rec = dict(Hq=Hq, Hkv=Hkv, D=D, L=L, gh=gh, gw=gw, grids_per_chunk=gpc, n_chunks=nch, ratio=ratio, reforge=True,
+                   mrope_section=np.array(mrope, dtype=np.int64), attention_scaling=S, inv_freq=inv_f, seed=seed, layer=0,
+                   raw=raw, theta=1e6, dtype="bf16")
+        rng = np.random.default_rng(seed + 7)
+        captured = {}
+        orig_topk = torch.Tensor.topk
+
+        def spy_topk(self, *args, **kw):
+            captured["score"] = self.detach().clone()
+            return orig_topk(self, *args, **kw)
+
+        for c in range(nch):
+            q0, k0, v = map(torch.from_numpy, synth.qkv_chunk(seed * 100 + c, Hq, Hkv, L, D))
+            pos = torch.from_numpy(synth.mrope_position_ids(5 + c * gpc, gpc, gh, gw, hw0=5))
+            prev = cache.get_prev_temporal_idx(0)
+            if prev + 1 != pos[0, 0, 0]:
+                pos = pos.clone()
+                pos[0, 0, :] += prev + 1 - pos[0, 0, 0]
+            q = synth.rope_forward(q0, pos, rotary, mrope).bfloat16()   # what a bf16 model hands to update
+            k = synth.rope_forward(k0, pos, rotary, mrope).bfloat16()
+            v = v.bfloat16()
+            mask = torch.from_numpy(rng.uniform(size=L) < mrate)
+            cache.keypatches_mask_chunk = mask
+            cache.kvcache_compression = True
+            kw = {"sin": None, "cos": None, "cache_position": None, "query_states": q, "position_ids": pos.clone(),
+                  "rotary_emb": rotary, "mrope_section": list(mrope)}
+            prev_len = 0 if not len(cache.key_cache) or len(cache.key_cache[0]) == 0 else cache.key_cache[0].shape[2]
+            torch.Tensor.topk = spy_topk
+            try:
+                cache.update(k, v, 0, kw)
+            finally:
+                torch.Tensor.topk = orig_topk
+            keep = max(1, int(ratio * L))
+            kept_k = cache.key_cache[0][:, :, prev_len:]
+            kept_v = cache.value_cache[0][:, :, prev_len:]
+            vb, kvb = bf16_bits(v), bf16_bits(kept_v)
+            idx = np.empty(keep, dtype=np.int64)        # kept rows are exact copies of V rows
+            look = {}
+            for i in range(L):
+                look.setdefault(vb[0, 0, i, :8].tobytes(), []).append(i)
+            for r in range(keep):
+                m = [i for i in look[kvb[0, 0, r, :8].tobytes()] if np.array_equal(vb[0, :, i], kvb[0, :, r])]
+                assert len(m) == 1
+                idx[r] = m[0]
+            assert (np.diff(idx) > 0).all()
+            score_ref = captured["score"]                  # bf16 [L], after masked_fill_
+            assert score_ref.dtype == torch.bfloat16
+            # the reference's own un-rotated operands (its helper, its dtype) and the exact score they define
+            cos, sin = rotary(v, pos)
+            qt, kt = lc.apply_multimodal_rotary_pos_emb(q, k, cos, sin, mrope, reverse=True, attention_scaling=S)
+            s64 = score_fp64(qt, kt, Hkv)
+            pre = f"c{c}_"
+            rec[pre + "pos"] = pos.numpy()
+            rec[pre + "mask"] = mask.numpy()
+            rec[pre + "score_bf16"] = bf16_bits(score_ref)
+            rec[pre + "score64"] = s64                      # before the mask override
+            rec[pre + "keep_idx"] = idx
+            rec[pre + "kept_k_bits"] = bf16_bits(kept_k)
+            rec[pre + "position_cache"] = cache.position_cache[0].numpy().copy()
+            if raw:
+                rec[pre + "q_bits"], rec[pre + "k_bits"], rec[pre + "v_bits"] = bf16_bits(q), bf16_bits(k), vb
+            else:
+                rec[pre + "q_crc"], rec[pre + "k_crc"] = synth.checksum(bf16_bits(q)), synth.checksum(bf16_bits(k))
+                rec[pre + "v_crc"] = synth.checksum(vb)
+            sr = score_ref.float().numpy()
+            s64m = s64.copy()
+            s64m[mask.numpy()] = 1.0
+            exact = np.sort(np.lexsort((np.arange(L), -s64m))[:keep])
+            thr = np.sort(sr)[::-1][keep - 1]
+            print(f"pivotkv_{name} c{c}: L={L} keep={keep} distinct bf16 scores {len(np.unique(sr))}, kept-set overlap "
+                  f"with exact scoring {np.intersect1d(idx, exact).size}/{keep}, ties at the threshold "
+                  f"{int((sr == thr).sum())}, max |score_bf16 - exact| {np.abs(sr - s64m).max():.4f}")
+        rec["keep"] = keep
+        np.savez_compressed(os.path.join(outdir, f"pivotkv_{name}.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -565,6 +661,8 @@ def main():
         gen_dpselect(vc, HERE)
     if args.only in (None, "pivotkv"):
         gen_pivotkv(lc, HERE)
+    if args.only in (None, "pivotkv_bf16"):
+        gen_pivotkv_bf16(lc, HERE)
     if args.only in (None, "glue"):
         gen_glue(HERE)
     if args.only in (None, "mallm"):
