@@ -35,7 +35,16 @@ extern "C" {
 
 typedef void* rtk_stream_t; /* hipStream_t */
 
-enum rtk_dtype { RTK_F32 = 0, RTK_BF16 = 1 };
+enum rtk_dtype {
+    RTK_F32 = 0,
+    RTK_BF16 = 1,
+    /* Scoring entry points only (rtk_pivotkv_score*, rtk_pivotkv_select_batched): bf16 payloads AND the reference's
+     * bf16 rounding chain for the score (longvideo_cache.py:264-270 on a bf16 model rounds the logits, the
+     * probabilities, the per-head column sums and both means to bf16).  RTK_BF16 keeps exact bf16 products with fp32
+     * accumulation, softmax and sums - more accurate than the reference; this code reproduces the reference's own
+     * quantised scores (head_dim 128 only).  Workspace / partial sizes differ: query them with the same code. */
+    RTK_BF16_REFROUND = 2
+};
 
 enum rtk_status {
     RTK_OK = 0,
@@ -225,7 +234,10 @@ typedef struct rtk_select_unit {
 } rtk_select_unit;
 #define RTK_SELECT_MAX_UNITS 28
 int rtk_pivotkv_select_batched(const rtk_select_unit* units, int n_units, int Hkv, int RS, int G, int L,
-                               int keep, int P, int reforge, int64_t pos_out_stride, rtk_stream_t stream);
+                               int keep, int P, int reforge, int64_t pos_out_stride,
+                               int score_dtype /* RTK_BF16_REFROUND: partials are per head [Hkv*G, RS, L] and the
+                                                  finalize applies the reference's bf16 roundings; else 0 */,
+                               rtk_stream_t stream);
 
 /* Layout of the column partials rtk_pivotkv_score_stages(RTK_SCORE_PASSES) produces for these sizes: returns the
  * number of floats (Hkv * RS * L) and writes RS (row splits actually used) to *rs_out. */

@@ -751,7 +751,7 @@ def test_select_batched_equals_single_units(n, L, keep, P):
         u.partial, u.score, u.mask, u.pos = part.data_ptr(), score.data_ptr(), (mask.data_ptr() if mask is not None else None), pos.data_ptr()
         u.keep_idx, u.rank, u.pos_out, u.workspace = keep_idx.data_ptr(), None, pos_new.data_ptr() + i * keep * 8, ws.data_ptr()
         hold.append((part, mask, pos, score, keep_idx, ws))
-    nv.check(nv.lib.rtk_pivotkv_select_batched(units, n, Hkv, RS, G, L, keep, P, 1, ld, nv.stream()), "select_batched")
+    nv.check(nv.lib.rtk_pivotkv_select_batched(units, n, Hkv, RS, G, L, keep, P, 1, ld, 0, nv.stream()), "select_batched")
     torch.cuda.synchronize()
     for i, (part, mask, pos, score, keep_idx, ws) in enumerate(hold):
         ref = ((part.sum(1) / G).sum(0) / Hkv)
@@ -1282,3 +1282,119 @@ def test_attention_patch_with_pivotkv_cache_matches_reference(model):
         assert np.abs(cache.value_cache[l].cpu().numpy() - g[f"cache_v{l}"]).max() <= 1e-5
         np.testing.assert_array_equal(cache.position_cache[l].cpu().numpy(), g[f"cache_pos{l}"])
     assert cache.num_evicted_tokens == g["num_evicted"].tolist()
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 (production dtype) against the reference run on bf16 tensors (fixtures pivotkv_bf16_*)
+# ---------------------------------------------------------------------------------------------------
+class _CpuTablesRotary:
+    """rotary_emb stand-in that computes cos/sin on the CPU like the fixture generator did and hands them to the device:
+    keeps the bf16 tables bit-identical to the reference run (torch's device cos/sin may differ in the last fp32 bit)."""
+
+    def __init__(self, inv_f, scaling, device):
+        self._cpu = synth.RotaryStub(inv_f, scaling)
+        self.inv_freq = self._cpu.inv_freq.to(device)
+        self.attention_scaling = float(scaling)
+
+    def __call__(self, x, position_ids):
+        cos, sin = self._cpu(x.cpu(), position_ids.cpu())
+        return cos.to(x.device), sin.to(x.device)
+
+
+@pytest.mark.parametrize("rounding", ["reference", "fp32"])
+@pytest.mark.parametrize("name", gu.names("pivotkv_bf16_"))
+def test_pivotkv_bf16_against_reference_bf16(name, rounding):
+    """The HIP cache on bf16 tensors against the REFERENCE's own bf16 run (longvideo_cache.py:248-318 on a bf16 model).
+      score_rounding='reference': the reference's rounding chain - scores equal its bf16 scores except isolated entries
+        by one bf16 ulp (summation order inside ATen's bf16 gemm / sums), kept set equal up to torch.topk's
+        backend-defined pick among exact ties, kept keys bit-exact, ids exact;
+      score_rounding='fp32' (default, what bench.py runs): more accurate than the reference; every token the two kept
+        sets disagree on has a reference score within ONE bf16 ulp of the reference's threshold (the quantisation the
+        reference's own scores carry), and the count is reported."""
+    import retake.longvideo_cache as lc
+    import test_oracle_golden as tog
+
+    g = gu.load(name)
+    Hq, Hkv, D, L, keep = (int(g[k]) for k in ("Hq", "Hkv", "D", "L", "keep"))
+    sec = [int(x) for x in g["mrope_section"]]
+    llm = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=1, num_attention_heads=Hq, num_key_value_heads=Hkv,
+                                longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
+                                    "compression_ratio": float(g["ratio"]), "compression_method": "pivotkv",
+                                    "pos_embed_reforge": True, "score_rounding": rounding}})
+    cache = lc.build_kvcache(llm)
+    rot = _CpuTablesRotary(g["inv_freq"], float(g["attention_scaling"]), dev())
+    q, k, v, pos, mask = gu.pivotkv_bf16_chunk_inputs(g, 0)     # later chunks depend on which tied tokens were kept
+
+    def dv(bits):
+        return torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16).to(dev())
+
+    cache.keypatches_mask_chunk = torch.from_numpy(mask).to(dev())
+    kw = {"query_states": dv(q), "position_ids": torch.from_numpy(pos).to(dev()), "rotary_emb": rot,
+          "mrope_section": list(sec)}
+    cache.update(dv(k), dv(v), 0, kw)
+    score = cache.last_scores.cpu().numpy()
+    idx = cache.last_keep_indices.cpu().numpy()
+    kk = cache.key_cache[0].cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+    pos_new = cache.position_cache[0].cpu().numpy()
+    ref = orc.bf16_bits_to_f32(g["c0_score_bf16"])
+    ref_idx = g["c0_keep_idx"]
+    if rounding == "reference":
+        nbad, nxor, a, b = tog.check_bf16_against_reference(g, 0, score, idx, kk, pos_new, "HIP reference rounding")
+        np.testing.assert_array_equal(a, b)
+        print(f"{name}: {nbad} of {L} scores differ from the reference's by one bf16 ulp, kept xor {nxor} (ties)")
+    else:
+        s64 = g["c0_score64"].copy()
+        s64[mask] = 1.0
+        assert np.abs(score - s64).max() < 2e-5                  # fp32-accurate on the reference's own bf16 operands
+        thr = np.sort(ref)[::-1][keep - 1]
+        xor = np.setxor1d(idx, ref_idx)
+        assert (np.abs(ref[xor] - thr) <= gu.bf16_ulp(np.full(xor.size, thr))).all()
+        assert xor.size <= max(4, L // 100)
+        print(f"{name}: default mode vs the reference's bf16 kept set: {xor.size // 2} of {keep} tokens differ, all within "
+              f"one bf16 ulp of its threshold score {thr}")
+    assert np.array_equal(cache.value_cache[0].cpu().view(torch.int16).numpy().view(np.uint16)[0], v[0][:, idx])
+
+
+def test_pivotkv_reference_rounding_batched_equals_per_layer():
+    """score_rounding='reference' through the chunk-batched launches (gridDim.y = layers, per-head partials, the bf16
+    finalize inside rtk_pivotkv_select_batched) must leave the cache that flushing every layer on its own leaves."""
+    import retake.longvideo_cache as lc
+
+    Hq, Hkv, D, L, layers, n_chunks = 28, 4, 128, 640, 3, 2
+    sec = [16, 24, 24]
+    rot = synth.RotaryStub(synth.inv_freq(D), synth.YARN_FACTOR4_ATTENTION_SCALING, device=dev())
+
+    def run(eager):
+        cfg = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=layers, num_attention_heads=Hq,
+                                    num_key_value_heads=Hkv,
+                                    longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
+                                        "compression_ratio": 0.25, "compression_method": "pivotkv",
+                                        "pos_embed_reforge": True, "score_rounding": "reference"}})
+        cache = lc.build_kvcache(cfg)
+        scores = []
+        for c in range(n_chunks):
+            pos = torch.from_numpy(synth.mrope_position_ids(10 + 10 * c, L // 64, 8, 8, hw0=2)).to(dev())
+            cache.keypatches_mask_chunk = torch.from_numpy(np.random.default_rng(c).uniform(size=L) < 0.3).to(dev())
+            cache.kvcache_compression = True
+            for l in range(layers):
+                q0, k0, v = synth.qkv_chunk(900 + 10 * c + l, Hq, Hkv, L, D)
+                cache.shift_temporal_ids_(pos, l)
+                q = synth.rope_forward(torch.from_numpy(q0).to(dev()), pos, rot, sec).bfloat16()
+                k = synth.rope_forward(torch.from_numpy(k0).to(dev()), pos, rot, sec).bfloat16()
+                cache.update(k, torch.from_numpy(v).to(dev()).bfloat16(), l, {"query_states": q, "position_ids": pos,
+                                                                             "rotary_emb": rot, "mrope_section": sec})
+                if eager:
+                    scores.append(cache.last_scores.clone())
+            cache.after_forward()
+            if not eager:
+                scores += [cache._batch.score[l].clone() for l in range(layers)]
+        return cache, scores
+
+    a, sa = run(False)
+    b, sb = run(True)
+    for x, y in zip(sa, sb):
+        assert torch.equal(x, y)
+        assert torch.equal(x, x.bfloat16().float()) and len(torch.unique(x)) < 300     # bf16-valued, heavily quantised
+    for l in range(layers):
+        assert torch.equal(a.key_cache[l], b.key_cache[l]) and torch.equal(a.value_cache[l], b.value_cache[l])
+        assert torch.equal(a.position_cache[l], b.position_cache[l])

@@ -42,6 +42,23 @@ __device__ __forceinline__ uint32_t f2key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// the reference's three bf16 roundings after the probabilities (longvideo_cache.py:268-270) for key j:
+//   partial [Hq][RS][L] fp32 sums of bf16 probabilities  ->  score (a bf16 value held in fp32)
+__device__ __forceinline__ float finalize_ref_column(const float* __restrict__ partial, int Hkv, int RS, int G, int L, int j) {
+    float tot = 0.f;
+    for (int g = 0; g < Hkv; ++g) {
+        float gs = 0.f;
+        for (int hh = 0; hh < G; ++hh) {
+            const float* p = partial + (size_t)(g * G + hh) * RS * L + j;
+            float hs = 0.f;
+            for (int r = 0; r < RS; ++r) hs += p[(size_t)r * L];
+            gs += rbf(hs);                         // .sum(1) -> bf16 (sums of <= 7 bf16 values are exact in fp32)
+        }
+        tot += rbf(__fdiv_rn(gs, (float)G));       // .mean(1) -> bf16
+    }
+    return rbf(__fdiv_rn(tot, (float)Hkv));        // .mean(0) -> bf16
+}
+
 // 16-byte vector types
 // native 4 x u32 vector: loads/stores are first-class 16-byte operations (a struct would be copied with
 // llvm.memcpy, which keeps register staging arrays in scratch memory)

@@ -7,6 +7,8 @@
 // gather the kept 1/ratio of the rows (through keep_idx) into the compacted staging rows —
 // algorithmic bytes per (layer, chunk): 2*Hkv*L*D*s read + 2*Hkv*keep*D*s written (+ the tail
 // append 2*Hkv*L*D*s, which the reference pays as an O(cache) torch.cat).
+#include <atomic>
+
 #include "common.cuh"
 #include "select.cuh"
 
@@ -309,6 +311,15 @@ __global__ __launch_bounds__(256) void finalize_units_kernel(SelUnits units, int
         for (int g = 0; g < Hkv; ++g) tot += fin_gs[g * 64 + jl];
         un.score[j] = tot / (float)Hkv;
     }
+}
+
+// the same for RTK_BF16_REFROUND partials ([Hkv*G][RS][L], per head): the reference's bf16 roundings of the per-head
+// sums and the two means (longvideo_cache.py:268-270), finalize_ref_column() in common.cuh
+__global__ __launch_bounds__(256) void finalize_units_ref_kernel(SelUnits units, int Hkv, int RS, int G, int L) {
+    const rtk_select_unit& un = units.u[blockIdx.y];
+    if (!un.partial) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < L) un.score[j] = finalize_ref_column(un.partial, Hkv, RS, G, L, j);
 }
 
 __global__ __launch_bounds__(RANK_BLOCK) void pivotkv_rank_kernel(SelUnits units, int L, int keep, int reforge) {
@@ -821,11 +832,16 @@ static bool chipwide_ok(int L) {
 // finalize (units that carry partials) -> rank -> emit, every unit in the same three launches
 constexpr int UNITS_ONE_WG = 8;   // batched launches with at least this many units select one workgroup per unit
 static int select_units(const rtk_select_unit* units, int n, int Hkv, int RS, int G, int L, int keep, int P, int reforge,
-                        int64_t pos_out_stride, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)pivotkv_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+                        int64_t pos_out_stride, hipStream_t st, bool refround = false) {
+    {   // > 64 KiB of dynamic LDS: opt-in per device, remembered in one atomic bit per device
+        static std::atomic<uint64_t> opted{0};
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        const uint64_t bit = 1ull << (dev_id & 63);
+        if (!(opted.load(std::memory_order_relaxed) & bit)) {
+            (void)hipFuncSetAttribute((const void*)pivotkv_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            opted.fetch_or(bit, std::memory_order_relaxed);
+        }
     }
     const size_t lds = ((size_t)((L + RANK_TOK - 1) / RANK_TOK) * RANK_TOK + RANK_BLOCK) * sizeof(uint32_t);
     for (int b = 0; b < n; b += RTK_SELECT_MAX_UNITS) {
@@ -837,8 +853,11 @@ static int select_units(const rtk_select_unit* units, int n, int Hkv, int RS, in
             any_partial = any_partial || (i < m && su.u[i].partial != nullptr);
         }
         if (any_partial) {
-            RTK_LAUNCH(KID_FINALIZE, finalize_units_kernel, dim3((L + 63) / 64, m), dim3(256), (size_t)Hkv * 64 * sizeof(float),
-                       st, su, Hkv, RS, G, L);
+            if (refround)
+                RTK_LAUNCH(KID_FINALIZE, finalize_units_ref_kernel, dim3((L + 255) / 256, m), dim3(256), 0, st, su, Hkv, RS, G, L);
+            else
+                RTK_LAUNCH(KID_FINALIZE, finalize_units_kernel, dim3((L + 63) / 64, m), dim3(256),
+                           (size_t)Hkv * 64 * sizeof(float), st, su, Hkv, RS, G, L);
             RTK_LAUNCH_CHECK("finalize_units_kernel");
         }
         const int per = (L + PSEL_BLOCK - 1) / PSEL_BLOCK;
@@ -864,7 +883,8 @@ static int select_units(const rtk_select_unit* units, int n, int Hkv, int RS, in
 }
 
 extern "C" int rtk_pivotkv_select_batched(const rtk_select_unit* units, int n_units, int Hkv, int RS, int G, int L,
-                                          int keep, int P, int reforge, int64_t pos_out_stride, rtk_stream_t stream) {
+                                          int keep, int P, int reforge, int64_t pos_out_stride, int score_dtype,
+                                          rtk_stream_t stream) {
     RTK_CHECK_ARG(units && n_units >= 1, "rtk_pivotkv_select_batched: no units");
     RTK_CHECK_ARG(L >= 1 && keep >= 1 && keep <= L, "rtk_pivotkv_select_batched: keep=%d out of range for L=%d", keep, L);
     RTK_CHECK_ARG(P == 0 || P == 1 || P == 3, "rtk_pivotkv_select_batched: P must be 0, 1 or 3, got %d", P);
@@ -883,7 +903,8 @@ extern "C" int rtk_pivotkv_select_batched(const rtk_select_unit* units, int n_un
         set_error("rtk_pivotkv_select_batched: L=%d is outside the chip-wide selection path (use rtk_pivotkv_select)", L);
         return RTK_EUNSUPPORTED;
     }
-    return select_units(units, n_units, Hkv, RS, G, L, keep, P, reforge, pos_out_stride, (hipStream_t)stream);
+    return select_units(units, n_units, Hkv, RS, G, L, keep, P, reforge, pos_out_stride, (hipStream_t)stream,
+                        score_dtype == RTK_BF16_REFROUND);
 }
 
 extern "C" int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep, const int64_t* pos, int P,

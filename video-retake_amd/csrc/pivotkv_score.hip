@@ -1194,6 +1194,10 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void score_pass1_dma_kernel(const char
     if (hf == 0 && i < L) lse_part[((size_t)ks * Hq + h) * L + i] = out;
 }
 
+}  // namespace rtk
+#include "score_refround.cuh"
+namespace rtk {
+
 // ------------------------------------------------------------------------------------------------
 // generic fallback (any head_dim; small problems): plain fp32 VALU, same two passes.
 // ------------------------------------------------------------------------------------------------
@@ -1350,23 +1354,25 @@ static bool bf16_rcp_is_exact(float a2) {
 struct ScoreWs {
     size_t q_off, k_off, lse_off, part_off, total;
     int RS, KS;
+    bool ref;   // RTK_BF16_REFROUND: row statistics are (max, sum) pairs, column partials are per head
 };
 static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
-    const size_t es = dtype == RTK_BF16 ? 2 : 4;
+    const size_t es = dtype == RTK_F32 ? 4 : 2;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     ScoreWs w;
-    const int nbr = REG_ROWS * (dtype == RTK_BF16 ? RegBlocks<RTK_BF16>::NB : RegBlocks<RTK_F32>::NB);
+    w.ref = dtype == RTK_BF16_REFROUND;
+    const int nbr = REG_ROWS;
     const int reg_tiles = (L + nbr - 1) / nbr, stream_tiles = (L + TILE_ROWS - 1) / TILE_ROWS;
     w.RS = (D == HD) ? pick_splits(reg_tiles, Hkv, stream_tiles, 32, Hkv) : 1;
     w.KS = (D == HD) ? pick_splits(reg_tiles, Hq, stream_tiles, 8, Hkv) : 1;
     // bf16 production path: the chunk-batched launches bring their own parallelism (28 layers), so pass 1 prefers
     // longer key streams per workgroup (measured: 2 splits -1.7 % over 4) and half the lse partials
-    if (D == HD && dtype == RTK_BF16) w.KS = std::min(w.KS, 2);
+    if (D == HD && dtype != RTK_F32) w.KS = std::min(w.KS, 2);
     w.q_off = 0;
     w.k_off = al((size_t)Hq * L * D * es);
     w.lse_off = w.k_off + al((size_t)Hkv * L * D * es);
-    w.part_off = w.lse_off + al((size_t)w.KS * Hq * L * 4);
-    w.total = w.part_off + al((size_t)Hkv * w.RS * L * 4);
+    w.part_off = w.lse_off + al((size_t)(w.ref ? 2 : 1) * w.KS * Hq * L * 4);
+    w.total = w.part_off + al((size_t)(w.ref ? Hq : Hkv) * w.RS * L * 4);
     return w;
 }
 
@@ -1422,6 +1428,47 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
     }
     const int G = Hq / Hkv;
     int rs_n = 1;
+    if (w.ref) {
+        if constexpr (DT == RTK_BF16) {
+            if (D != HD) {
+                set_error("rtk_pivotkv_score: RTK_BF16_REFROUND needs head_dim %d", HD);
+                return RTK_EUNSUPPORTED;
+            }
+            constexpr int TILE_BYTES = Tile<DT>::BYTES;
+            constexpr int LDS1 = 2 * TILE_BYTES, LDS2 = 2 * TILE_BYTES + 4 * TILE_ROWS * (int)sizeof(float);
+            const int jt = (L + REG_ROWS - 1) / REG_ROWS;
+            auto per_split = [](int n, int parts) { return (((n + parts - 1) / parts + TILE_ROWS - 1) / TILE_ROWS) * TILE_ROWS; };
+            const int kps = per_split(L, w.KS), rps = per_split(L, w.RS);
+            const int ks_n = (L + kps - 1) / kps;
+            rs_n = (L + rps - 1) / rps;
+            const float sqrt_d = (float)sqrt((double)HD);   // python: math.sqrt(self.head_dim), then an fp32 opmath scalar
+            const bool rcp_ok = bf16_rcp_is_exact(sqrt_d);
+            const float rcp_sd = 1.0f / sqrt_d;
+            float* stat = lse;
+            if (stages & RTK_SCORE_PASSES) {
+                const dim3 g1(Hkv * ks_n * jt * G, n_units), g2(Hkv * rs_n * jt, n_units);
+                const int x1 = (int)((Hkv * ks_n) % NXCD == 0), x2 = (int)((Hkv * rs_n) % NXCD == 0);
+                const size_t su = ws_stride / sizeof(float);
+#define RTK_REF_PASSES(DIV)                                                                                              \
+    RTK_LAUNCH(KID_PASS1, (score_pass1_ref_kernel<DIV>), g1, dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt,   \
+               Hq, Hkv, L, kps, jt, x1, w.KS, stat, ws_stride, k_stride, su, sqrt_d, rcp_sd);                              \
+    RTK_LAUNCH(KID_FINALIZE, stat_combine_ref_kernel, dim3((unsigned)(((size_t)Hq * L + 255) / 256), n_units), dim3(256), \
+               0, st, stat, (size_t)Hq * L, ks_n, w.KS, su);                                                               \
+    RTK_LAUNCH(KID_PASS2, (score_pass2_ref_kernel<DIV>), g2, dim3(SC_BLOCK), LDS2, st, (const char*)qt, (const char*)kt,   \
+               (const float*)stat, Hq, Hkv, L, rps, jt, rs_n, x2, w.KS, part, ws_stride, k_stride, su, part_stride,        \
+               sqrt_d, rcp_sd)
+                if (rcp_ok) { RTK_REF_PASSES(1); } else { RTK_REF_PASSES(2); }
+#undef RTK_REF_PASSES
+                RTK_LAUNCH_CHECK("score_ref_passes");
+            }
+            if (stages & RTK_SCORE_FINALIZE) {
+                RTK_LAUNCH(KID_FINALIZE, score_finalize_ref_kernel, dim3((L + 255) / 256), dim3(256), 0, st, part, Hkv, rs_n,
+                           G, L, score);
+                RTK_LAUNCH_CHECK("score_finalize_ref_kernel");
+            }
+        }
+        return RTK_OK;
+    }
     if (D == HD) {
         constexpr int TILE_BYTES = Tile<DT>::BYTES;
         constexpr int NBR = RegBlocks<DT>::NB;
@@ -1500,7 +1547,7 @@ extern "C" int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspa
                   "rtk_pivotkv_score_passes_batched: workspaces must be 256-byte aligned");
     const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
     RTK_CHECK_ARG(n_units == 1 || workspace_stride >= w.total, "rtk_pivotkv_score_passes_batched: workspace stride too small");
-    if (dtype != RTK_BF16 || D != HD) {
+    if ((dtype != RTK_BF16 && dtype != RTK_BF16_REFROUND) || D != HD) {
         set_error("rtk_pivotkv_score_passes_batched: bf16 with head_dim %d only (call RTK_SCORE_PASSES per unit)", HD);
         return RTK_EUNSUPPORTED;
     }
@@ -1519,7 +1566,7 @@ extern "C" size_t rtk_pivotkv_score_partials(int Hq, int Hkv, int L, int D, int 
         rs_n = (L + rps - 1) / rps;
     }
     if (rs_out) *rs_out = rs_n;
-    return (size_t)Hkv * rs_n * L;
+    return (size_t)(w.ref ? Hq : Hkv) * rs_n * L;
 }
 
 extern "C" int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k,
@@ -1531,7 +1578,8 @@ extern "C" int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0, "rtk_pivotkv_score: Hq=%d must be a multiple of Hkv=%d", Hq, Hkv);
     RTK_CHECK_ARG(L >= 1 && D >= 2 && D % 2 == 0, "rtk_pivotkv_score: bad shape L=%d D=%d", L, D);
     RTK_CHECK_ARG((cosv == nullptr) == (sinv == nullptr), "rtk_pivotkv_score: cos and sin must both be given or both NULL");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_score: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_BF16_REFROUND,
+                  "rtk_pivotkv_score: unsupported dtype %d", dtype);
     RTK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "rtk_pivotkv_score: workspace must be 256-byte aligned");
     RTK_CHECK_ARG(stages > 0 && stages <= 7, "rtk_pivotkv_score: stages mask %d out of range", stages);
     const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
@@ -1540,7 +1588,7 @@ extern "C" int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64
         return RTK_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == RTK_BF16)
+    if (dtype != RTK_F32)
         return score_impl<RTK_BF16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, cosv, sinv,
                                     attention_scaling, score, k_unrot, (char*)workspace, w, stages, partial_out, st);
     return score_impl<RTK_F32>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, cosv, sinv,

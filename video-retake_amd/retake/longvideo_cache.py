@@ -184,8 +184,10 @@ class _Side:
 class _Batch:
     """Per-chunk batch of pending evictions: slot = layer index.  All units share the chunk geometry."""
 
-    def __init__(self, key, slots, Hq, Hkv, L, D, keep, P, reforge, dtype, device):
+    def __init__(self, key, slots, Hq, Hkv, L, D, keep, P, reforge, dtype, device, refround=False):
         self.key, self.slots, self.keep, self.P, self.reforge = key, slots, keep, P, reforge
+        # dtype code of the scoring entry points: bf16 payloads with the reference's bf16 rounding chain on request
+        self.score_dt = (nv.RTK_BF16_REFROUND if refround else nv.RTK_BF16) if dtype == torch.bfloat16 else nv.RTK_F32
         self.Hkv, self.L, self.D, self.dtype, self.device = Hkv, L, D, dtype, device
         self.keep_idx = torch.empty((slots, keep), dtype=torch.int64, device=device)
         self.pos_new = torch.empty((P, slots, keep), dtype=torch.int64, device=device) if P else None
@@ -193,8 +195,7 @@ class _Batch:
         # final score, a private copy of the chunk's position ids (the caller shifts its tensor in place for the next
         # layer), the key-patch mask of the update and the selection scratch
         self.rs_n = C.c_int(0)
-        self.part_floats = nv.lib.rtk_pivotkv_score_partials(Hq, Hkv, L, D, nv.RTK_BF16 if dtype == torch.bfloat16 else nv.RTK_F32,
-                                                             C.byref(self.rs_n))
+        self.part_floats = nv.lib.rtk_pivotkv_score_partials(Hq, Hkv, L, D, self.score_dt, C.byref(self.rs_n))
         self.partials = torch.empty((slots, self.part_floats), dtype=torch.float32, device=device)
         self.score = torch.empty((slots, L), dtype=torch.float32, device=device)
         self.pos_old = torch.empty((slots, P, L), dtype=torch.int64, device=device) if P else None
@@ -205,8 +206,7 @@ class _Batch:
         self.scored = set()        # layers whose matrix passes already ran inside update
         self.Hq = Hq
         # one score workspace per slot (q~, lse partials): the matrix passes of all layers run in one launch each
-        dtc = nv.RTK_BF16 if dtype == torch.bfloat16 else nv.RTK_F32
-        self.ws_bytes = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dtc)
+        self.ws_bytes = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, self.score_dt)
         self.ws_stride = (self.ws_bytes + 255) & ~255
         self.batched_passes = dtype == torch.bfloat16 and D == 128 and L >= 512
         self.score_ws = torch.empty(slots * self.ws_stride + 256, dtype=torch.uint8, device=device) \
@@ -294,6 +294,12 @@ class PivotKVCache(DynamicCache):
         # MI355X build option: compute cos/sin tables in a HIP kernel from rotary_emb.inv_freq instead of
         # calling the rotary module (valid for the default / YaRN inv_freq*position rotary modules)
         self.native_rope = bool(kv_compression_kwargs.get("native_rope", False))
+        # MI355X build option for bf16 models: "fp32" (default) scores with exact bf16 products, fp32 accumulation, softmax
+        # and sums; "reference" reproduces the reference's own bf16 roundings of the logits, probabilities, per-head
+        # sums and means (longvideo_cache.py:264-270 on bf16 tensors) - coarser, but what the reference computes
+        self.score_rounding = str(kv_compression_kwargs.get("score_rounding", "fp32"))
+        if self.score_rounding not in ("fp32", "reference"):
+            raise ValueError(f"score_rounding must be 'fp32' or 'reference', got {self.score_rounding!r}")
         # MI355X build option: run scoring / selection of each update on one of N worker HIP streams.  Only
         # the tail append stays on the caller's stream (it is all the layer's attention needs); the flush
         # waits for the workers' events.  Independent updates then overlap on the GPU.
@@ -552,14 +558,17 @@ class PivotKVCache(DynamicCache):
 
     # ---- deferred eviction -----------------------------------------------------------------------
     def _get_batch(self, layer_idx, Hq, Hkv, L, D, keep, P, dtype, device) -> _Batch:
-        key = (Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device)
+        refround = self.score_rounding == "reference" and dtype == torch.bfloat16
+        if refround and D != 128:
+            raise NotImplementedError("score_rounding='reference' needs head_dim 128")
+        key = (Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround)
         b = self._batch
         if b is not None and b.key == key and layer_idx < b.slots:
             return b
         self._flush()
         slots = max(int(self.num_hidden_layers), layer_idx + 1, b.slots if b is not None and b.key == key else 0)
         self._batch = None  # release the old buffers before allocating the new ones
-        self._batch = _Batch(key, slots, Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device)
+        self._batch = _Batch(key, slots, Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround)
         return self._batch
 
     def _flush(self):
@@ -589,7 +598,7 @@ class PivotKVCache(DynamicCache):
                 nv.check(nv.lib.rtk_pivotkv_score_passes_batched(
                     C.c_void_p(b.score_ws_base + l0 * b.ws_stride), b.ws_stride,
                     nv.ptr(b.k_unrot[l0]) if b.reforge else None, b.L * D * Hkv * es,
-                    nv.ptr(b.partials[l0]), b.part_floats, n, b.Hq, Hkv, b.L, D, dt, nv.stream()),
+                    nv.ptr(b.partials[l0]), b.part_floats, n, b.Hq, Hkv, b.L, D, b.score_dt, nv.stream()),
                     "rtk_pivotkv_score_passes_batched")
                 i = j + 1
             b.scored.clear()
@@ -608,7 +617,7 @@ class PivotKVCache(DynamicCache):
                     u.pos_out = (b.pos_new.data_ptr() + l * keep * 8) if P else None
                     u.workspace = b.sel_ws[l].data_ptr()
                 nv.check(nv.lib.rtk_pivotkv_select_batched(su, len(todo), Hkv, b.rs_n.value, b.Hq // Hkv, b.L, keep, P,
-                                                           int(b.reforge), b.slots * keep, nv.stream()),
+                                                           int(b.reforge), b.slots * keep, b.score_dt, nv.stream()),
                          "rtk_pivotkv_select_batched")
             b.selected.clear()
             b.masks.clear()
@@ -758,7 +767,7 @@ class PivotKVCache(DynamicCache):
         esz = st.k.element_size()
 
         a_scale = float(getattr(rotary_emb_fn, "attention_scaling", 1.0)) if reforge else 1.0
-        ws_bytes = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
+        ws_bytes = batch.ws_bytes
         sel_bytes = nv.lib.rtk_pivotkv_select_workspace_bytes(L)
         keep_idx = batch.keep_idx[layer_idx]
         shared = {}   # values handed from one stage to the next
@@ -778,7 +787,7 @@ class PivotKVCache(DynamicCache):
             nv.check(nv.lib.rtk_pivotkv_score_stages(
                 nv.ptr(query_states), query_states.stride(1), query_states.stride(2),
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
-                Hq, Hkv, L, D, dt, nv.ptr(shared.get("cos")), nv.ptr(shared.get("sin")), a_scale,
+                Hq, Hkv, L, D, batch.score_dt, nv.ptr(shared.get("cos")), nv.ptr(shared.get("sin")), a_scale,
                 nv.ptr(score), nv.ptr(k_unrot), C.c_void_p(ws_ptr), ws_bytes, stages, nv.ptr(batch.partials[layer_idx]),
                 nv.stream()), "rtk_pivotkv_score")
             return score
