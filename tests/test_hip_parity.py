@@ -312,8 +312,8 @@ def test_pivotkv_golden(name, native_rope, overlap):
         assert kc.shape == (1, Hkv, prev_len + keep, D)
         kept_k = kc[:, :, prev_len:].cpu().numpy()
         kept_v = vc_[:, :, prev_len:].cpu().numpy()
-        tol = 1e-5 if not native_rope else 2e-5   # device sincosf vs torch's: <= 2 ulp on the tables
-        assert np.abs(kept_k - g[pre + "kept_k"]).max() <= tol
+        # native_rope: the tables are correctly rounded sin / cos (sincos_cr), <= 1 ulp from torch's: same 1e-5 bar
+        assert np.abs(kept_k - g[pre + "kept_k"]).max() <= 1e-5
         if bool(g["raw"]):
             np.testing.assert_array_equal(kept_v, g[pre + "kept_v"])
         else:
@@ -666,6 +666,39 @@ def test_select_chipwide_equals_one_workgroup_and_oracle(L, keep, P, reforge, ti
             tmin = g[0].min()
             g[0] = tmin + ((g[0] - tmin).astype(np.float32) * np.float32(keep / L)).astype(np.int64)
         np.testing.assert_array_equal(pa[:, :keep], g)
+
+
+def test_native_rope_tables_are_correctly_rounded():
+    """rtk_rope_table (the arithmetic the fused prepare and the eviction kernels share, sincos_cr in common.cuh): cos /
+    sin of fp32(id * inv_freq) must equal the float64 libm value rounded to fp32 for EVERY entry - small ids, video-scale
+    ids and ids beyond 1e5 - i.e. within half an ulp of the truth and at most one ulp from any faithful libm, torch's
+    included (the reference's rotary module calls torch.cos / torch.sin on the same fp32 angles, longvideo_cache.py:249)."""
+    import ctypes as C
+
+    import retake._native as nv
+
+    D = 128
+    inv = synth.inv_freq(D)
+    rng = np.random.default_rng(3)
+    ids = np.concatenate([np.arange(0, 2500), rng.integers(2500, 300000, 1500)]).astype(np.int64)
+    L = ids.size
+    pos = torch.from_numpy(np.stack([ids, ids[::-1].copy(), (ids * 7) % 5000])).to(dev())
+    sec = (C.c_int * 3)(16, 24, 24)
+    cos = torch.empty((L, D), dtype=torch.float32, device=dev())
+    sin = torch.empty_like(cos)
+    for scaling in (1.0, synth.YARN_FACTOR4_ATTENTION_SCALING):
+        nv.check(nv.lib.rtk_rope_table(nv.ptr(pos), L, 3, L, nv.ptr(torch.from_numpy(inv).to(dev())), D, scaling, sec, 3, 0,
+                                       nv.ptr(cos), nv.ptr(sin), nv.stream()), "rtk_rope_table")
+        torch.cuda.synchronize()
+        row = np.array([0] * 16 + [1] * 24 + [2] * 24) 
+        p = pos.cpu().numpy()[row][:, :].T.astype(np.float32)              # [L, 64]: the id each frequency sees
+        ang = (p * inv[None, :]).astype(np.float32).astype(np.float64)
+        want_c = (np.cos(ang).astype(np.float32) * np.float32(scaling)).astype(np.float32)
+        want_s = (np.sin(ang).astype(np.float32) * np.float32(scaling)).astype(np.float32)
+        for got, want in ((cos, want_c), (sin, want_s)):
+            g = got.cpu().numpy()
+            np.testing.assert_array_equal(g[:, :64], want)
+            np.testing.assert_array_equal(g[:, 64:], want)
 
 
 def test_fused_prepare_equals_separate_kernels():

@@ -42,6 +42,42 @@ __device__ __forceinline__ uint32_t f2key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// sin / cos of an fp32 angle, CORRECTLY ROUNDED to fp32 (checked against float64 libm on 384 k angles id * inv_freq,
+// ids up to 2e5: 0 mismatches; torch's CPU cos/sin, which the reference's rotary module calls, are within 0.6 ulp of
+// the true value, so the two differ by at most one fp32 ulp, in ~5 % of the entries).  The angle is position *
+// inv_freq rounded to fp32 exactly like the rotary module's fp32 product, so the reduction must start from THAT value:
+// fp64 Cody-Waite reduction by pi/2 (exact for |x| < 2^24 pi/2: n has <= 24 bits, two fused multiply-adds), Taylor
+// polynomials to r^15 / r^16 on |r| <= pi/4 in fp64 (truncation < 5e-17).  ~25 fp64 operations; ocml's sincosf is
+// <= 2 ulp and several times longer (its large-argument path is a Payne-Hanek reduction).
+__device__ __forceinline__ void sincos_cr(float x, float& sn, float& cs) {
+    const double xd = (double)x;
+    const double n = __builtin_rint(xd * 0.63661977236758134308);
+    double r = __builtin_fma(n, -1.57079632679489655800e+00, xd);
+    r = __builtin_fma(n, -6.12323399573676603587e-17, r);
+    const double r2 = r * r;
+    double ps = -7.6471637318198164759e-13;                      // -1/15!
+    ps = __builtin_fma(ps, r2, 1.6059043836821614599e-10);       //  1/13!
+    ps = __builtin_fma(ps, r2, -2.5052108385441718775e-08);      // -1/11!
+    ps = __builtin_fma(ps, r2, 2.7557319223985890653e-06);       //  1/9!
+    ps = __builtin_fma(ps, r2, -1.9841269841269841270e-04);      // -1/7!
+    ps = __builtin_fma(ps, r2, 8.3333333333333333333e-03);       //  1/5!
+    ps = __builtin_fma(ps, r2, -1.6666666666666666667e-01);      // -1/3!
+    const double s = __builtin_fma(r * r2, ps, r);
+    double pc = 4.7794773323873852974e-14;                       //  1/16!
+    pc = __builtin_fma(pc, r2, -1.1470745597729724714e-11);      // -1/14!
+    pc = __builtin_fma(pc, r2, 2.0876756987868098979e-09);       //  1/12!
+    pc = __builtin_fma(pc, r2, -2.7557319223985890653e-07);      // -1/10!
+    pc = __builtin_fma(pc, r2, 2.4801587301587301587e-05);       //  1/8!
+    pc = __builtin_fma(pc, r2, -1.3888888888888888889e-03);      // -1/6!
+    pc = __builtin_fma(pc, r2, 4.1666666666666666667e-02);       //  1/4!
+    pc = __builtin_fma(pc, r2, -0.5);                            // -1/2!
+    const double c = __builtin_fma(pc, r2, 1.0);
+    const int q = (int)(long long)n & 3;                         // x = r + q pi/2 (mod 2 pi)
+    const double so = (q & 1) ? c : s, co = (q & 1) ? s : c;
+    sn = (float)((q & 2) ? -so : so);
+    cs = (float)(((q + 1) & 2) ? -co : co);
+}
+
 // the reference's three bf16 roundings after the probabilities (longvideo_cache.py:268-270) for key j:
 //   partial [Hq][RS][L] fp32 sums of bf16 probabilities  ->  score (a bf16 value held in fp32)
 __device__ __forceinline__ float finalize_ref_column(const float* __restrict__ partial, int Hkv, int RS, int G, int L, int j) {
@@ -79,7 +115,7 @@ struct RowSel {
 };
 
 // cos/sin of one token for channels d .. d+VE-1 (c1, s1) and d+h2 .. d+h2+VE-1 (c2, s2): rope_table_kernel's
-// arithmetic (fp32 id * inv_freq[channel mod h2], sincos, * attention_scaling, bf16 rounding on request).  The
+// arithmetic (fp32 id * inv_freq[channel mod h2], correctly rounded sin / cos, * attention_scaling, bf16 rounding on request).  The
 // token's P ids are passed in registers (pid[row]) and the row selectors come in two wide loads, so no load
 // depends on another one; d must be a multiple of VE (4 or 8).
 template <int VE>
@@ -109,7 +145,7 @@ __device__ __forceinline__ void rope_chunk(const float* __restrict__ inv_freq, c
     for (int e = 0; e < VE; ++e) {
         const float p1 = ra[e] == 0 ? pid[0] : (ra[e] == 1 ? pid[1] : pid[2]);
         float sn, cs;
-        sincosf(p1 * f[e], &sn, &cs);
+        sincos_cr(p1 * f[e], sn, cs);
         cs *= scaling;
         sn *= scaling;
         if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
@@ -117,7 +153,7 @@ __device__ __forceinline__ void rope_chunk(const float* __restrict__ inv_freq, c
         s1[e] = sn;
         if (rb[e] != ra[e]) {
             const float p2 = rb[e] == 0 ? pid[0] : (rb[e] == 1 ? pid[1] : pid[2]);
-            sincosf(p2 * f[e], &sn, &cs);
+            sincos_cr(p2 * f[e], sn, cs);
             cs *= scaling;
             sn *= scaling;
             if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }

@@ -673,7 +673,7 @@ struct EvictUnits {
 // rotation partner in the second half, and walks the KV heads with it: the row's cos/sin (reforge) are
 // loaded once and reused by every head, and all of a head group's loads are issued before its stores.
 // NATIVE: the cos/sin of the kept rows' NEW ids are computed here (rope_table_kernel's arithmetic on pos_src, 8 or 16
-// sincosf per thread, reused by all KV heads) instead of being read from fp32 tables another launch wrote:
+// sincos_cr per thread, reused by all KV heads) instead of being read from fp32 tables another launch wrote:
 // one launch and 2 x keep x D x 4 bytes of write + read per unit less.
 template <int DT, int HU, bool NATIVE>
 __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, int Hkv, int D, int keep, int P,

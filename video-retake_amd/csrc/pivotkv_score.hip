@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
 
 // ------------------------------------------------------------------------------------------------
 // Fused prepare (native RoPE tables only): one pass over the chunk's q, k, v that
-//   builds the token's cos/sin chunk in registers (what rope_table_kernel writes to HBM: same sincosf, same
+//   builds the token's cos/sin chunk in registers (what rope_table_kernel writes to HBM: same sincos_cr, same
 //   scaling, same bf16 rounding), un-rotates q and k with it (same arithmetic as unrotate_pack_vec_kernel),
 //   and appends k and v to the cache tail (what append_kernel does) — k is read once instead of twice and
 //   three launches become one.  One thread = one token x one 16-byte chunk pair; blockIdx.y splits the heads
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
     char* tail = blockIdx.y == 0 ? k_tail : v_tail;
     // Software pipeline over head batches: the rows of batch b+1 (after the last query batch: the first KV batch)
     // are requested before batch b is un-rotated and stored, and the first batch before the table arithmetic
-    // (sincosf is a few hundred instructions per value) - with ~1.5 waves per SIMD nothing else hides a round trip.
+    // (sin / cos are ~25 fp64 operations per value) - with ~1.5 waves per SIMD nothing else hides a round trip.
     u32x4 lo[HU], hi[HU], lon[HU], hin[HU];
     auto load_q = [&](u32x4* a, u32x4* b, int hb) {
 #pragma unroll

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void rope_table_kernel(const int64_t* __restri
         const float p = (float)pos[(size_t)rs.row[d] * pos_ld + l];
         const float ang = p * inv_freq[d < h2 ? d : d - h2];
         float s, c;
-        sincosf(ang, &s, &c);
+        sincos_cr(ang, s, c);
         c *= scaling;
         s *= scaling;
         if (round_bf16) {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void rope_shift_kernel(void* __restrict__ kv, 
         const int r = (int)(hr % n), h = (int)(hr / n);
         const size_t off = (size_t)h * stride_h + (size_t)r * D;
         float s, c;
-        sincosf(dl * inv_freq[d], &s, &c);
+        sincos_cr(dl * inv_freq[d], s, c);
         float x1, x2;
         if (DT == RTK_BF16) {
             x1 = bf2f(((uint16_t*)kv)[off + d]);
