@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--L", type=int, default=6272)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--units", type=int, default=0, help="time rtk_pivotkv_score_passes_batched over this many units")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     td = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -40,6 +41,44 @@ def main():
         nv.check(nv.lib.rtk_pivotkv_score(nv.ptr(q), q.stride(1), q.stride(2), nv.ptr(k), k.stride(1), k.stride(2), Hq, Hkv,
                                           L, D, dt, nv.ptr(cos), nv.ptr(sin), 1.1386, nv.ptr(score), nv.ptr(kun),
                                           C.c_void_p(wsp), wsb, st), "score")
+    if a.units:
+        # the chunk-batched launches bench.py times: one launch per kernel over `units` prepared workspaces
+        stride = (wsb + 255) & ~255
+        big = torch.empty(a.units * stride + 256, dtype=torch.uint8, device=dev)
+        base = (big.data_ptr() + 255) & ~255
+        kuns = torch.empty((a.units, Hkv, L, D), dtype=td, device=dev)
+        rs_n = C.c_int(0)
+        pf = nv.lib.rtk_pivotkv_score_partials(Hq, Hkv, L, D, dt, C.byref(rs_n))
+        parts = torch.empty((a.units, pf), dtype=torch.float32, device=dev)
+        for u in range(a.units):
+            q, k = sets[u % len(sets)]
+            nv.check(nv.lib.rtk_pivotkv_score_stages(nv.ptr(q), q.stride(1), q.stride(2), nv.ptr(k), k.stride(1), k.stride(2),
+                                                     Hq, Hkv, L, D, dt, nv.ptr(cos), nv.ptr(sin), 1.1386, nv.ptr(score),
+                                                     nv.ptr(kuns[u]), C.c_void_p(base + u * stride), wsb, nv.SCORE_PREPARE,
+                                                     None, st), "prepare")
+
+        def runb():
+            nv.check(nv.lib.rtk_pivotkv_score_passes_batched(C.c_void_p(base), stride, nv.ptr(kuns), Hkv * L * D * kuns.element_size(),
+                                                             nv.ptr(parts), pf, a.units, Hq, Hkv, L, D, dt, st), "batched")
+        for _ in range(2):
+            runb()
+        torch.cuda.synchronize()
+        nv.lib.rtk_profile_reset()
+        nv.lib.rtk_profile_enable(1)
+        for _ in range(a.iters):
+            runb()
+        torch.cuda.synchronize()
+        nv.lib.rtk_profile_enable(0)
+        prof = nv.profile_read()
+        flops = 2.0 * Hq * L * L * D * a.units
+        for k, (n, ms) in prof.items():
+            us = ms / n * 1e3
+            extra = f"  {flops / (us * 1e-6) / 1e12:7.1f} TFLOP/s" if k.startswith("score_pass") else ""
+            print(f"{k:16s} n={n:4d} avg={us:9.1f} us{extra}")
+        G = Hq // Hkv
+        sc = (parts.view(a.units, Hkv, rs_n.value, L).sum(2) / G).mean(1)
+        print("units", a.units, "score mean %.7f" % float(sc.mean()), "checksum %.9e" % float((sc.double() * torch.arange(1, L + 1, device=dev).double()).sum()))
+        return
     for i in range(3):
         run(*sets[i % len(sets)])
     torch.cuda.synchronize()

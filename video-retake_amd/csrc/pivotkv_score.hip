@@ -568,6 +568,21 @@ struct RowStat {  // online max / sum of one query row, over the keys this lane 
 //        needs ~250 VGPRs (1-2 waves per SIMD): no gain over NB = 1 with 2-3 waves.
 //   PF = how many streamed tiles ahead the global loads run (register staging sets, counted vmcnt waits).
 //        PF = 2 did not help either: the kernels are bound by instruction issue, not by load latency.
+// Shape of the bf16 LDS-DMA kernels (measured on MI355X at L = 6272, 28 units per launch, same box):
+//   32-row register blocks per wave: 2 (every A fragment read from LDS feeds two MFMAs on independent accumulators;
+//       half the fragment reads, DMA issues, barriers and waits per MFMA; ~160 VGPRs -> 3 waves per SIMD)
+//       pass 1 7749 -> 7401 us, pass 2 7630 -> 7141 us; 3 and 4 blocks (2 waves per SIMD) were slower again
+//   lazy max in pass 1 (RowStatB::update_lazy): 7401 -> 7030 us
+// The macros stay overridable so that tools/variants.sh can rebuild the other shapes for A/B runs.
+#ifndef RTK_P1_NB
+#define RTK_P1_NB 2
+#endif
+#ifndef RTK_P1_LAZY
+#define RTK_P1_LAZY true
+#endif
+#ifndef RTK_P2_NB
+#define RTK_P2_NB 2
+#endif
 template <int DT> struct RegBlocks {
     static constexpr int NB = 1;
     static constexpr int PF = 1;
@@ -713,6 +728,36 @@ struct RowStatB {  // online max / sum of one query row over the keys this lane 
         float add = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(fmaf(a[r], c2, nb));
+        sum = sum * __builtin_amdgcn_exp2f((m - mn) * c2) + add;
+        m = mn;
+    }
+    // Lazy form: the 16 exponentials are taken against the offset of the LAST rescale (no max over the block, no
+    // rescale of the running sum); only when some lane's block sum is not a finite number below 2^96 - a key beat the
+    // stale offset by ~96 binary orders, or nothing has been seen yet (m = -inf makes the offset +inf) - the whole wave
+    // takes the ordinary online step for this block.  Any offset gives the same sum mathematically and fp32 keeps its
+    // relative precision over that range, so the result is as exact as the eager form (not bitwise equal to it).
+    // Saves ~13 of the ~64 VALU instructions per 32 x 32 block in a kernel that is bound by instruction issue.
+    template <bool RAGGED>
+    __device__ __forceinline__ void update_lazy(f32x16& a, int j0, int j_end, int hf, float c2) {
+        if (RAGGED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (j0 + acc_row(r, hf) >= j_end) a[r] = -INFINITY;
+        }
+        const float nb = -m * c2;
+        float add = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(fmaf(a[r], c2, nb));
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(add < 0x1p96f)) == 0, 1)) {
+            sum += add;
+            return;
+        }
+        const float mn = fmaxf(m, max16(a));
+        if (mn == -INFINITY) return;   // no key seen yet on this lane and none in this block
+        const float nb2 = -mn * c2;
+        add = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(fmaf(a[r], c2, nb2));
         sum = sum * __builtin_amdgcn_exp2f((m - mn) * c2) + add;
         m = mn;
     }
@@ -943,8 +988,10 @@ _Pragma("unroll") \
 // LDS position p of row r receives chunk p ^ (r & 15), the same involution the fragment reads apply.
 // NB = 32-key register blocks per wave (NB = 2: every A fragment read from LDS feeds two MFMAs).
 // ------------------------------------------------------------------------------------------------
+#define RTK_ACC_INIT(acc, ls) acc = f32x16{0};
+#define RTK_COLSUM(col, acc, ls, c2, sd) colsum_block<DT>(col, acc, ls, c2, sd)
 template <int NB>
-__global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass2_dma_kernel(
+__global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 2 : 2)))) void score_pass2_dma_kernel(
     const char* __restrict__ q, const char* __restrict__ k, const float* __restrict__ lse, int Hq, int Hkv, int L,
     int rows_per_split, int col_tiles, int RS, int xcd_remap, float* __restrict__ partial, size_t q_unit_bytes,
     size_t k_unit_bytes, size_t lse_unit_floats, size_t part_unit_floats) {
@@ -1036,13 +1083,13 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass2_dma_k
             f32x16 acc[NB];                                                                               \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) {                                                             \
-                acc[nb] = f32x16{0};                                                                      \
+                RTK_ACC_INIT(acc[nb], ls)                                                                 \
                 _Pragma("unroll")                                                                         \
                 for (int r = 0; r < M::NREG; ++r) M::mma(acc[nb], a[r], kf[nb][r]);                       \
             }                                                                                             \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) {                                                             \
-                colsum_block<DT>(col[nb], acc[nb], ls, c2, sqrt_d);                                       \
+                RTK_COLSUM(col[nb], acc[nb], ls, c2, sqrt_d);                                             \
                 asm volatile("" : "+v"(col[nb]) : : "memory");                                            \
                 __builtin_amdgcn_sched_barrier(0);                                                        \
             }                                                                                             \
@@ -1084,7 +1131,8 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass2_dma_k
 // registers, 64-key tiles streamed), with the key tile DMA'd straight into the swizzled LDS image and one
 // 32-key block in flight per wave (~100 VGPRs -> 4 waves per SIMD).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SC_BLOCK, 4) void score_pass1_dma_kernel(const char* __restrict__ q,
+template <int NB, bool LAZY>
+__global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_kernel(const char* __restrict__ q,
                                                                       const char* __restrict__ k, int Hq, int Hkv, int L,
                                                                       int keys_per_split, int row_tiles, int xcd_remap,
                                                                       float* __restrict__ lse_part, size_t q_unit_bytes,
@@ -1117,13 +1165,14 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void score_pass1_dma_kernel(const char
         bx = w % row_tiles;
     }
     const int g = h / G;
-    const int i0 = bx * REG_ROWS + wid * 32;
+    const int i0 = bx * (REG_ROWS * NB) + wid * (32 * NB);   // this wave's NB x 32 query rows
     const int jb = ks * keys_per_split, je = min(L, jb + keys_per_split);
     const int nkeys = je - jb;
     const int nfull = nkeys / TILE_ROWS;
     const int ntiles = (nkeys + TILE_ROWS - 1) / TILE_ROWS;
-    u32x4 qf[M::NREG];
-    load_reg_frag<DT>(q + (size_t)h * L * HD * M::ESIZE, i0, L, lane, qf);
+    u32x4 qf[NB][M::NREG];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) load_reg_frag<DT>(q + (size_t)h * L * HD * M::ESIZE, i0 + 32 * nb, L, lane, qf[nb]);
     int frag_off[M::NREG];
     {
         const int row = lane & 31;
@@ -1131,8 +1180,9 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void score_pass1_dma_kernel(const char
         for (int r = 0; r < M::NREG; ++r) frag_off[r] = row * T::ROWB + ((M::chunk_of(r, hf) ^ (row & 15)) * 16);
     }
     const float c2 = 1.4426950408889634f / sqrtf((float)HD);
-    RowStatB rs;
-    rs.init();
+    RowStatB rs[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) rs[nb].init();
     const int drow = 4 * wid + (lane >> 4);
     const int dvoff = drow * T::ROWB + (((lane & 15) ^ (drow & 15)) * 16);
     const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -1155,12 +1205,21 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void score_pass1_dma_kernel(const char
             u32x4 a[M::NREG];                                                                             \
             _Pragma("unroll")                                                                             \
             for (int r = 0; r < M::NREG; ++r) a[r] = *(const u32x4*)(cur + blk * 32 * T::ROWB + frag_off[r]); \
-            f32x16 acc = f32x16{0};                                                                       \
+            f32x16 acc[NB];                                                                               \
             _Pragma("unroll")                                                                             \
-            for (int r = 0; r < M::NREG; ++r) M::mma(acc, a[r], qf[r]);                                   \
-            rs.update<RAG>(acc, (JT) * TILE_ROWS + 32 * blk, nkeys, hf, c2);                              \
-            asm volatile("" : "+v"(rs.sum), "+v"(rs.m) : : "memory");                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                            \
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x16{0};                                          \
+            _Pragma("unroll")                                                                             \
+            for (int r = 0; r < M::NREG; ++r) {                                                           \
+                _Pragma("unroll")                                                                         \
+                for (int nb = 0; nb < NB; ++nb) M::mma(acc[nb], a[r], qf[nb][r]);                         \
+            }                                                                                             \
+            _Pragma("unroll")                                                                             \
+            for (int nb = 0; nb < NB; ++nb) {                                                             \
+                if constexpr (LAZY) rs[nb].template update_lazy<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf, c2); \
+                else rs[nb].template update<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf, c2);    \
+                asm volatile("" : "+v"(rs[nb].sum), "+v"(rs[nb].m) : : "memory");                         \
+                __builtin_amdgcn_sched_barrier(0);                                                        \
+            }                                                                                             \
         }                                                                                                 \
         __syncthreads(); /* drains the DMA (vmcnt(0)) and the LDS reads of this tile */                   \
     }
@@ -1189,9 +1248,12 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void score_pass1_dma_kernel(const char
 #undef RTK_DMA1_TAIL
 #undef RTK_DMA1_STEP
 #undef RTK_DMA1_ISSUE
-    const float out = rs.finish(c2);
-    const int i = i0 + (lane & 31);
-    if (hf == 0 && i < L) lse_part[((size_t)ks * Hq + h) * L + i] = out;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const float out = rs[nb].finish(c2);
+        const int i = i0 + 32 * nb + (lane & 31);
+        if (hf == 0 && i < L) lse_part[((size_t)ks * Hq + h) * L + i] = out;
+    }
 }
 
 }  // namespace rtk
@@ -1481,8 +1543,8 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         const uint64_t dev_bit = 1ull << (dev_id & 63);
         if (!(opted[DT == RTK_BF16].load(std::memory_order_relaxed) & dev_bit)) {
             if constexpr (DT == RTK_BF16) {
-                (void)hipFuncSetAttribute((const void*)score_pass1_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
-                (void)hipFuncSetAttribute((const void*)score_pass2_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+                (void)hipFuncSetAttribute((const void*)score_pass1_dma_kernel<RTK_P1_NB, RTK_P1_LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+                (void)hipFuncSetAttribute((const void*)score_pass2_dma_kernel<RTK_P2_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
             } else {
                 (void)hipFuncSetAttribute((const void*)score_pass1_kernel<DT, NBR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
                 (void)hipFuncSetAttribute((const void*)score_pass2_kernel<DT, NBR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
@@ -1498,10 +1560,12 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         // bf16: the LDS-DMA kernels; fp32 (parity dtype): the register-staged kernels
         constexpr bool dma = (DT == RTK_BF16);
         if (stages & RTK_SCORE_PASSES) {
-            if constexpr (dma)
-                RTK_LAUNCH(KID_PASS1, score_pass1_dma_kernel, dim3(Hkv * ks_n * jt * G, n_units), dim3(SC_BLOCK), LDS1, st,
-                           (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse,
-                           ws_stride, k_stride, ws_stride / sizeof(float));
+            if constexpr (dma) {
+                const int jt1 = (L + REG_ROWS * RTK_P1_NB - 1) / (REG_ROWS * RTK_P1_NB);
+                RTK_LAUNCH(KID_PASS1, (score_pass1_dma_kernel<RTK_P1_NB, RTK_P1_LAZY>), dim3(Hkv * ks_n * jt1 * G, n_units),
+                           dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
+                           (int)((Hkv * ks_n) % NXCD == 0), lse, ws_stride, k_stride, ws_stride / sizeof(float));
+            }
             else
                 RTK_LAUNCH(KID_PASS1, (score_pass1_kernel<DT, NBR>), dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,
                            (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt, (int)((Hkv * ks_n) % NXCD == 0), lse);
@@ -1511,11 +1575,13 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                 RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<DT>, dim3((unsigned)((n + 255) / 256), n_units), dim3(256), 0, st, lse, n,
                            ks_n, ws_stride / sizeof(float));
             }
-            if constexpr (dma)
-                RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<1>), dim3(Hkv * rs_n * jt, n_units), dim3(SC_BLOCK), LDS2, st,
-                           (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
+            if constexpr (dma) {
+                const int jt2 = (L + REG_ROWS * RTK_P2_NB - 1) / (REG_ROWS * RTK_P2_NB);
+                RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<RTK_P2_NB>), dim3(Hkv * rs_n * jt2, n_units), dim3(SC_BLOCK), LDS2, st,
+                           (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n,
                            (int)((Hkv * rs_n) % NXCD == 0), part, ws_stride, k_stride, ws_stride / sizeof(float),
                            part_stride);
+            }
             else
                 RTK_LAUNCH(KID_PASS2, (score_pass2_kernel<DT, NBR>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
                            (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
