@@ -143,13 +143,15 @@ def self_check(cache, pool, mask, n_chunks, layers, rotary):
     inputs = {l: pool[(c * layers + l) % len(pool)][:2] for l in lay}
     masks = {l: mask[c * L:(c + 1) * L] for l in lay}
     res = uc.check_batch_against_units(cache, lay, inputs, masks, keep, rotary.inv_freq, A_SCALE, MROPE)
+    low = []
     for l, _, idx in res:
+        low.append(float((idx < keep).float().mean()))
         v = pool[(c * layers + l) % len(pool)][2]
         if not torch.equal(cache.value_cache[l][0, :, -keep:], v[0][:, idx]):
             raise AssertionError(f"self-check: layer {l} kept V rows are not copies of the selected rows")
         if cache.key_cache[l].shape[2] != n_chunks * keep:
             raise AssertionError(f"self-check: layer {l} cache length {cache.key_cache[l].shape[2]} != {n_chunks * keep}")
-    return {"status": "ok", "chunk": c, "layers": lay,
+    return {"status": "ok", "chunk": c, "layers": lay, "staged_fraction": sum(low) / len(low),
             "checked": "batched score / keep_idx / new ids == one-unit launches (bitwise); kept V rows == gather"}
 
 
@@ -307,12 +309,13 @@ def main():
     check = self_check(cache, pool, kp_mask, n_chunks, args.layers, rotary) if not args.no_self_check else None
     del cache
     if use_events:
-        # untimed: every kernel, 2 chunks' worth of frames / updates on one stream
+        # untimed: every kernel, up to 64 chunks' worth of frames / updates on one stream (>= 64 launches of the per-chunk
+        # kernels, ~1800 of the per-update ones)
         saved = OVERLAP_STREAMS
         OVERLAP_STREAMS = 0
         nv.check(nv.lib.rtk_profile_reset(), "profile_reset")
         nv.check(nv.lib.rtk_profile_enable(1), "profile_enable")
-        run_video(frames[:, : 2 * FRAMES_PER_CHUNK], pool, masks, pos_base, rotary, args.layers, tdtype)
+        run_video(frames[:, : min(T, 64 * FRAMES_PER_CHUNK)], pool, masks, pos_base, rotary, args.layers, tdtype)
         torch.cuda.synchronize()
         dp_names = ("dpselect_dis", "dpselect_select", "gather_frames")
         prof_all = {k: v for k, v in nv.profile_read().items() if k not in dp_names}
@@ -360,8 +363,13 @@ def main():
         # kept K and V rows read + written, kept-index read, ids read + written; the fp32 cos/sin tables only when a
         # separate launch wrote them (third-party rotary module) - with the native RoPE the kernel computes them
         tables = "rope_table" in kern
-        evu_bytes = 2 * 2 * Hkv * keep * D * es + (2 * keep * D * 4 if tables else 0) + 8 * keep + 2 * 8 * 3 * keep
-        cmu_bytes = 2 * Hkv * keep * D * es
+        # eviction launch: kept K rows read (k~) + written (re-rotated, straight into the cache), the V rows whose source
+        # lies inside the destination range read + parked (fraction f of the kept rows, measured by the self-check;
+        # ~ratio), kept-index read, ids read + written.  Placement launch: every kept V row read (in place or parked)
+        # + written to the head of the tail.
+        f_low = (check or {}).get("staged_fraction", RATIO)
+        evu_bytes = (2 + 2 * f_low) * Hkv * keep * D * es + (2 * keep * D * 4 if tables else 0) + 8 * keep + 2 * 8 * 3 * keep
+        cmu_bytes = 2 * Hkv * keep * D * es + 8 * keep
         ev_bytes = 5 * L + 2 * Hkv * L * D * es + 2 * Hkv * keep * D * es + 8 * 3 * (L + keep)
         dp_bytes = T * N_PATCH * C_EMB * es + 4 * T * N_PATCH
         ga_bytes = 2 * T * N_PATCH * C_EMB * es

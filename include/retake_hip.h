@@ -317,7 +317,11 @@ typedef struct rtk_evict_unit {
  * Hkv, D, keep, P and dtype:  K: k' = (k~*cos_new) + (rotate_half(k~)*sin_new) (or a copy), V: copy,
  * position ids: copy.  `units` is a HOST array. */
 int rtk_pivotkv_evict_batched(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P,
-                              int dtype, rtk_stream_t stream);
+                              int dtype, int stage_low_only, rtk_stream_t stream);
+/* stage_low_only != 0 (what PivotKVCache uses, together with rtk_pivotkv_place_batched): rows that are copied verbatim
+ * (V; K when there are no tables) are written to k_dst / v_dst ONLY when keep_idx[r] < keep, i.e. when their source
+ * lies inside the destination range of the compaction and has to be parked; the other rows are moved in place by
+ * rtk_pivotkv_place_batched.  Re-rotated K rows are always written. */
 
 /* The same with the tables of the NEW ids computed in the kernel (reference :297-298: rotary_emb(compressed ids) and
  * the M-RoPE section merge :68-74, i.e. rtk_rope_table's arithmetic: fp32 sincosf(id * inv_freq[d mod D/2]) *
@@ -326,7 +330,8 @@ int rtk_pivotkv_evict_batched(const rtk_evict_unit* units, int n_units, int Hkv,
  * 2 x keep x D x 4 bytes of write + read per unit. */
 int rtk_pivotkv_evict_batched_rope(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P,
                                    int dtype, const float* inv_freq, float attention_scaling,
-                                   const int* sections_host, int nsec, int round_bf16, rtk_stream_t stream);
+                                   const int* sections_host, int nsec, int round_bf16, int stage_low_only,
+                                   rtk_stream_t stream);
 
 typedef struct rtk_copy_unit {
     const void* src;
@@ -340,6 +345,22 @@ typedef struct rtk_copy_unit {
  * `units` is a HOST array. */
 int rtk_pivotkv_commit_batched(const rtk_copy_unit* units, int n_units, int H, int rows, int D, int dtype,
                                rtk_stream_t stream);
+
+/* P13 without a full staging copy: for every unit, kept row r (r < keep) of the tail block `tail` (element (h, l, d) at
+ * h*tail_stride_h_bytes + l*D*es) becomes row r of the same block.  Its source is chunk row keep_idx[r]: read in place
+ * when keep_idx[r] >= keep (outside the destination range), from stage[h][r] otherwise (parked there by
+ * rtk_pivotkv_evict_batched with stage_low_only).  Only ~ratio of the kept rows take the staging hop.  One unit per
+ * tensor (V of a layer; K of a layer when it is not re-rotated).  `units` is a HOST array. */
+typedef struct rtk_place_unit {
+    const void* stage;             /* [H, keep, D] staged rows (only rows with keep_idx[r] < keep are read) */
+    int64_t stage_stride_h_bytes;
+    void* tail;                    /* the uncompressed chunk inside the cache: rows [0, L) per head */
+    int64_t tail_stride_h_bytes;
+    const int64_t* keep_idx;       /* [keep] ascending */
+} rtk_place_unit;
+#define RTK_PLACE_MAX_UNITS 64
+int rtk_pivotkv_place_batched(const rtk_place_unit* units, int n_units, int H, int keep, int D, int dtype,
+                              rtk_stream_t stream);
 
 /* G1  qwen2_vl.py:68-73 / llava_onevision.py:68-72, without the host round trip of the reference's
  * `if position_ids[0,0,0] != prev + 1`:  t[0:n] += (prev + 1) - t[0]  in place, where t is the temporal

@@ -802,9 +802,12 @@ def test_select_batched_equals_single_units(n, L, keep, P):
             assert len(set(keep_idx.tolist()) ^ set(k1.tolist())) <= 4
 
 
-def test_evict_batched_abi_vs_torch_gather():
-    """rtk_pivotkv_append / rtk_pivotkv_evict_batched / rtk_pivotkv_commit_batched straight through the C ABI:
-    5 units, no reforge -> K and V rows must be byte-identical to torch.gather; ids copied."""
+@pytest.mark.parametrize("low_only", [0, 1])
+def test_evict_batched_abi_vs_torch_gather(low_only):
+    """rtk_pivotkv_append / rtk_pivotkv_evict_batched + the compaction straight through the C ABI: 5 units, no reforge ->
+    K and V rows must be byte-identical to torch.gather; ids copied.  low_only = 0: every kept row staged, then
+    rtk_pivotkv_commit_batched; low_only = 1 (what PivotKVCache runs): only the rows whose source lies inside the
+    destination range are staged, rtk_pivotkv_place_batched moves the rest in place."""
     import ctypes as C
 
     import retake._native as nv
@@ -814,6 +817,7 @@ def test_evict_batched_abi_vs_torch_gather():
     cap = 700
     units = (nv.EvictUnit * n)()
     copies = (nv.CopyUnit * (2 * n))()
+    places = (nv.PlaceUnit * (2 * n))()
     hold = []
     for i in range(n):
         k = torch.randn((1, L, Hkv, D), generator=g, device=dev()).bfloat16().transpose(1, 2)   # HF layout
@@ -826,8 +830,12 @@ def test_evict_batched_abi_vs_torch_gather():
                                            C.c_void_p(vc_.data_ptr() + P0 * D * 2), cap * D, nv.stream()), "append")
         assert torch.equal(kc[:, :, P0:P0 + L], k) and torch.equal(vc_[:, :, P0:P0 + L], v)
         idx = torch.sort(torch.randperm(L, generator=g, device=dev())[:keep]).values
-        ks = torch.empty((Hkv, keep, D), dtype=torch.bfloat16, device=dev())
-        vs = torch.empty_like(ks)
+        if i == 1:
+            idx = torch.arange(keep, device=dev())            # every source inside the destination range
+        if i == 2:
+            idx = torch.arange(L - keep, L, device=dev())     # every source beyond it
+        ks = torch.full((Hkv, keep, D), 7.0, dtype=torch.bfloat16, device=dev())
+        vs = torch.full_like(ks, 7.0)
         pos_src = torch.randint(0, 1000, (3, keep), generator=g, device=dev())
         pos_dst = torch.zeros((3, 90), dtype=torch.int64, device=dev())
         u = units[i]
@@ -840,9 +848,20 @@ def test_evict_batched_abi_vs_torch_gather():
             cu = copies[2 * i + j]
             cu.src, cu.src_stride_h_bytes = src.data_ptr(), keep * D * 2
             cu.dst, cu.dst_stride_h_bytes = dst.data_ptr() + P0 * D * 2, cap * D * 2
+            pu = places[2 * i + j]
+            pu.stage, pu.stage_stride_h_bytes = src.data_ptr(), keep * D * 2
+            pu.tail, pu.tail_stride_h_bytes = dst.data_ptr() + P0 * D * 2, cap * D * 2
+            pu.keep_idx = idx.data_ptr()
         hold.append((k, v, kc, vc_, idx, ks, vs, pos_src, pos_dst, P0))
-    nv.check(nv.lib.rtk_pivotkv_evict_batched(units, n, Hkv, D, keep, 3, nv.RTK_BF16, nv.stream()), "evict_batched")
-    nv.check(nv.lib.rtk_pivotkv_commit_batched(copies, 2 * n, Hkv, keep, D, nv.RTK_BF16, nv.stream()), "commit_batched")
+    nv.check(nv.lib.rtk_pivotkv_evict_batched(units, n, Hkv, D, keep, 3, nv.RTK_BF16, low_only, nv.stream()), "evict_batched")
+    if low_only:
+        torch.cuda.synchronize()
+        for k, v, kc, vc_, idx, ks, vs, pos_src, pos_dst, P0 in hold:   # only the low rows were parked
+            low = (idx < keep).cpu()
+            assert torch.equal(vs[:, low], v[0][:, idx[low.to(dev())]]) and bool((vs[:, ~low] == 7.0).all())
+        nv.check(nv.lib.rtk_pivotkv_place_batched(places, 2 * n, Hkv, keep, D, nv.RTK_BF16, nv.stream()), "place_batched")
+    else:
+        nv.check(nv.lib.rtk_pivotkv_commit_batched(copies, 2 * n, Hkv, keep, D, nv.RTK_BF16, nv.stream()), "commit_batched")
     torch.cuda.synchronize()
     for k, v, kc, vc_, idx, ks, vs, pos_src, pos_dst, P0 in hold:
         assert torch.equal(kc[0, :, P0:P0 + keep], k[0][:, idx]) and torch.equal(vc_[0, :, P0:P0 + keep], v[0][:, idx])
@@ -895,9 +914,9 @@ def test_evict_batched_rope_equals_table_path(dtype, P, scaling):
             hold.append((ku, v, idx, pos_new, kd, vd, pos_dst, cos_t, sin_t))
         if native:
             nv.check(nv.lib.rtk_pivotkv_evict_batched_rope(units, n, Hkv, D, keep, P, dt, nv.ptr(inv), float(scaling), sec,
-                                                           nsec, int(dtype == torch.bfloat16), nv.stream()), "evict_rope")
+                                                           nsec, int(dtype == torch.bfloat16), 0, nv.stream()), "evict_rope")
         else:
-            nv.check(nv.lib.rtk_pivotkv_evict_batched(units, n, Hkv, D, keep, P, dt, nv.stream()), "evict_batched")
+            nv.check(nv.lib.rtk_pivotkv_evict_batched(units, n, Hkv, D, keep, P, dt, 0, nv.stream()), "evict_batched")
         torch.cuda.synchronize()
         outs.append([(h[4].clone(), h[5].clone(), h[6].clone()) for h in hold])
     for (ka, va, pa), (kb, vb, pb) in zip(*outs):
@@ -918,9 +937,9 @@ def test_evict_batched_rope_argument_errors():
     u.k_dst, u.k_dst_stride_h, u.v_dst, u.v_dst_stride_h = y.data_ptr(), 4 * 128, y.data_ptr(), 4 * 128
     u.pos_src = u.pos_dst = None
     inv = torch.ones(64, device=dev())
-    rc = nv.lib.rtk_pivotkv_evict_batched_rope(units, 1, 4, 128, 4, 1, nv.RTK_BF16, nv.ptr(inv), 1.0, None, 0, 1, nv.stream())
+    rc = nv.lib.rtk_pivotkv_evict_batched_rope(units, 1, 4, 128, 4, 1, nv.RTK_BF16, nv.ptr(inv), 1.0, None, 0, 1, 0, nv.stream())
     assert rc != 0 and b"pos_src" in nv.lib.rtk_last_error()
-    rc = nv.lib.rtk_pivotkv_evict_batched_rope(units, 1, 4, 128, 4, 1, nv.RTK_BF16, None, 1.0, None, 0, 1, nv.stream())
+    rc = nv.lib.rtk_pivotkv_evict_batched_rope(units, 1, 4, 128, 4, 1, nv.RTK_BF16, None, 1.0, None, 0, 1, 0, nv.stream())
     assert rc != 0
 
 

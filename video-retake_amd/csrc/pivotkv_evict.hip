@@ -678,7 +678,7 @@ struct EvictUnits {
 template <int DT, int HU, bool NATIVE>
 __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, int Hkv, int D, int keep, int P,
                                                             const float* __restrict__ inv_freq, float scaling,
-                                                            RowSel rs, int round_bf16) {
+                                                            RowSel rs, int round_bf16, int low_only) {
     using R = Row16<DT>;
     constexpr int VE = R::VE;
     constexpr int ES = 16 / VE;
@@ -696,6 +696,9 @@ __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, in
     const int d = (id - r * lpr) * VE;
     const int l = (int)un.keep_idx[r];
     const bool reforge = NATIVE || un.cos_new != nullptr;
+    // low_only: rows copied verbatim (V; K without reforge) are staged only when their source lies inside the
+    // destination range [0, keep) of the tail they will overwrite; the others are moved in place by place_batched_kernel
+    const bool copy_rows = !low_only || l < keep;
     const char* ks = (const char*)un.k_src;
     const char* vs = (const char*)un.v_src;
     char* kd = (char*)un.k_dst;
@@ -707,10 +710,14 @@ __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, in
             const int h = min(hb + u, Hkv - 1);
             const char* kr = ks + ((size_t)h * un.k_src_stride_h + (size_t)l * D) * ES;
             const char* vr = vs + ((size_t)h * un.v_src_stride_h + (size_t)l * D) * ES;
-            k_lo[u] = *(const u32x4*)(kr + (size_t)d * ES);
-            k_hi[u] = *(const u32x4*)(kr + (size_t)(d + h2) * ES);
-            v_lo[u] = *(const u32x4*)(vr + (size_t)d * ES);
-            v_hi[u] = *(const u32x4*)(vr + (size_t)(d + h2) * ES);
+            if (reforge || copy_rows) {
+                k_lo[u] = *(const u32x4*)(kr + (size_t)d * ES);
+                k_hi[u] = *(const u32x4*)(kr + (size_t)(d + h2) * ES);
+            }
+            if (copy_rows) {
+                v_lo[u] = *(const u32x4*)(vr + (size_t)d * ES);
+                v_hi[u] = *(const u32x4*)(vr + (size_t)(d + h2) * ES);
+            }
         }
     };
     load_batch(0);   // the rows are requested before the table arithmetic / table reads below
@@ -751,12 +758,14 @@ __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, in
                 }
                 *(u32x4*)(ko + (size_t)d * ES) = R::pack(o1);
                 *(u32x4*)(ko + (size_t)(d + h2) * ES) = R::pack(o2);
-            } else {        // torch.gather(key_states, 2, keep)  (:279)
+            } else if (copy_rows) {   // torch.gather(key_states, 2, keep)  (:279)
                 *(u32x4*)(ko + (size_t)d * ES) = k_lo[u];
                 *(u32x4*)(ko + (size_t)(d + h2) * ES) = k_hi[u];
             }
-            *(u32x4*)(vo + (size_t)d * ES) = v_lo[u];  // torch.gather(value_states, 2, keep)  (:280)
-            *(u32x4*)(vo + (size_t)(d + h2) * ES) = v_hi[u];
+            if (copy_rows) {
+                *(u32x4*)(vo + (size_t)d * ES) = v_lo[u];  // torch.gather(value_states, 2, keep)  (:280)
+                *(u32x4*)(vo + (size_t)(d + h2) * ES) = v_hi[u];
+            }
         }
     }
 }
@@ -788,6 +797,41 @@ __global__ __launch_bounds__(256) void commit_batched_kernel(CopyUnits units, in
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (id + u * stride < total) *(u32x4*)(dst + o[u]) = t[u];
+    }
+}
+
+struct PlaceUnits {
+    rtk_place_unit u[RTK_PLACE_MAX_UNITS];
+};
+
+// P13 (longvideo_cache.py:313-318) without a full staging copy: kept row r of a unit goes to tail[h][r].  Its source
+// is the chunk row keep_idx[r] of the same tail; rows whose source lies below `keep` would race with the rows being
+// written there, so an earlier launch (evict_batched_kernel, low_only) parked exactly those in `stage`; every other
+// row is read where it sits - beyond the destination range, which nothing writes.  ~ratio of the rows take the hop.
+__global__ __launch_bounds__(256) void place_batched_kernel(PlaceUnits units, int H, int keep, int vec_per_row) {
+    const rtk_place_unit& un = units.u[blockIdx.y];
+    const size_t total = (size_t)H * keep * vec_per_row;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    constexpr int U = 4;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += U * stride) {
+        u32x4 t[U];
+        size_t o[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = id + u * stride;
+            const size_t ic = i < total ? i : id;
+            const int j = (int)(ic % vec_per_row);
+            const size_t hr = ic / vec_per_row;
+            const int r = (int)(hr % keep), h = (int)(hr / keep);
+            const int64_t l = un.keep_idx[r];
+            const char* src = l < keep ? (const char*)un.stage + ((size_t)h * un.stage_stride_h_bytes + (size_t)r * vec_per_row * 16)
+                                       : (const char*)un.tail + ((size_t)h * un.tail_stride_h_bytes + (size_t)l * vec_per_row * 16);
+            t[u] = *(const u32x4*)(src + (size_t)j * 16);
+            o[u] = (size_t)h * un.tail_stride_h_bytes + ((size_t)r * vec_per_row + j) * 16;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (id + u * stride < total) *(u32x4*)((char*)un.tail + o[u]) = t[u];
     }
 }
 
@@ -1043,7 +1087,7 @@ extern "C" int rtk_pivotkv_append(const void* k, int64_t k_stride_h, int64_t k_s
 }
 
 static int evict_batched_impl(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P, int dtype,
-                              const float* inv_freq, float scaling, const RowSel* rsel, int round_bf16,
+                              const float* inv_freq, float scaling, const RowSel* rsel, int round_bf16, int low_only,
                               rtk_stream_t stream) {
     const bool native = inv_freq != nullptr;
     RowSel rs;
@@ -1085,7 +1129,7 @@ static int evict_batched_impl(const rtk_evict_unit* units, int n_units, int Hkv,
         for (int i = n; i < RTK_EVICT_MAX_UNITS; ++i) eu.u[i] = units[b];
 #define RTK_EVB(DTV, HUV, NAT)                                                                                    \
     RTK_LAUNCH(KID_EVICTB, (evict_batched_kernel<DTV, HUV, NAT>), dim3(gx, n), dim3(256), 0, st, eu, Hkv, D, keep, P, \
-               inv_freq, scaling, rs, round_bf16)
+               inv_freq, scaling, rs, round_bf16, low_only)
         if (dtype == RTK_BF16) {
             if (native) RTK_EVB(RTK_BF16, 4, true);
             else RTK_EVB(RTK_BF16, 4, false);
@@ -1100,20 +1144,49 @@ static int evict_batched_impl(const rtk_evict_unit* units, int n_units, int Hkv,
 }
 
 extern "C" int rtk_pivotkv_evict_batched(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P,
-                                         int dtype, rtk_stream_t stream) {
-    return evict_batched_impl(units, n_units, Hkv, D, keep, P, dtype, nullptr, 0.f, nullptr, 0, stream);
+                                         int dtype, int stage_low_only, rtk_stream_t stream) {
+    return evict_batched_impl(units, n_units, Hkv, D, keep, P, dtype, nullptr, 0.f, nullptr, 0, stage_low_only, stream);
 }
 
 extern "C" int rtk_pivotkv_evict_batched_rope(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P,
                                               int dtype, const float* inv_freq, float attention_scaling,
-                                              const int* sections_host, int nsec, int round_bf16,
+                                              const int* sections_host, int nsec, int round_bf16, int stage_low_only,
                                               rtk_stream_t stream) {
     RTK_CHECK_ARG(inv_freq, "rtk_pivotkv_evict_batched_rope: inv_freq is NULL");
     RTK_CHECK_ARG(P == 1 || P == 3, "rtk_pivotkv_evict_batched_rope: P must be 1 or 3, got %d", P);
     RowSel rs;
     const int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_pivotkv_evict_batched_rope");
     if (rc != RTK_OK) return rc;
-    return evict_batched_impl(units, n_units, Hkv, D, keep, P, dtype, inv_freq, attention_scaling, &rs, round_bf16, stream);
+    return evict_batched_impl(units, n_units, Hkv, D, keep, P, dtype, inv_freq, attention_scaling, &rs, round_bf16,
+                              stage_low_only, stream);
+}
+
+extern "C" int rtk_pivotkv_place_batched(const rtk_place_unit* units, int n_units, int H, int keep, int D, int dtype,
+                                         rtk_stream_t stream) {
+    RTK_CHECK_ARG(units && n_units >= 1, "rtk_pivotkv_place_batched: no units");
+    RTK_CHECK_ARG(H >= 1 && keep >= 1 && D >= 1, "rtk_pivotkv_place_batched: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_place_batched: unsupported dtype %d", dtype);
+    const size_t row = (size_t)D * (dtype == RTK_BF16 ? 2 : 4);
+    for (int i = 0; i < n_units; ++i) {
+        const rtk_place_unit& u = units[i];
+        RTK_CHECK_ARG(u.stage && u.tail && u.keep_idx, "rtk_pivotkv_place_batched: unit %d: NULL pointer", i);
+        if (row % 16 || u.stage_stride_h_bytes % 16 || u.tail_stride_h_bytes % 16 || (((uintptr_t)u.stage | (uintptr_t)u.tail) & 15)) {
+            set_error("rtk_pivotkv_place_batched: unit %d: rows must be 16-byte aligned", i);
+            return RTK_EUNSUPPORTED;
+        }
+    }
+    const size_t total = (size_t)H * keep * (row / 16);
+    const unsigned gx = (unsigned)std::min<size_t>((total + 4 * 256 - 1) / (4 * 256), 1024);
+    hipStream_t st = (hipStream_t)stream;
+    for (int b = 0; b < n_units; b += RTK_PLACE_MAX_UNITS) {
+        const int n = std::min(RTK_PLACE_MAX_UNITS, n_units - b);
+        PlaceUnits pu;
+        for (int i = 0; i < n; ++i) pu.u[i] = units[b + i];
+        for (int i = n; i < RTK_PLACE_MAX_UNITS; ++i) pu.u[i] = units[b];
+        RTK_LAUNCH(KID_COMMITB, place_batched_kernel, dim3(gx, n), dim3(256), 0, st, pu, H, keep, (int)(row / 16));
+        RTK_LAUNCH_CHECK("place_batched_kernel");
+    }
+    return RTK_OK;
 }
 
 extern "C" int rtk_pivotkv_commit_batched(const rtk_copy_unit* units, int n_units, int H, int rows, int D, int dtype,

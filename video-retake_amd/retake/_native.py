@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 RTK_F32, RTK_BF16, RTK_BF16_REFROUND = 0, 1, 2
 SCORE_PREPARE, SCORE_PASSES, SCORE_FINALIZE = 1, 2, 4
@@ -34,6 +34,12 @@ class SelectUnit(C.Structure):
     """rtk_select_unit (include/retake_hip.h)."""
     _fields_ = [("partial", _vp), ("score", _vp), ("mask", _vp), ("pos", _vp), ("keep_idx", _vp), ("rank", _vp),
                 ("pos_out", _vp), ("workspace", _vp)]
+
+
+class PlaceUnit(C.Structure):
+    """rtk_place_unit (include/retake_hip.h)."""
+    _fields_ = [("stage", _vp), ("stage_stride_h_bytes", _i64), ("tail", _vp), ("tail_stride_h_bytes", _i64),
+                ("keep_idx", _vp)]
 
 
 class CopyUnit(C.Structure):
@@ -71,8 +77,9 @@ _SIGNATURES = {
     "rtk_copy_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "rtk_pivotkv_commit": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "rtk_pivotkv_append": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
-    "rtk_pivotkv_evict_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "rtk_pivotkv_evict_batched_rope": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _i, _i, _vp]),
+    "rtk_pivotkv_evict_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rtk_pivotkv_evict_batched_rope": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _i, _i, _i, _vp]),
+    "rtk_pivotkv_place_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp]),
     "rtk_pivotkv_commit_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp]),
     "rtk_position_shift": (C.c_int, [_vp, _i, _vp, _vp]),
     "rtk_profile_enable": (C.c_int, [_i]),

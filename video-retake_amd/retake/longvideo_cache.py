@@ -632,7 +632,7 @@ class PivotKVCache(DynamicCache):
                 self._rope_tables(b.cos_new[lo * keep:], b.sin_new[lo * keep:], b.rotary_emb_fn, b.x_like, pos2d, ld,
                                   3 if P == 3 else 2, b.mrope_section, n, D)
             units = (nv.EvictUnit * len(layers))()
-            copies = (nv.CopyUnit * (len(layers) * (1 if b.reforge else 2)))()
+            places = (nv.PlaceUnit * (len(layers) * (1 if b.reforge else 2)))()
             nc = 0
             for i, l in enumerate(layers):
                 st = self._layers[l]
@@ -651,13 +651,15 @@ class PivotKVCache(DynamicCache):
                     u.k_src, u.k_src_stride_h = st.k.data_ptr() + tail, cap * D
                     u.cos_new = u.sin_new = None
                     u.k_dst, u.k_dst_stride_h = b.k_stage[l].data_ptr(), keep * D
-                    copies[nc].src, copies[nc].src_stride_h_bytes = b.k_stage[l].data_ptr(), keep * D * es
-                    copies[nc].dst, copies[nc].dst_stride_h_bytes = st.k.data_ptr() + tail, cap * D * es
+                    places[nc].stage, places[nc].stage_stride_h_bytes = b.k_stage[l].data_ptr(), keep * D * es
+                    places[nc].tail, places[nc].tail_stride_h_bytes = st.k.data_ptr() + tail, cap * D * es
+                    places[nc].keep_idx = b.keep_idx[l].data_ptr()
                     nc += 1
                 u.v_src, u.v_src_stride_h = st.v.data_ptr() + tail, cap * D
                 u.v_dst, u.v_dst_stride_h = b.v_stage[l].data_ptr(), keep * D
-                copies[nc].src, copies[nc].src_stride_h_bytes = b.v_stage[l].data_ptr(), keep * D * es
-                copies[nc].dst, copies[nc].dst_stride_h_bytes = st.v.data_ptr() + tail, cap * D * es
+                places[nc].stage, places[nc].stage_stride_h_bytes = b.v_stage[l].data_ptr(), keep * D * es
+                places[nc].tail, places[nc].tail_stride_h_bytes = st.v.data_ptr() + tail, cap * D * es
+                places[nc].keep_idx = b.keep_idx[l].data_ptr()
                 nc += 1
                 u.keep_idx = b.keep_idx[l].data_ptr()
                 if b.reforge and P:  # bookkeeping (reference :308-309)
@@ -676,12 +678,14 @@ class PivotKVCache(DynamicCache):
                 nv.check(nv.lib.rtk_pivotkv_evict_batched_rope(units, len(layers), Hkv, D, keep, P, dt, nv.ptr(inv),
                                                                float(fn.attention_scaling), sec,
                                                                len(b.mrope_section) if b.mrope_section else 0,
-                                                               int(b.x_like.dtype == torch.bfloat16), s),
+                                                               int(b.x_like.dtype == torch.bfloat16), 1, s),
                          "rtk_pivotkv_evict_batched_rope")
             else:
-                nv.check(nv.lib.rtk_pivotkv_evict_batched(units, len(layers), Hkv, D, keep, P if b.reforge else 0, dt, s),
+                nv.check(nv.lib.rtk_pivotkv_evict_batched(units, len(layers), Hkv, D, keep, P if b.reforge else 0, dt, 1, s),
                          "rtk_pivotkv_evict_batched")
-            nv.check(nv.lib.rtk_pivotkv_commit_batched(copies, nc, Hkv, keep, D, dt, s), "rtk_pivotkv_commit_batched")
+            # kept rows -> head of the tail: in place, except the ~ratio of them whose source lies inside the destination
+            # range (parked in the staging rows by the launch above) - reference :313-318 without a full second copy
+            nv.check(nv.lib.rtk_pivotkv_place_batched(places, nc, Hkv, keep, D, dt, s), "rtk_pivotkv_place_batched")
         for l in layers:
             st = self._layers[l]
             st.length += keep
