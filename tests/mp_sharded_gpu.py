@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Multi-rank GPU check of the chunk-sharded path, launched by tests/test_hip_parity.py::test_sharded_multi_rank_rccl as
+    python -m torch.distributed.run --nproc-per-node W --master-addr 127.0.0.1 --master-port P tests/mp_sharded_gpu.py
+Every rank compresses its block of one small synthetic video (bench.py's deterministic inputs) through
+retake.sharded.sharded_video_step - RCCL all-gathers of the distance rows, the temporal offsets and the compressed cache -
+and compares the assembled cache with the cache the same rank builds sequentially on its own: ids and V exact, K within
+1e-5 (fp32).  Two shapes: chunks divisible by the world size (per-chunk overlapped gathers) and one chunk more (ragged
+blocks, padded assembly at the end).  Prints MP_SHARDED_OK on rank 0.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "video-retake_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+import torch.distributed as dist
+
+
+def main():
+    import bench as B
+    import retake.longvideo_cache as lc
+    import retake.visual_compression as vc
+    from retake import sharded
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    td, layers = torch.float32, 2
+    L = B.FRAMES_PER_CHUNK * B.N_PATCH
+    rotary = B.Rotary(dev)
+    for n_chunks in (2 * world, 2 * world + 1):
+        T = n_chunks * B.FRAMES_PER_CHUNK
+        pool = [B.pool_set(i, dev, td) for i in range(n_chunks * layers)]
+        # sequential single-GPU reference on this rank
+        frames_all = torch.cat([B.chunk_frames(c, dev, td) for c in range(n_chunks)])[None]
+        _, mask = vc.memory_bank_compress_keyframe(frames_all, T, 3, sync=False)
+        seq = lc.build_kvcache(B.make_cache_config(layers))
+        for c in range(n_chunks):
+            seq.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
+            seq.kvcache_compression = True
+            pos = B.chunk_position_ids(c, dev)
+            for l in range(layers):
+                q, k, v = pool[(c * layers + l) % len(pool)]
+                seq.shift_temporal_ids_(pos, l)
+                seq.update(k, v, l, {"query_states": q, "position_ids": pos, "rotary_emb": rotary, "mrope_section": B.MROPE})
+            seq.after_forward()
+        # sharded
+        blocks = sharded.shard_chunks(n_chunks, world)
+        c0, c1 = blocks[rank]
+        even = len({b - a for a, b in blocks}) == 1
+        halo = c0 > 0
+        parts = ([B.chunk_frames(c0 - 1, dev, td)[-1:]] if halo else []) + [B.chunk_frames(c, dev, td) for c in range(c0, c1)]
+        pos_base = [B.chunk_position_ids(c, dev) for c in range(c0, c1)]
+        _, (keys, values, pos) = sharded.sharded_video_step(torch.cat(parts)[None], halo, T, c0, c1, layers, pool, pos_base,
+                                                            rotary, even)
+        keep = max(1, int(B.RATIO * L))
+        for l in range(layers):
+            assert keys[l].shape[2] == n_chunks * keep, (keys[l].shape, n_chunks * keep)
+            assert torch.equal(pos[l], seq.position_cache[l]), f"layer {l}: ids differ"
+            assert torch.equal(values[l], seq.value_cache[l]), f"layer {l}: V differs"
+            err = (keys[l] - seq.key_cache[l]).abs().max().item()
+            assert err <= 1e-5, f"layer {l}: K differs by {err}"
+        a, b = B.cache_checksum(keys, values, pos), B.cache_checksum([seq.key_cache[l] for l in range(layers)],
+                                                                    [seq.value_cache[l] for l in range(layers)],
+                                                                    seq.position_cache)
+        assert a["ids_sum"] == b["ids_sum"] and a["v_bits_sum"] == b["v_bits_sum"] and a["tokens_per_layer"] == b["tokens_per_layer"]
+        assert abs(a["k_abs_sum"] - b["k_abs_sum"]) <= 1e-6 * b["k_abs_sum"]
+        dist.barrier()
+        if rank == 0:
+            print(f"chunks {n_chunks} on {world} rank(s): blocks {blocks}, overlapped gathers {even}: assembled == sequential", flush=True)
+    dist.destroy_process_group()
+    if rank == 0:
+        print("MP_SHARDED_OK", flush=True)
+
+
+if __name__ == "__main__":
+    main()

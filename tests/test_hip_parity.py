@@ -4,6 +4,7 @@ Everything here goes through the product's public surface (retake.visual_compres
 retake.longvideo_cache), i.e. through the C ABI of libretake_hip.so.  Bar: frame and KV indices
 bit-exact, gathered frames / kept V byte-identical, kept K within 1e-5 (fp32).
 """
+import os
 import types
 
 import numpy as np
@@ -1142,7 +1143,8 @@ def test_dpselect_frame_exchange_emulated_ranks(sync):
 # BASELINE.json full sizes: size-independent properties (the oracle is too slow / too big here)
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("T,N,C,dtype", [(2048, 196, 1280, torch.float32),      # BASELINE configs[1-3]
-                                         (512, 729, 1152, torch.bfloat16)])     # configs[4]: SigLIP patches, bf16
+                                         (512, 729, 1152, torch.bfloat16),      # configs[4] geometry, quarter length
+                                         (2048, 729, 1152, torch.bfloat16)])    # configs[4]: 2048 frames of SigLIP patches
 def test_dpselect_full_size_properties(T, N, C, dtype):
     """Full BASELINE geometries: ratio 1.0 is the identity with a peak mask that obeys the stencil; ratio 0.5
     keeps sorted, distinct frames per patch, prefers peaks, and is idempotent on its own selection."""
@@ -1216,6 +1218,90 @@ def test_pivotkv_full_size_invariants_plain_rope_2d_ids():
         assert int(t_new[0]) >= last_t + 1 and bool((t_new[1:] >= t_new[:-1]).all())
         last_t = int(t_new[-1])
     assert cache.num_evicted_tokens == [4 * (L - keep)]
+
+
+@pytest.mark.parametrize("mrope", [True, False])
+def test_pivotkv_dynamic_ratio_keep624_vs_oracle(mrope):
+    """BASELINE configs[4] / SURVEY cfg 5: `dynamic_compression_ratio` with max_input_length 40000 on a 2048-frame
+    LLaVA-Video prompt gives ratio 40000 / 401409 = 0.0996..., i.e. keep = int(ratio * 6272) = 624 per chunk.  Two
+    layers x two chunks of L = 6272 in bf16 through the batched flush, plain RoPE with [1, L] ids (LLaVA) and M-RoPE
+    (Qwen2-VL): every layer bitwise against one-unit launches, layer 0 of the last chunk against the CPU oracle on the
+    same bf16-valued inputs (score <= 2e-5, kept set margin-aware), ids by the reference's rescale rule with
+    keep / L = 624 / 6272 in float32."""
+    import retake.longvideo_cache as lc
+    import unit_check as uc
+    from retake import _prefill
+
+    Hq, Hkv, D, L, layers = 28, 4, 128, 6272, 2
+    S = synth.YARN_FACTOR4_ATTENTION_SCALING
+    sec = [16, 24, 24] if mrope else None
+    kwc = {"compression_ratio": 0.5, "compression_method": "pivotkv", "pos_embed_reforge": True, "native_rope": True,
+           "dynamic_compression_ratio": True, "max_input_length": 40000}
+    llm = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=layers, num_attention_heads=Hq,
+                                num_key_value_heads=Hkv)
+    lk = {"kvcache_compression": True, "kvcache_compression_kwargs": kwc}
+    if mrope:
+        llm.longvideo_kwargs = lk
+        cfg = llm
+    else:
+        cfg = types.SimpleNamespace(text_config=llm, longvideo_kwargs=lk)
+    _prefill.apply_dynamic_compression_ratio(cfg, 2048 * 196 + 1)        # what the model forward does before build_kvcache
+    cache = lc.build_kvcache(cfg)
+    assert cache.compression_ratio == 40000 / 401409
+    keep = max(1, int(cache.compression_ratio * L))
+    assert keep == 624
+    inv_f = synth.inv_freq(D)
+    rot = synth.RotaryStub(inv_f, S, device=dev())
+    rot_cpu = synth.RotaryStub(inv_f, S)
+    gen = torch.Generator(device=dev()).manual_seed(77 + int(mrope))
+    for c in range(2):
+        if mrope:
+            pos = torch.from_numpy(synth.mrope_position_ids(20 + 32 * c, 32, 14, 14, hw0=3)).to(dev())
+        else:
+            pos = (torch.arange(L, device=dev()) + 20 + c * L)[None].contiguous()
+        mask = torch.rand(L, generator=gen, device=dev()) < 0.3
+        cache.keypatches_mask_chunk = mask
+        cache.kvcache_compression = True
+        inputs, prev_len = {}, cache.get_seq_length(0)
+        pos_used = {}
+        for l in range(layers):
+            p_l = cache.shift_temporal_ids_(pos if mrope else pos.clone(), l)   # Qwen shifts in place, LLaVA a clone
+            q = synth.rope_forward(1.7 * torch.randn((1, Hq, L, D), generator=gen, device=dev()), p_l, rot, sec).bfloat16()
+            k = synth.rope_forward(1.7 * torch.randn((1, Hkv, L, D), generator=gen, device=dev()), p_l, rot, sec).bfloat16()
+            v = (1.7 * torch.randn((1, Hkv, L, D), generator=gen, device=dev())).bfloat16()
+            kw = {"query_states": q, "position_ids": p_l, "rotary_emb": rot}
+            if mrope:
+                kw["mrope_section"] = list(sec)
+            cache.update(k, v, l, kw)
+            inputs[l], pos_used[l] = (q, k), p_l.clone()
+        cache.after_forward()
+        uc.check_batch_against_units(cache, range(layers), inputs, {l: mask for l in range(layers)}, keep, rot.inv_freq, S, sec)
+    b = cache._batch
+    q, k = (t.cpu() for t in inputs[0])
+    P = 3 if mrope else 1
+    pos_l = b.pos_old[0].cpu().reshape((3, 1, L) if mrope else (1, L))
+    cos, sin = rot_cpu(q, pos_l)
+    if mrope:
+        cos, sin = _bf16_tables_cpu(rot_cpu, pos_l, sec, q)
+    else:
+        cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
+    a2 = S ** 2
+    qt = ((q * cos) - (_rot_half(q) * sin)) / a2
+    kt = ((k * cos) - (_rot_half(k) * sin)) / a2
+    so = orc.pivotkv_score(qt.float().numpy()[0], kt.float().numpy()[0])
+    so[mask.cpu().numpy()] = 1.0
+    score, idx = b.score[0].cpu().numpy(), b.keep_idx[0].cpu().numpy()
+    assert np.abs(score - so).max() < 2e-5
+    want = np.sort(np.lexsort((np.arange(L), -so.astype(np.float64)))[:keep])
+    diff = np.setxor1d(idx, want)
+    if diff.size:
+        assert np.abs(so[diff] - np.sort(so)[::-1][keep - 1]).max() < 4e-5
+    assert diff.size <= 8
+    g = pos_l.reshape(P, L)[:, torch.from_numpy(idx)].numpy().astype(np.int64)
+    tmin = g[0].min()
+    g[0] = tmin + ((g[0] - tmin).astype(np.float32) * np.float32(keep / L)).astype(np.int64)
+    np.testing.assert_array_equal(cache.position_cache[0].reshape(P, -1)[:, prev_len:].cpu().numpy(), g)
+    assert cache.key_cache[0].shape[2] == 2 * keep and cache.num_evicted_tokens == [2 * (L - keep)] * layers
 
 
 def test_pivotkv_full_size_invariants():
@@ -1450,3 +1536,22 @@ def test_pivotkv_reference_rounding_batched_equals_per_layer():
     for l in range(layers):
         assert torch.equal(a.key_cache[l], b.key_cache[l]) and torch.equal(a.value_cache[l], b.value_cache[l])
         assert torch.equal(a.position_cache[l], b.position_cache[l])
+
+
+def test_sharded_multi_rank_rccl():
+    """The chunk-sharded path on min(2, visible GPUs) ranks over RCCL (tests/mp_sharded_gpu.py): assembled cache ==
+    sequential cache (ids exact, V exact, K <= 1e-5) for an even and a ragged chunk split.  On a 1-GPU box this still
+    drives the whole path through RCCL at world size 1; with >= 2 GPUs it is the first multi-rank run of the collectives."""
+    import socket
+    import subprocess
+    import sys
+
+    world = min(2, torch.cuda.device_count())
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "mp_sharded_gpu.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "MP_SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -236,3 +236,31 @@ def _chunk_gather(rank, world):
 def test_chunk_gather_equals_gather_at_the_end():
     assert all(_spawn("_chunk_gather"))
     assert all(_spawn("_chunk_gather", world=3))
+
+
+# ---------------------------------------------------------------------------------------------------
+# ragged blocks: a chunk count that is not a multiple of the world size gives the last ranks fewer rows
+# ---------------------------------------------------------------------------------------------------
+def _ragged(rank, world):
+    from retake import sharded
+
+    n = [5, 3, 3][rank]                                                 # rows this rank holds
+    counts = sharded.gather_counts(n, "cpu")
+    rows = torch.arange(n * 2, dtype=torch.float32).reshape(n, 2) + 100 * rank
+    full = sharded.all_gather_rows_ragged(rows)
+    layers, Hkv, D = 2, 2, 4
+    keys = [torch.full((1, Hkv, n, D), float(10 * rank + l)) + torch.arange(n)[None, None, :, None] for l in range(layers)]
+    vals = [k + 0.5 for k in keys]
+    pos = [torch.arange(n)[None, None].repeat(3, 1, 1) + 1000 * rank + l for l in range(layers)]
+    K, V, P = sharded.all_gather_caches(keys, vals, pos)
+    return counts, full.tolist(), [k.shape for k in K], K[1][0, 1, :, 2].tolist(), V[0][0, 0, :, 0].tolist(), P[1][2, 0].tolist()
+
+
+def test_ragged_blocks_are_padded_and_trimmed():
+    want_rows = [[0, 1], [2, 3], [4, 5], [6, 7], [8, 9], [100, 101], [102, 103], [104, 105], [200, 201], [202, 203], [204, 205]]
+    for counts, full, shapes, kcol, vcol, pcol in _spawn("_ragged", world=3):
+        assert counts == [5, 3, 3] and full == want_rows
+        assert all(tuple(s) == (1, 2, 11, 4) for s in shapes)
+        assert kcol == [1, 2, 3, 4, 5, 11, 12, 13, 21, 22, 23]                      # layer 1: 10*rank + 1 + row
+        assert vcol == [0.5, 1.5, 2.5, 3.5, 4.5, 10.5, 11.5, 12.5, 20.5, 21.5, 22.5]
+        assert pcol == [1, 2, 3, 4, 5, 1001, 1002, 1003, 2001, 2002, 2003]

@@ -88,6 +88,30 @@ def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+def gather_counts(n: int, device, group=None) -> List[int]:
+    """How many rows every rank is about to contribute (one tiny all-gather).  Equal-size collectives
+    (`all_gather_into_tensor`) hang or corrupt memory when the ranks disagree, so every assembly asks first."""
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(n)], dtype=torch.int64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return [int(p.item()) for p in parts]
+
+
+def all_gather_rows_ragged(local: torch.Tensor, group=None, counts: Optional[List[int]] = None) -> torch.Tensor:
+    """[rows_r, ...] with a different rows_r per rank -> [sum rows, ...] in rank order: the blocks are padded to the
+    longest one, exchanged with ONE equal-size all-gather and trimmed (a video whose chunk count is not a multiple of
+    the world size gives the last ranks one chunk less)."""
+    counts = counts if counts is not None else gather_counts(local.shape[0], local.device, group)
+    if len(set(counts)) == 1:
+        return all_gather_rows(local, group)
+    nmax = max(counts)
+    padded = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
+    full = all_gather_rows(padded, group).reshape((len(counts), nmax) + tuple(local.shape[1:]))
+    return torch.cat([full[r, :n] for r, n in enumerate(counts)], dim=0)
+
+
 def _all_gather_flat(send: torch.Tensor, group=None) -> torch.Tensor:
     """send [...] -> [world, ...] in rank order, one collective."""
     world = dist.get_world_size(group)
@@ -104,33 +128,51 @@ def all_gather_caches(keys: List[torch.Tensor], values: List[torch.Tensor], pos:
     large all-gathers use the links far better than 84 small ones, and each result needs one permute copy instead
     of a per-tensor scatter + cat).
 
-    keys / values: per layer [1, Hkv, n, D]; pos: per layer [3, 1, n] or [1, n] int64; n and the shapes are the same
-    on every rank (every chunk keeps exactly `keep` tokens and the ranks hold equally many chunks).  Returns the
-    per-layer lists [1, Hkv, world*n, D] / [..., world*n] in rank order - views into one buffer per kind."""
+    keys / values: per layer [1, Hkv, n, D]; pos: per layer [3, 1, n] or [1, n] int64.  The ranks first exchange their
+    row counts: equal counts (every chunk keeps exactly `keep` tokens and the ranks hold equally many chunks) move
+    exactly the rows, unequal ones are padded to the longest block and trimmed after the gather.  Returns the
+    per-layer lists [1, Hkv, sum n, D] / [..., sum n] in rank order."""
     world = dist.get_world_size(group)
     n_layers = len(keys)
     _, Hkv, n, D = keys[0].shape
-    send = torch.empty((2, n_layers, Hkv, n, D), dtype=keys[0].dtype, device=keys[0].device)
-    torch.stack([k[0] for k in keys], out=send[0])
-    torch.stack([v[0] for v in values], out=send[1])
-    recv = _all_gather_flat(send, group)                                        # [W, 2, layers, Hkv, n, D]
-    kv = recv.permute(1, 2, 3, 0, 4, 5).reshape(2, n_layers, Hkv, world * n, D)   # one copy: rank-major inside a head
+    counts = gather_counts(n, keys[0].device, group)
+    nmax = max(counts)
+    alloc = torch.empty if n == nmax and len(set(counts)) == 1 else torch.zeros
+    send = alloc((2, n_layers, Hkv, nmax, D), dtype=keys[0].dtype, device=keys[0].device)
+    if n == nmax:   # stack straight into the send buffer
+        torch.stack([k[0] for k in keys], out=send[0])
+        torch.stack([v[0] for v in values], out=send[1])
+    else:
+        send[0, :, :, :n].copy_(torch.stack([k[0] for k in keys]))
+        send[1, :, :, :n].copy_(torch.stack([v[0] for v in values]))
+    recv = _all_gather_flat(send, group)                                        # [W, 2, layers, Hkv, nmax, D]
+    if len(set(counts)) == 1:
+        kv = recv.permute(1, 2, 3, 0, 4, 5).reshape(2, n_layers, Hkv, world * n, D)   # one copy: rank-major inside a head
+    else:   # ragged blocks (chunk count not a multiple of the world size): drop every rank's padding
+        kv = torch.cat([recv[r, :, :, :, :c] for r, c in enumerate(counts)], dim=3)
     return ([kv[0, l][None] for l in range(n_layers)], [kv[1, l][None] for l in range(n_layers)],
-            all_gather_ids(pos, group))
+            all_gather_ids(pos, group, counts))
 
 
-def all_gather_ids(pos: List[torch.Tensor], group=None) -> List[torch.Tensor]:
-    """Per-layer position ids [..., n] of every rank -> [..., world*n] in rank order, one collective."""
+def all_gather_ids(pos: List[torch.Tensor], group=None, counts: Optional[List[int]] = None) -> List[torch.Tensor]:
+    """Per-layer position ids [..., n_r] of every rank -> [..., sum n_r] in rank order, one collective (blocks padded
+    to the longest one when the ranks hold different numbers of rows)."""
     world = dist.get_world_size(group)
     n_layers, n = len(pos), pos[0].shape[-1]
+    counts = counts if counts is not None else gather_counts(n, pos[0].device, group)
+    nmax, total = max(counts), sum(counts)
     pshape = tuple(pos[0].shape[:-1])
     rows = 1
     for d in pshape:
         rows *= d
-    psend = torch.stack([p.reshape(rows, n) for p in pos])                      # [layers, rows, n]
-    precv = _all_gather_flat(psend, group)                                      # [W, layers, rows, n]
-    pall = precv.permute(1, 2, 0, 3).reshape(n_layers, rows, world * n)
-    return [pall[l].reshape(pshape + (world * n,)) for l in range(n_layers)]
+    psend = torch.zeros((n_layers, rows, nmax), dtype=pos[0].dtype, device=pos[0].device)
+    psend[:, :, :n] = torch.stack([p.reshape(rows, n) for p in pos])            # [layers, rows, nmax]
+    precv = _all_gather_flat(psend, group)                                      # [W, layers, rows, nmax]
+    if len(set(counts)) == 1:
+        pall = precv.permute(1, 2, 0, 3).reshape(n_layers, rows, world * n)
+    else:
+        pall = torch.cat([precv[r, :, :, :c] for r, c in enumerate(counts)], dim=2)
+    return [pall[l].reshape(pshape + (total,)) for l in range(n_layers)]
 
 
 class ChunkGather:
@@ -144,7 +186,9 @@ class ChunkGather:
         self.items = []   # (work, recv [W, 2, layers, Hkv, n, D], send)
 
     def start(self, k_new: List[torch.Tensor], v_new: List[torch.Tensor]):
-        """k_new / v_new: per layer [Hkv, n, D] (any strides), the rows one chunk added."""
+        """k_new / v_new: per layer [Hkv, n, D] (any strides), the rows one chunk added.  Every rank must call this
+        equally often with equally many rows (callers whose ranks hold different chunk counts assemble at the end
+        instead: `finalize` checks the totals before it trusts the overlapped gathers)."""
         n_layers = len(k_new)
         Hkv, n, D = k_new[0].shape
         send = torch.empty((2, n_layers, Hkv, n, D), dtype=k_new[0].dtype, device=k_new[0].device)
@@ -235,7 +279,8 @@ def dpselect_sharded(frames_local: torch.Tensor, has_halo: bool, tgt_mem_len: in
         dis_l = torch.empty((Tl, N), dtype=torch.float32, device=dev)
         nv.check(nv.lib.rtk_dpselect_dis(nv.ptr(x), Tl, N, Cc, dt, nv.ptr(dis_l), st), "rtk_dpselect_dis")
         own = dis_l[1:] if has_halo else dis_l      # the halo frame only feeds the first own row
-        dis = all_gather_rows(own, group)
+        counts = gather_counts(own.shape[0], dev, group)
+        dis = all_gather_rows_ragged(own.contiguous(), group, counts)
         T = dis.shape[0]
         t = int(tgt_mem_len)
         if not 1 <= t <= T:
@@ -247,16 +292,17 @@ def dpselect_sharded(frames_local: torch.Tensor, has_halo: bool, tgt_mem_len: in
                                             nv.ptr(mask), nv.ptr(keys), st), "rtk_dpselect_select")
         own_x = (x[1:] if has_halo else x).contiguous()
         T_own = own_x.shape[0]
-        if T_own * world != T:
-            raise ValueError("sharded DPSelect: ranks must hold equally many frames")
+        f0 = sum(counts[:rank])                      # first global frame of this rank
         if t == T:
             # ratio 1.0: every frame is kept at its own index -> the local output is a copy of the own frames
-            idx_l = (idx[rank * T_own:(rank + 1) * T_own] - rank * T_own).contiguous()
+            idx_l = (idx[f0:f0 + T_own] - f0).contiguous()
             out = torch.empty((1, T_own, N, Cc), dtype=x.dtype, device=dev)
             nv.check(nv.lib.rtk_gather_frames(nv.ptr(own_x), T_own, N, Cc, dt, nv.ptr(idx_l), T_own,
                                               int(bool(sync)), nv.ptr(out), st), "rtk_gather_frames")
             return out, mask.flatten(), idx, dis
         # ratio < 1: own kept frames -> padded block -> all-gather -> output order
+        if len(set(counts)) != 1:
+            raise ValueError(f"sharded DPSelect at ratio < 1 needs equally many frames per rank, got {counts}")
         _, cmax, local, place = plan_frame_exchange(idx, T_own, world)
         mine = local[rank, :, 0].contiguous() if sync else local[rank].contiguous()
         block = torch.empty((cmax, N, Cc), dtype=x.dtype, device=dev)
@@ -340,6 +386,13 @@ class ShardedPivotKV:
             if g is not None and (not assemble or g.rows() != keys[0].shape[2]):
                 g.drop()   # not every chunk went through gather_chunk: fall back to the gather at the end
                 g = None
+            if assemble:   # the overlapped gathers moved equal blocks: only valid if every rank kept equally many rows
+                counts = gather_counts(keys[0].shape[2], dev, self.group)
+                use_g = torch.tensor([int(g is not None and len(set(counts)) == 1)], dtype=torch.int64, device=dev)
+                dist.all_reduce(use_g, op=dist.ReduceOp.MIN, group=self.group)   # one decision for all ranks
+                if g is not None and not int(use_g.item()):
+                    g.drop()
+                    g = None
             if assemble and g is not None:
                 kv = g.finish()                                   # [2, layers, Hkv, world*n, D], provisional positions
                 world = table.shape[0]
@@ -363,11 +416,41 @@ class ShardedPivotKV:
 # ---------------------------------------------------------------------------------------------------
 # bench.py --gpus N  (strong scaling: one video, chunks sharded over the ranks)
 # ---------------------------------------------------------------------------------------------------
+def sharded_video_step(frames, has_halo: bool, T: int, c0: int, c1: int, layers: int, pool, pos_base, rotary, overlap: bool,
+                       group=None):
+    """One rank's share of one video (what `bench.py --gpus N` times and tests/mp_sharded_gpu.py checks): DPSelect on
+    the rank's frames with the distance rows all-gathered, PivotKV on chunks [c0, c1) at provisional temporal ids, then
+    offsets + cache assembly.  `overlap`: the rows a chunk kept leave in one asynchronous all-gather right after its
+    flush (needs equally many chunks on every rank).  Returns (retained tokens of this rank, (keys, values, ids))."""
+    import bench as B
+
+    L = B.FRAMES_PER_CHUNK * B.N_PATCH
+    out, mask, idx, dis = dpselect_sharded(frames, has_halo, T, 3, sync=False, group=group)
+    sh = ShardedPivotKV(B.make_cache_config(layers), group=group)
+    cache = sh.cache
+    for ci, c in enumerate(range(c0, c1)):
+        cache.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
+        cache.kvcache_compression = True
+        pos = pos_base[ci].clone()
+        for layer in range(layers):
+            q, k, v = pool[(c * layers + layer) % len(pool)]
+            cache.shift_temporal_ids_(pos, layer)       # block-local ids start at 0 (provisional)
+            cache.update(k, v, layer, {"query_states": q, "position_ids": pos, "rotary_emb": rotary,
+                                       "mrope_section": B.MROPE})
+        cache.after_forward()
+        if overlap:
+            sh.gather_chunk()   # this chunk's kept rows leave now, beside the next chunk's scoring
+    keys, values, pos = sh.finalize(rotary.inv_freq, B.MROPE, assemble=True)
+    return (c1 - c0) * layers * max(1, int(B.RATIO * L)), (keys, values, pos)
+
+
 def bench_main(args, rank: int, world: int, local_rank: int):
     import bench as B
     from . import _native as nv
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")   # world size 1 without a launcher (RETAKE_FORCE_SHARDED=1)
+    os.environ.setdefault("MASTER_PORT", "29544")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     if not dist.is_initialized():
@@ -376,51 +459,20 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     T = args.frames
     n_chunks = T // B.FRAMES_PER_CHUNK
     L = B.FRAMES_PER_CHUNK * B.N_PATCH
-    c0, c1 = shard_chunks(n_chunks, world)[rank]
-    assert n_chunks % world == 0, "bench shards whole chunks evenly"
-    f0, f1 = c0 * B.FRAMES_PER_CHUNK, c1 * B.FRAMES_PER_CHUNK
-    halo = 1 if rank > 0 else 0
-    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
-    frames = torch.randn((1, f1 - f0 + halo, B.N_PATCH, B.C_EMB), generator=gen, device=dev).to(tdtype)
-    if world > 1:  # make the halo frame equal to the left neighbour's last frame
-        last = frames[:, -1].contiguous()
-        recv = torch.empty_like(last)
-        ops = []
-        if rank + 1 < world:
-            ops.append(dist.P2POp(dist.isend, last, rank + 1))
-        if rank > 0:
-            ops.append(dist.P2POp(dist.irecv, recv, rank - 1))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        if rank > 0:
-            frames[:, 0] = recv
-    n_calls = (c1 - c0) * args.layers
-    pool = []
-    for _ in range(min(args.pool, n_calls)):
-        pool.append(tuple((1.7 * torch.randn((1, h, L, B.D), generator=gen, device=dev)).to(tdtype)
-                          for h in (B.Hq, B.Hkv, B.Hkv)))
+    blocks = shard_chunks(n_chunks, world)
+    c0, c1 = blocks[rank]
+    even = len({b - a for a, b in blocks}) == 1     # else: padded assembly at the end instead of per-chunk gathers
+    # the synthetic inputs are functions of the chunk / update index (bench.chunk_frames, bench.pool_set), so every rank
+    # regenerates its share - halo frame included - and any world size compresses the very same video
+    halo = 1 if c0 > 0 and c1 > c0 else 0
+    parts = ([B.chunk_frames(c0 - 1, dev, tdtype)[-1:]] if halo else []) + [B.chunk_frames(c, dev, tdtype) for c in range(c0, c1)]
+    frames = torch.cat(parts)[None] if parts else torch.empty((1, 0, B.N_PATCH, B.C_EMB), dtype=tdtype, device=dev)
+    pool = [B.pool_set(i, dev, tdtype) for i in range(min(args.pool, n_chunks * args.layers))]
     pos_base = [B.chunk_position_ids(c, dev) for c in range(c0, c1)]
     rotary = B.Rotary(dev)
 
     def step():
-        out, mask, idx, dis = dpselect_sharded(frames, halo == 1, T, 3, sync=False)
-        sh = ShardedPivotKV(B.make_cache_config(args.layers))
-        cache = sh.cache
-        call = 0
-        for ci, c in enumerate(range(c0, c1)):
-            cache.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
-            cache.kvcache_compression = True
-            pos = pos_base[ci].clone()
-            for layer in range(args.layers):
-                q, k, v = pool[call % len(pool)]
-                call += 1
-                cache.shift_temporal_ids_(pos, layer)       # block-local ids start at 0 (provisional)
-                cache.update(k, v, layer, {"query_states": q, "position_ids": pos, "rotary_emb": rotary,
-                                           "mrope_section": B.MROPE})
-            cache.after_forward()
-            sh.gather_chunk()   # this chunk's kept rows leave now, beside the next chunk's scoring
-        keys, values, pos = sh.finalize(rotary.inv_freq, B.MROPE, assemble=True)
-        return (c1 - c0) * args.layers * max(1, int(B.RATIO * L)), keys
+        return sharded_video_step(frames, halo == 1, T, c0, c1, args.layers, pool, pos_base, rotary, even)
 
     for _ in range(args.warmup):
         step()
@@ -432,7 +484,7 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     t0 = time.perf_counter()
     retained = 0
     for _ in range(args.steps):
-        r, keys = step()
+        r, (keys, values, pos) = step()
         retained += r
     torch.cuda.synchronize()
     dist.barrier()
@@ -444,6 +496,7 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     dt = float(dt.item())
     nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
     kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in nv.profile_read().items()}
+    checksum = B.cache_checksum(keys, values, pos) if rank == 0 else None   # untimed; equals the N = 1 line's
     if rank == 0:
         out = {
             "metric": "frames/sec through DPSelect+PivotKV @2048 frames; retained-KV-tokens/sec",
@@ -457,6 +510,8 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                                    f"all-gather over RCCL (BASELINE configs[3])",
                        "frames": T, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L,
                        "parallelism": f"chunk-sharded x{world}", "assembled_cache_tokens": int(keys[0].shape[2])},
+            "cache_checksum": checksum,
+            "cpu_baseline": None,   # timed on rank 0 of the N = 1 run only (bench contract); see that line
             "kernels_timed_region_rank0": kern,
             "roofline": B.score_roofline(kern, args.dtype, L, T, (c1 - c0) * args.layers * args.steps),
         }
