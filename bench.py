@@ -422,7 +422,7 @@ def main():
                 tr = None
                 if args.dtype == "bf16" and T == 2048 and args.layers == LAYERS:
                     tr = pmc_traffic({"append": "append_kernel", "evict_batched": "evict_batched_kernel",
-                                      "commit_batched": "commit_batched_kernel",
+                                      "commit_batched": "place_batched_kernel",
                                       "prepare_fused": "prepare_native_kernel"}.get(name, "\0"))[0]
                 extra[name] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": gbs / HBM_PEAK_GBS, "traffic": tr, "algorithmic_bytes_per_launch": b}
