@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--L", type=int, default=6272)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--refround", action="store_true", help="bf16 payloads with the reference's bf16 score chain")
     ap.add_argument("--units", type=int, default=0, help="time rtk_pivotkv_score_passes_batched over this many units")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -30,6 +31,8 @@ def main():
     cos = torch.rand((L, D), generator=g, device=dev)
     sin = (1 - cos * cos).sqrt()
     dt = nv.dtype_code(sets[0][0])
+    if a.refround:
+        dt = nv.RTK_BF16_REFROUND
     wsb = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
     ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
     wsp = (ws.data_ptr() + 255) & ~255
