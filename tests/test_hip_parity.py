@@ -1555,3 +1555,52 @@ def test_sharded_multi_rank_rccl():
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "mp_sharded_gpu.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and "MP_SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("L", [1, 31, 130, 257, 515, 1000, 2303])
+def test_pivotkv_score_bf16_ragged_lengths_vs_oracle(L):
+    """The bf16 score kernels (two 32-row register blocks per wave, lazy max, LDS-DMA tiles of 64 rows) on chunk lengths
+    that leave partial register blocks, partial tiles and partial splits, through the one-unit entry point
+    (rtk_pivotkv_score) AND through a 3-unit batched launch: against the CPU oracle on the same bf16-valued operands."""
+    import ctypes as C
+
+    import retake._native as nv
+
+    Hq, Hkv, D, units = 28, 4, 128, 3
+    g = torch.Generator(device=dev()).manual_seed(L)
+    dt = nv.RTK_BF16
+    wsb = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
+    stride = (wsb + 255) & ~255
+    big = torch.zeros(units * stride + 256, dtype=torch.uint8, device=dev())
+    base = (big.data_ptr() + 255) & ~255
+    rs_n = C.c_int(0)
+    pf = nv.lib.rtk_pivotkv_score_partials(Hq, Hkv, L, D, dt, C.byref(rs_n))
+    parts = torch.zeros((units, pf), dtype=torch.float32, device=dev())
+    kuns = torch.zeros((units, Hkv, L, D), dtype=torch.bfloat16, device=dev())
+    qs, ks = [], []
+    for u in range(units):
+        q = (1.7 * torch.randn((1, Hq, L, D), generator=g, device=dev())).bfloat16()
+        k = (1.7 * torch.randn((1, Hkv, L, D), generator=g, device=dev())).bfloat16()
+        qs.append(q)
+        ks.append(k)
+        score = torch.empty(L, dtype=torch.float32, device=dev())
+        nv.check(nv.lib.rtk_pivotkv_score_stages(nv.ptr(q), q.stride(1), q.stride(2), nv.ptr(k), k.stride(1), k.stride(2), Hq,
+                                                 Hkv, L, D, dt, None, None, 1.0, nv.ptr(score), nv.ptr(kuns[u]),
+                                                 C.c_void_p(base + u * stride), wsb, nv.SCORE_PREPARE, None, nv.stream()),
+                 "prepare")
+    nv.check(nv.lib.rtk_pivotkv_score_passes_batched(C.c_void_p(base), stride, nv.ptr(kuns), Hkv * L * D * 2, nv.ptr(parts),
+                                                     pf, units, Hq, Hkv, L, D, dt, nv.stream()), "batched")
+    torch.cuda.synchronize()
+    G = Hq // Hkv
+    batched = (parts.view(units, Hkv, rs_n.value, L).sum(2) / G).mean(1)
+    for u in range(units):
+        so = orc.pivotkv_score(qs[u].float().cpu().numpy()[0], ks[u].float().cpu().numpy()[0])
+        ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev())
+        one = torch.empty(L, dtype=torch.float32, device=dev())
+        nv.check(nv.lib.rtk_pivotkv_score(nv.ptr(qs[u]), qs[u].stride(1), qs[u].stride(2), nv.ptr(ks[u]), ks[u].stride(1),
+                                          ks[u].stride(2), Hq, Hkv, L, D, dt, None, None, 1.0, nv.ptr(one), None,
+                                          C.c_void_p((ws.data_ptr() + 255) & ~255), wsb, nv.stream()), "score")
+        torch.cuda.synchronize()
+        assert np.abs(one.cpu().numpy() - so).max() < 2e-5, (L, u)
+        assert np.abs(batched[u].cpu().numpy() - so).max() < 2e-5, (L, u)
+        assert abs(float(one.mean()) - 1.0) < 1e-5
