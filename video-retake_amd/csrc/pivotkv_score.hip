@@ -988,8 +988,6 @@ _Pragma("unroll") \
 // LDS position p of row r receives chunk p ^ (r & 15), the same involution the fragment reads apply.
 // NB = 32-key register blocks per wave (NB = 2: every A fragment read from LDS feeds two MFMAs).
 // ------------------------------------------------------------------------------------------------
-#define RTK_ACC_INIT(acc, ls) acc = f32x16{0};
-#define RTK_COLSUM(col, acc, ls, c2, sd) colsum_block<DT>(col, acc, ls, c2, sd)
 template <int NB>
 __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 2 : 2)))) void score_pass2_dma_kernel(
     const char* __restrict__ q, const char* __restrict__ k, const float* __restrict__ lse, int Hq, int Hkv, int L,
@@ -1083,13 +1081,13 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
             f32x16 acc[NB];                                                                               \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) {                                                             \
-                RTK_ACC_INIT(acc[nb], ls)                                                                 \
+                acc[nb] = f32x16{0};                                                                      \
                 _Pragma("unroll")                                                                         \
                 for (int r = 0; r < M::NREG; ++r) M::mma(acc[nb], a[r], kf[nb][r]);                       \
             }                                                                                             \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) {                                                             \
-                RTK_COLSUM(col[nb], acc[nb], ls, c2, sqrt_d);                                             \
+                colsum_block<DT>(col[nb], acc[nb], ls, c2, sqrt_d);                                       \
                 asm volatile("" : "+v"(col[nb]) : : "memory");                                            \
                 __builtin_amdgcn_sched_barrier(0);                                                        \
             }                                                                                             \
