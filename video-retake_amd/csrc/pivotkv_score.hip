@@ -583,6 +583,12 @@ struct RowStat {  // online max / sum of one query row, over the keys this lane 
 #ifndef RTK_P2_NB
 #define RTK_P2_NB 2
 #endif
+#ifndef RTK_DMA_PLACE   // 0 = the next tile's LDS-DMA pieces are issued at the head of a tile step, 1 = inside block 0's softmax
+#define RTK_DMA_PLACE 1    // same-box A/B: pass 1 7048 -> 7016 us, pass 2 7138 -> 7083 us, bit-identical results
+#endif
+#ifndef RTK_LSE_W0      // 1 = only wave 0 fetches the tile's 64 row normalisers (the other waves used to load them too)
+#define RTK_LSE_W0 1       // same-box A/B: pass 2 7083 -> 7043 us, bit-identical results
+#endif
 template <int DT> struct RegBlocks {
     static constexpr int NB = 1;
     static constexpr int PF = 1;
@@ -1065,12 +1071,30 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
         nt = wrap__ ? 0 : nt + 1;                                                                         \
         nrow0 += wrap__ ? L : 0;                                                                          \
     }
+#define RTK_DMA_PIECES(b, rb, U0, U1)                                                                     \
+    {                                                                                                     \
+        _Pragma("unroll")                                                                                 \
+        for (int u = U0; u < U1; ++u)                                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                     \
+                qrsrc, (void __attribute__((address_space(3)))*)(smem + (b) * T::BYTES + (4 * u + wid) * 1024), 16, \
+                dvoff, ((rb) + 16 * u) * T::ROWB, 0, 0);                                                  \
+    }
+#define RTK_DMA_TAIL()                                                                                    \
+    {                                                                                                     \
+        const int r__ = nt * TILE_ROWS + (tid & (TILE_ROWS - 1));                                         \
+        if (!RTK_LSE_W0 || wid == 0) lstA = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : INFINITY;   \
+        const bool wrap__ = (nt + 1 == tiles_per_head);                                                   \
+        nt = wrap__ ? 0 : nt + 1;                                                                         \
+        nrow0 += wrap__ ? L : 0;                                                                          \
+    }
 #define RTK_DMA_STEP(BUF, ISSUE)                                                                          \
     {                                                                                                     \
         constexpr int buf = BUF;                                                                          \
         const char* cur = smem + buf * T::BYTES;                                                          \
         const float* lcur = lse_s + buf * TILE_ROWS;                                                      \
-        if constexpr (ISSUE) RTK_DMA_ISSUE(buf ^ 1)                                                       \
+        const int rb__ = nrow0 + nt * TILE_ROWS;                                                          \
+        if constexpr (ISSUE && RTK_DMA_PLACE == 0) RTK_DMA_ISSUE(buf ^ 1)                                 \
+        if constexpr (ISSUE && RTK_DMA_PLACE != 0) RTK_DMA_TAIL()                                         \
         _Pragma("unroll")                                                                                 \
         for (int blk = 0; blk < 2; ++blk) {                                                               \
             u32x4 a[M::NREG];                                                                             \
@@ -1090,6 +1114,14 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
                 colsum_block<DT>(col[nb], acc[nb], ls, c2, sqrt_d);                                       \
                 asm volatile("" : "+v"(col[nb]) : : "memory");                                            \
                 __builtin_amdgcn_sched_barrier(0);                                                        \
+                if constexpr (ISSUE && RTK_DMA_PLACE != 0) {                                              \
+                    if (blk == 0) {                                                                       \
+                        if (NB == 1) RTK_DMA_PIECES(buf ^ 1, rb__, 0, 4)                                  \
+                        else if (nb == 0) RTK_DMA_PIECES(buf ^ 1, rb__, 0, 2)                             \
+                        else if (nb == 1) RTK_DMA_PIECES(buf ^ 1, rb__, 2, 4)                             \
+                        __builtin_amdgcn_sched_barrier(0);                                                \
+                    }                                                                                     \
+                }                                                                                         \
             }                                                                                             \
         }                                                                                                 \
         if constexpr (ISSUE) {                                                                            \
@@ -1193,11 +1225,19 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
                 krsrc, (void __attribute__((address_space(3)))*)(smem + (b) * T::BYTES + (4 * u + wid) * 1024), 16, \
                 dvoff, (jb + (t) * TILE_ROWS + 16 * u) * T::ROWB, 0, 0);                                  \
     }
+#define RTK_DMA1_PIECES(t, b, U0, U1)                                                                     \
+    {                                                                                                     \
+        _Pragma("unroll")                                                                                 \
+        for (int u = U0; u < U1; ++u)                                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                     \
+                krsrc, (void __attribute__((address_space(3)))*)(smem + (b) * T::BYTES + (4 * u + wid) * 1024), 16, \
+                dvoff, (jb + (t) * TILE_ROWS + 16 * u) * T::ROWB, 0, 0);                                  \
+    }
 #define RTK_DMA1_STEP(JT, BUF, ISSUE, RAG)                                                                \
     {                                                                                                     \
         constexpr int buf = BUF;                                                                          \
         const char* cur = smem + buf * T::BYTES;                                                          \
-        if constexpr (ISSUE) RTK_DMA1_ISSUE((JT) + 1, buf ^ 1)                                            \
+        if constexpr (ISSUE && RTK_DMA_PLACE == 0) RTK_DMA1_ISSUE((JT) + 1, buf ^ 1)                      \
         _Pragma("unroll")                                                                                 \
         for (int blk = 0; blk < 2; ++blk) {                                                               \
             u32x4 a[M::NREG];                                                                             \
@@ -1217,6 +1257,14 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
                 else rs[nb].template update<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf, c2);    \
                 asm volatile("" : "+v"(rs[nb].sum), "+v"(rs[nb].m) : : "memory");                         \
                 __builtin_amdgcn_sched_barrier(0);                                                        \
+                if constexpr (ISSUE && RTK_DMA_PLACE != 0) {   /* next tile's DMA pieces inside block 0's softmax */ \
+                    if (blk == 0) {                                                                       \
+                        if (NB == 1) RTK_DMA1_PIECES((JT) + 1, buf ^ 1, 0, 4)                             \
+                        else if (nb == 0) RTK_DMA1_PIECES((JT) + 1, buf ^ 1, 0, 2)                        \
+                        else if (nb == 1) RTK_DMA1_PIECES((JT) + 1, buf ^ 1, 2, 4)                        \
+                        __builtin_amdgcn_sched_barrier(0);                                                \
+                    }                                                                                     \
+                }                                                                                         \
             }                                                                                             \
         }                                                                                                 \
         __syncthreads(); /* drains the DMA (vmcnt(0)) and the LDS reads of this tile */                   \
@@ -1245,6 +1293,7 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
     RTK_DMA1_TAIL(0)
 #undef RTK_DMA1_TAIL
 #undef RTK_DMA1_STEP
+#undef RTK_DMA1_PIECES
 #undef RTK_DMA1_ISSUE
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
