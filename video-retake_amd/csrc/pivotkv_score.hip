@@ -586,6 +586,9 @@ struct RowStat {  // online max / sum of one query row, over the keys this lane 
 #ifndef RTK_DMA_PLACE   // 0 = the next tile's LDS-DMA pieces are issued at the head of a tile step, 1 = inside block 0's softmax
 #define RTK_DMA_PLACE 1    // same-box A/B: pass 1 7048 -> 7016 us, pass 2 7138 -> 7083 us, bit-identical results
 #endif
+#ifndef RTK_MFMA_ORDER  // 1 = all fragment reads of a block first, then its MFMAs strictly alternating between the two accumulators
+#define RTK_MFMA_ORDER 1   // (no MFMA waits for its predecessor; the compiler's own order ran 5 dependent ones in a row and padded
+#endif                     // others with s_nop 9); same-box A/B: pass 1 7019 -> 6878 us, pass 2 7054 -> 6908 us, bit-identical results
 #ifndef RTK_LSE_W0      // 1 = only wave 0 fetches the tile's 64 row normalisers (the other waves used to load them too)
 #define RTK_LSE_W0 1       // same-box A/B: pass 2 7083 -> 7043 us, bit-identical results
 #endif
@@ -1104,11 +1107,17 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
             load_ls(ls, lcur, blk, hf);                                                                   \
             f32x16 acc[NB];                                                                               \
             _Pragma("unroll")                                                                             \
-            for (int nb = 0; nb < NB; ++nb) {                                                             \
-                acc[nb] = f32x16{0};                                                                      \
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x16{0};                                          \
+            if (RTK_MFMA_ORDER) __builtin_amdgcn_sched_barrier(0);                                        \
+            _Pragma("unroll")                                                                             \
+            for (int r = 0; r < M::NREG; ++r) {                                                           \
                 _Pragma("unroll")                                                                         \
-                for (int r = 0; r < M::NREG; ++r) M::mma(acc[nb], a[r], kf[nb][r]);                       \
+                for (int nb = 0; nb < NB; ++nb) {                                                         \
+                    M::mma(acc[nb], a[r], kf[nb][r]);                                                     \
+                    if (RTK_MFMA_ORDER) __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);            \
+                }                                                                                         \
             }                                                                                             \
+            if (RTK_MFMA_ORDER) __builtin_amdgcn_sched_barrier(0);                                        \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) {                                                             \
                 colsum_block<DT>(col[nb], acc[nb], ls, c2, sqrt_d);                                       \
@@ -1246,11 +1255,16 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
             f32x16 acc[NB];                                                                               \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x16{0};                                          \
+            if (RTK_MFMA_ORDER) __builtin_amdgcn_sched_barrier(0);                                        \
             _Pragma("unroll")                                                                             \
             for (int r = 0; r < M::NREG; ++r) {                                                           \
                 _Pragma("unroll")                                                                         \
-                for (int nb = 0; nb < NB; ++nb) M::mma(acc[nb], a[r], qf[nb][r]);                         \
+                for (int nb = 0; nb < NB; ++nb) {                                                         \
+                    M::mma(acc[nb], a[r], qf[nb][r]);                                                     \
+                    if (RTK_MFMA_ORDER) __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);            \
+                }                                                                                         \
             }                                                                                             \
+            if (RTK_MFMA_ORDER) __builtin_amdgcn_sched_barrier(0);                                        \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) {                                                             \
                 if constexpr (LAZY) rs[nb].template update_lazy<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf, c2); \
