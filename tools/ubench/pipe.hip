@@ -9,6 +9,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 pipe.hip -o pipe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
@@ -90,10 +91,21 @@ __global__ __launch_bounds__(256, W) void k(int iters, float* out, unsigned long
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[r]), __builtin_bit_cast(bf16x8, kf[nb][r]), acc[nb], 0, 0, 0);
             if constexpr (PIPE) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    softmax_block<V>(col[nb], pend[nb], pls, c2);
-                    pend[nb] = acc[nb];
+                for (int nb = 0; nb < NB; ++nb) softmax_block<V>(col[nb], pend[nb], pls, c2);
+                if constexpr (PIPE == 2) {
+                    // forced interleave: after each MFMA, the softmax instructions of 16 / 8 = 2 logits of the pending block
+                    if (LDS) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+                    for (int i = 0; i < 8 * NB; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) pend[nb] = acc[nb];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pls[r] = ls[r];
             } else {
@@ -145,6 +157,21 @@ int main() {
     unsigned long long* cyc;
     hipMalloc(&out, 4096);
     hipMalloc(&cyc, 8);
+    if (getenv("PIPE2")) {
+        printf("-- forced interleave (PIPE=2) vs compiler (PIPE=1) vs unpipelined\n");
+        run<3, 1, 3, 1, 0>(out, cyc);
+        run<3, 1, 3, 1, 1>(out, cyc);
+        run<3, 1, 3, 1, 2>(out, cyc);
+        run<2, 1, 3, 1, 2>(out, cyc);
+        run<1, 1, 3, 1, 2>(out, cyc);
+        run<2, 2, 3, 1, 0>(out, cyc);
+        run<2, 2, 3, 1, 1>(out, cyc);
+        run<2, 2, 3, 1, 2>(out, cyc);
+        run<1, 2, 3, 1, 2>(out, cyc);
+        run<1, 2, 3, 0, 2>(out, cyc);
+        run<1, 4, 3, 1, 2>(out, cyc);
+        return 0;
+    }
     printf("-- W=4 NB=1, LDS fragments, softmax forms\n");
     run<4, 1, 0, 0, 0>(out, cyc);
     run<4, 1, 1, 1, 0>(out, cyc);
