@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--also-streams", type=int, default=0,
                     help="after the contract measurement, time the same steps again with this many worker streams "
                          "(reported under 'overlap'; 0 = skip)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "p2p"],
+                    help="N > 1: torch.distributed collectives over RCCL, or the direct peer-to-peer pushes of retake/p2p.py")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-check", action="store_true")

@@ -369,6 +369,39 @@ int rtk_pivotkv_place_batched(const rtk_place_unit* units, int n_units, int H, i
 int rtk_position_shift(int64_t* temporal_ids, int n, const int64_t* prev_dev, rtk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Direct peer-to-peer all-gather over xGMI (SURVEY §5 "Distributed backend", §8(b) rtk_allgather_*; used by
+ * retake/p2p.py and, opt-in, retake/sharded.py).  xGMI is point to point: a rank that has mapped its peers'
+ * receive buffers pushes its block into all of them at once (one hop per link) instead of walking a ring.
+ *   - buffers: rtk_p2p_alloc (device memory; uncached != 0 for the flag words, which are polled while
+ *     kernels of other ranks write them), exported / opened as hipIpc handles between the processes of a node;
+ *   - rtk_p2p_push: nseg segments of seg_bytes from src (+ s * src_stride) to byte dst_offset + s * dst_stride
+ *     of EVERY mapped buffer (the own one included), then - after all of it, system-scope release - the value
+ *     `epoch` into word `rank` of every peer's flag array.  `counter` is one zero-initialised device word
+ *     owned by the caller's context; pushes that share it must be stream ordered;
+ *   - rtk_p2p_wait: returns (on the stream) once every sender has published an epoch >= `epoch`; bounded:
+ *     after ~timeout_ms the kernel gives up and stores 1 + (first missing sender) into *status (device word,
+ *     0 = fine), so that a lost peer is an error, not a hung GPU.
+ * Epochs count up from 1; receivers that reuse a landing zone alternate two of them (a sender can be one
+ * epoch ahead of a receiver, never two).  All sizes, strides and offsets are multiples of 16 bytes.
+ * ------------------------------------------------------------------------------------------- */
+#define RTK_IPC_HANDLE_BYTES 64
+#define RTK_P2P_MAX_RANKS 16
+typedef struct rtk_p2p_peers {
+    void* buf[RTK_P2P_MAX_RANKS];        /* rank q's receive buffer as mapped in THIS process (own: the local pointer) */
+    uint32_t* flag[RTK_P2P_MAX_RANKS];   /* rank q's flag array [world] */
+} rtk_p2p_peers;
+int rtk_p2p_alloc(size_t bytes, int uncached, void** ptr);      /* zero-filled */
+int rtk_p2p_free(void* ptr);
+int rtk_p2p_export(const void* ptr, void* handle_out /* RTK_IPC_HANDLE_BYTES */, size_t* offset_out);
+int rtk_p2p_open(const void* handle, void** base_out);          /* ptr in this process = *base_out + offset */
+int rtk_p2p_close(void* base);
+int rtk_p2p_push(const void* src, size_t seg_bytes, int nseg, size_t src_stride_bytes, const rtk_p2p_peers* peers,
+                 int rank, int world, size_t dst_offset_bytes, size_t dst_stride_bytes, uint32_t epoch,
+                 uint32_t* counter, rtk_stream_t stream);
+int rtk_p2p_wait(const uint32_t* own_flags, int world, uint32_t epoch, int timeout_ms, uint32_t* status,
+                 rtk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement support (bench.py).  When enabled, every kernel launch of this library is bracketed
  * by two hipEvents recorded on the launch stream; rtk_profile_collect() waits for them and folds
  * the elapsed times into per-kernel totals.  Process-wide, off by default.

@@ -1,0 +1,85 @@
+"""Multi-process check of the direct p2p all-gather (retake/p2p.py, rtk_p2p_*), launched by
+tests/test_hip_parity.py::test_p2p_allgather_two_processes as
+
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tests/mp_p2p_gpu.py
+
+The control plane is gloo; rank r uses GPU r % device_count, so on a 1-GPU box both ranks map each other's buffers
+on the same device (same protocol, same kernels; the stores just do not cross a link)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "video-retake_amd"))
+
+
+def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from retake.p2p import P2PGroup
+
+    g = P2PGroup(device=dev)
+
+    def block(r, i, shape, dtype):
+        gen = torch.Generator().manual_seed(1000 * i + r)
+        x = torch.randint(-100, 100, shape, generator=gen).to(dtype)
+        return x
+
+    # 1. all_gather: shapes with odd byte counts, a growing payload (buffer regrowth), an empty one, repeated calls
+    cases = [((3,), torch.int64), ((5, 7), torch.float32), ((1,), torch.bfloat16), ((0, 4), torch.float32),
+             ((128, 196), torch.float32), ((4, 1568, 128), torch.bfloat16), ((33,), torch.uint8), ((3,), torch.int64)]
+    held = []
+    for i, (shape, dtype) in enumerate(cases):
+        out = g.all_gather(block(rank, i, shape, dtype).to(dev))
+        want = torch.stack([block(r, i, shape, dtype) for r in range(world)])
+        assert out.shape == want.shape and out.dtype == want.dtype, (out.shape, want.shape)
+        assert torch.equal(out.cpu(), want), f"all_gather case {i} differs"
+        held.append((out, want, i))
+        if len(held) >= 2:   # the previous result must still be intact (two alternating halves) unless the buffer grew
+            pout, pwant, pi = held[-2]
+            if pout.untyped_storage().data_ptr() == out.untyped_storage().data_ptr():
+                assert torch.equal(pout.cpu(), pwant), f"result of call {pi} was overwritten by call {i}"
+    for i in range(8, 40):   # many epochs through the same halves
+        out = g.all_gather(block(rank, i, (64, 128), torch.float32).to(dev))
+        assert torch.equal(out.cpu(), torch.stack([block(r, i, (64, 128), torch.float32) for r in range(world)]))
+
+    # 2. strided pushes into the final layout: [heads, world, rows, D] assembled from per-rank [heads, rows, D] in two
+    #    row batches, one wait at the end (the cache-assembly pattern)
+    H, rows, D = 4, 48, 128
+    buf = g.symmetric(H * world * rows * D * 2)
+    mine = block(rank, 77, (H, rows, D), torch.bfloat16).to(dev)
+    row_b = D * 2
+    for r0, n in ((0, 16), (16, 32)):
+        part = mine[:, r0:r0 + n].contiguous()
+        buf.push(part, n * row_b, H, n * row_b, (rank * rows + r0) * row_b, world * rows * row_b)
+    buf.wait()
+    got = buf.local.view(torch.bfloat16).view(H, world, rows, D)
+    want = torch.stack([block(r, 77, (H, rows, D), torch.bfloat16) for r in range(world)], dim=1)
+    assert torch.equal(got.cpu(), want), "strided push layout differs"
+    g.check()
+
+    # 3. a sender that never arrives is an error, not a hang: rank 0 waits 100 ms for a push rank 1 never makes
+    lost = g.symmetric(1024)
+    if rank == 0:
+        lost.epoch += 1           # pretend a push round happened
+        lost.wait(timeout_ms=100)
+        try:
+            lost.check()
+            raise AssertionError("the bounded wait did not report the missing sender")
+        except RuntimeError as e:
+            assert "rank 0" in str(e) or "rank 1" in str(e), str(e)
+        lost.status.zero_()
+    g.close()
+    dist.barrier()
+    if rank == 0:
+        print("MP_P2P_OK", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

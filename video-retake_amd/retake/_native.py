@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 RTK_F32, RTK_BF16, RTK_BF16_REFROUND = 0, 1, 2
 SCORE_PREPARE, SCORE_PASSES, SCORE_FINALIZE = 1, 2, 4
@@ -40,6 +40,14 @@ class PlaceUnit(C.Structure):
     """rtk_place_unit (include/retake_hip.h)."""
     _fields_ = [("stage", _vp), ("stage_stride_h_bytes", _i64), ("tail", _vp), ("tail_stride_h_bytes", _i64),
                 ("keep_idx", _vp)]
+
+
+P2P_MAX_RANKS, IPC_HANDLE_BYTES = 16, 64
+
+
+class P2PPeers(C.Structure):
+    """rtk_p2p_peers (include/retake_hip.h)."""
+    _fields_ = [("buf", _vp * P2P_MAX_RANKS), ("flag", _vp * P2P_MAX_RANKS)]
 
 
 class CopyUnit(C.Structure):
@@ -82,6 +90,13 @@ _SIGNATURES = {
     "rtk_pivotkv_place_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp]),
     "rtk_pivotkv_commit_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp]),
     "rtk_position_shift": (C.c_int, [_vp, _i, _vp, _vp]),
+    "rtk_p2p_alloc": (C.c_int, [_sz, _i, C.POINTER(_vp)]),
+    "rtk_p2p_free": (C.c_int, [_vp]),
+    "rtk_p2p_export": (C.c_int, [_vp, _vp, C.POINTER(_sz)]),
+    "rtk_p2p_open": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "rtk_p2p_close": (C.c_int, [_vp]),
+    "rtk_p2p_push": (C.c_int, [_vp, _sz, _i, _sz, C.POINTER(P2PPeers), _i, _i, _sz, _sz, C.c_uint32, _vp, _vp]),
+    "rtk_p2p_wait": (C.c_int, [_vp, _i, C.c_uint32, _i, _vp, _vp]),
     "rtk_profile_enable": (C.c_int, [_i]),
     "rtk_profile_enable_mask": (C.c_int, [C.c_uint]),
     "rtk_profile_collect": (C.c_int, []),

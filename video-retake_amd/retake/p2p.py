@@ -1,0 +1,193 @@
+"""Direct peer-to-peer all-gather over xGMI for the ranks of one node (`rtk_p2p_*`, include/retake_hip.h).
+
+xGMI is point to point: every GPU has its own link to every other GPU of the node.  A ring all-gather walks
+world - 1 serial steps; the exchanges of this path are small (distance rows 1.6 MB, id offsets a few hundred bytes, one
+chunk's kept rows 11 MB per rank at 8 ranks), so they are bound by those steps, not by the links.  Here every rank maps
+its peers' landing buffers once (hipIpc handles, exchanged through the process group's control plane) and then PUSHES
+its block into all of them with one kernel: one hop, all links at once, no intermediate copies - the landing buffer can
+be the final layout (`SymmetricBuffer.push` takes strided segments).
+
+    p2p = P2PGroup(group)                 # once per process group
+    out = p2p.all_gather(x)               # [world, *x.shape], valid until the second next all_gather
+    buf = p2p.symmetric(nbytes)           # same-sized landing buffer on every rank
+    buf.push(src, seg_bytes, nseg, src_stride, dst_offset, dst_stride); ...; buf.wait()
+
+No collective library is involved; `torch.distributed` is only used to hand the 64-byte handles around
+(`all_gather_object`), so any backend works for that - the 2-process tests run it over gloo with both ranks on one GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _native as nv
+
+_TIMEOUT_MS = 20000
+
+
+class _DeviceMem:
+    """Device memory owned by the library (rtk_p2p_alloc), viewable as a torch tensor without a copy."""
+
+    def __init__(self, nbytes: int, uncached: bool = False):
+        p = C.c_void_p()
+        nv.check(nv.lib.rtk_p2p_alloc(nbytes, int(uncached), C.byref(p)), "rtk_p2p_alloc")
+        self.ptr, self.nbytes = int(p.value), int(nbytes)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3, "strides": None}
+
+    def tensor(self, device) -> torch.Tensor:
+        t = torch.as_tensor(self, device=device)
+        if t.data_ptr() != self.ptr:
+            raise RuntimeError("torch copied the p2p buffer instead of viewing it")
+        return t
+
+    def free(self):
+        if self.ptr:
+            nv.lib.rtk_p2p_free(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+
+class SymmetricBuffer:
+    """One landing buffer of `nbytes` on every rank, mapped into every rank.  `push` writes this rank's segments into
+    all of them; `wait` returns (on the current stream) once every rank's pushes up to the same count have landed here.
+    Every rank must call push / wait equally often; a region may be rewritten only after a later `wait` (a sender can be
+    one push ahead of a receiver, never two: alternate two regions when reusing)."""
+
+    def __init__(self, owner: "P2PGroup", nbytes: int):
+        self.owner = owner
+        g, dev = owner, owner.device
+        self.nbytes = (int(nbytes) + 15) // 16 * 16
+        with torch.cuda.device(dev):
+            self.mem = _DeviceMem(self.nbytes)
+            self.flags = _DeviceMem(4 * nv.P2P_MAX_RANKS, uncached=True)
+            self.local = self.mem.tensor(dev)                        # uint8 [nbytes]
+            self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+            handles = []
+            for m in (self.mem, self.flags):
+                h = (C.c_char * nv.IPC_HANDLE_BYTES)()
+                off = C.c_size_t()
+                nv.check(nv.lib.rtk_p2p_export(C.c_void_p(m.ptr), h, C.byref(off)), "rtk_p2p_export")
+                handles.append((bytes(h), int(off.value)))
+            table: List[Optional[list]] = [None] * g.world
+            dist.all_gather_object(table, handles, group=g.group)
+            self.peers = nv.P2PPeers()
+            self._opened = []
+            for r, hs in enumerate(table):
+                ptrs = []
+                for (h, off), own in zip(hs, (self.mem, self.flags)):
+                    if r == g.rank:
+                        ptrs.append(own.ptr)
+                        continue
+                    base = C.c_void_p()
+                    nv.check(nv.lib.rtk_p2p_open((C.c_char * nv.IPC_HANDLE_BYTES).from_buffer_copy(h), C.byref(base)),
+                             "rtk_p2p_open")
+                    self._opened.append(int(base.value))
+                    ptrs.append(int(base.value) + off)
+                self.peers.buf[r], self.peers.flag[r] = ptrs
+        self.epoch = 0
+        dist.barrier(group=g.group)   # nobody pushes before everybody has mapped everybody
+
+    def push(self, src: torch.Tensor, seg_bytes: int, nseg: int, src_stride: int, dst_offset: int, dst_stride: int,
+             stream=None):
+        """`nseg` segments of `seg_bytes` from src.data_ptr() + s * src_stride -> byte dst_offset + s * dst_stride of
+        every rank's buffer (all byte counts multiples of 16), then this rank's arrival flag on every rank."""
+        if dst_offset + (nseg - 1) * dst_stride + seg_bytes > self.nbytes and nseg > 0:
+            raise ValueError("p2p push outside the symmetric buffer")
+        g = self.owner
+        self.epoch += 1
+        st = nv.stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        nv.check(nv.lib.rtk_p2p_push(C.c_void_p(src.data_ptr()), seg_bytes, nseg, src_stride, C.byref(self.peers),
+                                     g.rank, g.world, dst_offset, dst_stride, self.epoch, nv.ptr(self.counter), st),
+                 "rtk_p2p_push")
+
+    def wait(self, stream=None, timeout_ms: int = _TIMEOUT_MS):
+        g = self.owner
+        st = nv.stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        nv.check(nv.lib.rtk_p2p_wait(C.c_void_p(self.flags.ptr), g.world, self.epoch, timeout_ms, nv.ptr(self.status),
+                                     st), "rtk_p2p_wait")
+
+    def check(self):
+        """Host-side check of the bounded waits (synchronises): raises if a sender never arrived."""
+        s = int(self.status.item())
+        if s:
+            raise RuntimeError(f"p2p wait on rank {self.owner.rank} timed out: nothing arrived from rank {s - 1}")
+
+    def close(self):
+        for base in self._opened:
+            nv.lib.rtk_p2p_close(C.c_void_p(base))
+        self._opened = []
+        self.local = None
+        self.mem.free()
+        self.flags.free()
+
+
+class P2PGroup:
+    """The ranks of `group` (one process per GPU, all on one node) with their buffers mapped into each other."""
+
+    def __init__(self, group=None, device=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if self.world > nv.P2P_MAX_RANKS:
+            raise ValueError(f"p2p all-gather supports up to {nv.P2P_MAX_RANKS} ranks, got {self.world}")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._scratch: Optional[SymmetricBuffer] = None
+        self._slot = 0
+        self._calls = 0
+        self._buffers: List[SymmetricBuffer] = []
+
+    def symmetric(self, nbytes: int) -> SymmetricBuffer:
+        b = SymmetricBuffer(self, nbytes)
+        self._buffers.append(b)
+        return b
+
+    def all_gather(self, x: torch.Tensor) -> torch.Tensor:
+        """x (same shape and dtype on every rank) -> [world, *x.shape] in rank order.  The result is a view of the landing
+        buffer: it stays valid until the second next call (two alternating halves)."""
+        nv.require_device(x)
+        x = x.contiguous()
+        nb = x.numel() * x.element_size()
+        slot = (nb + 15) // 16 * 16
+        if self._scratch is None or slot > self._slot:   # (re)size: collective, like the call itself
+            if self._scratch is not None:
+                torch.cuda.synchronize(self.device)
+                dist.barrier(group=self.group)
+                self._buffers.remove(self._scratch)
+                self._scratch.close()
+            self._slot = max(slot, 1 << 16)
+            self._scratch = self.symmetric(2 * self.world * self._slot)
+            self._calls = 0
+        buf = self._scratch
+        half = (self._calls & 1) * self.world * self._slot
+        self._calls += 1
+        with torch.cuda.device(self.device):
+            src = x
+            if nb != slot or x.data_ptr() % 16:   # pad to the 16-byte granule of the push kernel
+                src = torch.zeros(slot, dtype=torch.uint8, device=x.device)
+                src[:nb] = x.reshape(-1).view(torch.uint8)
+            if slot:
+                buf.push(src, slot, 1, slot, half + self.rank * self._slot, self._slot)
+            else:
+                buf.push(src, 0, 0, 16, half, 16)
+            buf.wait()
+        out = buf.local[half:half + self.world * self._slot].view(self.world, self._slot)[:, :nb]
+        if nb == slot:
+            return out.view(x.dtype).view((self.world,) + tuple(x.shape))
+        return out.contiguous().view(x.dtype).view((self.world,) + tuple(x.shape))
+
+    def check(self):
+        for b in self._buffers:
+            b.check()
+
+    def close(self):
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)
+        for b in self._buffers:
+            b.close()
+        self._buffers, self._scratch = [], None

@@ -23,6 +23,11 @@ No collective sits inside the scoring path; the exchanges are one small all-gath
 (distances), one tiny all-gather per video (offsets) and, for the cache assembly, either two all-gathers per
 video (K and V of every layer in one, the ids in the other) or - `gather_chunk` - one asynchronous all-gather per
 chunk that overlaps the next chunk's scoring, plus the ids at the end.
+
+Transport: `torch.distributed` collectives (RCCL) by default.  `enable_p2p(group)` switches every device-side exchange
+of that group to the direct peer-to-peer pushes of retake/p2p.py (`rtk_p2p_*`: mapped peer buffers, one hop on every
+xGMI link at once, no ring); with it `gather_chunk` pushes a chunk's kept rows straight into their final position of
+every rank's assembled cache, so `finalize` has nothing left to copy.
 """
 from __future__ import annotations
 
@@ -36,6 +41,47 @@ from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+# ---------------------------------------------------------------------------------------------------
+# transport: torch.distributed collectives, or the direct p2p pushes of retake/p2p.py for groups that enabled them
+# ---------------------------------------------------------------------------------------------------
+_P2P = {}   # process group (None = the default group) -> retake.p2p.P2PGroup
+
+
+def enable_p2p(group=None, device=None):
+    """Route this group's device-side exchanges through mapped peer buffers (collective: every rank must call it)."""
+    from .p2p import P2PGroup
+
+    if group not in _P2P:
+        _P2P[group] = P2PGroup(group, device)
+    return _P2P[group]
+
+
+def disable_p2p(group=None):
+    g = _P2P.pop(group, None)
+    if g is not None:
+        g.close()
+
+
+def _p2p_for(t: torch.Tensor, group):
+    g = _P2P.get(group)
+    return g if g is not None and t.is_cuda else None
+
+
+def _gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
+    """t (same shape on every rank) -> [world, *t.shape] in rank order: THE collective of this module."""
+    t = t.contiguous()
+    g = _p2p_for(t, group)
+    if g is not None:
+        return g.all_gather(t).clone()   # the landing buffer is reused by the second next exchange
+    world = dist.get_world_size(group)
+    recv = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    if t.is_cuda:
+        dist.all_gather_into_tensor(recv, t, group=group)
+    else:  # gloo has no all_gather_into_tensor on every build
+        dist.all_gather(list(recv.unbind(0)), t, group=group)
+    return recv
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -58,11 +104,8 @@ def exchange_temporal_offsets(local_last: torch.Tensor, first_start: int = 0, gr
     start at 0; -1 if the block kept nothing).  Returns delta [layers] int64 for this rank: the true start
     of the block, i.e. first_start + sum over previous ranks of (last + 1); with all_ranks the whole
     [world, layers] table (every rank computes the same one)."""
-    world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    gathered = [torch.empty_like(local_last) for _ in range(world)]
-    dist.all_gather(gathered, local_last.contiguous(), group=group)
-    spans = torch.stack(gathered) + 1                      # [world, layers]
+    spans = _gather_stack(local_last, group) + 1           # [world, layers]
     prefix = torch.cumsum(spans, dim=0) - spans            # exclusive
     table = (prefix + first_start).contiguous()
     return table if all_ranks else table[rank]
@@ -70,32 +113,20 @@ def exchange_temporal_offsets(local_last: torch.Tensor, first_start: int = 0, gr
 
 def all_gather_cat(t: torch.Tensor, dim: int, group=None) -> torch.Tensor:
     """All-gather equally shaped tensors and concatenate along `dim` in rank order."""
-    world = dist.get_world_size(group)
-    parts = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(parts, t.contiguous(), group=group)
-    return torch.cat(parts, dim=dim)
+    return torch.cat(list(_gather_stack(t, group).unbind(0)), dim=dim)
 
 
 def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
     """[rows_local, ...] -> [world*rows_local, ...] in rank order (distance rows)."""
-    world = dist.get_world_size(group)
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    if local.is_cuda:
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-    else:  # gloo has no all_gather_into_tensor on every build
-        parts = list(out.chunk(world, dim=0))
-        dist.all_gather(parts, local.contiguous(), group=group)
-    return out
+    full = _gather_stack(local, group)
+    return full.reshape((full.shape[0] * local.shape[0],) + tuple(local.shape[1:]))
 
 
 def gather_counts(n: int, device, group=None) -> List[int]:
     """How many rows every rank is about to contribute (one tiny all-gather).  Equal-size collectives
     (`all_gather_into_tensor`) hang or corrupt memory when the ranks disagree, so every assembly asks first."""
-    world = dist.get_world_size(group)
     mine = torch.tensor([int(n)], dtype=torch.int64, device=device)
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
-    return [int(p.item()) for p in parts]
+    return [int(c) for c in _gather_stack(mine, group).reshape(-1).tolist()]
 
 
 def all_gather_rows_ragged(local: torch.Tensor, group=None, counts: Optional[List[int]] = None) -> torch.Tensor:
@@ -113,14 +144,12 @@ def all_gather_rows_ragged(local: torch.Tensor, group=None, counts: Optional[Lis
 
 
 def _all_gather_flat(send: torch.Tensor, group=None) -> torch.Tensor:
-    """send [...] -> [world, ...] in rank order, one collective."""
-    world = dist.get_world_size(group)
-    recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
-    if send.is_cuda:
-        dist.all_gather_into_tensor(recv, send, group=group)
-    else:  # gloo has no all_gather_into_tensor on every build
-        dist.all_gather(list(recv.unbind(0)), send, group=group)
-    return recv
+    """send [...] -> [world, ...] in rank order, one collective.  With the p2p transport the result is the landing
+    buffer itself (no copy): consume it before the second next exchange of the group."""
+    g = _p2p_for(send, group)
+    if g is not None:
+        return g.all_gather(send.contiguous())
+    return _gather_stack(send, group)
 
 
 def all_gather_caches(keys: List[torch.Tensor], values: List[torch.Tensor], pos: List[torch.Tensor], group=None):
@@ -227,6 +256,67 @@ class ChunkGather:
         return out.view(2, n_layers, Hkv, world * total, D)
 
 
+class ChunkGatherP2P:
+    """`ChunkGather` over mapped peer buffers: the rows a chunk kept are pushed (side stream, beside the next chunk's
+    scoring) straight to their FINAL position in every rank's assembled cache `[2, layers, Hkv, world * total, D]` -
+    rank-major, then chunk order, inside every head - so `finish` only waits for the arrival flags; there is no receive
+    buffer to permute.  Needs the rows per rank and video (`total`) up front.  Two landing buffers alternate between
+    videos (a rank can be one video ahead of a peer that still reads the last one, never two): an assembled cache stays
+    valid until the video after next begins."""
+
+    def __init__(self, p2p, total: int, n_layers: int, Hkv: int, D: int, dtype):
+        self.p2p, self.total = p2p, int(total)
+        self.shape = (2, n_layers, Hkv, p2p.world, self.total, D)
+        self.dtype = dtype
+        self.es = torch.empty((), dtype=dtype).element_size()
+        nbytes = 2 * n_layers * Hkv * p2p.world * self.total * D * self.es
+        self.bufs = [p2p.symmetric(nbytes), p2p.symmetric(nbytes)]
+        self.side = torch.cuda.Stream(device=p2p.device)
+        self.gen, self.at = 1, 0
+        self.begin_video()
+
+    def matches(self, total, n_layers, Hkv, D, dtype) -> bool:
+        return self.shape == (2, n_layers, Hkv, self.p2p.world, int(total), D) and self.dtype == dtype
+
+    def begin_video(self):
+        self.gen ^= 1
+        self.at = 0
+
+    def start(self, k_new: List[torch.Tensor], v_new: List[torch.Tensor]):
+        n_layers = len(k_new)
+        Hkv, n, D = k_new[0].shape
+        if self.at + n > self.total:
+            raise ValueError(f"p2p chunk gather: {self.at + n} rows pushed, the landing buffer was sized for {self.total}")
+        send = torch.empty((2, n_layers, Hkv, n, D), dtype=k_new[0].dtype, device=k_new[0].device)
+        torch.stack(list(k_new), out=send[0])
+        torch.stack(list(v_new), out=send[1])
+        self.side.wait_stream(torch.cuda.current_stream(send.device))
+        send.record_stream(self.side)
+        row = D * self.es
+        world, rank = self.p2p.world, self.p2p.rank
+        self.bufs[self.gen].push(send, n * row, 2 * n_layers * Hkv, n * row, (rank * self.total + self.at) * row,
+                                 world * self.total * row, stream=self.side)
+        self.at += n
+
+    def rows(self) -> int:
+        return self.at
+
+    def drop(self):
+        """The pushes already made must still be matched by a wait so that the epochs of all ranks stay in step."""
+        torch.cuda.current_stream(self.p2p.device).wait_stream(self.side)
+        self.bufs[self.gen].wait()
+
+    def finish(self) -> torch.Tensor:
+        """-> [2, layers, Hkv, world * total, D], a view of the landing buffer."""
+        if self.at != self.total:
+            raise ValueError(f"p2p chunk gather: {self.at} of {self.total} rows pushed")
+        buf = self.bufs[self.gen]
+        torch.cuda.current_stream(self.p2p.device).wait_stream(self.side)
+        buf.wait()
+        two, n_layers, Hkv, world, total, D = self.shape
+        return buf.local.view(self.dtype).view(two, n_layers, Hkv, world * total, D)
+
+
 def plan_frame_exchange(idx: torch.Tensor, T_own: int, world: int):
     """Who sends which kept frame where (DPSelect at ratio < 1 on frames sharded `T_own` per rank).
 
@@ -319,12 +409,18 @@ def dpselect_sharded(frames_local: torch.Tensor, has_halo: bool, tgt_mem_len: in
 class ShardedPivotKV:
     """A rank's share of one video's PivotKV compression (see the module docstring)."""
 
-    def __init__(self, config, group=None, first_start: int = 0):
+    def __init__(self, config, group=None, first_start: int = 0, expected_rows: Optional[int] = None,
+                 chunk_gather: Optional[ChunkGatherP2P] = None):
+        """expected_rows: rows this rank will keep per layer over the whole video (equal on all ranks); with the p2p
+        transport it lets `gather_chunk` push rows to their final position (else the assembly happens at the end).
+        chunk_gather: the ChunkGatherP2P of the previous video of the same shape, to reuse its mapped buffers."""
         from .longvideo_cache import PivotKVCache
 
         self.cache = PivotKVCache(config)
         self.group = group
         self.first_start = first_start
+        self.expected_rows = expected_rows
+        self.chunk_gather = chunk_gather
         self._gather = None
         self._seen: List[int] = []
 
@@ -339,7 +435,19 @@ class ShardedPivotKV:
         cache.after_forward()
         kc, vc = cache.key_cache, cache.value_cache
         if self._gather is None:
-            self._gather = ChunkGather(self.group)
+            p2p = _p2p_for(kc[0], self.group)
+            if p2p is None:
+                self._gather = ChunkGather(self.group)
+            elif self.expected_rows is None:
+                return          # p2p pushes need their final position: assemble at the end instead
+            else:
+                _, Hkv, _, D = kc[0].shape
+                cg = self.chunk_gather
+                if cg is None or not cg.matches(self.expected_rows, len(kc), Hkv, D, kc[0].dtype):
+                    cg = ChunkGatherP2P(p2p, self.expected_rows, len(kc), Hkv, D, kc[0].dtype)
+                else:
+                    cg.begin_video()
+                self._gather = self.chunk_gather = cg
             self._seen = [0] * len(kc)
         ks, vs = [], []
         for layer in range(len(kc)):
@@ -389,8 +497,8 @@ class ShardedPivotKV:
             if assemble:   # the overlapped gathers moved equal blocks: only valid if every rank kept equally many rows
                 counts = gather_counts(keys[0].shape[2], dev, self.group)
                 use_g = torch.tensor([int(g is not None and len(set(counts)) == 1)], dtype=torch.int64, device=dev)
-                dist.all_reduce(use_g, op=dist.ReduceOp.MIN, group=self.group)   # one decision for all ranks
-                if g is not None and not int(use_g.item()):
+                use_all = int(_gather_stack(use_g, self.group).min().item())     # one decision for all ranks
+                if g is not None and not use_all:
                     g.drop()
                     g = None
             if assemble and g is not None:
@@ -417,31 +525,40 @@ class ShardedPivotKV:
 # bench.py --gpus N  (strong scaling: one video, chunks sharded over the ranks)
 # ---------------------------------------------------------------------------------------------------
 def sharded_video_step(frames, has_halo: bool, T: int, c0: int, c1: int, layers: int, pool, pos_base, rotary, overlap: bool,
-                       group=None):
+                       group=None, state: Optional[dict] = None, inputs=None):
     """One rank's share of one video (what `bench.py --gpus N` times and tests/mp_sharded_gpu.py checks): DPSelect on
     the rank's frames with the distance rows all-gathered, PivotKV on chunks [c0, c1) at provisional temporal ids, then
     offsets + cache assembly.  `overlap`: the rows a chunk kept leave in one asynchronous all-gather right after its
-    flush (needs equally many chunks on every rank).  Returns (retained tokens of this rank, (keys, values, ids))."""
+    flush (needs equally many chunks on every rank).  `state`: a dict the caller keeps between videos (the p2p
+    transport reuses its mapped landing buffers through it).  `inputs(c, layer, pos) -> (q, k, v)`: the layer's rotated
+    q / k at the ids `pos` the update will see (what a model produces; tests/mp_sharded_gpu.py rotates fixed contents
+    with it).  Without it the resident pool set is taken AS the rotated input, whatever the ids: right for timing, but
+    then a block's K corresponds to different content than the single-GPU run's (ids and V still agree).
+    Returns (retained tokens of this rank, (keys, values, ids))."""
     import bench as B
 
     L = B.FRAMES_PER_CHUNK * B.N_PATCH
     out, mask, idx, dis = dpselect_sharded(frames, has_halo, T, 3, sync=False, group=group)
-    sh = ShardedPivotKV(B.make_cache_config(layers), group=group)
+    keep = max(1, int(B.RATIO * L))
+    sh = ShardedPivotKV(B.make_cache_config(layers), group=group, expected_rows=(c1 - c0) * keep if overlap else None,
+                        chunk_gather=(state or {}).get("chunk_gather"))
     cache = sh.cache
     for ci, c in enumerate(range(c0, c1)):
         cache.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
         cache.kvcache_compression = True
         pos = pos_base[ci].clone()
         for layer in range(layers):
-            q, k, v = pool[(c * layers + layer) % len(pool)]
             cache.shift_temporal_ids_(pos, layer)       # block-local ids start at 0 (provisional)
+            q, k, v = pool[(c * layers + layer) % len(pool)] if inputs is None else inputs(c, layer, pos)
             cache.update(k, v, layer, {"query_states": q, "position_ids": pos, "rotary_emb": rotary,
                                        "mrope_section": B.MROPE})
         cache.after_forward()
         if overlap:
             sh.gather_chunk()   # this chunk's kept rows leave now, beside the next chunk's scoring
     keys, values, pos = sh.finalize(rotary.inv_freq, B.MROPE, assemble=True)
-    return (c1 - c0) * layers * max(1, int(B.RATIO * L)), (keys, values, pos)
+    if state is not None:
+        state["chunk_gather"] = sh.chunk_gather
+    return (c1 - c0) * layers * keep, (keys, values, pos)
 
 
 def bench_main(args, rank: int, world: int, local_rank: int):
@@ -455,6 +572,8 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     torch.cuda.set_device(dev)
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    transport = getattr(args, "transport", "rccl")
+    p2p = enable_p2p(device=dev) if transport == "p2p" else None
     tdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     T = args.frames
     n_chunks = T // B.FRAMES_PER_CHUNK
@@ -471,8 +590,10 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     pos_base = [B.chunk_position_ids(c, dev) for c in range(c0, c1)]
     rotary = B.Rotary(dev)
 
+    state = {}
+
     def step():
-        return sharded_video_step(frames, halo == 1, T, c0, c1, args.layers, pool, pos_base, rotary, even)
+        return sharded_video_step(frames, halo == 1, T, c0, c1, args.layers, pool, pos_base, rotary, even, state=state)
 
     for _ in range(args.warmup):
         step()
@@ -496,7 +617,10 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     dt = float(dt.item())
     nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
     kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in nv.profile_read().items()}
-    checksum = B.cache_checksum(keys, values, pos) if rank == 0 else None   # untimed; equals the N = 1 line's
+    # untimed; ids_sum / v_bits_sum / tokens equal the N = 1 line's (k_abs_sum does not: see sharded_video_step)
+    checksum = B.cache_checksum(keys, values, pos) if rank == 0 else None
+    if p2p is not None:
+        p2p.check()   # a bounded wait that gave up would have left garbage: fail the run instead
     if rank == 0:
         out = {
             "metric": "frames/sec through DPSelect+PivotKV @2048 frames; retained-KV-tokens/sec",
@@ -507,15 +631,19 @@ def bench_main(args, rank: int, world: int, local_rank: int):
             "config": {"workload": f"Qwen2-VL-7B geometry, one {T}-frame synthetic video sharded by frame chunk over "
                                    f"{world} GPUs: DPSelect (distance rows all-gathered) + PivotKV 4x on "
                                    f"{n_chunks} chunks x {args.layers} layers, L={L}; offsets + whole-cache "
-                                   f"all-gather over RCCL (BASELINE configs[3])",
+                                   f"all-gather over {'RCCL' if p2p is None else 'direct xGMI pushes (retake/p2p.py)'} "
+                                   f"(BASELINE configs[3])",
                        "frames": T, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L,
-                       "parallelism": f"chunk-sharded x{world}", "assembled_cache_tokens": int(keys[0].shape[2])},
+                       "parallelism": f"chunk-sharded x{world}", "transport": transport,
+                       "assembled_cache_tokens": int(keys[0].shape[2])},
             "cache_checksum": checksum,
             "cpu_baseline": None,   # timed on rank 0 of the N = 1 run only (bench contract); see that line
             "kernels_timed_region_rank0": kern,
             "roofline": B.score_roofline(kern, args.dtype, L, T, (c1 - c0) * args.layers * args.steps),
         }
     dist.barrier()
+    if p2p is not None:
+        disable_p2p()
     dist.destroy_process_group()
     if rank == 0:
         # RCCL writes its version banner to stdout through C stdio, which a pipe only sees at exit - after anything
