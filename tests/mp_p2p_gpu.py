@@ -1,5 +1,5 @@
 """Multi-process check of the direct p2p all-gather (retake/p2p.py, rtk_p2p_*), launched by
-tests/test_hip_parity.py::test_p2p_allgather_two_processes as
+tests/test_hip_parity.py::test_p2p_allgather_processes as
 
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tests/mp_p2p_gpu.py
 
@@ -63,7 +63,7 @@ def main():
     assert torch.equal(got.cpu(), want), "strided push layout differs"
     g.check()
 
-    # 3. a sender that never arrives is an error, not a hang: rank 0 waits 100 ms for a push rank 1 never makes
+    # 3. a sender that never arrives is an error, not a hang: rank 0 waits 100 ms for pushes the others never make
     lost = g.symmetric(1024)
     if rank == 0:
         lost.epoch += 1           # pretend a push round happened

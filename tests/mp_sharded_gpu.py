@@ -75,7 +75,11 @@ def main():
         keep = max(1, int(B.RATIO * L))
         for l in range(layers):
             assert keys[l].shape[2] == n_chunks * keep, (keys[l].shape, n_chunks * keep)
-            assert torch.equal(pos[l], seq.position_cache[l]), f"layer {l}: ids differ"
+            if not torch.equal(pos[l], seq.position_cache[l]):
+                bad = (pos[l] != seq.position_cache[l]).reshape(-1, pos[l].shape[-1]).any(0).reshape(-1, keep).sum(1)
+                raise AssertionError(f"layer {l}: ids differ; wrong ids per kept chunk {bad.tolist()}; first rows "
+                                     f"{pos[l].reshape(-1, pos[l].shape[-1])[0, ::keep].tolist()} vs "
+                                     f"{seq.position_cache[l].reshape(-1, pos[l].shape[-1])[0, ::keep].tolist()}")
             assert torch.equal(values[l], seq.value_cache[l]), f"layer {l}: V differs"
             # R(delta) R(p) vs R(p + delta) in fp32: the two angle roundings differ by up to an ulp of the angle, so the
             # bound scales with |k| (1.7 sigma inputs here; 1e-5 at unit scale): 3e-6 relative to the largest key

@@ -1571,21 +1571,23 @@ def _launch_ranks(script, world, env=None, timeout=600):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root, env={**os.environ, **(env or {})})
 
 
-def test_p2p_allgather_two_processes():
-    """retake/p2p.py over the C ABI (rtk_p2p_*): two processes map each other's landing buffers through hipIpc handles
+@pytest.mark.parametrize("world", [2, 3])
+def test_p2p_allgather_processes(world):
+    """retake/p2p.py over the C ABI (rtk_p2p_*): two / three processes map each other's landing buffers through hipIpc handles
     and push into them - all_gather of odd-sized / empty / growing payloads over 40 epochs, strided pushes into a final
     layout, and the bounded wait reporting a sender that never arrives.  Rank r runs on GPU r % device_count: on a 1-GPU
     box both ranks share the device (same protocol and kernels; the stores do not cross an xGMI link)."""
-    r = _launch_ranks("mp_p2p_gpu.py", 2)
+    r = _launch_ranks("mp_p2p_gpu.py", world)
     assert r.returncode == 0 and "MP_P2P_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
-def test_sharded_two_ranks_over_p2p():
-    """The chunk-sharded path at WORLD SIZE 2 with the p2p transport (tests/mp_sharded_gpu.py, RETAKE_TEST_TRANSPORT=p2p):
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ranks_over_p2p(world):
+    """The chunk-sharded path at WORLD SIZE 2 and 3 with the p2p transport (tests/mp_sharded_gpu.py, RETAKE_TEST_TRANSPORT=p2p):
     distance rows, counts, temporal offsets, per-chunk pushes of the kept rows into their final position (landing buffers
     reused over four videos) and the ragged assembly at the end; assembled cache == sequential cache on every rank.
     Unlike RCCL, the p2p transport lets two ranks share one GPU, so this runs on the 1-GPU test box."""
-    r = _launch_ranks("mp_sharded_gpu.py", 2, env={"RETAKE_TEST_TRANSPORT": "p2p"})
+    r = _launch_ranks("mp_sharded_gpu.py", world, env={"RETAKE_TEST_TRANSPORT": "p2p"})
     assert r.returncode == 0 and "MP_SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 

@@ -65,6 +65,9 @@ extern "C" int rtk_p2p_alloc(size_t bytes, int uncached, void** ptr) {
     if (e != hipSuccess) return hip_fail(e, "rtk_p2p_alloc");
     e = hipMemset(*ptr, 0, bytes);
     if (e != hipSuccess) return hip_fail(e, "rtk_p2p_alloc: memset");
+    // the fill is asynchronous; peers may write as soon as they hold the handle, and nothing orders THEIR kernels behind it
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "rtk_p2p_alloc: synchronize");
     return RTK_OK;
 }
 

@@ -119,6 +119,9 @@ class SymmetricBuffer:
             raise RuntimeError(f"p2p wait on rank {self.owner.rank} timed out: nothing arrived from rank {s - 1}")
 
     def close(self):
+        """Unmap and free.  Only at the very end (P2PGroup.close): re-allocating after a free can hand a peer a handle its
+        runtime still associates with the freed memory (seen on ROCm 7.2 as pushes that never arrive), so buffers are
+        never recycled mid-run."""
         for base in self._opened:
             nv.lib.rtk_p2p_close(C.c_void_p(base))
         self._opened = []
@@ -155,11 +158,8 @@ class P2PGroup:
         nb = x.numel() * x.element_size()
         slot = (nb + 15) // 16 * 16
         if self._scratch is None or slot > self._slot:   # (re)size: collective, like the call itself
-            if self._scratch is not None:
-                torch.cuda.synchronize(self.device)
-                dist.barrier(group=self.group)
-                self._buffers.remove(self._scratch)
-                self._scratch.close()
+            # a grown payload gets a new, larger buffer; the old one stays mapped until close() (results handed out
+            # earlier may still be read, and nothing is gained by unmapping mid-run)
             self._slot = max(slot, 1 << 16)
             self._scratch = self.symmetric(2 * self.world * self._slot)
             self._calls = 0
