@@ -1591,6 +1591,35 @@ def test_sharded_ranks_over_p2p(world):
     assert r.returncode == 0 and "MP_SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def test_bench_two_ranks_share_one_gpu_p2p():
+    """`bench.py --gpus 2 --transport p2p` end to end (rank start-up, halo frame, chunk blocks, timed loop, JSON line) with
+    both ranks on the visible GPUs round robin (RETAKE_BENCH_SHARE_GPU=1: gloo control plane, p2p data plane), on a
+    256-frame / 2-layer video.  The assembled cache must have the single-GPU run's size; its CONTENT is not comparable
+    (the bench takes its resident tensors as the rotated inputs at whatever ids a block runs at, i.e. later blocks see
+    different content - equality of sharded and sequential caches is tests/mp_sharded_gpu.py's job)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--frames", "256", "--layers", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--transport", "p2p"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=root,
+                         env={**os.environ, "RETAKE_BENCH_SHARE_GPU": "1"})
+    assert two.returncode == 0, (two.stdout[-2000:], two.stderr[-3000:])
+    b = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["config"]["transport"] == "p2p"
+    assert b["metric"] == a["metric"] and b["unit"] == a["unit"] and b["value"] > 0
+    for key in ("tokens_per_layer", "layers"):
+        assert b["cache_checksum"][key] == a["cache_checksum"][key], (key, a["cache_checksum"], b["cache_checksum"])
+    assert b["config"]["assembled_cache_tokens"] == a["cache_checksum"]["tokens_per_layer"]
+    assert b["roofline"]["frac"] > 0 and b["cpu_baseline"] is None
+
+
 @pytest.mark.parametrize("L", [1, 31, 130, 257, 515, 1000, 2303])
 def test_pivotkv_score_bf16_ragged_lengths_vs_oracle(L):
     """The bf16 score kernels (two 32-row register blocks per wave, lazy max, LDS-DMA tiles of 64 rows) on chunk lengths

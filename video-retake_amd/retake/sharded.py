@@ -533,7 +533,7 @@ def sharded_video_step(frames, has_halo: bool, T: int, c0: int, c1: int, layers:
     transport reuses its mapped landing buffers through it).  `inputs(c, layer, pos) -> (q, k, v)`: the layer's rotated
     q / k at the ids `pos` the update will see (what a model produces; tests/mp_sharded_gpu.py rotates fixed contents
     with it).  Without it the resident pool set is taken AS the rotated input, whatever the ids: right for timing, but
-    then a block's K corresponds to different content than the single-GPU run's (ids and V still agree).
+    a later block then scores different content than the single-GPU run (its scores, kept set and K differ; sizes agree).
     Returns (retained tokens of this rank, (keys, values, ids))."""
     import bench as B
 
@@ -568,11 +568,18 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")   # world size 1 without a launcher (RETAKE_FORCE_SHARDED=1)
     os.environ.setdefault("MASTER_PORT", "29544")
-    dev = torch.device("cuda", local_rank)
+    transport = getattr(args, "transport", "rccl")
+    # RETAKE_BENCH_SHARE_GPU=1 (tests only, p2p transport): ranks share the visible GPUs round robin over a gloo control
+    # plane, so that the multi-rank bench path can run on a 1-GPU box (RCCL refuses two ranks on one device)
+    share = os.environ.get("RETAKE_BENCH_SHARE_GPU") == "1" and transport == "p2p"
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if share else local_rank)
     torch.cuda.set_device(dev)
     if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    transport = getattr(args, "transport", "rccl")
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    red_dev = torch.device("cpu") if share else dev     # gloo reduces host tensors
     p2p = enable_p2p(device=dev) if transport == "p2p" else None
     tdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     T = args.frames
@@ -610,14 +617,14 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    tot = torch.tensor([float(retained)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(retained)], dtype=torch.float64, device=red_dev)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt = float(dt.item())
     nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
     kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in nv.profile_read().items()}
-    # untimed; ids_sum / v_bits_sum / tokens equal the N = 1 line's (k_abs_sum does not: see sharded_video_step)
+    # untimed; the token count equals the N = 1 line's, the sums only at N = 1 (see sharded_video_step on `inputs`)
     checksum = B.cache_checksum(keys, values, pos) if rank == 0 else None
     if p2p is not None:
         p2p.check()   # a bounded wait that gave up would have left garbage: fail the run instead
