@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "video-retake_amd"))
 def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dev = torch.device("cuda", rank % torch.cuda.device_count())
+    dev = torch.device("cuda", 0 if os.environ.get("RETAKE_TEST_ONE_GPU") == "1" else rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from retake.p2p import P2PGroup

@@ -32,7 +32,8 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     p2p = os.environ.get("RETAKE_TEST_TRANSPORT") == "p2p"
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    dev = torch.device("cuda", 0 if os.environ.get("RETAKE_TEST_ONE_GPU") == "1"
+                       else int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if p2p:
         dist.init_process_group("gloo", rank=rank, world_size=world)

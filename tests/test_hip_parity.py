@@ -1575,9 +1575,9 @@ def _launch_ranks(script, world, env=None, timeout=600):
 def test_p2p_allgather_processes(world):
     """retake/p2p.py over the C ABI (rtk_p2p_*): two / three processes map each other's landing buffers through hipIpc handles
     and push into them - all_gather of odd-sized / empty / growing payloads over 40 epochs, strided pushes into a final
-    layout, and the bounded wait reporting a sender that never arrives.  Rank r runs on GPU r % device_count: on a 1-GPU
-    box both ranks share the device (same protocol and kernels; the stores do not cross an xGMI link)."""
-    r = _launch_ranks("mp_p2p_gpu.py", world)
+    layout, and the bounded wait reporting a sender that never arrives.  All ranks share GPU 0 (same protocol and
+    kernels as across GPUs; the stores just do not cross an xGMI link - test_p2p_across_gpus does that where it can)."""
+    r = _launch_ranks("mp_p2p_gpu.py", world, env={"RETAKE_TEST_ONE_GPU": "1"})
     assert r.returncode == 0 and "MP_P2P_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
@@ -1586,14 +1586,26 @@ def test_sharded_ranks_over_p2p(world):
     """The chunk-sharded path at WORLD SIZE 2 and 3 with the p2p transport (tests/mp_sharded_gpu.py, RETAKE_TEST_TRANSPORT=p2p):
     distance rows, counts, temporal offsets, per-chunk pushes of the kept rows into their final position (landing buffers
     reused over four videos) and the ragged assembly at the end; assembled cache == sequential cache on every rank.
-    Unlike RCCL, the p2p transport lets two ranks share one GPU, so this runs on the 1-GPU test box."""
+    Unlike RCCL, the p2p transport lets the ranks share one GPU, so this runs on the 1-GPU test box."""
+    r = _launch_ranks("mp_sharded_gpu.py", world, env={"RETAKE_TEST_TRANSPORT": "p2p", "RETAKE_TEST_ONE_GPU": "1"})
+    assert r.returncode == 0 and "MP_SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_p2p_across_gpus():
+    """The same two scripts with one rank per GPU (needs >= 2 visible GPUs): the pushes cross xGMI links."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one visible GPU: the p2p stores cannot cross a link here")
+    world = min(n, 4)
+    r = _launch_ranks("mp_p2p_gpu.py", world)
+    assert r.returncode == 0 and "MP_P2P_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
     r = _launch_ranks("mp_sharded_gpu.py", world, env={"RETAKE_TEST_TRANSPORT": "p2p"})
     assert r.returncode == 0 and "MP_SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_bench_two_ranks_share_one_gpu_p2p():
     """`bench.py --gpus 2 --transport p2p` end to end (rank start-up, halo frame, chunk blocks, timed loop, JSON line) with
-    both ranks on the visible GPUs round robin (RETAKE_BENCH_SHARE_GPU=1: gloo control plane, p2p data plane), on a
+    both ranks on GPU 0 (RETAKE_BENCH_SHARE_GPU=1: gloo control plane, p2p data plane), on a
     256-frame / 2-layer video.  The assembled cache must have the single-GPU run's size; its CONTENT is not comparable
     (the bench takes its resident tensors as the rotated inputs at whatever ids a block runs at, i.e. later blocks see
     different content - equality of sharded and sequential caches is tests/mp_sharded_gpu.py's job)."""

@@ -569,10 +569,10 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")   # world size 1 without a launcher (RETAKE_FORCE_SHARDED=1)
     os.environ.setdefault("MASTER_PORT", "29544")
     transport = getattr(args, "transport", "rccl")
-    # RETAKE_BENCH_SHARE_GPU=1 (tests only, p2p transport): ranks share the visible GPUs round robin over a gloo control
-    # plane, so that the multi-rank bench path can run on a 1-GPU box (RCCL refuses two ranks on one device)
+    # RETAKE_BENCH_SHARE_GPU=1 (tests only, p2p transport): every rank runs on GPU 0 over a gloo control plane, so that
+    # the multi-rank bench path can run on a 1-GPU box (RCCL refuses two ranks on one device)
     share = os.environ.get("RETAKE_BENCH_SHARE_GPU") == "1" and transport == "p2p"
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if share else local_rank)
+    dev = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(dev)
     if not dist.is_initialized():
         if share:
