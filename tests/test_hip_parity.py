@@ -1632,17 +1632,23 @@ def test_bench_two_ranks_share_one_gpu_p2p():
     assert b["roofline"]["frac"] > 0 and b["cpu_baseline"] is None
 
 
-@pytest.mark.parametrize("L", [1, 31, 130, 257, 515, 1000, 2303])
-def test_pivotkv_score_bf16_ragged_lengths_vs_oracle(L):
+@pytest.mark.parametrize("L,Hq,Hkv", [(1, 28, 4), (31, 28, 4), (130, 28, 4), (257, 28, 4), (515, 28, 4), (1000, 28, 4),
+                                       (2303, 28, 4),
+                                       (777, 12, 2),     # Qwen2-VL-2B heads (group of 6)
+                                       (777, 64, 8),     # Qwen2-VL-72B heads (group of 8)
+                                       (300, 16, 16),    # no grouping
+                                       (300, 5, 1)])     # odd group, one KV head
+def test_pivotkv_score_bf16_ragged_lengths_vs_oracle(L, Hq, Hkv):
     """The bf16 score kernels (two 32-row register blocks per wave, lazy max, LDS-DMA tiles of 64 rows) on chunk lengths
-    that leave partial register blocks, partial tiles and partial splits, through the one-unit entry point
-    (rtk_pivotkv_score) AND through a 3-unit batched launch: against the CPU oracle on the same bf16-valued operands."""
+    that leave partial register blocks, partial tiles and partial splits, and on the head geometries of the other model
+    sizes the reference ships configs for, through the one-unit entry point (rtk_pivotkv_score) AND through a 3-unit
+    batched launch: against the CPU oracle on the same bf16-valued operands."""
     import ctypes as C
 
     import retake._native as nv
 
-    Hq, Hkv, D, units = 28, 4, 128, 3
-    g = torch.Generator(device=dev()).manual_seed(L)
+    D, units = 128, 3
+    g = torch.Generator(device=dev()).manual_seed(L + Hq)
     dt = nv.RTK_BF16
     wsb = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
     stride = (wsb + 255) & ~255
