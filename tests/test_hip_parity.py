@@ -104,9 +104,11 @@ def test_dpselect_async_single_patch_raises_like_reference():
 
 
 @pytest.mark.parametrize("T,N,C,tgt,sync", [(33, 7, 40, 11, False), (9, 3, 6, 9, True), (3, 2, 1000, 2, False),
-                                            (130, 5, 4100, 40, False), (17, 4, 18, 5, True)])
+                                            (130, 5, 4100, 40, False), (17, 4, 18, 5, True),
+                                            (5000, 2, 64, 1234, False), (4097, 1, 32, 4096, True), (8200, 3, 128, 1, False)])
 def test_dpselect_odd_shapes_vs_oracle(T, N, C, tgt, sync):
-    """Ragged channel counts (generic kernel), tiny T, C beyond the register path."""
+    """Ragged channel counts (generic kernel), tiny T, C beyond the register path, and frame counts well past the 2048 of
+    the benchmark (several strips per patch position, selection rows longer than one workgroup's sweep)."""
     import retake.visual_compression as vc
 
     x = synth.frames_video(900 + T + C, T, N, C)
