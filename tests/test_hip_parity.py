@@ -616,7 +616,8 @@ def test_pivotkv_benchmarked_batched_path_vs_units_and_oracle(L, layers, n_chunk
 
 
 @pytest.mark.parametrize("L,keep,P,reforge,ties", [(6272, 1568, 3, 1, False), (2304, 576, 1, 1, False),
-                                                   (1000, 333, 3, 0, True), (515, 1, 0, 0, True), (4099, 4098, 3, 1, True)])
+                                                   (1000, 333, 3, 0, True), (515, 1, 0, 0, True), (4099, 4098, 3, 1, True),
+                                                   (10000, 2500, 3, 1, False), (20001, 77, 1, 1, True)])
 def test_select_chipwide_equals_one_workgroup_and_oracle(L, keep, P, reforge, ties):
     """rtk_pivotkv_select: the rank-by-counting path (workspace given) and the one-workgroup radix path must
     produce identical keep_idx / rank / ids, equal to the CPU oracle's canonical top-k (ties: lowest index
@@ -1635,7 +1636,7 @@ def test_bench_two_ranks_share_one_gpu_p2p():
 
 
 @pytest.mark.parametrize("L,Hq,Hkv", [(1, 28, 4), (31, 28, 4), (130, 28, 4), (257, 28, 4), (515, 28, 4), (1000, 28, 4),
-                                       (2303, 28, 4),
+                                       (2303, 28, 4), (8500, 4, 2),
                                        (777, 12, 2),     # Qwen2-VL-2B heads (group of 6)
                                        (777, 64, 8),     # Qwen2-VL-72B heads (group of 8)
                                        (300, 16, 16),    # no grouping
