@@ -521,7 +521,7 @@ def _rot_half(x):
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
 
 
-@pytest.mark.parametrize("L,layers,n_chunks", [(6272, 28, 2), (2304, 28, 2), (1024, 5, 3)])
+@pytest.mark.parametrize("L,layers,n_chunks", [(6272, 28, 2), (2304, 28, 2), (1024, 5, 3), (12544, 2, 2)])
 def test_pivotkv_benchmarked_batched_path_vs_units_and_oracle(L, layers, n_chunks):
     """The configuration bench.py times: bf16, D 128, L >= 512, all layers of a chunk scored / selected / evicted by ONE
     launch per kernel (gridDim.y = layers: rtk_pivotkv_score_passes_batched, rtk_pivotkv_select_batched,
