@@ -140,7 +140,8 @@ def run_video(frames, pool, masks, pos_base, rotary, layers, tdtype):
     out, mask = vc.memory_bank_compress_keyframe(frames, T, 3, sync=False)
     n_chunks = T // FRAMES_PER_CHUNK
     L = FRAMES_PER_CHUNK * N_PATCH
-    cache = lc.build_kvcache(make_cache_config(layers))
+    # capacity hint, as the patched model forward gives it (_prefill.expected_cache_tokens): compressed video + one chunk
+    cache = lc.build_kvcache(make_cache_config(layers), reserve_tokens=n_chunks * max(1, int(RATIO * L)) + L)
     retained = 0
     call = 0
     for c in range(n_chunks):

@@ -507,6 +507,54 @@ def test_pivotkv_batched_flush_equals_per_layer_flush(reforge, dtype, streams, L
     assert len(a.position_cache) == (layers if reforge else 0)
 
 
+def test_pivotkv_reserve_tokens_hint_is_only_an_allocation_hint():
+    """build_kvcache(config, reserve_tokens=...): the layer buffers are allocated once (same base pointer after every
+    chunk, also when the hint was too small and the cache has to grow) and the cache contents equal those of a cache
+    built without the hint; _prefill.expected_cache_tokens gives prompt * ratio + one chunk + room for generation."""
+    import retake.longvideo_cache as lc
+    from retake import _prefill
+
+    Hq, Hkv, D, layers, n_chunks, L = 28, 4, 128, 2, 4, 640
+    keep = L // 4
+    sec = [16, 24, 24]
+    rot = synth.RotaryStub(synth.inv_freq(D), synth.YARN_FACTOR4_ATTENTION_SCALING, device=dev())
+    cfg = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=layers, num_attention_heads=Hq, num_key_value_heads=Hkv,
+                                longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
+                                    "compression_ratio": 0.25, "compression_method": "pivotkv", "pos_embed_reforge": True}})
+    assert _prefill.expected_cache_tokens(cfg, n_chunks * L, L) == n_chunks * keep + L + 2048
+    assert _prefill.expected_cache_tokens(types.SimpleNamespace(longvideo_kwargs=None), 100, L) is None
+    g = torch.Generator(device=dev()).manual_seed(5)
+    data = [[tuple((1.7 * torch.randn((1, h, L, D), generator=g, device=dev())).bfloat16() for h in (Hq, Hkv, Hkv))
+             for _ in range(layers)] for _ in range(n_chunks)]
+
+    def run(cache):
+        ptrs = []
+        for c in range(n_chunks):
+            pos = torch.from_numpy(synth.mrope_position_ids(10 + 5 * c, L // 64, 8, 8, hw0=2)).to(dev())
+            cache.keypatches_mask_chunk = torch.zeros(L, dtype=torch.bool, device=dev())
+            cache.kvcache_compression = True
+            for l in range(layers):
+                q, k, v = data[c][l]
+                cache.shift_temporal_ids_(pos, l)
+                cache.update(k, v, l, {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": sec})
+            cache.after_forward()
+            ptrs.append(cache._layers[0].k.data_ptr())
+        return ptrs
+
+    plain = lc.build_kvcache(cfg)
+    p_plain = run(plain)
+    exact = lc.build_kvcache(cfg, reserve_tokens=n_chunks * keep + L)
+    p_exact = run(exact)
+    small = lc.build_kvcache(cfg, reserve_tokens=L + 8)      # too small: must still grow correctly
+    run(small)
+    assert len(set(p_exact)) == 1 and len(set(p_plain)) > 1
+    for l in range(layers):
+        for other in (exact, small):
+            assert torch.equal(other.key_cache[l], plain.key_cache[l])
+            assert torch.equal(other.value_cache[l], plain.value_cache[l])
+            assert torch.equal(other.position_cache[l], plain.position_cache[l])
+
+
 def _bf16_tables_cpu(rot_cpu, pos3, sec, like):
     """cos/sin [1,1,L,D] in the dtype of `like`, section-merged (reference :249 + :68-74), torch CPU."""
     cos, sin = rot_cpu(like, pos3)

@@ -6,7 +6,7 @@ prefill loop); retake/llava_onevision.py:164-198, :337-347, :499-545 are the sam
 from __future__ import annotations
 
 import math
-from typing import Callable, List, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import torch
 
@@ -36,6 +36,16 @@ def apply_dynamic_compression_ratio(config, input_length: int) -> None:
     if comp.get("dynamic_compression_ratio", False):
         max_len = comp["max_input_length"]
         comp["compression_ratio"] = 1 if input_length <= max_len else max_len / input_length
+
+
+def expected_cache_tokens(config, input_length: int, chunk_size: Optional[int]) -> Optional[int]:
+    """Capacity hint for the pre-allocated PivotKV cache (not in the reference): the prompt compressed at the configured
+    ratio, plus one uncompressed chunk in flight, plus room for generation.  An over-long answer only costs a regrowth."""
+    kwargs = getattr(config, "longvideo_kwargs", None)
+    if not kwargs or not kwargs.get("kvcache_compression", False) or chunk_size is None:
+        return None
+    ratio = float(kwargs["kvcache_compression_kwargs"].get("compression_ratio", 1.0))
+    return int(math.ceil(min(1.0, ratio) * input_length)) + int(chunk_size) + 2048
 
 
 def prompt_guided(config) -> bool:

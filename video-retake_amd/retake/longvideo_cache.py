@@ -267,7 +267,11 @@ class _CacheView:
 class PivotKVCache(DynamicCache):
     """Drop-in for the reference's PivotKVCache (longvideo_cache.py:119-323)."""
 
-    def __init__(self, config) -> None:
+    def __init__(self, config, reserve_tokens: Optional[int] = None) -> None:
+        """reserve_tokens (not in the reference): tokens per layer this cache is expected to hold at most - compressed
+        prompt + one uncompressed chunk + generation.  The first allocation of a layer takes that size, which saves the
+        geometric regrowth copies (~0.4 % of a 2048-frame prefill) and half the memory; without it buffers double."""
+        self.reserve_tokens = int(reserve_tokens) if reserve_tokens else 0
         self._layers: List[_LayerStore] = []
         self._batch: Optional[_Batch] = None
         self._last_slot = None
@@ -413,7 +417,7 @@ class PivotKVCache(DynamicCache):
         need = st.pos_len + more
         if st.pos is not None and st.pos.shape[1] >= need:
             return
-        cap = max(need, 2 * (st.pos.shape[1] if st.pos is not None else 0), 4096)
+        cap = max(need, 2 * (st.pos.shape[1] if st.pos is not None else 0), 4096, self.reserve_tokens)
         buf = torch.empty((P, cap), dtype=torch.int64, device=device)
         if st.pos is not None and st.pos_len:
             buf[:, :st.pos_len].copy_(st.pos[:, :st.pos_len])
@@ -498,7 +502,7 @@ class PivotKVCache(DynamicCache):
         if st.k is not None and st.k.shape[2] >= need and st.k.is_contiguous() and st.v.is_contiguous() \
                 and st.v.shape[2] == st.k.shape[2]:
             return st
-        cap = max(need, 2 * (st.k.shape[2] if st.k is not None else 0), 1024)
+        cap = max(need, 2 * (st.k.shape[2] if st.k is not None else 0), 1024, self.reserve_tokens)
         shape = (1, like.shape[1], cap, like.shape[3])
         nk = torch.empty(shape, dtype=like.dtype, device=like.device)
         nvv = torch.empty(shape, dtype=like.dtype, device=like.device)
@@ -908,11 +912,12 @@ class PivotKVCache(DynamicCache):
         return st.k[:, :, :P0 + n_new], st.v[:, :, :P0 + n_new]
 
 
-def build_kvcache(config):
-    """DynamicCache unless longvideo_kwargs enables 'pivotkv' compression (reference :326-334)."""
+def build_kvcache(config, reserve_tokens: Optional[int] = None):
+    """DynamicCache unless longvideo_kwargs enables 'pivotkv' compression (reference :326-334).  reserve_tokens: optional
+    capacity hint for the pre-allocated PivotKV cache (see PivotKVCache.__init__)."""
     if getattr(config, "longvideo_kwargs", None) is None or not config.longvideo_kwargs.get("kvcache_compression", False):
         return DynamicCache()
     compression_method = config.longvideo_kwargs["kvcache_compression_kwargs"]["compression_method"]
     if compression_method.lower() == "pivotkv":
-        return PivotKVCache(config)
+        return PivotKVCache(config, reserve_tokens=reserve_tokens)
     raise NotImplementedError

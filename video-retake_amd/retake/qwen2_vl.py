@@ -300,7 +300,8 @@ def retake_Qwen2VLForConditionalGeneration_forward(
         _prefill.apply_dynamic_compression_ratio(self.config, input_ids.shape[1])
         if chunk_size is not None:
             modality_segments = self.segment_input_ids(input_ids)
-            past_key_values = build_kvcache(self.config)
+            past_key_values = build_kvcache(self.config, reserve_tokens=_prefill.expected_cache_tokens(
+                self.config, input_ids.shape[1], chunk_size))
             use_cache = True
 
     output_attentions = output_attentions if output_attentions is not None else self.config.output_attentions

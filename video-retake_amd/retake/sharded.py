@@ -410,13 +410,13 @@ class ShardedPivotKV:
     """A rank's share of one video's PivotKV compression (see the module docstring)."""
 
     def __init__(self, config, group=None, first_start: int = 0, expected_rows: Optional[int] = None,
-                 chunk_gather: Optional[ChunkGatherP2P] = None):
+                 chunk_gather: Optional[ChunkGatherP2P] = None, reserve_tokens: Optional[int] = None):
         """expected_rows: rows this rank will keep per layer over the whole video (equal on all ranks); with the p2p
         transport it lets `gather_chunk` push rows to their final position (else the assembly happens at the end).
         chunk_gather: the ChunkGatherP2P of the previous video of the same shape, to reuse its mapped buffers."""
         from .longvideo_cache import PivotKVCache
 
-        self.cache = PivotKVCache(config)
+        self.cache = PivotKVCache(config, reserve_tokens=reserve_tokens)   # capacity hint: kept rows + one chunk
         self.group = group
         self.first_start = first_start
         self.expected_rows = expected_rows
@@ -541,7 +541,7 @@ def sharded_video_step(frames, has_halo: bool, T: int, c0: int, c1: int, layers:
     out, mask, idx, dis = dpselect_sharded(frames, has_halo, T, 3, sync=False, group=group)
     keep = max(1, int(B.RATIO * L))
     sh = ShardedPivotKV(B.make_cache_config(layers), group=group, expected_rows=(c1 - c0) * keep if overlap else None,
-                        chunk_gather=(state or {}).get("chunk_gather"))
+                        chunk_gather=(state or {}).get("chunk_gather"), reserve_tokens=(c1 - c0) * keep + L)
     cache = sh.cache
     for ci, c in enumerate(range(c0, c1)):
         cache.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
