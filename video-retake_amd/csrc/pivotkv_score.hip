@@ -1205,6 +1205,11 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
     }
     const int g = h / G;
     const int i0 = bx * (REG_ROWS * NB) + wid * (32 * NB);   // this wave's NB x 32 query rows
+    // L = 6272 is 24.5 workgroup tiles: in the last row tile of every head half the waves own no query row.  They keep
+    // their DMA pieces and barriers but skip the MFMAs and the softmax (2 % of the launch's arithmetic; wave-uniform).
+    // Same-box A/B: 6788 -> 6748 us.  The same skip in pass 2 measured +0.5 % (the branch costs the live waves' schedule
+    // more than the dead waves' energy returns) and is not taken there.
+    const bool live = __builtin_amdgcn_readfirstlane(i0) < L;
     const int jb = ks * keys_per_split, je = min(L, jb + keys_per_split);
     const int nkeys = je - jb;
     const int nfull = nkeys / TILE_ROWS;
@@ -1247,6 +1252,9 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
         constexpr int buf = BUF;                                                                          \
         const char* cur = smem + buf * T::BYTES;                                                          \
         if constexpr (ISSUE && RTK_DMA_PLACE == 0) RTK_DMA1_ISSUE((JT) + 1, buf ^ 1)                      \
+        if (!live) { /* this wave's query rows lie past L: it only moves its share of the next tile */    \
+            if constexpr (ISSUE && RTK_DMA_PLACE != 0) RTK_DMA1_PIECES((JT) + 1, buf ^ 1, 0, 4)           \
+        } else {                                                                                          \
         _Pragma("unroll")                                                                                 \
         for (int blk = 0; blk < 2; ++blk) {                                                               \
             u32x4 a[M::NREG];                                                                             \
@@ -1280,6 +1288,7 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
                     }                                                                                     \
                 }                                                                                         \
             }                                                                                             \
+        }                                                                                                 \
         }                                                                                                 \
         __syncthreads(); /* drains the DMA (vmcnt(0)) and the LDS reads of this tile */                   \
     }
