@@ -589,6 +589,9 @@ struct RowStat {  // online max / sum of one query row, over the keys this lane 
 #ifndef RTK_MFMA_ORDER  // 1 = all fragment reads of a block first, then its MFMAs strictly alternating between the two accumulators
 #define RTK_MFMA_ORDER 1   // (no MFMA waits for its predecessor; the compiler's own order ran 5 dependent ones in a row and padded
 #endif                     // others with s_nop 9); same-box A/B: pass 1 7019 -> 6878 us, pass 2 7054 -> 6908 us, bit-identical results
+#ifndef RTK_HALF_TAIL
+#define RTK_HALF_TAIL 1    // a last tile that is at most half full runs the one-block body (see score_pass2_dma_kernel)
+#endif
 #ifndef RTK_LSE_W0      // 1 = only wave 0 fetches the tile's 64 row normalisers (the other waves used to load them too)
 #define RTK_LSE_W0 1       // same-box A/B: pass 2 7083 -> 7043 us, bit-identical results
 #endif
@@ -997,38 +1000,21 @@ _Pragma("unroll") \
 // LDS position p of row r receives chunk p ^ (r & 15), the same involution the fragment reads apply.
 // NB = 32-key register blocks per wave (NB = 2: every A fragment read from LDS feeds two MFMAs).
 // ------------------------------------------------------------------------------------------------
+// The work of one workgroup: NB x 32 keys per wave starting at key j_base + wid * 32 * NB, the query rows of split rs.
 template <int NB>
-__global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 2 : 2)))) void score_pass2_dma_kernel(
-    const char* __restrict__ q, const char* __restrict__ k, const float* __restrict__ lse, int Hq, int Hkv, int L,
-    int rows_per_split, int col_tiles, int RS, int xcd_remap, float* __restrict__ partial, size_t q_unit_bytes,
-    size_t k_unit_bytes, size_t lse_unit_floats, size_t part_unit_floats) {
+__device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q, const char* __restrict__ k,
+                                                     const float* __restrict__ lse, int Hq, int Hkv, int L,
+                                                     int rows_per_split, int RS, float* __restrict__ partial, int j_base,
+                                                     int g, int rs) {
     constexpr int DT = RTK_BF16;
     using M = MM<DT>;
     using T = Tile<DT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lse_s = (float*)(smem + 2 * T::BYTES);  // [2][TILE_ROWS]
-    q += blockIdx.y * q_unit_bytes;           // blockIdx.y = unit of a batched launch
-    k += blockIdx.y * k_unit_bytes;
-    lse += blockIdx.y * lse_unit_floats;
-    partial += blockIdx.y * part_unit_floats;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), hf = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const int G = Hq / Hkv;
-    int bx, g, rs;
-    {
-        int grp;
-        if (xcd_remap) {
-            const int xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
-            grp = xcd + NXCD * (slot / col_tiles);
-            bx = slot % col_tiles;
-        } else {
-            grp = blockIdx.x / col_tiles;
-            bx = blockIdx.x % col_tiles;
-        }
-        g = grp % Hkv;
-        rs = grp / Hkv;
-    }
-    const int j0 = bx * (REG_ROWS * NB) + wid * (32 * NB);
+    const int j0 = j_base + wid * (32 * NB);
     const char* kg = k + (size_t)g * L * HD * M::ESIZE;
     const int ib = rs * rows_per_split, ie = min(L, ib + rows_per_split);
     const int nrows = ie - ib;
@@ -1165,50 +1151,65 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
     }
 }
 
+// blockIdx.x -> (key tile bx, KV head g, row split rs), blockIdx.y = unit of a batched launch.  A key tile is
+// REG_ROWS * NB keys (4 waves x NB x 32).  When the LAST tile holds at most half of that (L = 6272 = 24.5 tiles of 256),
+// its workgroups run the one-block body on 32 keys per wave instead of leaving two of four waves without a key: the
+// tile costs half the MFMAs (2 % of the launch's arithmetic was spent on keys past L).
+template <int NB>
+__global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 2 : 2)))) void score_pass2_dma_kernel(
+    const char* __restrict__ q, const char* __restrict__ k, const float* __restrict__ lse, int Hq, int Hkv, int L,
+    int rows_per_split, int col_tiles, int RS, int xcd_remap, float* __restrict__ partial, size_t q_unit_bytes,
+    size_t k_unit_bytes, size_t lse_unit_floats, size_t part_unit_floats) {
+    q += blockIdx.y * q_unit_bytes;
+    k += blockIdx.y * k_unit_bytes;
+    lse += blockIdx.y * lse_unit_floats;
+    partial += blockIdx.y * part_unit_floats;
+    int bx, g, rs;
+    {
+        int grp;
+        if (xcd_remap) {
+            const int xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+            grp = xcd + NXCD * (slot / col_tiles);
+            bx = slot % col_tiles;
+        } else {
+            grp = blockIdx.x / col_tiles;
+            bx = blockIdx.x % col_tiles;
+        }
+        g = grp % Hkv;
+        rs = grp / Hkv;
+    }
+    const int j_base = bx * (REG_ROWS * NB);
+    if constexpr (NB == 2 && RTK_HALF_TAIL) {
+        if (L - j_base <= REG_ROWS) {   // uniform per workgroup
+            score_pass2_dma_body<1>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs);
+            return;
+        }
+    }
+    score_pass2_dma_body<NB>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs);
+}
+
 // ------------------------------------------------------------------------------------------------
 // pass 1, LDS-DMA form (bf16): same decomposition as score_pass1_kernel (32 query rows per wave in
 // registers, 64-key tiles streamed), with the key tile DMA'd straight into the swizzled LDS image and one
 // 32-key block in flight per wave (~100 VGPRs -> 4 waves per SIMD).
 // ------------------------------------------------------------------------------------------------
+// The work of one workgroup: NB x 32 query rows of head h per wave starting at row i_base + wid * 32 * NB, key split ks.
 template <int NB, bool LAZY>
-__global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_kernel(const char* __restrict__ q,
-                                                                      const char* __restrict__ k, int Hq, int Hkv, int L,
-                                                                      int keys_per_split, int row_tiles, int xcd_remap,
-                                                                      float* __restrict__ lse_part, size_t q_unit_bytes,
-                                                                      size_t k_unit_bytes, size_t lse_unit_floats) {
+__device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv,
+                                                     int L, int keys_per_split, float* __restrict__ lse_part, int i_base, int h,
+                                                     int ks) {
     constexpr int DT = RTK_BF16;
     using M = MM<DT>;
     using T = Tile<DT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // blockIdx.y = (layer, chunk) unit of a batched launch: same shapes, operands one unit stride apart
-    q += blockIdx.y * q_unit_bytes;
-    k += blockIdx.y * k_unit_bytes;
-    lse_part += blockIdx.y * lse_unit_floats;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), hf = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const int G = Hq / Hkv;
-    int bx, h, ks;
-    {
-        const int per_group = row_tiles * G;
-        int grp, w;
-        if (xcd_remap) {
-            const int xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
-            grp = xcd + NXCD * (slot / per_group);
-            w = slot % per_group;
-        } else {
-            grp = blockIdx.x / per_group;
-            w = blockIdx.x % per_group;
-        }
-        ks = grp / Hkv;
-        h = (grp % Hkv) * G + w / row_tiles;
-        bx = w % row_tiles;
-    }
     const int g = h / G;
-    const int i0 = bx * (REG_ROWS * NB) + wid * (32 * NB);   // this wave's NB x 32 query rows
-    // L = 6272 is 24.5 workgroup tiles: in the last row tile of every head half the waves own no query row.  They keep
-    // their DMA pieces and barriers but skip the MFMAs and the softmax (2 % of the launch's arithmetic; wave-uniform).
-    // Same-box A/B: 6788 -> 6748 us.  The same skip in pass 2 measured +0.5 % (the branch costs the live waves' schedule
-    // more than the dead waves' energy returns) and is not taken there.
+    const int i0 = i_base + wid * (32 * NB);   // this wave's NB x 32 query rows
+    // A wave whose rows all lie past L (a last tile that is between half and three quarters full) keeps its DMA pieces and
+    // barriers but skips the MFMAs and the softmax; wave-uniform.  (A last tile that is at most half full runs the
+    // one-block body instead, see score_pass1_dma_kernel.)
     const bool live = __builtin_amdgcn_readfirstlane(i0) < L;
     const int jb = ks * keys_per_split, je = min(L, jb + keys_per_split);
     const int nkeys = je - jb;
@@ -1324,6 +1325,45 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
         const int i = i0 + 32 * nb + (lane & 31);
         if (hf == 0 && i < L) lse_part[((size_t)ks * Hq + h) * L + i] = out;
     }
+}
+
+// blockIdx.x -> (row tile bx, head h, key split ks), blockIdx.y = (layer, chunk) unit of a batched launch: same shapes,
+// operands one unit stride apart.  Like pass 2, a last row tile that is at most half full (L = 6272 = 24.5 tiles) runs the
+// one-block body on 32 rows per wave.
+template <int NB, bool LAZY>
+__global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_kernel(const char* __restrict__ q,
+                                                                      const char* __restrict__ k, int Hq, int Hkv, int L,
+                                                                      int keys_per_split, int row_tiles, int xcd_remap,
+                                                                      float* __restrict__ lse_part, size_t q_unit_bytes,
+                                                                      size_t k_unit_bytes, size_t lse_unit_floats) {
+    q += blockIdx.y * q_unit_bytes;
+    k += blockIdx.y * k_unit_bytes;
+    lse_part += blockIdx.y * lse_unit_floats;
+    const int G = Hq / Hkv;
+    int bx, h, ks;
+    {
+        const int per_group = row_tiles * G;
+        int grp, w;
+        if (xcd_remap) {
+            const int xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+            grp = xcd + NXCD * (slot / per_group);
+            w = slot % per_group;
+        } else {
+            grp = blockIdx.x / per_group;
+            w = blockIdx.x % per_group;
+        }
+        ks = grp / Hkv;
+        h = (grp % Hkv) * G + w / row_tiles;
+        bx = w % row_tiles;
+    }
+    const int i_base = bx * (REG_ROWS * NB);
+    if constexpr (NB == 2 && RTK_HALF_TAIL) {
+        if (L - i_base <= REG_ROWS) {   // uniform per workgroup
+            score_pass1_dma_body<1, LAZY>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks);
+            return;
+        }
+    }
+    score_pass1_dma_body<NB, LAZY>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks);
 }
 
 }  // namespace rtk
