@@ -725,8 +725,8 @@ _Pragma("unroll") \
 
 // online max / sum of one query row, one 32-key block at a time (bf16 path, log2 domain)
 struct RowStatB {  // online max / sum of one query row over the keys this lane sees (bf16 path, log2 domain)
-    float m, sum;
-    __device__ __forceinline__ void init() { m = -INFINITY; sum = 0.f; }
+    float m, sum, off;   // off = -m * c2, the exponent offset of the lazy form (kept so that a block does not recompute it)
+    __device__ __forceinline__ void init() { m = -INFINITY; sum = 0.f; off = INFINITY; }
     template <bool RAGGED>
     __device__ __forceinline__ void update(f32x16& a, int j0, int j_end, int hf, float c2) {
         if (RAGGED) {  // keys >= j_end do not exist
@@ -742,6 +742,7 @@ struct RowStatB {  // online max / sum of one query row over the keys this lane 
         for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(fmaf(a[r], c2, nb));
         sum = sum * __builtin_amdgcn_exp2f((m - mn) * c2) + add;
         m = mn;
+        off = nb;
     }
     // Lazy form: the 16 exponentials are taken against the offset of the LAST rescale (no max over the block, no
     // rescale of the running sum); only when some lane's block sum is not a finite number below 2^96 - a key beat the
@@ -756,10 +757,9 @@ struct RowStatB {  // online max / sum of one query row over the keys this lane 
             for (int r = 0; r < 16; ++r)
                 if (j0 + acc_row(r, hf) >= j_end) a[r] = -INFINITY;
         }
-        const float nb = -m * c2;
-        float add = 0.f;
+        float add = __builtin_amdgcn_exp2f(fmaf(a[0], c2, off));   // (0 + e0 would cost an instruction: -0 semantics)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(fmaf(a[r], c2, nb));
+        for (int r = 1; r < 16; ++r) add += __builtin_amdgcn_exp2f(fmaf(a[r], c2, off));
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(add < 0x1p96f)) == 0, 1)) {
             sum += add;
             return;
@@ -772,6 +772,7 @@ struct RowStatB {  // online max / sum of one query row over the keys this lane 
         for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(fmaf(a[r], c2, nb2));
         sum = sum * __builtin_amdgcn_exp2f((m - mn) * c2) + add;
         m = mn;
+        off = nb2;
     }
     __device__ __forceinline__ float finish(float c2) const {
         const float m2 = __shfl_xor(m, 32, WAVE), s2 = __shfl_xor(sum, 32, WAVE);
