@@ -592,6 +592,9 @@ struct RowStat {  // online max / sum of one query row, over the keys this lane 
 #ifndef RTK_HALF_TAIL
 #define RTK_HALF_TAIL 1    // a last tile that is at most half full runs the one-block body (see score_pass2_dma_kernel)
 #endif
+#ifndef RTK_LSE_DMA
+#define RTK_LSE_DMA 1
+#endif
 #ifndef RTK_LSE_W0      // 1 = only wave 0 fetches the tile's 64 row normalisers (the other waves used to load them too)
 #define RTK_LSE_W0 1       // same-box A/B: pass 2 7083 -> 7043 us, bit-identical results
 #endif
@@ -1042,6 +1045,8 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
     const int drow = 4 * wid + (lane >> 4);                                        // row inside a 16-row group
     const int dvoff = drow * T::ROWB + (((lane & 15) ^ (drow & 15)) * 16);          // + u * 16 rows via soffset
     const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, Hq * L * HD * M::ESIZE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)lse, 0, Hq * L * 4, 0x00020000);
+    const bool lse_dma = RTK_LSE_DMA && (nrows % TILE_ROWS == 0);   // uniform: no row of a tile lies past the split
     float lstA = 0.f;
     int nt = 0;
     const int last_row = Hq * L - 1;
@@ -1069,10 +1074,15 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
                 qrsrc, (void __attribute__((address_space(3)))*)(smem + (b) * T::BYTES + (4 * u + wid) * 1024), 16, \
                 dvoff, ((rb) + 16 * u) * T::ROWB, 0, 0);                                                  \
     }
-#define RTK_DMA_TAIL()                                                                                    \
+#define RTK_DMA_TAIL(b)                                                                                   \
     {                                                                                                     \
         const int r__ = nt * TILE_ROWS + (tid & (TILE_ROWS - 1));                                         \
-        if (!RTK_LSE_W0 || wid == 0) lstA = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : INFINITY;   \
+        if (lse_dma) { /* whole tiles only: the 64 normalisers go HBM/L2 -> LDS like the tile itself */   \
+            if (wid == 0)                                                                                 \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                 \
+                    lrsrc, (void __attribute__((address_space(3)))*)(lse_s + (b) * TILE_ROWS), 4, lane * 4, \
+                    (nrow0 + nt * TILE_ROWS) * 4, 0, 0);                                                  \
+        } else if (!RTK_LSE_W0 || wid == 0) lstA = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : INFINITY; \
         const bool wrap__ = (nt + 1 == tiles_per_head);                                                   \
         nt = wrap__ ? 0 : nt + 1;                                                                         \
         nrow0 += wrap__ ? L : 0;                                                                          \
@@ -1084,7 +1094,7 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
         const float* lcur = lse_s + buf * TILE_ROWS;                                                      \
         const int rb__ = nrow0 + nt * TILE_ROWS;                                                          \
         if constexpr (ISSUE && RTK_DMA_PLACE == 0) RTK_DMA_ISSUE(buf ^ 1)                                 \
-        if constexpr (ISSUE && RTK_DMA_PLACE != 0) RTK_DMA_TAIL()                                         \
+        if constexpr (ISSUE && RTK_DMA_PLACE != 0) RTK_DMA_TAIL(buf ^ 1)                                  \
         _Pragma("unroll")                                                                                 \
         for (int blk = 0; blk < 2; ++blk) {                                                               \
             u32x4 a[M::NREG];                                                                             \
@@ -1121,7 +1131,7 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
             }                                                                                             \
         }                                                                                                 \
         if constexpr (ISSUE) {                                                                            \
-            if (tid < TILE_ROWS) lse_s[(buf ^ 1) * TILE_ROWS + tid] = lstA;                               \
+            if (!lse_dma && tid < TILE_ROWS) lse_s[(buf ^ 1) * TILE_ROWS + tid] = lstA;                   \
         }                                                                                                 \
         __syncthreads(); /* drains the DMA (vmcnt(0)) and the LDS reads of this tile */                   \
     }
