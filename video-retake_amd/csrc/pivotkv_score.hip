@@ -1154,11 +1154,13 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
     }
 #undef RTK_DMA_STEP
 #undef RTK_DMA_ISSUE
+    int lane_late = lane;
+    asm volatile("" : "+v"(lane_late));   // the output address is formed here, not carried (and spilled) through the loop
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const float c = col[nb] + __shfl_xor(col[nb], 32, WAVE);
-        const int j = j0 + 32 * nb + (lane & 31);
-        if (hf == 0 && j < L) partial[((size_t)g * RS + rs) * L + j] = c;
+        const int j = j0 + 32 * nb + (lane_late & 31);
+        if (lane_late < 32 && j < L) partial[((size_t)g * RS + rs) * L + j] = c;
     }
 }
 
