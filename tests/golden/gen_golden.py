@@ -179,6 +179,13 @@ def gen_dpselect(vc, outdir):
               ("llava48x729x1152_async_r50", "video", 34, 48, 729, 1152, 24, False, "fp32", False)]
     cases += [("video64x16x64_async_r50_bf16", "video", 41, 64, 16, 64, 32, False, "bf16", True),
               ("video64x16x64_sync_r50_bf16", "video", 42, 64, 16, 64, 32, True, "bf16", True)]
+    # production dtype at production shapes (round 3): the key-patch mask of the async ratio-1.0 call is DPSelect's only
+    # product in the shipped configs; BASELINE patch geometry 196 x 1280 and Qwen2-VL's 144 x 3584
+    cases += [("video64x196x1280_async_r100_bf16", "video", 43, 64, 196, 1280, 64, False, "bf16", False),
+              ("video64x196x1280_async_r50_bf16", "video", 44, 64, 196, 1280, 32, False, "bf16", False),
+              ("video32x144x3584_async_r100_bf16", "video", 45, 32, 144, 3584, 32, False, "bf16", False),
+              ("video32x144x3584_async_r50_bf16", "video", 46, 32, 144, 3584, 16, False, "bf16", False),
+              ("video64x196x1280_sync_r50_bf16", "video", 47, 64, 196, 1280, 32, True, "bf16", False)]
 
     for (name, kind, seed, T, N, C, tgt, sync, dtype, raw) in cases:
         for attempt in range(50):

@@ -51,24 +51,35 @@ def test_dpselect_fp32_golden(name):
 
 @pytest.mark.parametrize("name", DP_BF16)
 def test_dpselect_bf16_golden(name):
+    """The production dtype against the reference's own bf16 run, row by row (golden_util.check_dpselect_bf16): rows whose
+    distances equal the reference's bit for bit must reproduce its indices AND its key-patch mask; a row with a flipped
+    bf16 rounding may differ only at the stencil sites / threshold keys that flip can reach."""
     import retake.visual_compression as vc
 
     g = gu.load(name)
     x = gu.dpselect_input(g)  # uint16 bits
     xt = torch.from_numpy(x.view(np.int16)).to(dev()).view(torch.bfloat16)
-    out, mask, idx, dis, keys = vc.dpselect_stages(xt, int(g["tgt"]), int(g["window"]), bool(g["sync"]))
-    d = np.abs(dis.cpu().numpy() - g["dis32"])
+    tgt, sync = int(g["tgt"]), bool(g["sync"])
+    out, mask, idx, dis, keys = vc.dpselect_stages(xt, tgt, int(g["window"]), sync)
+    disn = dis.cpu().numpy()
+    d = np.abs(disn - g["dis32"])
     # the bf16 rounding chain of the reference is reproduced; a different fp32 summation order can
     # flip the final bf16 rounding of a few sums by one ulp (2^-8 at most near 1)
-    assert d.max() <= 2 ** -7 and (d > 0).mean() < 0.02
-    sync = bool(g["sync"])
-    ref_idx = g["idx"]
-    k = keys.cpu().numpy()
-    idxn = idx.cpu().numpy()
-    if (d == 0).all():
-        rows = [(k[0], idxn, ref_idx)] if sync else [(k[n], idxn[:, n], ref_idx[:, n]) for n in range(idxn.shape[1])]
-        for krow, mine, theirs in rows:
-            np.testing.assert_array_equal(np.sort(krow[mine]), np.sort(krow[theirs]))
+    assert d.max() <= 2 ** -7 and (d > 0).mean() < 0.005
+    st = gu.check_dpselect_bf16(g, disn, idx.cpu().numpy(), mask.flatten().cpu().numpy())
+    print(f"\n[{name}] rows {st['rows']}: exact {st['exact']}, tied-boundary {st['tied']}, relaxed {st['relaxed']} "
+          f"({st['flipped_entries']} of {d.size} distances flipped, {st['peak_flags_differing']} peak flags and "
+          f"{st['indices_differing']} picks differ from the reference's)")
+    assert st["exact"] + st["tied"] >= 0.5 * st["rows"] or sync
+    # the gathered frames are copies of the frames the product's own indices name
+    xi = xt[0]
+    ii = idx if not sync else idx[:, None].expand(-1, xi.shape[1])
+    want = torch.gather(xi, 0, ii[:, :, None].expand(-1, -1, xi.shape[2]))
+    assert torch.equal(out[0], want)
+    if tgt == xi.shape[0]:
+        assert torch.equal(out[0], xi)          # ratio 1.0: the identity copy (SURVEY A4)
+    out2, mask2 = vc.memory_bank_compress_keyframe(xt, tgt, int(g["window"]), sync=sync)
+    assert torch.equal(out2, out) and torch.equal(mask2, mask.flatten())
 
 
 @pytest.mark.parametrize("sync", [True, False])

@@ -32,23 +32,20 @@ def test_dpselect_fp32_matches_reference(name):
 
 @pytest.mark.parametrize("name", DP_BF16)
 def test_dpselect_bf16_matches_reference(name):
+    """Oracle vs the reference's bf16 run, row by row (golden_util.check_dpselect_bf16): rows whose distances equal the
+    reference's must carry its indices and its mask; a flipped bf16 rounding may only move what it can reach."""
     g = gu.load(name)
     x = gu.dpselect_input(g)  # uint16 bf16 bits
     out, mask, idx, dis = orc.dpselect(x, int(g["tgt"]), int(g["window"]), bool(g["sync"]))
     # bf16 distance has bf16 resolution (2^-8 near 1); the emulated rounding chain reproduces the
     # reference up to one bf16 ulp of the cosine on rare elements
     d = np.abs(dis - g["dis32"])
-    assert d.max() <= 2 ** -7 and (d > 0).mean() < 0.02
-    if (d == 0).all():
-        # bf16 distances tie massively; torch's top-k tie order is backend-specific,
-        # so the selected KEY multiset per row must match, and the peak flags of common picks too.
-        sync = bool(g["sync"])
-        _, _, keys = orc.dpselect_select(dis, int(g["tgt"]), int(g["window"]), sync)
-        ref_idx = g["idx"]
-        rows = [(keys, idx, ref_idx)] if sync else [(keys[n], idx[:, n], ref_idx[:, n]) for n in range(idx.shape[1])]
-        for krow, mine, theirs in rows:
-            np.testing.assert_array_equal(np.sort(krow[mine]), np.sort(krow[theirs]))
-        assert mask.sum() == g["mask"].sum()
+    assert d.max() <= 2 ** -7 and (d > 0).mean() < 0.005
+    st = gu.check_dpselect_bf16(g, dis, idx, mask)
+    print(f"\n[{name}] rows {st['rows']}: exact {st['exact']}, tied-boundary {st['tied']}, relaxed {st['relaxed']} "
+          f"({st['flipped_entries']} of {d.size} distances flipped, {st['peak_flags_differing']} peak flags and "
+          f"{st['indices_differing']} picks differ from the reference's)")
+    assert st["exact"] + st["tied"] >= 0.5 * st["rows"] or bool(g["sync"])
 
 
 @pytest.mark.parametrize("sync", [True, False])
