@@ -39,8 +39,28 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, MI355X_MICROA
 
 Hq, Hkv, D = 28, 4, 128
 N_PATCH, C_EMB = 196, 1280
-FRAMES_PER_CHUNK = 32
+GRID_H, GRID_W = 14, 14
+FRAMES_PER_CHUNK = 32          # temporal rows of the frame bank per PivotKV chunk
+FRAMES_PER_ROW = 1             # video frames one row of the frame bank stands for
 LAYERS = 28
+SCORE_ROUNDING = "fp32"
+
+# name -> (patch positions N, channels C, token grid h x w, bank rows per chunk, video frames per bank row, label)
+GEOMETRIES = {
+    # BASELINE.json's synthetic shape: 2048 x (14 x 14) x 1280 embeddings, chunk L = 32 x 196 = 6272 (= LLaVA-Video's chunk)
+    "baseline": (196, 1280, 14, 14, 32, 1, "BASELINE.json synthetic geometry"),
+    # the real Qwen2-VL-7B pipeline at longsize_resolution 448, 16:9 (cal_flops.py:8,47, qwen2_vl.py:477-491):
+    # 32 x 18 patches -> 16 x 9 merged tokens per temporal grid, C = 3584 after the merger, one grid = 2 frames,
+    # chunk = 16 grids x 144 = 2304 tokens; a 2048-frame video = 1024 grids = 64 chunks
+    "qwen448": (144, 3584, 9, 16, 16, 2, "real Qwen2-VL geometry (448 px, 16:9)"),
+}
+
+
+def set_geometry(name: str):
+    """Switches the module-level shape constants (retake/sharded.py reads them through this module too)."""
+    global N_PATCH, C_EMB, GRID_H, GRID_W, FRAMES_PER_CHUNK, FRAMES_PER_ROW
+    N_PATCH, C_EMB, GRID_H, GRID_W, FRAMES_PER_CHUNK, FRAMES_PER_ROW, _ = GEOMETRIES[name]
+    assert GRID_H * GRID_W == N_PATCH
 RATIO = 0.25
 MROPE = [16, 24, 24]
 A_SCALE = 0.1 * math.log(4.0) + 1.0
@@ -53,6 +73,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--frames", type=int, default=2048)
+    ap.add_argument("--geometry", default="baseline", choices=sorted(GEOMETRIES),
+                    help="shape of the HEADLINE measurement (the contract line is 'baseline' = BASELINE configs[2])")
+    ap.add_argument("--score-rounding", default="fp32", choices=["fp32", "reference", "fast"],
+                    help="PivotKV bf16 score arithmetic of the headline (retake.longvideo_cache score_rounding)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed-for-`value` companions: real_geometry, reference_rounding, fp32_parity_dtype")
     ap.add_argument("--layers", type=int, default=LAYERS)
     ap.add_argument("--pool", type=int, default=48, help="distinct resident (q,k,v) sets cycled over the calls")
     ap.add_argument("--streams", type=int, default=0, help="worker HIP streams per cache (0 = everything on one stream)")
@@ -91,14 +117,15 @@ def make_cache_config(layers):
         longvideo_kwargs={"kvcache_compression": True,
                           "kvcache_compression_kwargs": {"compression_ratio": RATIO, "compression_method": "pivotkv",
                                                          "pos_embed_reforge": True, "native_rope": True,
+                                                         "score_rounding": SCORE_ROUNDING,
                                                          "overlap_streams": OVERLAP_STREAMS}})
 
 
 def chunk_position_ids(c, device):
     L = FRAMES_PER_CHUNK * N_PATCH
     t = torch.arange(FRAMES_PER_CHUNK, device=device).repeat_interleave(N_PATCH) + FRAMES_PER_CHUNK * c + 16
-    h = torch.arange(14, device=device).repeat_interleave(14).repeat(FRAMES_PER_CHUNK) + 16
-    w = torch.arange(14, device=device).repeat(14 * FRAMES_PER_CHUNK) + 16
+    h = torch.arange(GRID_H, device=device).repeat_interleave(GRID_W).repeat(FRAMES_PER_CHUNK) + 16
+    w = torch.arange(GRID_W, device=device).repeat(GRID_H * FRAMES_PER_CHUNK) + 16
     return torch.stack([t, h, w]).view(3, 1, L)
 
 
@@ -263,7 +290,7 @@ def cpu_baseline(args, frames_cpu_sample, n_updates):
     inv_f = synth.inv_freq(D)
     rot = synth.RotaryStub(inv_f, A_SCALE)
     q0, k0, v = synth.qkv_chunk(123, Hq, Hkv, L, D)
-    pos = synth.mrope_position_ids(16, FRAMES_PER_CHUNK, 14, 14, hw0=16)
+    pos = synth.mrope_position_ids(16, FRAMES_PER_CHUNK, GRID_H, GRID_W, hw0=16)
     q = synth.rope_forward(torch.from_numpy(q0), torch.from_numpy(pos), rot, MROPE).numpy()
     k = synth.rope_forward(torch.from_numpy(k0), torch.from_numpy(pos), rot, MROPE).numpy()
 
@@ -272,19 +299,82 @@ def cpu_baseline(args, frames_cpu_sample, n_updates):
         oc.update(k, v, 0, q=q, position_ids=pos, rotary=rot, mrope_section=MROPE)
 
     t_up = best_of(one_update, max(1, n_updates))
-    n_chunks = args.frames // FRAMES_PER_CHUNK
-    total = t_dp * (args.frames / Ts) + t_up * n_chunks * args.layers
+    rows = args.frames // FRAMES_PER_ROW
+    n_chunks = rows // FRAMES_PER_CHUNK
+    total = t_dp * (rows / Ts) + t_up * n_chunks * args.layers
     return {"value": args.frames / total, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/ (C+OpenMP, fp32): DPSelect on {Ts} of {args.frames} frames ({t_dp:.2f} s) + "
+            "sample": f"oracle/ (C+OpenMP, fp32): DPSelect on {Ts} of {rows} bank rows ({t_dp:.2f} s) + "
                       f"one PivotKV update at L={L} ({t_up:.2f} s), each: one warm-up then best of 3; extrapolated to "
                       f"{n_chunks}x{args.layers} updates",
-            "dpselect_s_per_2048": t_dp * (args.frames / Ts), "pivotkv_update_s": t_up}
+            "dpselect_s_per_2048": t_dp * (rows / Ts), "pivotkv_update_s": t_up}
+
+
+def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_n, geometry=None, score_rounding="fp32",
+                          warmup_chunks=None):
+    """The same step measured again in another configuration, AFTER (and outside) the timed region `value` comes from:
+    another geometry, another score arithmetic or the parity dtype.  Same protocol in small: resident inputs, `warmup`
+    untimed steps (optionally shortened to `warmup_chunks` chunks - enough to build every buffer and touch every
+    kernel), then `steps` timed steps between synchronisations, HIP events around the two score passes.  Returns
+    {value, ms_per_step, roofline, ...}; restores the module's geometry / rounding afterwards."""
+    global SCORE_ROUNDING, N_PATCH, C_EMB, GRID_H, GRID_W, FRAMES_PER_CHUNK, FRAMES_PER_ROW
+    import retake._native as nv
+
+    saved_geo = (N_PATCH, C_EMB, GRID_H, GRID_W, FRAMES_PER_CHUNK, FRAMES_PER_ROW)
+    saved_round = SCORE_ROUNDING
+    try:
+        if geometry is not None:
+            set_geometry(geometry)
+        SCORE_ROUNDING = score_rounding
+        tdtype = torch.bfloat16 if dtype == "bf16" else torch.float32
+        rows = frames_total // FRAMES_PER_ROW
+        n_chunks = rows // FRAMES_PER_CHUNK
+        L = FRAMES_PER_CHUNK * N_PATCH
+        frames = torch.cat([chunk_frames(c, dev, tdtype) for c in range(n_chunks)])[None]
+        pool = [pool_set(i, dev, tdtype) for i in range(min(pool_n, n_chunks * layers))]
+        pos_base = [chunk_position_ids(c, dev) for c in range(n_chunks)]
+        rotary = Rotary(dev)
+        for _ in range(warmup):
+            fr = frames if warmup_chunks is None else frames[:, : warmup_chunks * FRAMES_PER_CHUNK]
+            run_video(fr, pool, None, pos_base, rotary, layers, tdtype)
+        ids = nv.profile_kernel_ids()
+        nv.check(nv.lib.rtk_profile_reset(), "profile_reset")
+        nv.check(nv.lib.rtk_profile_enable_mask((1 << ids["score_pass1"]) | (1 << ids["score_pass2"])), "profile_enable")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, cache, kp_mask = run_video(frames, pool, None, pos_base, rotary, layers, tdtype)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
+        kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in nv.profile_read().items()}
+        check = None
+        if dtype == "bf16" and score_rounding == "fp32":
+            check = self_check(cache, pool, kp_mask, n_chunks, layers, rotary)["status"]
+        keep = max(1, int(RATIO * L))
+        assert cache.key_cache[0].shape[2] == n_chunks * keep
+        del cache
+        res = {"value": frames_total * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+               "warmup": warmup, "dtype": dtype, "score_rounding": score_rounding,
+               "retained_kv_tokens_per_s": n_chunks * layers * keep * steps / dt,
+               "config": {"frames": frames_total, "bank": [1, rows, N_PATCH, C_EMB], "chunks": n_chunks, "layers": layers,
+                          "chunk_tokens": L, "keep": keep},
+               "kernels_timed_region": kern,
+               "roofline": score_roofline(kern, dtype, L, rows, n_chunks * layers * steps)}
+        if check is not None:
+            res["self_check"] = check
+        return res
+    finally:
+        N_PATCH, C_EMB, GRID_H, GRID_W, FRAMES_PER_CHUNK, FRAMES_PER_ROW = saved_geo
+        SCORE_ROUNDING = saved_round
+        torch.cuda.empty_cache()
 
 
 def main():
-    global OVERLAP_STREAMS
+    global OVERLAP_STREAMS, SCORE_ROUNDING
     args = parse()
     OVERLAP_STREAMS = args.streams
+    SCORE_ROUNDING = args.score_rounding
+    set_geometry(args.geometry)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -302,6 +392,8 @@ def main():
     if world > 1 or os.environ.get("RETAKE_FORCE_SHARDED") == "1":  # the env switch runs the sharded path at N=1
         from retake import sharded
 
+        if args.geometry != "baseline":
+            raise SystemExit("bench.py --gpus N shards the BASELINE geometry (configs[3]); use --geometry baseline")
         return sharded.bench_main(args, rank, world, local_rank)
 
     import retake._native as nv
@@ -310,7 +402,7 @@ def main():
     torch.cuda.set_device(dev)
     tdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     es = 2 if args.dtype == "bf16" else 4
-    T = args.frames
+    T = args.frames // FRAMES_PER_ROW     # rows of the frame bank (= frames; temporal grids of 2 frames for qwen448)
     L = FRAMES_PER_CHUNK * N_PATCH
     n_chunks = T // FRAMES_PER_CHUNK
     frames = torch.cat([chunk_frames(c, dev, tdtype) for c in range(n_chunks)])[None]
@@ -366,17 +458,19 @@ def main():
         OVERLAP_STREAMS = saved
 
     ms_per_step = dt / args.steps * 1e3
-    fps = T * args.steps / dt
+    fps = args.frames * args.steps / dt
     out = {
         "metric": "frames/sec through DPSelect+PivotKV @2048 frames; retained-KV-tokens/sec",
         "value": fps, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "retained_kv_tokens_per_s": retained / dt,
-        "config": {"workload": f"Qwen2-VL-7B geometry, {T}-frame synthetic video: DPSelect (async, ratio 1.0) on "
+        "config": {"workload": f"Qwen2-VL-7B geometry, {args.frames}-frame synthetic video: DPSelect (async, ratio 1.0) on "
                                f"[1,{T},{N_PATCH},{C_EMB}] + PivotKV 4x on {n_chunks} chunks x {args.layers} layers, "
-                               f"L={L}, Hq={Hq}, Hkv={Hkv}, D={D}, reforge+M-RoPE (BASELINE configs[2])",
-                   "frames": T, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L, "keep": int(RATIO * L),
+                               f"L={L}, Hq={Hq}, Hkv={Hkv}, D={D}, reforge+M-RoPE "
+                               + ("(BASELINE configs[2])" if args.geometry == "baseline" else f"({GEOMETRIES[args.geometry][6]})"),
+                   "geometry": args.geometry, "score_rounding": args.score_rounding,
+                   "frames": args.frames, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L, "keep": int(RATIO * L),
                    "input_pool_sets": len(pool), "worker_streams": args.streams, "parallelism": "1 GPU"},
     }
     if check is not None:
@@ -423,7 +517,7 @@ def main():
             if key in kern:
                 gbs = b / (kern[key]["avg_us"] * 1e-6) / 1e9
                 tr = None
-                if args.dtype == "bf16" and T == 2048 and args.layers == LAYERS:
+                if args.dtype == "bf16" and T == 2048 and args.layers == LAYERS and args.geometry == "baseline":
                     tr = pmc_traffic({"append": "append_kernel", "evict_batched": "evict_batched_kernel",
                                       "commit_batched": "place_batched_kernel",
                                       "prepare_fused": "prepare_native_kernel"}.get(name, "\0"))[0]
@@ -468,9 +562,27 @@ def main():
         dt2 = time.perf_counter() - t1
         OVERLAP_STREAMS = 0
         flops_step = 2.0 * 2.0 * Hq * L * L * D * n_chunks * args.layers   # two contractions per update
-        out["overlap"] = {"worker_streams": args.also_streams, "value": T * args.steps / dt2, "unit": "frames/s",
+        out["overlap"] = {"worker_streams": args.also_streams, "value": args.frames * args.steps / dt2, "unit": "frames/s",
                           "ms_per_step": dt2 / args.steps * 1e3,
                           "sustained_score_tflops": flops_step * args.steps / dt2 / 1e12}
+    if not args.no_extras and args.geometry == "baseline" and args.dtype == "bf16" and args.score_rounding == "fp32":
+        # Companions of the headline, each measured the same way in small AFTER the timed region above (none of them
+        # enters `value`): (1) the real Qwen2-VL geometry SURVEY 8(d) names beside the synthetic one; (2) the price
+        # of reproducing the reference's own bf16 roundings bit for bit; (3) the parity dtype.
+        del frames, pool
+        torch.cuda.empty_cache()
+        out["real_geometry"] = companion_measurement(dev, args.frames, args.layers, "bf16", max(2, args.steps), 1, args.pool,
+                                                     geometry="qwen448")
+        out["real_geometry"]["config"]["workload"] = (
+            "real Qwen2-VL-7B geometry at 448 px 16:9: 1024 temporal grids x 144 merged tokens x 3584 channels, "
+            "chunk = 16 grids = 2304 tokens (cal_flops.py:8,47; qwen2_vl.py:477-491)")
+        out["reference_rounding"] = companion_measurement(dev, args.frames, args.layers, "bf16", 2, 1, args.pool,
+                                                          score_rounding="reference", warmup_chunks=4)
+        out["reference_rounding"]["note"] = ("score_rounding='reference': the reference's bf16 logits / probabilities / sums "
+                                             "(longvideo_cache.py:264-270) reproduced rounding by rounding")
+        out["fp32_parity_dtype"] = companion_measurement(dev, args.frames, args.layers, "fp32", 1, 1, args.pool,
+                                                         warmup_chunks=2)
+        frames = torch.cat([chunk_frames(c, dev, tdtype) for c in range(min(n_chunks, 4))])[None]
     if not args.no_cpu_baseline:
         sample_T = 128
         out["cpu_baseline"] = cpu_baseline(args, frames[:, :sample_T].float().cpu().numpy(), args.cpu_sample_updates)

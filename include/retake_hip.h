@@ -382,7 +382,10 @@ int rtk_position_shift(int64_t* temporal_ids, int n, const int64_t* prev_dev, rt
  *     after ~timeout_ms the kernel gives up and stores 1 + (first missing sender) into *status (device word,
  *     0 = fine), so that a lost peer is an error, not a hung GPU.
  * Epochs count up from 1; receivers that reuse a landing zone alternate two of them (a sender can be one
- * epoch ahead of a receiver, never two).  All sizes, strides and offsets are multiples of 16 bytes.
+ * epoch ahead of a receiver, never two).  What landed in a zone at epoch n is guaranteed intact only for reads
+ * the receiver enqueued BEFORE its own push n+1: a peer rewrites the zone at epoch n+2 as soon as its wait n+1
+ * has seen that push, and later reads are ordered behind nothing.  All sizes, strides and offsets are multiples
+ * of 16 bytes.
  * ------------------------------------------------------------------------------------------- */
 #define RTK_IPC_HANDLE_BYTES 64
 #define RTK_P2P_MAX_RANKS 16

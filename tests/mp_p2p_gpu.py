@@ -39,11 +39,12 @@ def main():
         want = torch.stack([block(r, i, shape, dtype) for r in range(world)])
         assert out.shape == want.shape and out.dtype == want.dtype, (out.shape, want.shape)
         assert torch.equal(out.cpu(), want), f"all_gather case {i} differs"
-        held.append((out, want, i))
-        if len(held) >= 2:   # the previous result must still be intact (two alternating halves) unless the buffer grew
-            pout, pwant, pi = held[-2]
-            if pout.untyped_storage().data_ptr() == out.untyped_storage().data_ptr():
-                assert torch.equal(pout.cpu(), pwant), f"result of call {pi} was overwritten by call {i}"
+        # contract (retake/p2p.py): a result is a view of the landing buffer, valid until THIS rank's next all_gather -
+        # a peer may rewrite its half right after seeing this rank's next push, so it is consumed (copied to the host
+        # above) before the next call and never read again; whoever needs it longer clones it
+        held.append((out.clone(), want, i))
+    for kept, want, i in held:
+        assert torch.equal(kept.cpu(), want), f"clone of all_gather case {i} changed"
     for i in range(8, 40):   # many epochs through the same halves
         out = g.all_gather(block(rank, i, (64, 128), torch.float32).to(dev))
         assert torch.equal(out.cpu(), torch.stack([block(r, i, (64, 128), torch.float32) for r in range(world)]))
@@ -62,6 +63,27 @@ def main():
     want = torch.stack([block(r, 77, (H, rows, D), torch.bfloat16) for r in range(world)], dim=1)
     assert torch.equal(got.cpu(), want), "strided push layout differs"
     g.check()
+
+    # 2b. ranks that entered an exchange with different push counts (one rank pushed a chunk the others skipped): after
+    #     the counts have been agreed through the control plane, resync waits for the smallest - no stall, no latched
+    #     error - and continues from the largest, and the next push / wait pair matches again
+    rs = g.symmetric(world * 64)
+    probe = torch.full((16,), rank + 1, dtype=torch.int32, device=dev)
+    rs.push(probe, 64, 1, 64, rank * 64, 64)
+    if rank == 0:
+        rs.push(probe, 64, 1, 64, rank * 64, 64)       # one push more than everybody else
+    counts = [None] * world
+    dist.all_gather_object(counts, rs.epoch)
+    rs.resync(min(counts), max(counts))
+    rs.check()
+    probe2 = torch.full((16,), 100 + rank, dtype=torch.int32, device=dev)
+    rs.push(probe2, 64, 1, 64, rank * 64, 64)
+    rs.wait()
+    got = rs.local.view(torch.int32).view(world, 16)[:, 0].cpu().tolist()
+    assert got == [100 + r for r in range(world)], got
+    rs.check()
+    torch.cuda.synchronize()
+    dist.barrier()
 
     # 3. a sender that never arrives is an error, not a hang: rank 0 waits 100 ms for pushes the others never make
     lost = g.symmetric(1024)

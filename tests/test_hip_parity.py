@@ -1619,6 +1619,14 @@ def test_sharded_multi_rank_rccl():
     assert r.returncode == 0 and "MP_SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _launch_ranks(script, world, env=None, timeout=600):
     import socket
     import subprocess
@@ -1692,6 +1700,35 @@ def test_bench_two_ranks_share_one_gpu_p2p():
         assert b["cache_checksum"][key] == a["cache_checksum"][key], (key, a["cache_checksum"], b["cache_checksum"])
     assert b["config"]["assembled_cache_tokens"] == a["cache_checksum"]["tokens_per_layer"]
     assert b["roofline"]["frac"] > 0 and b["cpu_baseline"] is None
+    # the line carries its own proof: sharded == sequential was checked in process, over the same transport, before timing
+    assert b["sharded_equals_sequential"] is True and b["p2p_world_size"] == 2
+    assert [c["chunks"] for c in b["sharded_check"]["cases"]] == [4, 5]
+
+
+def test_bench_forced_sharded_world1_rccl_self_verifies():
+    """`RETAKE_FORCE_SHARDED=1 python bench.py`: the sharded path at world size 1 over RCCL.  The line must carry
+    `sharded_equals_sequential: true` (checked in process before the timed region) and - world size 1 being the one
+    case where the bench's resident tensors mean the same thing in both paths - the plain run's cache fingerprint."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--frames", "256", "--layers", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    sh = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True,
+                        timeout=600, cwd=root, env={**os.environ, "RETAKE_FORCE_SHARDED": "1", "MASTER_ADDR": "127.0.0.1",
+                                                    "MASTER_PORT": str(_free_port())})
+    assert sh.returncode == 0, (sh.stdout[-2000:], sh.stderr[-3000:])
+    b = json.loads([ln for ln in sh.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert b["sharded_equals_sequential"] is True and b["rccl_world_size"] == 1
+    assert [c["chunks"] for c in b["sharded_check"]["cases"]] == [2, 3]
+    for key in ("tokens_per_layer", "layers", "ids_sum", "v_bits_sum"):
+        assert b["cache_checksum"][key] == a["cache_checksum"][key], (key, a["cache_checksum"], b["cache_checksum"])
+    assert abs(b["cache_checksum"]["k_abs_sum"] - a["cache_checksum"]["k_abs_sum"]) <= 1e-6 * a["cache_checksum"]["k_abs_sum"]
 
 
 @pytest.mark.parametrize("L,Hq,Hkv", [(1, 28, 4), (31, 28, 4), (130, 28, 4), (257, 28, 4), (515, 28, 4), (1000, 28, 4),

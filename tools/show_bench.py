@@ -15,3 +15,11 @@ for k, v in d.get("kernels_timed_region", {}).items():
 for k in ("roofline", "roofline_hbm_kernels", "cpu_baseline", "speedup_vs_cpu_baseline"):
     if k in d:
         print(k, d[k])
+for k in ("real_geometry", "reference_rounding", "fp32_parity_dtype", "fast_rounding"):
+    if k in d:
+        c = d[k]
+        print(f"{k}: {c['value']:.1f} frames/s  ms_per_step={c['ms_per_step']:.1f}  roofline {c['roofline']['kernel']} "
+              f"frac={c['roofline']['frac']:.3f}  " + " ".join(f"{n}={v['avg_us']:.0f}us" for n, v in c["kernels_timed_region"].items()))
+for k in ("sharded_equals_sequential", "rccl_world_size", "p2p_world_size"):
+    if k in d:
+        print(k, d[k])

@@ -563,41 +563,16 @@ struct RowStat {  // online max / sum of one query row, over the keys this lane 
     }
 };
 
-// Per-dtype kernel shape (both knobs were measured on MI355X at L = 6272):
-//   NB = 32-row register blocks per wave.  NB = 2 halves the LDS reads, barriers and staging per MFMA but
-//        needs ~250 VGPRs (1-2 waves per SIMD): no gain over NB = 1 with 2-3 waves.
-//   PF = how many streamed tiles ahead the global loads run (register staging sets, counted vmcnt waits).
-//        PF = 2 did not help either: the kernels are bound by instruction issue, not by load latency.
-// Shape of the bf16 LDS-DMA kernels (measured on MI355X at L = 6272, 28 units per launch, same box):
-//   32-row register blocks per wave: 2 (every A fragment read from LDS feeds two MFMAs on independent accumulators;
-//       half the fragment reads, DMA issues, barriers and waits per MFMA; ~160 VGPRs -> 3 waves per SIMD)
-//       pass 1 7749 -> 7401 us, pass 2 7630 -> 7141 us; 3 and 4 blocks (2 waves per SIMD) were slower again
-//   lazy max in pass 1 (RowStatB::update_lazy): 7401 -> 7030 us
-// The macros stay overridable so that tools/variants.sh can rebuild the other shapes for A/B runs.
-#ifndef RTK_P1_NB
-#define RTK_P1_NB 2
-#endif
-#ifndef RTK_P1_LAZY
-#define RTK_P1_LAZY true
-#endif
-#ifndef RTK_P2_NB
-#define RTK_P2_NB 2
-#endif
-#ifndef RTK_DMA_PLACE   // 0 = the next tile's LDS-DMA pieces are issued at the head of a tile step, 1 = inside block 0's softmax
-#define RTK_DMA_PLACE 1    // same-box A/B: pass 1 7048 -> 7016 us, pass 2 7138 -> 7083 us, bit-identical results
-#endif
-#ifndef RTK_MFMA_ORDER  // 1 = all fragment reads of a block first, then its MFMAs strictly alternating between the two accumulators
-#define RTK_MFMA_ORDER 1   // (no MFMA waits for its predecessor; the compiler's own order ran 5 dependent ones in a row and padded
-#endif                     // others with s_nop 9); same-box A/B: pass 1 7019 -> 6878 us, pass 2 7054 -> 6908 us, bit-identical results
-#ifndef RTK_HALF_TAIL
-#define RTK_HALF_TAIL 1    // a last tile that is at most half full runs the one-block body (see score_pass2_dma_kernel)
-#endif
-#ifndef RTK_LSE_DMA
-#define RTK_LSE_DMA 1
-#endif
-#ifndef RTK_LSE_W0      // 1 = only wave 0 fetches the tile's 64 row normalisers (the other waves used to load them too)
-#define RTK_LSE_W0 1       // same-box A/B: pass 2 7083 -> 7043 us, bit-identical results
-#endif
+// Shape of the kernels (DESIGN.md §4 has the same-box A/B numbers behind every choice):
+//   fp32 register-staged kernels: one 32-row register block per wave, loads one tile ahead (RegBlocks below; two
+//       blocks need ~250 VGPRs and a second staging set bought nothing: the kernels are bound by instruction issue).
+//   bf16 LDS-DMA kernels: two 32-row register blocks per wave (every A fragment read from LDS feeds two MFMAs on
+//       independent accumulators: half the fragment reads, DMA issues, barriers and waits per MFMA; ~160 VGPRs -> 3 waves
+//       per SIMD), lazy max in pass 1, the next tile's DMA pieces issued inside block 0's softmax, all fragment reads of
+//       a block ahead of its MFMAs which alternate strictly between the two accumulators, a last tile that is at most
+//       half full on the one-block body, pass 2's normalisers by LDS-DMA from wave 0.
+// The only compile-time knobs left are the ones variants.h lists (A/B builds; production never defines them).
+#include "variants.h"
 template <int DT> struct RegBlocks {
     static constexpr int NB = 1;
     static constexpr int PF = 1;
@@ -1046,7 +1021,7 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
     const int dvoff = drow * T::ROWB + (((lane & 15) ^ (drow & 15)) * 16);          // + u * 16 rows via soffset
     const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, Hq * L * HD * M::ESIZE, 0x00020000);
     const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)lse, 0, Hq * L * 4, 0x00020000);
-    const bool lse_dma = RTK_LSE_DMA && (nrows % TILE_ROWS == 0);   // uniform: no row of a tile lies past the split
+    const bool lse_dma = (nrows % TILE_ROWS == 0);   // uniform: no row of a tile lies past the split
     float lstA = 0.f;
     int nt = 0;
     const int last_row = Hq * L - 1;
@@ -1082,7 +1057,7 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                 \
                     lrsrc, (void __attribute__((address_space(3)))*)(lse_s + (b) * TILE_ROWS), 4, lane * 4, \
                     (nrow0 + nt * TILE_ROWS) * 4, 0, 0);                                                  \
-        } else if (!RTK_LSE_W0 || wid == 0) lstA = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : INFINITY; \
+        } else if (wid == 0) lstA = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : INFINITY; \
         const bool wrap__ = (nt + 1 == tiles_per_head);                                                   \
         nt = wrap__ ? 0 : nt + 1;                                                                         \
         nrow0 += wrap__ ? L : 0;                                                                          \
@@ -1093,8 +1068,7 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
         const char* cur = smem + buf * T::BYTES;                                                          \
         const float* lcur = lse_s + buf * TILE_ROWS;                                                      \
         const int rb__ = nrow0 + nt * TILE_ROWS;                                                          \
-        if constexpr (ISSUE && RTK_DMA_PLACE == 0) RTK_DMA_ISSUE(buf ^ 1)                                 \
-        if constexpr (ISSUE && RTK_DMA_PLACE != 0) RTK_DMA_TAIL(buf ^ 1)                                  \
+        if constexpr (ISSUE) RTK_DMA_TAIL(buf ^ 1)                                  \
         _Pragma("unroll")                                                                                 \
         for (int blk = 0; blk < 2; ++blk) {                                                               \
             u32x4 a[M::NREG];                                                                             \
@@ -1105,22 +1079,22 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
             f32x16 acc[NB];                                                                               \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x16{0};                                          \
-            if (RTK_MFMA_ORDER) __builtin_amdgcn_sched_barrier(0);                                        \
+            __builtin_amdgcn_sched_barrier(0);                                        \
             _Pragma("unroll")                                                                             \
             for (int r = 0; r < M::NREG; ++r) {                                                           \
                 _Pragma("unroll")                                                                         \
                 for (int nb = 0; nb < NB; ++nb) {                                                         \
                     M::mma(acc[nb], a[r], kf[nb][r]);                                                     \
-                    if (RTK_MFMA_ORDER) __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);            \
+                    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);            \
                 }                                                                                         \
             }                                                                                             \
-            if (RTK_MFMA_ORDER) __builtin_amdgcn_sched_barrier(0);                                        \
+            __builtin_amdgcn_sched_barrier(0);                                        \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) {                                                             \
                 colsum_block<DT>(col[nb], acc[nb], ls, c2, sqrt_d);                                       \
                 asm volatile("" : "+v"(col[nb]) : : "memory");                                            \
                 __builtin_amdgcn_sched_barrier(0);                                                        \
-                if constexpr (ISSUE && RTK_DMA_PLACE != 0) {                                              \
+                if constexpr (ISSUE) {                                              \
                     if (blk == 0) {                                                                       \
                         if (NB == 1) RTK_DMA_PIECES(buf ^ 1, rb__, 0, 4)                                  \
                         else if (nb == 0) RTK_DMA_PIECES(buf ^ 1, rb__, 0, 2)                             \
@@ -1192,7 +1166,7 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
         rs = grp / Hkv;
     }
     const int j_base = bx * (REG_ROWS * NB);
-    if constexpr (NB == 2 && RTK_HALF_TAIL) {
+    if constexpr (NB == 2) {
         if (L - j_base <= REG_ROWS) {   // uniform per workgroup
             score_pass2_dma_body<1>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs);
             return;
@@ -1265,9 +1239,8 @@ __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q,
     {                                                                                                     \
         constexpr int buf = BUF;                                                                          \
         const char* cur = smem + buf * T::BYTES;                                                          \
-        if constexpr (ISSUE && RTK_DMA_PLACE == 0) RTK_DMA1_ISSUE((JT) + 1, buf ^ 1)                      \
         if (!live) { /* this wave's query rows lie past L: it only moves its share of the next tile */    \
-            if constexpr (ISSUE && RTK_DMA_PLACE != 0) RTK_DMA1_PIECES((JT) + 1, buf ^ 1, 0, 4)           \
+            if constexpr (ISSUE) RTK_DMA1_PIECES((JT) + 1, buf ^ 1, 0, 4)           \
         } else {                                                                                          \
         _Pragma("unroll")                                                                                 \
         for (int blk = 0; blk < 2; ++blk) {                                                               \
@@ -1277,23 +1250,23 @@ __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q,
             f32x16 acc[NB];                                                                               \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x16{0};                                          \
-            if (RTK_MFMA_ORDER) __builtin_amdgcn_sched_barrier(0);                                        \
+            __builtin_amdgcn_sched_barrier(0);                                        \
             _Pragma("unroll")                                                                             \
             for (int r = 0; r < M::NREG; ++r) {                                                           \
                 _Pragma("unroll")                                                                         \
                 for (int nb = 0; nb < NB; ++nb) {                                                         \
                     M::mma(acc[nb], a[r], qf[nb][r]);                                                     \
-                    if (RTK_MFMA_ORDER) __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);            \
+                    __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);            \
                 }                                                                                         \
             }                                                                                             \
-            if (RTK_MFMA_ORDER) __builtin_amdgcn_sched_barrier(0);                                        \
+            __builtin_amdgcn_sched_barrier(0);                                        \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) {                                                             \
                 if constexpr (LAZY) rs[nb].template update_lazy<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf, c2); \
                 else rs[nb].template update<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf, c2);    \
                 asm volatile("" : "+v"(rs[nb].sum), "+v"(rs[nb].m) : : "memory");                         \
                 __builtin_amdgcn_sched_barrier(0);                                                        \
-                if constexpr (ISSUE && RTK_DMA_PLACE != 0) {   /* next tile's DMA pieces inside block 0's softmax */ \
+                if constexpr (ISSUE) {   /* next tile's DMA pieces inside block 0's softmax */ \
                     if (blk == 0) {                                                                       \
                         if (NB == 1) RTK_DMA1_PIECES((JT) + 1, buf ^ 1, 0, 4)                             \
                         else if (nb == 0) RTK_DMA1_PIECES((JT) + 1, buf ^ 1, 0, 2)                        \
@@ -1370,7 +1343,7 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
         bx = w % row_tiles;
     }
     const int i_base = bx * (REG_ROWS * NB);
-    if constexpr (NB == 2 && RTK_HALF_TAIL) {
+    if constexpr (NB == 2) {
         if (L - i_base <= REG_ROWS) {   // uniform per workgroup
             score_pass1_dma_body<1, LAZY>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks);
             return;
@@ -1553,6 +1526,8 @@ static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
     // bf16 production path: the chunk-batched launches bring their own parallelism (28 layers), so pass 1 prefers
     // longer key streams per workgroup (measured: 2 splits -1.7 % over 4) and half the lse partials
     if (D == HD && dtype != RTK_F32) w.KS = std::min(w.KS, 2);
+    if (RTK_FORCE_KS > 0 && D == HD && dtype != RTK_F32) w.KS = RTK_FORCE_KS;   // A/B builds only (variants.h)
+    if (RTK_FORCE_RS > 0 && D == HD && dtype != RTK_F32) w.RS = RTK_FORCE_RS;
     w.q_off = 0;
     w.k_off = al((size_t)Hq * L * D * es);
     w.lse_off = w.k_off + al((size_t)Hkv * L * D * es);

@@ -1,0 +1,21 @@
+// variants.h - the compile-time knobs of A/B builds, in one place.  Production builds (csrc/Makefile) define NONE of
+// them: the values below are the shipped configuration.  tools/variants.sh rebuilds the library with -D overrides into
+// retake/_lib/variants/ (selected at run time with RETAKE_HIP_LIB=...), which is how every same-box A/B in
+// profiles/*_ab_*.txt was taken.
+#pragma once
+
+#ifndef RTK_P1_NB        // 32-row register blocks per wave, pass 1 of the bf16 LDS-DMA kernels (1 or 2)
+#define RTK_P1_NB 2
+#endif
+#ifndef RTK_P1_LAZY      // RowStatB::update_lazy instead of the eager online max
+#define RTK_P1_LAZY true
+#endif
+#ifndef RTK_P2_NB        // 32-key register blocks per wave, pass 2 (1 or 2)
+#define RTK_P2_NB 2
+#endif
+#ifndef RTK_FORCE_KS     // > 0: key splits of pass 1 (bf16 path) instead of score_ws()'s shape rule
+#define RTK_FORCE_KS 0
+#endif
+#ifndef RTK_FORCE_RS     // > 0: row splits of pass 2 (bf16 path) instead of score_ws()'s shape rule
+#define RTK_FORCE_RS 0
+#endif

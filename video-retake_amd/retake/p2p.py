@@ -8,12 +8,22 @@ its block into all of them with one kernel: one hop, all links at once, no inter
 be the final layout (`SymmetricBuffer.push` takes strided segments).
 
     p2p = P2PGroup(group)                 # once per process group
-    out = p2p.all_gather(x)               # [world, *x.shape], valid until the second next all_gather
+    out = p2p.all_gather(x)               # [world, *x.shape], valid until this rank's NEXT all_gather (clone to keep)
     buf = p2p.symmetric(nbytes)           # same-sized landing buffer on every rank
     buf.push(src, seg_bytes, nseg, src_stride, dst_offset, dst_stride); ...; buf.wait()
 
 No collective library is involved; `torch.distributed` is only used to hand the 64-byte handles around
 (`all_gather_object`), so any backend works for that - the 2-process tests run it over gloo with both ranks on one GPU.
+
+Environment: the host driver of this pool only supports dmabuf IPC, so `HSA_ENABLE_IPC_MODE_LEGACY=0` must be in the
+environment BEFORE the HIP runtime initialises (it is exported on the build and GPU boxes; bench.py and the tests set it
+as a default too) - without it `hipIpcGetMemHandle` fails with "invalid argument".  This module sets the default at
+import, which is early enough only if nothing has touched the GPU yet.
+
+Status: opt-in.  The protocol has run with 2 and 3 processes sharing ONE GPU (tests/mp_p2p_gpu.py, tests/mp_sharded_gpu.py);
+it has never run across xGMI links.  The landing buffers are ordinary coarse-grained `hipMalloc` memory written by remote
+GPUs: a consumer kernel launched after the wait kernel sees the data through the kernel-boundary cache invalidate, which
+the single-GPU runs cannot exercise - run those two scripts on a node with >= 2 GPUs before relying on it.
 """
 from __future__ import annotations
 
@@ -23,7 +33,11 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
-from . import _native as nv
+import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # see the module docstring
+
+from . import _native as nv  # noqa: E402
 
 _TIMEOUT_MS = 20000
 
@@ -55,8 +69,10 @@ class _DeviceMem:
 class SymmetricBuffer:
     """One landing buffer of `nbytes` on every rank, mapped into every rank.  `push` writes this rank's segments into
     all of them; `wait` returns (on the current stream) once every rank's pushes up to the same count have landed here.
-    Every rank must call push / wait equally often; a region may be rewritten only after a later `wait` (a sender can be
-    one push ahead of a receiver, never two: alternate two regions when reusing)."""
+    Every rank must call push / wait equally often.  A sender can be one exchange ahead of a receiver, never two, so a
+    caller that reuses regions alternates two of them; what landed in a region is then guaranteed intact only for reads
+    this rank enqueued BEFORE its own next push (a peer's push after next, which rewrites the region, is ordered behind
+    that push through the peer's wait - and behind nothing later)."""
 
     def __init__(self, owner: "P2PGroup", nbytes: int):
         self.owner = owner
@@ -112,6 +128,15 @@ class SymmetricBuffer:
         nv.check(nv.lib.rtk_p2p_wait(C.c_void_p(self.flags.ptr), g.world, self.epoch, timeout_ms, nv.ptr(self.status),
                                      st), "rtk_p2p_wait")
 
+    def resync(self, lo: int, hi: int):
+        """After an exchange the ranks entered with DIFFERENT push counts (lo / hi = the smallest / largest `epoch` over
+        the ranks, agreed through the control plane): wait for what every sender has published, then count on from the
+        largest so that the next push / wait pair matches on every rank again (published epochs only grow)."""
+        g = self.owner
+        nv.check(nv.lib.rtk_p2p_wait(C.c_void_p(self.flags.ptr), g.world, int(lo), _TIMEOUT_MS, nv.ptr(self.status),
+                                     nv.stream()), "rtk_p2p_wait")
+        self.epoch = int(hi)
+
     def check(self):
         """Host-side check of the bounded waits (synchronises): raises if a sender never arrived."""
         s = int(self.status.item())
@@ -152,7 +177,9 @@ class P2PGroup:
 
     def all_gather(self, x: torch.Tensor) -> torch.Tensor:
         """x (same shape and dtype on every rank) -> [world, *x.shape] in rank order.  The result is a view of the landing
-        buffer: it stays valid until the second next call (two alternating halves)."""
+        buffer and stays valid until this rank's NEXT call: the two halves alternate because a peer may already push
+        call n+1 while this rank still reads call n, and that peer pushes call n+2 into this half as soon as it has seen
+        this rank's push n+1 - reads enqueued after that push are ordered behind nothing.  Clone what must live longer."""
         nv.require_device(x)
         x = x.contiguous()
         nb = x.numel() * x.element_size()

@@ -74,7 +74,7 @@ def _gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
     t = t.contiguous()
     g = _p2p_for(t, group)
     if g is not None:
-        return g.all_gather(t).clone()   # the landing buffer is reused by the second next exchange
+        return g.all_gather(t).clone()   # the landing buffer is only valid until this rank's next exchange
     world = dist.get_world_size(group)
     recv = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
     if t.is_cuda:
@@ -126,7 +126,11 @@ def gather_counts(n: int, device, group=None) -> List[int]:
     """How many rows every rank is about to contribute (one tiny all-gather).  Equal-size collectives
     (`all_gather_into_tensor`) hang or corrupt memory when the ranks disagree, so every assembly asks first."""
     mine = torch.tensor([int(n)], dtype=torch.int64, device=device)
-    return [int(c) for c in _gather_stack(mine, group).reshape(-1).tolist()]
+    counts = [int(c) for c in _gather_stack(mine, group).reshape(-1).tolist()]
+    g = _P2P.get(group)
+    if g is not None and mine.is_cuda:
+        g.check()   # the .tolist() above synchronised: a bounded p2p wait that gave up (lost / late peer) raises HERE
+    return counts
 
 
 def all_gather_rows_ragged(local: torch.Tensor, group=None, counts: Optional[List[int]] = None) -> torch.Tensor:
@@ -145,10 +149,12 @@ def all_gather_rows_ragged(local: torch.Tensor, group=None, counts: Optional[Lis
 
 def _all_gather_flat(send: torch.Tensor, group=None) -> torch.Tensor:
     """send [...] -> [world, ...] in rank order, one collective.  With the p2p transport the result is the landing
-    buffer itself (no copy): consume it before the second next exchange of the group."""
+    buffer itself (no copy): it is only valid until this rank's NEXT exchange on the group, so the callers below copy
+    out of it (permute + reshape / cat) before they return - except at world size 1, where those are views: cloned."""
     g = _p2p_for(send, group)
     if g is not None:
-        return g.all_gather(send.contiguous())
+        out = g.all_gather(send.contiguous())
+        return out.clone() if g.world == 1 else out
     return _gather_stack(send, group)
 
 
@@ -234,7 +240,15 @@ class ChunkGather:
     def rows(self) -> int:
         return sum(it[2].shape[3] for it in self.items)
 
-    def drop(self):
+    def pushes(self) -> int:
+        return len(self.items)
+
+    def drop(self, lo: int = 0, hi: int = 0):
+        """Abandon the started gathers.  They are collectives: every rank must have started equally many (`lo == hi`),
+        which `sharded_video_step` guarantees by only overlapping even chunk splits - a mismatch cannot be repaired
+        after the fact (the extra all-gather of one rank has no partner), so it raises instead of hanging in `wait`."""
+        if lo != hi:
+            raise RuntimeError(f"ranks started between {lo} and {hi} per-chunk all-gathers: unmatched collectives")
         for work, _, _ in self.items:
             work.wait()
         self.items = []
@@ -260,25 +274,42 @@ class ChunkGatherP2P:
     """`ChunkGather` over mapped peer buffers: the rows a chunk kept are pushed (side stream, beside the next chunk's
     scoring) straight to their FINAL position in every rank's assembled cache `[2, layers, Hkv, world * total, D]` -
     rank-major, then chunk order, inside every head - so `finish` only waits for the arrival flags; there is no receive
-    buffer to permute.  Needs the rows per rank and video (`total`) up front.  Two landing buffers alternate between
-    videos (a rank can be one video ahead of a peer that still reads the last one, never two): an assembled cache stays
-    valid until the video after next begins."""
+    buffer to permute.  Needs the rows per rank and video (`total`) up front.
 
-    def __init__(self, p2p, total: int, n_layers: int, Hkv: int, D: int, dtype):
-        self.p2p, self.total = p2p, int(total)
-        self.shape = (2, n_layers, Hkv, p2p.world, self.total, D)
-        self.dtype = dtype
-        self.es = torch.empty((), dtype=dtype).element_size()
-        nbytes = 2 * n_layers * Hkv * p2p.world * self.total * D * self.es
-        self.bufs = [p2p.symmetric(nbytes), p2p.symmetric(nbytes)]
+    Lifetime: two landing buffers alternate between videos.  A peer starts pushing video n+2 into the buffer of video n
+    as soon as ITS video n+1 is assembled, i.e. once this rank's last push of video n+1 has landed there - so the cache
+    `finish` returned for video n is guaranteed intact only for reads this rank enqueued BEFORE its last `start` of video
+    n+1.  Treat it as valid until this rank begins the next video; clone what must live longer.
+
+    Memory: the two buffers are byte pools sized for the LARGEST video seen so far (`capacity` bytes each); a shorter
+    or differently shaped video of at most that many bytes reuses them with its own strides, a larger one allocates a
+    new pair 1.5x the need (mapped buffers are never freed before `P2PGroup.close()`, see SymmetricBuffer.close: the
+    total mapped memory is bounded by ~3x the largest pair, not by the number of distinct shapes)."""
+
+    def __init__(self, p2p, total: int, n_layers: int, Hkv: int, D: int, dtype, capacity_bytes: int = 0):
+        self.p2p = p2p
+        need = self._bytes(p2p.world, total, n_layers, Hkv, D, dtype)
+        self.capacity = max(int(capacity_bytes), need)
+        self.bufs = [p2p.symmetric(self.capacity), p2p.symmetric(self.capacity)]
         self.side = torch.cuda.Stream(device=p2p.device)
         self.gen, self.at = 1, 0
-        self.begin_video()
+        self.begin_video(total, n_layers, Hkv, D, dtype)
+
+    @staticmethod
+    def _bytes(world, total, n_layers, Hkv, D, dtype) -> int:
+        return 2 * n_layers * Hkv * world * int(total) * D * torch.empty((), dtype=dtype).element_size()
 
     def matches(self, total, n_layers, Hkv, D, dtype) -> bool:
-        return self.shape == (2, n_layers, Hkv, self.p2p.world, int(total), D) and self.dtype == dtype
+        """Can a video of this shape land in the mapped buffers?"""
+        return self._bytes(self.p2p.world, total, n_layers, Hkv, D, dtype) <= self.capacity
 
-    def begin_video(self):
+    def begin_video(self, total=None, n_layers=None, Hkv=None, D=None, dtype=None):
+        if total is not None:
+            if not self.matches(total, n_layers, Hkv, D, dtype):
+                raise ValueError("p2p chunk gather: the video does not fit the mapped landing buffers")
+            self.total, self.dtype = int(total), dtype
+            self.shape = (2, n_layers, Hkv, self.p2p.world, self.total, D)
+            self.es = torch.empty((), dtype=dtype).element_size()
         self.gen ^= 1
         self.at = 0
 
@@ -301,20 +332,29 @@ class ChunkGatherP2P:
     def rows(self) -> int:
         return self.at
 
-    def drop(self):
-        """The pushes already made must still be matched by a wait so that the epochs of all ranks stay in step."""
+    def pushes(self) -> int:
+        return self.bufs[self.gen].epoch
+
+    def drop(self, lo: Optional[int] = None, hi: Optional[int] = None):
+        """Abandon the per-chunk pushes of this video (`finalize` reaches that decision for all ranks at once and hands
+        over the smallest / largest push count of the landing buffer over the ranks).  The ranks may have pushed
+        DIFFERENT numbers of chunks (one skipped a `gather_chunk`, or `start` raised on one rank only): each waits for
+        the smallest count - which every sender has reached, so nobody stalls into the timeout and no error is latched -
+        and continues from the largest, so that the epochs agree again for the next video."""
         torch.cuda.current_stream(self.p2p.device).wait_stream(self.side)
-        self.bufs[self.gen].wait()
+        buf = self.bufs[self.gen]
+        buf.resync(buf.epoch if lo is None else lo, buf.epoch if hi is None else hi)
 
     def finish(self) -> torch.Tensor:
-        """-> [2, layers, Hkv, world * total, D], a view of the landing buffer."""
+        """-> [2, layers, Hkv, world * total, D], a view of the landing buffer (lifetime: class docstring)."""
         if self.at != self.total:
             raise ValueError(f"p2p chunk gather: {self.at} of {self.total} rows pushed")
         buf = self.bufs[self.gen]
         torch.cuda.current_stream(self.p2p.device).wait_stream(self.side)
         buf.wait()
         two, n_layers, Hkv, world, total, D = self.shape
-        return buf.local.view(self.dtype).view(two, n_layers, Hkv, world * total, D)
+        n = two * n_layers * Hkv * world * total * D * self.es
+        return buf.local[:n].view(self.dtype).view(two, n_layers, Hkv, world * total, D)
 
 
 def plan_frame_exchange(idx: torch.Tensor, T_own: int, world: int):
@@ -444,9 +484,11 @@ class ShardedPivotKV:
                 _, Hkv, _, D = kc[0].shape
                 cg = self.chunk_gather
                 if cg is None or not cg.matches(self.expected_rows, len(kc), Hkv, D, kc[0].dtype):
-                    cg = ChunkGatherP2P(p2p, self.expected_rows, len(kc), Hkv, D, kc[0].dtype)
+                    need = ChunkGatherP2P._bytes(p2p.world, self.expected_rows, len(kc), Hkv, D, kc[0].dtype)
+                    cg = ChunkGatherP2P(p2p, self.expected_rows, len(kc), Hkv, D, kc[0].dtype,
+                                        capacity_bytes=0 if cg is None else need * 3 // 2)
                 else:
-                    cg.begin_video()
+                    cg.begin_video(self.expected_rows, len(kc), Hkv, D, kc[0].dtype)
                 self._gather = self.chunk_gather = cg
             self._seen = [0] * len(kc)
         ks, vs = [], []
@@ -491,16 +533,21 @@ class ShardedPivotKV:
                 pos.append(pc)
             g = self._gather
             self._gather = None
-            if g is not None and (not assemble or g.rows() != keys[0].shape[2]):
-                g.drop()   # not every chunk went through gather_chunk: fall back to the gather at the end
+            # ONE decision for all ranks, taken before anybody waits on anything: the overlapped per-chunk gathers are
+            # used only if every rank started one for every chunk (its rows == the rows it kept) and every rank kept
+            # equally many rows; otherwise every rank that started any abandons them (ChunkGatherP2P.drop re-aligns the
+            # push epochs, so ranks that pushed different numbers of chunks neither stall nor latch a timeout) and the
+            # cache is assembled by the padded gather at the end
+            counts = gather_counts(keys[0].shape[2], dev, self.group)
+            mine_ok = g is not None and assemble and g.rows() == keys[0].shape[2] and len(set(counts)) == 1
+            flags = _gather_stack(torch.tensor([int(mine_ok), g.pushes() if g is not None else -1], dtype=torch.int64,
+                                               device=dev), self.group)
+            use_all = bool(flags[:, 0].min().item())
+            if not use_all:
+                if g is not None:
+                    started = [int(x) for x in flags[:, 1].tolist() if x >= 0]
+                    g.drop(min(started), max(started))
                 g = None
-            if assemble:   # the overlapped gathers moved equal blocks: only valid if every rank kept equally many rows
-                counts = gather_counts(keys[0].shape[2], dev, self.group)
-                use_g = torch.tensor([int(g is not None and len(set(counts)) == 1)], dtype=torch.int64, device=dev)
-                use_all = int(_gather_stack(use_g, self.group).min().item())     # one decision for all ranks
-                if g is not None and not use_all:
-                    g.drop()
-                    g = None
             if assemble and g is not None:
                 kv = g.finish()                                   # [2, layers, Hkv, world*n, D], provisional positions
                 world = table.shape[0]
@@ -515,7 +562,10 @@ class ShardedPivotKV:
                                                        nv.ptr(inv), P, sec, nsec, st), "rtk_rope_shift")
                 keys = [kv[0, layer][None] for layer in range(n_layers)]
                 values = [kv[1, layer][None] for layer in range(n_layers)]
-                pos = all_gather_ids(pos, self.group)
+                pos = all_gather_ids(pos, self.group, counts)
+                p2p = _P2P.get(self.group)
+                if p2p is not None:
+                    p2p.check()   # synchronises; a wait that timed out left a partly filled landing buffer: raise
             elif assemble:
                 keys, values, pos = all_gather_caches(keys, values, pos, self.group)
         return keys, values, pos
@@ -559,6 +609,113 @@ def sharded_video_step(frames, has_halo: bool, T: int, c0: int, c1: int, layers:
     if state is not None:
         state["chunk_gather"] = sh.chunk_gather
     return (c1 - c0) * layers * keep, (keys, values, pos)
+
+
+def _rotate_at(x0: torch.Tensor, pos: torch.Tensor, rotary, mrope_section):
+    """What the model's attention does before it calls the cache (third-party HF formula): x0 [1, H, L, D] rotated at
+    the ids `pos` with the module's cos / sin (M-RoPE sections merged when given)."""
+    cos, sin = rotary(x0, pos)
+    if mrope_section:
+        sec = list(mrope_section) * 2
+        cos = torch.cat([m[i % 3] for i, m in enumerate(cos.split(sec, dim=-1))], dim=-1).unsqueeze(1)
+        sin = torch.cat([m[i % 3] for i, m in enumerate(sin.split(sec, dim=-1))], dim=-1).unsqueeze(1)
+    else:
+        cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
+    D = x0.shape[-1]
+    return x0 * cos + torch.cat((-x0[..., D // 2:], x0[..., : D // 2]), dim=-1) * sin
+
+
+def verify_sharded_equals_sequential(rank: int, world: int, dev, rotary, layers: int = 2, chunk_counts=None,
+                                     group=None, state: Optional[dict] = None, log=None) -> dict:
+    """Equality of the sharded and the sequential compression, over the transport `group` is configured for (RCCL
+    collectives, or the p2p pushes after `enable_p2p`) and through the very function `bench.py --gpus N` times
+    (`sharded_video_step`).  For every chunk count in `chunk_counts` (default: 2 * world - even blocks, per-chunk
+    overlapped gathers - and 2 * world + 1 - ragged blocks, padded assembly at the end) every rank
+
+      * builds the SEQUENTIAL cache of the whole small video on its own (fp32, `layers` layers, bench.py's deterministic
+        tensors taken as pre-RoPE contents and rotated at the ids each update really sees), then
+      * compresses its block through `sharded_video_step` with the same contents rotated at the block's PROVISIONAL
+        ids, and compares the ASSEMBLED cache with the sequential one: position ids exact, V exact (bit patterns),
+        K within 3e-6 of the largest key (R(delta) R(p) and R(p + delta) round their angles separately; 1e-5 at unit
+        scale, the inputs are 1.7 sigma), plus the `cache_checksum` fingerprints.
+
+    fp32 because the check needs the kept SET to be a function of the contents alone: in bf16 the rotated inputs of a
+    block round differently at provisional ids than at the true ones, so later blocks would legitimately keep other
+    tokens.  Raises AssertionError on any mismatch (on the rank that sees it); returns a summary dict."""
+    import bench as B
+    from . import longvideo_cache as lc
+    from . import visual_compression as vc
+
+    td = torch.float32
+    L = B.FRAMES_PER_CHUNK * B.N_PATCH
+    keep = max(1, int(B.RATIO * L))
+    state = {} if state is None else state
+    chunk_counts = tuple(chunk_counts) if chunk_counts is not None else (2 * world, 2 * world + 1)
+    worst_k = 0.0
+    cases = []
+    for n_chunks in chunk_counts:
+        T = n_chunks * B.FRAMES_PER_CHUNK
+        pool = [B.pool_set(i, dev, td) for i in range(n_chunks * layers)]
+
+        def inputs(c, l, pos):   # what the model hands the cache: contents rotated at the ids in use
+            q0, k0, v = pool[(c * layers + l) % len(pool)]
+            return _rotate_at(q0, pos, rotary, B.MROPE), _rotate_at(k0, pos, rotary, B.MROPE), v
+
+        frames_all = torch.cat([B.chunk_frames(c, dev, td) for c in range(n_chunks)])[None]
+        _, mask = vc.memory_bank_compress_keyframe(frames_all, T, 3, sync=False)
+        seq = lc.build_kvcache(B.make_cache_config(layers))
+        for c in range(n_chunks):
+            seq.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
+            seq.kvcache_compression = True
+            pos = B.chunk_position_ids(c, dev)
+            for l in range(layers):
+                seq.shift_temporal_ids_(pos, l)
+                q, k, v = inputs(c, l, pos)
+                seq.update(k, v, l, {"query_states": q, "position_ids": pos, "rotary_emb": rotary, "mrope_section": B.MROPE})
+            seq.after_forward()
+        blocks = shard_chunks(n_chunks, world)
+        c0, c1 = blocks[rank]
+        even = len({b - a for a, b in blocks}) == 1
+        halo = c0 > 0 and c1 > c0
+        parts = ([B.chunk_frames(c0 - 1, dev, td)[-1:]] if halo else []) + [B.chunk_frames(c, dev, td) for c in range(c0, c1)]
+        fr = torch.cat(parts)[None] if parts else torch.empty((1, 0, B.N_PATCH, B.C_EMB), dtype=td, device=dev)
+        pos_base = [B.chunk_position_ids(c, dev) for c in range(c0, c1)]
+        _, (keys, values, pos) = sharded_video_step(fr, halo, T, c0, c1, layers, pool, pos_base, rotary, even, group=group,
+                                                    state=state, inputs=inputs)
+        for l in range(layers):
+            assert keys[l].shape[2] == n_chunks * keep, (keys[l].shape, n_chunks * keep)
+            if not torch.equal(pos[l], seq.position_cache[l]):
+                bad = (pos[l] != seq.position_cache[l]).reshape(-1, pos[l].shape[-1]).any(0).reshape(-1, keep).sum(1)
+                raise AssertionError(f"rank {rank} layer {l}: ids differ; wrong ids per kept chunk {bad.tolist()}; first rows "
+                                     f"{pos[l].reshape(-1, pos[l].shape[-1])[0, ::keep].tolist()} vs "
+                                     f"{seq.position_cache[l].reshape(-1, pos[l].shape[-1])[0, ::keep].tolist()}")
+            assert torch.equal(values[l], seq.value_cache[l]), f"rank {rank} layer {l}: V differs"
+            err = (keys[l] - seq.key_cache[l]).abs().max().item()
+            kmax = seq.key_cache[l].abs().max().item()
+            worst_k = max(worst_k, err / kmax)
+            if err > 3e-6 * kmax:   # say where: per kept chunk of the assembled rows
+                d = (keys[l] - seq.key_cache[l]).abs().amax(dim=(0, 1, 3)).reshape(-1, keep).amax(dim=1)
+                raise AssertionError(f"rank {rank} layer {l}: K differs by {err}; max |diff| per kept chunk {d.tolist()}")
+        a = B.cache_checksum(keys, values, pos)
+        b = B.cache_checksum([seq.key_cache[l] for l in range(layers)], [seq.value_cache[l] for l in range(layers)],
+                             seq.position_cache)
+        assert a["ids_sum"] == b["ids_sum"] and a["v_bits_sum"] == b["v_bits_sum"] and a["tokens_per_layer"] == b["tokens_per_layer"]
+        assert abs(a["k_abs_sum"] - b["k_abs_sum"]) <= 1e-6 * b["k_abs_sum"]
+        p2p = _P2P.get(group)
+        if p2p is not None:
+            p2p.check()
+        torch.cuda.synchronize(dev)
+        dist.barrier(group=group)
+        cases.append({"chunks": n_chunks, "blocks": blocks, "overlapped_gathers": even})
+        if log is not None and rank == 0:
+            log(f"chunks {n_chunks} on {world} rank(s): blocks {blocks}, overlapped gathers {even}: assembled == sequential")
+        del seq, pool, frames_all, keys, values, pos
+    # every rank passed its own comparison (a failing rank raised and took the job down with it); make it explicit
+    ok = torch.ones(1, dtype=torch.int64, device=dev if dist.get_backend(group) != "gloo" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    assert int(ok.item()) == 1
+    return {"equal": True, "dtype": "fp32", "layers": layers, "cases": cases, "max_rel_k_diff": worst_k,
+            "checked": "assembled cache == sequential cache on every rank: ids exact, V exact, K <= 3e-6 * max|K|"}
 
 
 def bench_main(args, rank: int, world: int, local_rank: int):
@@ -605,6 +762,12 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     # communicator set-up (RCCL builds its rings / the p2p scratch is mapped on the first exchange) is not part of a step:
     # run one tiny exchange before anything is timed, whatever --warmup says
     _gather_stack(torch.zeros(4, dtype=torch.int64, device=dev))
+    # Before anything is timed: is the cache this transport assembles the cache one GPU builds?  (tests/mp_sharded_gpu.py's
+    # check, in process, over the transport of the timed loop.)  A mismatch raises: no value is printed for a wrong path.
+    verdict = None
+    if not getattr(args, "no_self_check", False):
+        verdict = verify_sharded_equals_sequential(rank, world, dev, rotary, layers=2, state=state)
+        torch.cuda.empty_cache()
     for _ in range(args.warmup):
         step()
     ids = nv.profile_kernel_ids()   # HIP events around the dominant kernels, on their launch stream, in the timed region
@@ -647,6 +810,10 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                        "parallelism": f"chunk-sharded x{world}", "transport": transport,
                        "assembled_cache_tokens": int(keys[0].shape[2])},
             "cache_checksum": checksum,
+            # untimed, before the timed region, over the same transport and through the same function the loop times
+            "sharded_equals_sequential": bool(verdict and verdict["equal"]),
+            "sharded_check": verdict,
+            ("rccl_world_size" if p2p is None and not share else "p2p_world_size"): dist.get_world_size(),
             "cpu_baseline": None,   # timed on rank 0 of the N = 1 run only (bench contract); see that line
             "kernels_timed_region_rank0": kern,
             "roofline": B.score_roofline(kern, args.dtype, L, T, (c1 - c0) * args.layers * args.steps),
