@@ -26,6 +26,14 @@ def dev():
     return torch.device("cuda:0")
 
 
+# Fraction of kept-K bf16 values allowed to differ (by one bf16 ulp) from the torch-bf16 re-rotation of the same rows.
+# The kernels' cos / sin are correctly rounded fp32 (`sincos_cr`), torch's are libm's to <= 1 ulp: the two fp32 values
+# differ at all in ~1 % of the table entries, and such a difference survives the bf16 rounding of the table only when
+# it straddles a bf16 midpoint (2^-16 of the cases), so a mismatch needs a table-midpoint case.  Measured on MI355X
+# (round 3, printed by the test): see the value below = 10x the largest fraction seen over L in {1024, 2304, 6272}.
+KEPT_K_MISMATCH_BAR = 5e-3
+
+
 # ---------------------------------------------------------------------------------------------------
 # DPSelect
 # ---------------------------------------------------------------------------------------------------
@@ -669,7 +677,9 @@ def test_pivotkv_benchmarked_batched_path_vs_units_and_oracle(L, layers, n_chunk
             kr = (kk * cn) + (_rot_half(kk) * sn)
             got = cache.key_cache[l][:, :, prev_len:].cpu()
             ne = got != kr
-            assert ne.float().mean().item() < 5e-3        # device sincosf vs torch's cos/sin: rare bf16 table flips
+            frac = ne.float().mean().item()
+            print(f"\n[kept K vs torch-bf16 re-rotation] L={L} layer {l}: {int(ne.sum())} of {ne.numel()} entries differ ({frac:.2e})")
+            assert frac < KEPT_K_MISMATCH_BAR
             assert ((got.float() - kr.float()).abs() <= kr.float().abs() * 2.0 ** -7 + 1e-3).all()
     assert cache.num_evicted_tokens == [n_chunks * (L - keep)] * layers
 
@@ -1517,7 +1527,9 @@ def test_pivotkv_bf16_against_reference_bf16(name, rounding):
     g = gu.load(name)
     Hq, Hkv, D, L, keep = (int(g[k]) for k in ("Hq", "Hkv", "D", "L", "keep"))
     sec = [int(x) for x in g["mrope_section"]]
-    llm = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=1, num_attention_heads=Hq, num_key_value_heads=Hkv,
+    n_layers = 3   # the same fixture chunk through three layers: L >= 512 takes the chunk-batched flush (one launch per
+                   # kernel for all three, what bench.py times), L = 256 the per-update stages - every layer must reproduce it
+    llm = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=n_layers, num_attention_heads=Hq, num_key_value_heads=Hkv,
                                 longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
                                     "compression_ratio": float(g["ratio"]), "compression_method": "pivotkv",
                                     "pos_embed_reforge": True, "score_rounding": rounding}})
@@ -1529,30 +1541,42 @@ def test_pivotkv_bf16_against_reference_bf16(name, rounding):
         return torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16).to(dev())
 
     cache.keypatches_mask_chunk = torch.from_numpy(mask).to(dev())
-    kw = {"query_states": dv(q), "position_ids": torch.from_numpy(pos).to(dev()), "rotary_emb": rot,
-          "mrope_section": list(sec)}
-    cache.update(dv(k), dv(v), 0, kw)
-    score = cache.last_scores.cpu().numpy()
-    idx = cache.last_keep_indices.cpu().numpy()
-    kk = cache.key_cache[0].cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
-    pos_new = cache.position_cache[0].cpu().numpy()
+    cache.kvcache_compression = True
+    qd, kd, vd = dv(q), dv(k), dv(v)
+    for l in range(n_layers):
+        kw = {"query_states": qd, "position_ids": torch.from_numpy(pos).to(dev()), "rotary_emb": rot,
+              "mrope_section": list(sec)}
+        cache.update(kd, vd, l, kw)
+    if L >= 512:
+        assert cache._batch.batched_passes and len(cache._batch.pending) == n_layers
+    cache.after_forward()
     ref = orc.bf16_bits_to_f32(g["c0_score_bf16"])
     ref_idx = g["c0_keep_idx"]
-    if rounding == "reference":
-        nbad, nxor, a, b = tog.check_bf16_against_reference(g, 0, score, idx, kk, pos_new, "HIP reference rounding")
-        np.testing.assert_array_equal(a, b)
-        print(f"{name}: {nbad} of {L} scores differ from the reference's by one bf16 ulp, kept xor {nxor} (ties)")
-    else:
-        s64 = g["c0_score64"].copy()
-        s64[mask] = 1.0
-        assert np.abs(score - s64).max() < 2e-5                  # fp32-accurate on the reference's own bf16 operands
-        thr = np.sort(ref)[::-1][keep - 1]
-        xor = np.setxor1d(idx, ref_idx)
-        assert (np.abs(ref[xor] - thr) <= gu.bf16_ulp(np.full(xor.size, thr))).all()
-        assert xor.size <= max(4, L // 100)
-        print(f"{name}: default mode vs the reference's bf16 kept set: {xor.size // 2} of {keep} tokens differ, all within "
-              f"one bf16 ulp of its threshold score {thr}")
-    assert np.array_equal(cache.value_cache[0].cpu().view(torch.int16).numpy().view(np.uint16)[0], v[0][:, idx])
+    for l in range(n_layers):
+        score = cache._batch.score[l].cpu().numpy()
+        idx = cache._batch.keep_idx[l].cpu().numpy()
+        kk = cache.key_cache[l].cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+        pos_new = cache.position_cache[l].cpu().numpy()
+        if rounding == "reference":
+            nbad, nxor, a, b = tog.check_bf16_against_reference(g, 0, score, idx, kk, pos_new, "HIP reference rounding")
+            np.testing.assert_array_equal(a, b)
+            if l == 0:
+                print(f"{name}: {nbad} of {L} scores differ from the reference's by one bf16 ulp, kept xor {nxor} (ties)")
+        else:
+            s64 = g["c0_score64"].copy()
+            s64[mask] = 1.0
+            assert np.abs(score - s64).max() < 2e-5                  # fp32-accurate on the reference's own bf16 operands
+            thr = np.sort(ref)[::-1][keep - 1]
+            xor = np.setxor1d(idx, ref_idx)
+            assert (np.abs(ref[xor] - thr) <= gu.bf16_ulp(np.full(xor.size, thr))).all()
+            assert xor.size <= max(4, L // 100)
+            if l == 0:
+                print(f"{name}: default mode vs the reference's bf16 kept set: {xor.size // 2} of {keep} tokens differ, all "
+                      f"within one bf16 ulp of its threshold score {thr}")
+        assert np.array_equal(cache.value_cache[l].cpu().view(torch.int16).numpy().view(np.uint16)[0], v[0][:, idx])
+        if l:   # identical inputs: identical layers, bit for bit
+            assert torch.equal(cache._batch.score[l], cache._batch.score[0])
+            assert torch.equal(cache.key_cache[l], cache.key_cache[0])
 
 
 def test_pivotkv_reference_rounding_batched_equals_per_layer():
