@@ -580,6 +580,10 @@ def main():
                                                           score_rounding="reference", warmup_chunks=4)
         out["reference_rounding"]["note"] = ("score_rounding='reference': the reference's bf16 logits / probabilities / sums "
                                              "(longvideo_cache.py:264-270) reproduced rounding by rounding")
+        out["fast_rounding"] = companion_measurement(dev, args.frames, args.layers, "bf16", 2, 1, args.pool,
+                                                     score_rounding="fast", warmup_chunks=4)
+        out["fast_rounding"]["note"] = ("score_rounding='fast' (opt in): q~ pre-scaled and both operands as fp16 on "
+                                        "v_mfma_f32_32x32x16_f16, two instructions per logit; scores within ~1e-5 of the default")
         out["fp32_parity_dtype"] = companion_measurement(dev, args.frames, args.layers, "fp32", 1, 1, args.pool,
                                                          warmup_chunks=2)
         frames = torch.cat([chunk_frames(c, dev, tdtype) for c in range(min(n_chunks, 4))])[None]

@@ -43,7 +43,15 @@ enum rtk_dtype {
      * probabilities, the per-head column sums and both means to bf16).  RTK_BF16 keeps exact bf16 products with fp32
      * accumulation, softmax and sums - more accurate than the reference; this code reproduces the reference's own
      * quantised scores (head_dim 128 only).  Workspace / partial sizes differ: query them with the same code. */
-    RTK_BF16_REFROUND = 2
+    RTK_BF16_REFROUND = 2,
+    /* Scoring entry points and rtk_pivotkv_prepare only: bf16 payloads, scored through the fp16 matrix instruction.  The
+     * un-rotated q~ is stored as fp16(q~ * log2(e)/sqrt(D)) - ONE extra rounding, to 11 significant bits - and k~ is
+     * re-encoded as fp16 exactly (a second copy inside the score workspace; the bf16 k~ the eviction re-rotates is
+     * unchanged), so the accumulators are base-2 logits and both passes spend two instructions per logit instead of
+     * three.  Scores move by ~1e-5 relative against RTK_BF16 (far inside the reference's own bf16 rounding of the
+     * logits); everything downstream of the score is identical.  Opt in: score_rounding="fast".  head_dim 128 only;
+     * |k~| beyond fp16's range (65504) saturates. */
+    RTK_BF16_FAST = 3
 };
 
 enum rtk_status {

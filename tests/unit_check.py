@@ -12,7 +12,8 @@ import ctypes as C
 import torch
 
 
-def per_unit_score_select(q, k, pos2d, mask, keep, reforge, inv_freq, attention_scaling, sections, stream_sync=True):
+def per_unit_score_select(q, k, pos2d, mask, keep, reforge, inv_freq, attention_scaling, sections, stream_sync=True,
+                          score_dt=None):
     """q [1,Hq,L,D], k [1,Hkv,L,D] (rotated, any head/token strides), pos2d [P,L] int64 contiguous, mask [L] bool or
     None.  Returns (score [L] fp32 with the mask override applied, keep_idx [keep] int64, pos_out [P,keep] int64)."""
     import retake._native as nv
@@ -21,7 +22,7 @@ def per_unit_score_select(q, k, pos2d, mask, keep, reforge, inv_freq, attention_
     _, Hq, L, D = q.shape
     Hkv = k.shape[1]
     P = pos2d.shape[0]
-    dt = nv.dtype_code(q)
+    dt = nv.dtype_code(q) if score_dt is None else score_dt   # e.g. nv.RTK_BF16_FAST: same payload, other score arithmetic
     cos = sin = None
     if reforge:
         cos = torch.empty((L, D), dtype=torch.float32, device=dev)
@@ -62,7 +63,8 @@ def check_batch_against_units(cache, layers, inputs, masks, keep, inv_freq, atte
     for l in layers:
         q, k = inputs[l]
         pos2d = b.pos_old[l].contiguous()
-        s1, i1, p1 = per_unit_score_select(q, k, pos2d, masks[l], keep, b.reforge, inv_freq, attention_scaling, sections)
+        s1, i1, p1 = per_unit_score_select(q, k, pos2d, masks[l], keep, b.reforge, inv_freq, attention_scaling, sections,
+                                           score_dt=b.score_dt if getattr(b, "fast", False) else None)
         sb, ib = b.score[l], b.keep_idx[l]
         if not torch.equal(sb, s1):
             bad = (sb != s1).nonzero().flatten()

@@ -118,6 +118,28 @@ struct RowSel {
 // arithmetic (fp32 id * inv_freq[channel mod h2], correctly rounded sin / cos, * attention_scaling, bf16 rounding on request).  The
 // token's P ids are passed in registers (pid[row]) and the row selectors come in two wide loads, so no load
 // depends on another one; d must be a multiple of VE (4 or 8).
+// one channel pair (dch, dch + h2) of one token: (c1, s1) for channel dch, (c2, s2) for its rotation partner
+__device__ __forceinline__ void rope_elem(float f, int ra, int rb, const float (&pid)[3], float scaling, int round_bf16,
+                                          float& c1, float& s1, float& c2, float& s2) {
+    const float p1 = ra == 0 ? pid[0] : (ra == 1 ? pid[1] : pid[2]);
+    float sn, cs;
+    sincos_cr(p1 * f, sn, cs);
+    cs *= scaling;
+    sn *= scaling;
+    if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
+    c1 = cs;
+    s1 = sn;
+    if (rb != ra) {
+        const float p2 = rb == 0 ? pid[0] : (rb == 1 ? pid[1] : pid[2]);
+        sincos_cr(p2 * f, sn, cs);
+        cs *= scaling;
+        sn *= scaling;
+        if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
+    }
+    c2 = cs;
+    s2 = sn;
+}
+
 template <int VE>
 __device__ __forceinline__ void rope_chunk(const float* __restrict__ inv_freq, const RowSel& rs, int d, int h2,
                                            const float (&pid)[3], float scaling, int round_bf16, float* c1, float* s1,
@@ -142,25 +164,7 @@ __device__ __forceinline__ void rope_chunk(const float* __restrict__ inv_freq, c
 #pragma unroll
     for (int e = 0; e < VE; ++e) f[e] = inv_freq[d + e];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) {
-        const float p1 = ra[e] == 0 ? pid[0] : (ra[e] == 1 ? pid[1] : pid[2]);
-        float sn, cs;
-        sincos_cr(p1 * f[e], sn, cs);
-        cs *= scaling;
-        sn *= scaling;
-        if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
-        c1[e] = cs;
-        s1[e] = sn;
-        if (rb[e] != ra[e]) {
-            const float p2 = rb[e] == 0 ? pid[0] : (rb[e] == 1 ? pid[1] : pid[2]);
-            sincos_cr(p2 * f[e], sn, cs);
-            cs *= scaling;
-            sn *= scaling;
-            if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
-        }
-        c2[e] = cs;
-        s2[e] = sn;
-    }
+    for (int e = 0; e < VE; ++e) rope_elem(f[e], ra[e], rb[e], pid, scaling, round_bf16, c1[e], s1[e], c2[e], s2[e]);
 }
 
 inline int make_rowsel(RowSel& rs, int P, int D, const int* sections, int nsec, const char* who) {

@@ -86,15 +86,34 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
 
+// RTK_BF16_FAST operands: the un-rotated bf16 values re-encoded as fp16 for v_mfma_f32_32x32x16_f16.  A bf16 value has 8
+// significant bits, fp16 holds 11: k~ converts EXACTLY (inside fp16's range; saturated to +-65504 beyond it, 24-bit
+// subnormals below 6e-5), and q~ * log2(e)/sqrt(D) is rounded once, to 11 bits (relative 2^-12), so the matrix pipe
+// delivers the base-2 logits directly and the softmax needs no multiply.
+using f16x2_t = __attribute__((ext_vector_type(2))) _Float16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+__device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
+    const f32x2_t v = {__builtin_fminf(__builtin_fmaxf(lo, -65504.f), 65504.f),
+                       __builtin_fminf(__builtin_fmaxf(hi, -65504.f), 65504.f)};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));   // v_cvt_f16_f32: round to nearest even
+}
+__device__ __forceinline__ u32x4 bf16x8_to_f16x8(const u32x4& v, float scale) {
+    return u32x4{pack2_f16(bf_lo(v.x) * scale, bf_hi(v.x) * scale), pack2_f16(bf_lo(v.y) * scale, bf_hi(v.y) * scale),
+                 pack2_f16(bf_lo(v.z) * scale, bf_hi(v.z) * scale), pack2_f16(bf_lo(v.w) * scale, bf_hi(v.w) * scale)};
+}
+
 // DIV: 0 = no division (attention_scaling^2 == 1), 1 = multiply by the reciprocal (bf16 only, the host has
 // verified EXHAUSTIVELY over all 65536 bf16 inputs that bf16(x * rcp) == bf16(x / a2) for this a2), 2 = IEEE
-template <int DT, int DIV>
+// FAST (RTK_BF16_FAST, bf16 inputs only): q~ is stored as fp16(q~ * qscale) and k~ additionally as fp16 in k_fast (the
+// bf16 k~ in k_out - what the eviction re-rotates - is skipped when k_out is NULL).
+template <int DT, int DIV, bool FAST = false>
 __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __restrict__ q, int64_t q_sh, int64_t q_sl,
                                                                 const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
                                                                 int Hq, int Hkv, int L, int D,
                                                                 const float* __restrict__ cosv,
                                                                 const float* __restrict__ sinv, float a2, float rcp_a2,
-                                                                char* __restrict__ q_out, char* __restrict__ k_out) {
+                                                                char* __restrict__ q_out, char* __restrict__ k_out,
+                                                                char* __restrict__ k_fast = nullptr, float qscale = 1.f) {
     using V = Vec16<DT>;
     constexpr int VE = V::VE;
     constexpr int ES = 16 / VE;
@@ -135,7 +154,23 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
         const int h = hb + u;
         if (h >= H) break;
         char* orow = dst + ((size_t)h * L + l) * D * ES;
+        // FAST: where the un-rotated chunk pair (bf16 values) goes - q as scaled fp16, k as bf16 (if wanted) + fp16
+        auto store_fast = [&](const u32x4& a, const u32x4& b) {
+            if (is_q) {
+                *(u32x4*)(orow + (size_t)d * ES) = bf16x8_to_f16x8(a, qscale);
+                *(u32x4*)(orow + (size_t)(d + h2) * ES) = bf16x8_to_f16x8(b, qscale);
+            } else {
+                if (dst) {
+                    *(u32x4*)(orow + (size_t)d * ES) = a;
+                    *(u32x4*)(orow + (size_t)(d + h2) * ES) = b;
+                }
+                char* frow = k_fast + ((size_t)h * L + l) * D * ES;
+                *(u32x4*)(frow + (size_t)d * ES) = bf16x8_to_f16x8(a, 1.f);
+                *(u32x4*)(frow + (size_t)(d + h2) * ES) = bf16x8_to_f16x8(b, 1.f);
+            }
+        };
         if (!cosv) {
+            if constexpr (FAST) { store_fast(lo[u], hi[u]); continue; }
             *(u32x4*)(orow + (size_t)d * ES) = lo[u];
             *(u32x4*)(orow + (size_t)(d + h2) * ES) = hi[u];
             continue;
@@ -165,8 +200,12 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
                 r1[w] = t1;
                 r2[w] = t2;
             }
-            *(u32x4*)(orow + (size_t)d * ES) = u32x4{r1[0], r1[1], r1[2], r1[3]};
-            *(u32x4*)(orow + (size_t)(d + h2) * ES) = u32x4{r2[0], r2[1], r2[2], r2[3]};
+            if constexpr (FAST) {
+                store_fast(u32x4{r1[0], r1[1], r1[2], r1[3]}, u32x4{r2[0], r2[1], r2[2], r2[3]});
+            } else {
+                *(u32x4*)(orow + (size_t)d * ES) = u32x4{r1[0], r1[1], r1[2], r1[3]};
+                *(u32x4*)(orow + (size_t)(d + h2) * ES) = u32x4{r2[0], r2[1], r2[2], r2[3]};
+            }
         } else {
             float x1[VE], x2[VE], o1[VE], o2[VE];
             V::unpack(lo[u], x1);
@@ -194,7 +233,7 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
 //   three launches become one.  One thread = one token x one 16-byte chunk pair; blockIdx.y splits the heads
 //   in two: y = 0 the first half of the q heads + k (k~ and the k tail), y = 1 the second half + the v tail.
 // ------------------------------------------------------------------------------------------------
-template <int DT, int DIV>
+template <int DT, int DIV, bool FAST = false>
 __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restrict__ q, int64_t q_sh, int64_t q_sl,
                                                             const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
                                                             const char* __restrict__ v, int64_t v_sh, int64_t v_sl,
@@ -204,7 +243,8 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
                                                             int round_bf16, float a2, float rcp_a2,
                                                             char* __restrict__ q_out, char* __restrict__ k_out,
                                                             char* __restrict__ k_tail, char* __restrict__ v_tail,
-                                                            int64_t tail_sh, int P, int64_t* __restrict__ pos_copy) {
+                                                            int64_t tail_sh, int P, int64_t* __restrict__ pos_copy,
+                                                            char* __restrict__ k_fast = nullptr, float qscale = 1.f) {
     using V = Vec16<DT>;
     constexpr int VE = V::VE;
     constexpr int ES = 16 / VE;
@@ -303,6 +343,10 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
             if (h >= qe) break;
             u32x4 olo, ohi;
             unrot(lo[u], hi[u], olo, ohi);
+            if constexpr (FAST) {   // the score's A / B operand: fp16(q~ * log2(e)/sqrt(D))
+                olo = bf16x8_to_f16x8(olo, qscale);
+                ohi = bf16x8_to_f16x8(ohi, qscale);
+            }
             char* orow = q_out + ((size_t)h * L + l) * D * ES;
             *(u32x4*)(orow + (size_t)d * ES) = olo;
             *(u32x4*)(orow + (size_t)(d + h2) * ES) = ohi;
@@ -328,6 +372,11 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
                 char* orow = k_out + ((size_t)h * L + l) * D * ES;
                 *(u32x4*)(orow + (size_t)d * ES) = olo;
                 *(u32x4*)(orow + (size_t)(d + h2) * ES) = ohi;
+                if constexpr (FAST) {   // the same k~ as fp16 for the score passes (exact re-encoding)
+                    char* frow = k_fast + ((size_t)h * L + l) * D * ES;
+                    *(u32x4*)(frow + (size_t)d * ES) = bf16x8_to_f16x8(olo, 1.f);
+                    *(u32x4*)(frow + (size_t)(d + h2) * ES) = bf16x8_to_f16x8(ohi, 1.f);
+                }
             }
         }
 #pragma unroll
@@ -761,6 +810,87 @@ struct RowStatB {  // online max / sum of one query row over the keys this lane 
     }
 };
 
+// D = A x B + C on the bf16 (exact mode) or fp16 (RTK_BF16_FAST) matrix instruction; D and C may be different registers
+template <bool FAST>
+__device__ __forceinline__ void mma16(f32x16& d, const u32x4& a, const u32x4& b, const f32x16& c) {
+    if constexpr (FAST)
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// RTK_BF16_FAST pass 1: the accumulators ARE base-2 logits (q~ was pre-scaled), so a logit needs no multiply.
+// RowStatR - the production form - adds exp2(logit) to the row sum with NO offset and no test: two instructions per
+// logit, the minimum.  That is exact whenever the row's sum stays inside fp32's comfortable range; a row whose sum
+// left it (a logit beyond ~2^7 in base 2 -> inf, or every logit below ~-60 -> precision lost in subnormals) is
+// detected ONCE, at the end - inf and NaN are sticky in a sum of non-negative terms - and published as NaN; the
+// fix-up launch that follows (score_pass1_dma_kernel<.., FIXUP>) recomputes exactly the workgroups that own a NaN with
+// RowStatF, the offset-carrying form.  Deterministic: which rows take which path depends on the data only.
+struct RowStatR {
+    float sum;
+    __device__ __forceinline__ void init() { sum = 0.f; }
+    template <bool RAGGED>
+    __device__ __forceinline__ void update(f32x16& a, int j0, int j_end, int hf) {
+        if (RAGGED) {  // keys >= j_end do not exist
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (j0 + acc_row(r, hf) >= j_end) a[r] = -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(a[r]);
+    }
+    __device__ __forceinline__ float finish() const {
+        const float tot = sum + __shfl_xor(sum, 32, WAVE);
+        const bool fine = tot < 0x1p120f && tot > 0x1p-60f;      // false for inf and NaN as well
+        return fine ? __builtin_amdgcn_logf(tot) : __builtin_nanf("");   // v_log_f32 = log2
+    }
+};
+
+// The robust form (fix-up launch only): sum = sum_j exp2(s_j + off) over the keys this lane has seen, i.e. the true
+// total is sum * 2^-off.  Lazy like RowStatB: the offset is that of the last rescale; when some lane's block sum is
+// not a finite number below 2^96, or nothing has been seen yet (`primed`, wave-uniform), the wave re-bases on the
+// block's maximum.
+struct RowStatF {
+    float sum, off;
+    __device__ __forceinline__ void init() { sum = 0.f; off = 0.f; }
+    template <bool RAGGED>
+    __device__ __forceinline__ void update(f32x16& a, int j0, int j_end, int hf, bool& primed) {
+        if (RAGGED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (j0 + acc_row(r, hf) >= j_end) a[r] = -INFINITY;
+        }
+        if (primed) {
+            float add = __builtin_amdgcn_exp2f(a[0] + off);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) add += __builtin_amdgcn_exp2f(a[r] + off);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(add < 0x1p96f)) == 0, 1)) {
+                sum += add;
+                return;
+            }
+        }
+        const float mx = max16(a);
+        // a lane without a key in the block (ragged tail: mx = -inf) keeps its offset: add = 0, sum unchanged
+        const float noff = (mx == -INFINITY) ? off : (primed ? -fmaxf(mx, -off) : -mx);
+        float add = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(a[r] + noff);
+        // the first re-base starts from sum = 0 with a meaningless offset (0 * 2^(noff - 0) may be 0 * inf); later ones
+        // only ever lower the offset (noff <= off), so the rescale factor is <= 1
+        sum = primed ? sum * __builtin_amdgcn_exp2f(noff - off) + add : add;
+        off = noff;
+        primed = true;
+    }
+    __device__ __forceinline__ float finish() const {
+        const float m1 = sum > 0.f ? -off : -INFINITY;   // a half that saw no key (ragged tail) carries no scale
+        const float m2 = __shfl_xor(m1, 32, WAVE), s2 = __shfl_xor(sum, 32, WAVE);
+        const float mm = fmaxf(m1, m2);
+        if (mm == -INFINITY) return -INFINITY;            // an empty row
+        const float tot = sum * __builtin_amdgcn_exp2f(m1 - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+        return mm + __builtin_amdgcn_logf(tot);
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // pass 2: partial[g,split,j] = sum_{h in g} sum_{i in split} exp(s_hij - lse[h,i])
 // grid (ceil(L/128), Hkv, RS); wave w keeps keys j0 + 32w + (lane&31) in registers.
@@ -769,7 +899,7 @@ struct RowStatB {  // online max / sum of one query row over the keys this lane 
 // lse[h,i] = log sum_ks exp(lse_part[ks,h,i]), written over split 0 (one thread per row: no hazard)
 template <int DT>
 __global__ __launch_bounds__(256) void lse_combine_kernel(float* __restrict__ lse_part, size_t n, int KS,
-                                                          size_t unit_floats) {
+                                                          size_t unit_floats, int negate = 0) {
     lse_part += blockIdx.y * unit_floats;   // blockIdx.y = unit of a batched launch
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -781,7 +911,8 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(float* __restrict__ ls
     }
     float tot = 0.f;
     for (int s = 0; s < KS; ++s) tot += (DT == RTK_BF16) ? __builtin_amdgcn_exp2f(v[s] - mx) : expf(v[s] - mx);
-    lse_part[idx] = mx + ((DT == RTK_BF16) ? __builtin_amdgcn_logf(tot) : logf(tot));
+    const float out = mx + ((DT == RTK_BF16) ? __builtin_amdgcn_logf(tot) : logf(tot));
+    lse_part[idx] = negate ? -out : out;   // RTK_BF16_FAST: pass 2 starts its accumulators from -lse
 }
 
 // col += sum_r exp(acc[r]*scale - ls[r]) for one 32x32 block (16 values per lane)
@@ -980,7 +1111,7 @@ _Pragma("unroll") \
 // NB = 32-key register blocks per wave (NB = 2: every A fragment read from LDS feeds two MFMAs).
 // ------------------------------------------------------------------------------------------------
 // The work of one workgroup: NB x 32 keys per wave starting at key j_base + wid * 32 * NB, the query rows of split rs.
-template <int NB>
+template <int NB, bool FAST = false>
 __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q, const char* __restrict__ k,
                                                      const float* __restrict__ lse, int Hq, int Hkv, int L,
                                                      int rows_per_split, int RS, float* __restrict__ partial, int j_base,
@@ -1036,7 +1167,7 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
                 qrsrc, (void __attribute__((address_space(3)))*)(smem + (b) * T::BYTES + (4 * u + wid) * 1024), 16, \
                 dvoff, (row_base + 16 * u) * T::ROWB, 0, 0);                                              \
         const int r__ = nt * TILE_ROWS + (tid & (TILE_ROWS - 1));                                         \
-        lstA = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : INFINITY;                                \
+        lstA = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : (FAST ? -INFINITY : INFINITY);           \
         const bool wrap__ = (nt + 1 == tiles_per_head);                                                   \
         nt = wrap__ ? 0 : nt + 1;                                                                         \
         nrow0 += wrap__ ? L : 0;                                                                          \
@@ -1057,7 +1188,7 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                 \
                     lrsrc, (void __attribute__((address_space(3)))*)(lse_s + (b) * TILE_ROWS), 4, lane * 4, \
                     (nrow0 + nt * TILE_ROWS) * 4, 0, 0);                                                  \
-        } else if (wid == 0) lstA = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : INFINITY; \
+        } else if (wid == 0) lstA = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : (FAST ? -INFINITY : INFINITY); \
         const bool wrap__ = (nt + 1 == tiles_per_head);                                                   \
         nt = wrap__ ? 0 : nt + 1;                                                                         \
         nrow0 += wrap__ ? L : 0;                                                                          \
@@ -1076,22 +1207,30 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
             _Pragma("unroll")                                                                             \
             for (int r = 0; r < M::NREG; ++r) a[r] = *(const u32x4*)(cur + blk * 32 * T::ROWB + frag_off[r]); \
             load_ls(ls, lcur, blk, hf);                                                                   \
-            f32x16 acc[NB];                                                                               \
+            f32x16 acc[NB], lsv;                                                                          \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x16{0};                                          \
+            if constexpr (FAST) { /* the accumulator chains start from -lse (what `ls` holds in this mode) */ \
+                _Pragma("unroll")                                                                         \
+                for (int r = 0; r < 16; ++r) lsv[r] = ls[r];                                              \
+            }                                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                        \
             _Pragma("unroll")                                                                             \
             for (int r = 0; r < M::NREG; ++r) {                                                           \
                 _Pragma("unroll")                                                                         \
                 for (int nb = 0; nb < NB; ++nb) {                                                         \
-                    M::mma(acc[nb], a[r], kf[nb][r]);                                                     \
+                    if constexpr (FAST) mma16<true>(acc[nb], a[r], kf[nb][r], r == 0 ? lsv : acc[nb]);   \
+                    else M::mma(acc[nb], a[r], kf[nb][r]);                                                \
                     __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);            \
                 }                                                                                         \
             }                                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                        \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) {                                                             \
-                colsum_block<DT>(col[nb], acc[nb], ls, c2, sqrt_d);                                       \
+                if constexpr (FAST) {                                                                     \
+                    _Pragma("unroll")                                                                     \
+                    for (int r = 0; r < 16; ++r) col[nb] += __builtin_amdgcn_exp2f(acc[nb][r]);           \
+                } else colsum_block<DT>(col[nb], acc[nb], ls, c2, sqrt_d);                                \
                 asm volatile("" : "+v"(col[nb]) : : "memory");                                            \
                 __builtin_amdgcn_sched_barrier(0);                                                        \
                 if constexpr (ISSUE) {                                              \
@@ -1142,7 +1281,7 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
 // REG_ROWS * NB keys (4 waves x NB x 32).  When the LAST tile holds at most half of that (L = 6272 = 24.5 tiles of 256),
 // its workgroups run the one-block body on 32 keys per wave instead of leaving two of four waves without a key: the
 // tile costs half the MFMAs (2 % of the launch's arithmetic was spent on keys past L).
-template <int NB>
+template <int NB, bool FAST = false>
 __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 2 : 2)))) void score_pass2_dma_kernel(
     const char* __restrict__ q, const char* __restrict__ k, const float* __restrict__ lse, int Hq, int Hkv, int L,
     int rows_per_split, int col_tiles, int RS, int xcd_remap, float* __restrict__ partial, size_t q_unit_bytes,
@@ -1168,11 +1307,11 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
     const int j_base = bx * (REG_ROWS * NB);
     if constexpr (NB == 2) {
         if (L - j_base <= REG_ROWS) {   // uniform per workgroup
-            score_pass2_dma_body<1>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs);
+            score_pass2_dma_body<1, FAST>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs);
             return;
         }
     }
-    score_pass2_dma_body<NB>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs);
+    score_pass2_dma_body<NB, FAST>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1181,10 +1320,11 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
 // 32-key block in flight per wave (~100 VGPRs -> 4 waves per SIMD).
 // ------------------------------------------------------------------------------------------------
 // The work of one workgroup: NB x 32 query rows of head h per wave starting at row i_base + wid * 32 * NB, key split ks.
-template <int NB, bool LAZY>
+// MODE: 0 = exact bf16 (RowStatB), 1 = RTK_BF16_FAST production form (RowStatR), 2 = RTK_BF16_FAST fix-up (RowStatF)
+template <int NB, bool LAZY, int MODE = 0>
 __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv,
                                                      int L, int keys_per_split, float* __restrict__ lse_part, int i_base, int h,
-                                                     int ks) {
+                                                     int ks, int neg_out = 0) {
     constexpr int DT = RTK_BF16;
     using M = MM<DT>;
     using T = Tile<DT>;
@@ -1212,9 +1352,15 @@ __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q,
         for (int r = 0; r < M::NREG; ++r) frag_off[r] = row * T::ROWB + ((M::chunk_of(r, hf) ^ (row & 15)) * 16);
     }
     const float c2 = 1.4426950408889634f / sqrtf((float)HD);
-    RowStatB rs[NB];
+    constexpr bool FAST = MODE != 0;
+    using Stat = std::conditional_t<MODE == 1, RowStatR, std::conditional_t<MODE == 2, RowStatF, RowStatB>>;
+    Stat rs[NB];
+    bool primed[NB];       // MODE 2: has this wave re-based its rows yet?  (wave-uniform)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) rs[nb].init();
+    for (int nb = 0; nb < NB; ++nb) {
+        rs[nb].init();
+        primed[nb] = false;
+    }
     const int drow = 4 * wid + (lane >> 4);
     const int dvoff = drow * T::ROWB + (((lane & 15) ^ (drow & 15)) * 16);
     const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -1255,16 +1401,25 @@ __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q,
             for (int r = 0; r < M::NREG; ++r) {                                                           \
                 _Pragma("unroll")                                                                         \
                 for (int nb = 0; nb < NB; ++nb) {                                                         \
-                    M::mma(acc[nb], a[r], qf[nb][r]);                                                     \
+                    if constexpr (FAST) mma16<true>(acc[nb], a[r], qf[nb][r], acc[nb]);                   \
+                    else M::mma(acc[nb], a[r], qf[nb][r]);                                                \
                     __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);            \
                 }                                                                                         \
             }                                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                        \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) {                                                             \
+                if constexpr (MODE == 1) {                                                                \
+                    rs[nb].template update<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf);         \
+                    asm volatile("" : "+v"(rs[nb].sum) : : "memory");                                     \
+                } else if constexpr (MODE == 2) {                                                         \
+                    rs[nb].template update<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf, primed[nb]); \
+                    asm volatile("" : "+v"(rs[nb].sum), "+v"(rs[nb].off) : : "memory");                   \
+                } else {                                                                                  \
                 if constexpr (LAZY) rs[nb].template update_lazy<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf, c2); \
                 else rs[nb].template update<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf, c2);    \
                 asm volatile("" : "+v"(rs[nb].sum), "+v"(rs[nb].m) : : "memory");                         \
+                }                                                                                         \
                 __builtin_amdgcn_sched_barrier(0);                                                        \
                 if constexpr (ISSUE) {   /* next tile's DMA pieces inside block 0's softmax */ \
                     if (blk == 0) {                                                                       \
@@ -1307,21 +1462,22 @@ __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q,
 #undef RTK_DMA1_ISSUE
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const float out = rs[nb].finish(c2);
+        float out;
+        if constexpr (FAST) out = rs[nb].finish();
+        else out = rs[nb].finish(c2);
         const int i = i0 + 32 * nb + (lane & 31);
-        if (hf == 0 && i < L) lse_part[((size_t)ks * Hq + h) * L + i] = out;
+        if (hf == 0 && i < L) lse_part[((size_t)ks * Hq + h) * L + i] = neg_out ? -out : out;
     }
 }
 
 // blockIdx.x -> (row tile bx, head h, key split ks), blockIdx.y = (layer, chunk) unit of a batched launch: same shapes,
 // operands one unit stride apart.  Like pass 2, a last row tile that is at most half full (L = 6272 = 24.5 tiles) runs the
 // one-block body on 32 rows per wave.
-template <int NB, bool LAZY>
-__global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_kernel(const char* __restrict__ q,
-                                                                      const char* __restrict__ k, int Hq, int Hkv, int L,
-                                                                      int keys_per_split, int row_tiles, int xcd_remap,
-                                                                      float* __restrict__ lse_part, size_t q_unit_bytes,
-                                                                      size_t k_unit_bytes, size_t lse_unit_floats) {
+template <int NB, bool LAZY, int MODE = 0>
+__global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_kernel(
+    const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv, int L, int keys_per_split, int row_tiles,
+    int xcd_remap, float* __restrict__ lse_part, size_t q_unit_bytes, size_t k_unit_bytes, size_t lse_unit_floats,
+    int neg_out = 0) {
     q += blockIdx.y * q_unit_bytes;
     k += blockIdx.y * k_unit_bytes;
     lse_part += blockIdx.y * lse_unit_floats;
@@ -1343,13 +1499,20 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
         bx = w % row_tiles;
     }
     const int i_base = bx * (REG_ROWS * NB);
+    if constexpr (MODE == 2) {
+        // fix-up launch: only the workgroups that own a row RowStatR published as NaN do anything (normally none)
+        const int i = i_base + (int)threadIdx.x;
+        float v = 0.f;
+        if ((int)threadIdx.x < REG_ROWS * NB && i < L) v = lse_part[((size_t)ks * Hq + h) * L + i];
+        if (!__syncthreads_or(v != v)) return;
+    }
     if constexpr (NB == 2) {
         if (L - i_base <= REG_ROWS) {   // uniform per workgroup
-            score_pass1_dma_body<1, LAZY>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks);
+            score_pass1_dma_body<1, LAZY, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
             return;
         }
     }
-    score_pass1_dma_body<NB, LAZY>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks);
+    score_pass1_dma_body<NB, LAZY, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
 }
 
 }  // namespace rtk
@@ -1513,12 +1676,14 @@ struct ScoreWs {
     size_t q_off, k_off, lse_off, part_off, total;
     int RS, KS;
     bool ref;   // RTK_BF16_REFROUND: row statistics are (max, sum) pairs, column partials are per head
+    bool fast;  // RTK_BF16_FAST: q~ (pre-scaled) and a second copy of k~ (at k_off) are fp16
 };
 static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
     const size_t es = dtype == RTK_F32 ? 4 : 2;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     ScoreWs w;
     w.ref = dtype == RTK_BF16_REFROUND;
+    w.fast = dtype == RTK_BF16_FAST;
     const int nbr = REG_ROWS;
     const int reg_tiles = (L + nbr - 1) / nbr, stream_tiles = (L + TILE_ROWS - 1) / TILE_ROWS;
     w.RS = (D == HD) ? pick_splits(reg_tiles, Hkv, stream_tiles, 32, Hkv) : 1;
@@ -1553,7 +1718,8 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
     // n_units > 1 (RTK_SCORE_PASSES only): the same passes for n_units units whose workspaces / k~ / partials lie
     // ws_stride / k_stride bytes and part_stride floats apart — one launch per kernel, blockIdx.y = unit
     char* qt = ws + w.q_off;
-    char* kt = k_unrot ? (char*)k_unrot : ws + w.k_off;
+    char* kt = (k_unrot && !w.fast) ? (char*)k_unrot : ws + w.k_off;   // FAST scores on the fp16 copy inside the workspace
+    if (w.fast) k_stride = ws_stride;
     float* lse = (float*)(ws + w.lse_off);
     float* part = partial_out ? partial_out : (float*)(ws + w.part_off);
     const float a2 = (float)((double)a * (double)a);  // python float ** 2, then an fp32 tensor / scalar
@@ -1564,16 +1730,35 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                             ((ksh * es) % 16 == 0) && ((ksl * es) % 16 == 0) &&
                             ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)qt | (uintptr_t)kt) & 15) == 0) &&
                             (!cosv || (((uintptr_t)cosv | (uintptr_t)sinv) & 15) == 0);
+        if (w.fast && !(vec_ok && D == HD)) {
+            set_error("rtk_pivotkv_score: RTK_BF16_FAST needs head_dim %d and 16-byte aligned rows", HD);
+            return RTK_EUNSUPPORTED;
+        }
         if (vec_ok) {
             const int threads = L * (D / 2 / VE);
             const int groups = (Hq + UNROT_HEADS - 1) / UNROT_HEADS + (Hkv + UNROT_HEADS - 1) / UNROT_HEADS;
             const dim3 grid((threads + 255) / 256, groups);
             const int div = (!cosv || a2 == 1.0f) ? 0 : ((DT == RTK_BF16 && bf16_rcp_is_exact(a2)) ? 1 : 2);
             const float rcp = 1.0f / a2;
+            bool done = false;
+            if constexpr (DT == RTK_BF16) {
+                if (w.fast) {   // q~ -> fp16(q~ * log2(e)/sqrt(D)); k~ -> bf16 (only if the caller wants it) + fp16 at k_off
+                    const float qscale = 1.4426950408889634f / sqrtf((float)HD);
+#define RTK_UNROT_F(DIV)                                                                                           \
+    RTK_LAUNCH(KID_UNROT, (unrotate_pack_vec_kernel<DT, DIV, true>), grid, dim3(256), 0, st, (const char*)q, qsh, qsl, \
+               (const char*)k, ksh, ksl, Hq, Hkv, L, D, cosv, sinv, a2, rcp, qt, (char*)k_unrot, ws + w.k_off, qscale)
+                    if (div == 0) RTK_UNROT_F(0);
+                    else if (div == 1) RTK_UNROT_F(1);
+                    else RTK_UNROT_F(2);
+#undef RTK_UNROT_F
+                    done = true;
+                }
+            }
 #define RTK_UNROT(DIV)                                                                                             \
     RTK_LAUNCH(KID_UNROT, (unrotate_pack_vec_kernel<DT, DIV>), grid, dim3(256), 0, st, (const char*)q, qsh, qsl,     \
                (const char*)k, ksh, ksl, Hq, Hkv, L, D, cosv, sinv, a2, rcp, qt, kt)
-            if (div == 0) RTK_UNROT(0);
+            if (done) {}
+            else if (div == 0) RTK_UNROT(0);
             else if (div == 1) RTK_UNROT(1);
             else RTK_UNROT(2);
 #undef RTK_UNROT
@@ -1629,6 +1814,10 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         }
         return RTK_OK;
     }
+    if (w.fast && D != HD) {
+        set_error("rtk_pivotkv_score: RTK_BF16_FAST needs head_dim %d", HD);
+        return RTK_EUNSUPPORTED;
+    }
     if (D == HD) {
         constexpr int TILE_BYTES = Tile<DT>::BYTES;
         constexpr int NBR = RegBlocks<DT>::NB;
@@ -1660,6 +1849,17 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         if (stages & RTK_SCORE_PASSES) {
             if constexpr (dma) {
                 const int jt1 = (L + REG_ROWS * RTK_P1_NB - 1) / (REG_ROWS * RTK_P1_NB);
+                if (w.fast) {   // pass 2 starts its accumulators from -lse: whoever writes the final lse negates it
+                    RTK_LAUNCH(KID_PASS1, (score_pass1_dma_kernel<RTK_P1_NB, true, 1>), dim3(Hkv * ks_n * jt1 * G, n_units),
+                               dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
+                               (int)((Hkv * ks_n) % NXCD == 0), lse, ws_stride, k_stride, ws_stride / sizeof(float),
+                               (int)(ks_n == 1));
+                    // rows whose plain sum left fp32's range were published as NaN: their workgroups run again, robustly
+                    RTK_LAUNCH(KID_FINALIZE, (score_pass1_dma_kernel<RTK_P1_NB, true, 2>), dim3(Hkv * ks_n * jt1 * G, n_units),
+                               dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
+                               (int)((Hkv * ks_n) % NXCD == 0), lse, ws_stride, k_stride, ws_stride / sizeof(float),
+                               (int)(ks_n == 1));
+                } else
                 RTK_LAUNCH(KID_PASS1, (score_pass1_dma_kernel<RTK_P1_NB, RTK_P1_LAZY>), dim3(Hkv * ks_n * jt1 * G, n_units),
                            dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
                            (int)((Hkv * ks_n) % NXCD == 0), lse, ws_stride, k_stride, ws_stride / sizeof(float));
@@ -1671,10 +1871,16 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
             if (ks_n > 1) {
                 const size_t n = (size_t)Hq * L;
                 RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<DT>, dim3((unsigned)((n + 255) / 256), n_units), dim3(256), 0, st, lse, n,
-                           ks_n, ws_stride / sizeof(float));
+                           ks_n, ws_stride / sizeof(float), (int)w.fast);
             }
             if constexpr (dma) {
                 const int jt2 = (L + REG_ROWS * RTK_P2_NB - 1) / (REG_ROWS * RTK_P2_NB);
+                if (w.fast)
+                    RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<RTK_P2_NB, true>), dim3(Hkv * rs_n * jt2, n_units), dim3(SC_BLOCK), LDS2, st,
+                               (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n,
+                               (int)((Hkv * rs_n) % NXCD == 0), part, ws_stride, k_stride, ws_stride / sizeof(float),
+                               part_stride);
+                else
                 RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<RTK_P2_NB>), dim3(Hkv * rs_n * jt2, n_units), dim3(SC_BLOCK), LDS2, st,
                            (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n,
                            (int)((Hkv * rs_n) % NXCD == 0), part, ws_stride, k_stride, ws_stride / sizeof(float),
@@ -1711,7 +1917,7 @@ extern "C" int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspa
                   "rtk_pivotkv_score_passes_batched: workspaces must be 256-byte aligned");
     const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
     RTK_CHECK_ARG(n_units == 1 || workspace_stride >= w.total, "rtk_pivotkv_score_passes_batched: workspace stride too small");
-    if ((dtype != RTK_BF16 && dtype != RTK_BF16_REFROUND) || D != HD) {
+    if ((dtype != RTK_BF16 && dtype != RTK_BF16_REFROUND && dtype != RTK_BF16_FAST) || D != HD) {
         set_error("rtk_pivotkv_score_passes_batched: bf16 with head_dim %d only (call RTK_SCORE_PASSES per unit)", HD);
         return RTK_EUNSUPPORTED;
     }
@@ -1742,7 +1948,7 @@ extern "C" int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0, "rtk_pivotkv_score: Hq=%d must be a multiple of Hkv=%d", Hq, Hkv);
     RTK_CHECK_ARG(L >= 1 && D >= 2 && D % 2 == 0, "rtk_pivotkv_score: bad shape L=%d D=%d", L, D);
     RTK_CHECK_ARG((cosv == nullptr) == (sinv == nullptr), "rtk_pivotkv_score: cos and sin must both be given or both NULL");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_BF16_REFROUND,
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_BF16_REFROUND || dtype == RTK_BF16_FAST,
                   "rtk_pivotkv_score: unsupported dtype %d", dtype);
     RTK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "rtk_pivotkv_score: workspace must be 256-byte aligned");
     RTK_CHECK_ARG(stages > 0 && stages <= 7, "rtk_pivotkv_score: stages mask %d out of range", stages);
@@ -1772,7 +1978,7 @@ template <int DT>
 static int prepare_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, int64_t ksh, int64_t ksl, const void* v,
                         int64_t vsh, int64_t vsl, int Hq, int Hkv, int L, int D, const int64_t* pos, int64_t pos_stride,
                         const float* inv_freq, float a, const RowSel& rs, int round_bf16, char* qt, char* kt, void* k_tail,
-                        void* v_tail, int64_t tail_sh, int P, int64_t* pos_copy, hipStream_t st) {
+                        void* v_tail, int64_t tail_sh, int P, int64_t* pos_copy, hipStream_t st, char* k_fast = nullptr) {
     constexpr int VE = Vec16<DT>::VE;
     const float a2 = (float)((double)a * (double)a);
     const int div = (a2 == 1.0f) ? 0 : ((DT == RTK_BF16 && bf16_rcp_is_exact(a2)) ? 1 : 2);
@@ -1783,7 +1989,23 @@ static int prepare_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, 
     RTK_LAUNCH(KID_UNROT, (prepare_native_kernel<DT, DIV>), grid, dim3(64), 0, st, (const char*)q, qsh, qsl,          \
                (const char*)k, ksh, ksl, (const char*)v, vsh, vsl, Hq, Hkv, L, D, pos, pos_stride, inv_freq, a, rs,  \
                round_bf16, a2, rcp, qt, kt, (char*)k_tail, (char*)v_tail, tail_sh, P, pos_copy)
-    if (div == 0) RTK_PREP(0);
+    bool done = false;
+    if constexpr (DT == RTK_BF16) {
+        if (k_fast) {   // RTK_BF16_FAST: q~ as fp16(q~ * log2(e)/sqrt(D)), k~ as bf16 (eviction) and as fp16 (scoring)
+            const float qscale = 1.4426950408889634f / sqrtf((float)D);
+#define RTK_PREP_F(DIV)                                                                                             \
+    RTK_LAUNCH(KID_UNROT, (prepare_native_kernel<DT, DIV, true>), grid, dim3(64), 0, st, (const char*)q, qsh, qsl,    \
+               (const char*)k, ksh, ksl, (const char*)v, vsh, vsl, Hq, Hkv, L, D, pos, pos_stride, inv_freq, a, rs,  \
+               round_bf16, a2, rcp, qt, kt, (char*)k_tail, (char*)v_tail, tail_sh, P, pos_copy, k_fast, qscale)
+            if (div == 0) RTK_PREP_F(0);
+            else if (div == 1) RTK_PREP_F(1);
+            else RTK_PREP_F(2);
+#undef RTK_PREP_F
+            done = true;
+        }
+    }
+    if (done) {}
+    else if (div == 0) RTK_PREP(0);
     else if (div == 1) RTK_PREP(1);
     else RTK_PREP(2);
 #undef RTK_PREP
@@ -1800,15 +2022,20 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
                                    int64_t* pos_copy, rtk_stream_t stream) {
     RTK_CHECK_ARG(q && k && v && pos && inv_freq && k_unrot && workspace && k_tail && v_tail, "rtk_pivotkv_prepare: NULL pointer");
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && L >= 1 && D >= 2, "rtk_pivotkv_prepare: bad shape");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_prepare: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_BF16_FAST, "rtk_pivotkv_prepare: unsupported dtype %d", dtype);
     RTK_CHECK_ARG(pos_stride >= L, "rtk_pivotkv_prepare: pos_stride %lld < L %d", (long long)pos_stride, L);
+    const bool fast = dtype == RTK_BF16_FAST;
+    if (fast && D != HD) {
+        set_error("rtk_pivotkv_prepare: RTK_BF16_FAST needs head_dim %d", HD);
+        return RTK_EUNSUPPORTED;
+    }
     RTK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "rtk_pivotkv_prepare: workspace must be 256-byte aligned");
     const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
     if (workspace_bytes < w.total) {
         set_error("rtk_pivotkv_prepare: workspace %zu < required %zu bytes", workspace_bytes, w.total);
         return RTK_EWORKSPACE;
     }
-    const int ve = dtype == RTK_BF16 ? 8 : 4, es = dtype == RTK_BF16 ? 2 : 4;
+    const int ve = dtype != RTK_F32 ? 8 : 4, es = dtype != RTK_F32 ? 2 : 4;
     const bool ok = (D % (2 * ve) == 0) && D <= 256 && (q_stride_h * es) % 16 == 0 && (q_stride_l * es) % 16 == 0 &&
                     (k_stride_h * es) % 16 == 0 && (k_stride_l * es) % 16 == 0 && (v_stride_h * es) % 16 == 0 &&
                     (v_stride_l * es) % 16 == 0 && (tail_stride_h * es) % 16 == 0 &&
@@ -1822,10 +2049,11 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
     if (rc) return rc;
     char* qt = (char*)workspace + w.q_off;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == RTK_BF16)
+    if (dtype != RTK_F32)
         return prepare_impl<RTK_BF16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv,
                                       L, D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot,
-                                      k_tail, v_tail, tail_stride_h, P, pos_copy, st);
+                                      k_tail, v_tail, tail_stride_h, P, pos_copy, st,
+                                      fast ? (char*)workspace + w.k_off : nullptr);
     return prepare_impl<RTK_F32>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv, L,
                                  D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot, k_tail,
                                  v_tail, tail_stride_h, P, pos_copy, st);

@@ -13,9 +13,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
-RTK_F32, RTK_BF16, RTK_BF16_REFROUND = 0, 1, 2
+RTK_F32, RTK_BF16, RTK_BF16_REFROUND, RTK_BF16_FAST = 0, 1, 2, 3
 SCORE_PREPARE, SCORE_PASSES, SCORE_FINALIZE = 1, 2, 4
 RTK_EINVAL, RTK_EUNSUPPORTED, RTK_EWORKSPACE, RTK_EHIP, RTK_EREFCRASH = -1, -2, -3, -4, -5
 

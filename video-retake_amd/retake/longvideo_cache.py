@@ -184,10 +184,13 @@ class _Side:
 class _Batch:
     """Per-chunk batch of pending evictions: slot = layer index.  All units share the chunk geometry."""
 
-    def __init__(self, key, slots, Hq, Hkv, L, D, keep, P, reforge, dtype, device, refround=False):
+    def __init__(self, key, slots, Hq, Hkv, L, D, keep, P, reforge, dtype, device, refround=False, fast=False):
         self.key, self.slots, self.keep, self.P, self.reforge = key, slots, keep, P, reforge
-        # dtype code of the scoring entry points: bf16 payloads with the reference's bf16 rounding chain on request
-        self.score_dt = (nv.RTK_BF16_REFROUND if refround else nv.RTK_BF16) if dtype == torch.bfloat16 else nv.RTK_F32
+        # dtype code of the scoring entry points: bf16 payloads with the reference's bf16 rounding chain, or through the
+        # fp16 matrix instruction with pre-scaled queries (score_rounding="fast"), on request
+        self.score_dt = ((nv.RTK_BF16_REFROUND if refround else (nv.RTK_BF16_FAST if fast else nv.RTK_BF16))
+                         if dtype == torch.bfloat16 else nv.RTK_F32)
+        self.fast = self.score_dt == nv.RTK_BF16_FAST
         self.Hkv, self.L, self.D, self.dtype, self.device = Hkv, L, D, dtype, device
         self.keep_idx = torch.empty((slots, keep), dtype=torch.int64, device=device)
         self.pos_new = torch.empty((P, slots, keep), dtype=torch.int64, device=device) if P else None
@@ -302,8 +305,8 @@ class PivotKVCache(DynamicCache):
         # and sums; "reference" reproduces the reference's own bf16 roundings of the logits, probabilities, per-head
         # sums and means (longvideo_cache.py:264-270 on bf16 tensors) - coarser, but what the reference computes
         self.score_rounding = str(kv_compression_kwargs.get("score_rounding", "fp32"))
-        if self.score_rounding not in ("fp32", "reference"):
-            raise ValueError(f"score_rounding must be 'fp32' or 'reference', got {self.score_rounding!r}")
+        if self.score_rounding not in ("fp32", "reference", "fast"):
+            raise ValueError(f"score_rounding must be 'fp32', 'reference' or 'fast', got {self.score_rounding!r}")
         # MI355X build option: run scoring / selection of each update on one of N worker HIP streams.  Only
         # the tail append stays on the caller's stream (it is all the layer's attention needs); the flush
         # waits for the workers' events.  Independent updates then overlap on the GPU.
@@ -565,14 +568,16 @@ class PivotKVCache(DynamicCache):
         refround = self.score_rounding == "reference" and dtype == torch.bfloat16
         if refround and D != 128:
             raise NotImplementedError("score_rounding='reference' needs head_dim 128")
-        key = (Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround)
+        # "fast" (opt in): bf16 chunks of head_dim 128 on the fp16 matrix instruction; every other shape scores as usual
+        fast = self.score_rounding == "fast" and dtype == torch.bfloat16 and D == 128
+        key = (Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast)
         b = self._batch
         if b is not None and b.key == key and layer_idx < b.slots:
             return b
         self._flush()
         slots = max(int(self.num_hidden_layers), layer_idx + 1, b.slots if b is not None and b.key == key else 0)
         self._batch = None  # release the old buffers before allocating the new ones
-        self._batch = _Batch(key, slots, Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround)
+        self._batch = _Batch(key, slots, Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast)
         return self._batch
 
     def _flush(self):
@@ -865,7 +870,7 @@ class PivotKVCache(DynamicCache):
                 nv.ptr(query_states), query_states.stride(1), query_states.stride(2),
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
                 nv.ptr(value_states), value_states.stride(1), value_states.stride(2),
-                Hq, Hkv, L, D, dt, nv.ptr(pos_in), L, Pn, nv.ptr(inv), a_scale, sec,
+                Hq, Hkv, L, D, batch.score_dt if batch.fast else dt, nv.ptr(pos_in), L, Pn, nv.ptr(inv), a_scale, sec,
                 len(mrope_section) if mrope_section else 0, int(key_states.dtype == torch.bfloat16),
                 nv.ptr(batch.k_unrot[layer_idx]), C.c_void_p(ws_ptr), ws_bytes, k_tail, v_tail, cap * D,
                 nv.ptr(batch.pos_old[layer_idx]) if defer_select else None, nv.stream())
