@@ -214,14 +214,23 @@ def self_check(cache, pool, mask, n_chunks, layers, rotary):
             "checked": "batched score / keep_idx / new ids == one-unit launches (bitwise); kept V rows == gather"}
 
 
+def profile_key():
+    """Which committed PMC profile describes the kernels of the current configuration (tools/profile_round.sh names)."""
+    geo = [g for g, v in GEOMETRIES.items() if v[:2] == (N_PATCH, C_EMB)][0]
+    return geo + ("_fast" if SCORE_ROUNDING == "fast" else "")
+
+
 def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of a kernel from the newest committed PMC profile (profiles/rNN_pmc_hbm_traffic.csv:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 per MI355X_MICROARCH.md).  bench.py
-    cannot collect counters itself; the profile is of the same kernels on the same shapes."""
+    """HBM bytes per launch of a kernel from the newest committed PMC profile of the current geometry / score arithmetic
+    (profiles/rNN_<geometry>[_fast]_pmc_hbm_traffic.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    FETCH_SIZE x2 per MI355X_MICROARCH.md).  bench.py cannot collect counters itself; the profile is of the same
+    kernels on the same shapes, whole chunks (28 units) per launch."""
     import csv
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")))
+    if SCORE_ROUNDING == "reference":
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{profile_key()}_pmc_hbm_traffic.csv")))
     if not files:
         return None, None
     for row in csv.DictReader(open(files[-1])):
@@ -239,9 +248,8 @@ def score_roofline(kern, dtype, L, T, n_updates):
     flops = 2.0 * Hq * L * L * D * units_per_launch
     avg_s = kern[dom]["avg_us"] * 1e-6
     peak = MFMA_PEAK_TFLOPS[dtype]
-    traffic, src = pmc_traffic(dom) if dtype == "bf16" and L == FRAMES_PER_CHUNK * N_PATCH else (None, None)
-    if traffic is not None and "_u1_" in (src or ""):   # a per-unit profile: scale to the units of one launch
-        traffic *= units_per_launch
+    # the profile's launches cover 28 units; "score_pass1_dma_kernel<2, true, 2>" is the fast mode's fix-up launch
+    traffic, src = pmc_traffic(dom + "_dma_kernel") if dtype == "bf16" and units_per_launch == LAYERS else (None, None)
     return {"kernel": dom, "bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": peak, "unit": "TFLOP/s",
             "frac": flops / avg_s / 1e12 / peak, "traffic": traffic, "traffic_source": src,
             "units_per_launch": units_per_launch, "algorithmic_flops_per_launch": flops}
