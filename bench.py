@@ -365,7 +365,7 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
                "warmup": warmup, "dtype": dtype, "score_rounding": score_rounding,
                "retained_kv_tokens_per_s": n_chunks * layers * keep * steps / dt,
                "config": {"frames": frames_total, "bank": [1, rows, N_PATCH, C_EMB], "chunks": n_chunks, "layers": layers,
-                          "chunk_tokens": L, "keep": keep},
+                          "chunk_tokens": L, "keep": keep, "key_patch_mask_rate": float(kp_mask.float().mean().item())},
                "kernels_timed_region": kern,
                "roofline": score_roofline(kern, dtype, L, rows, n_chunks * layers * steps)}
         if check is not None:
@@ -481,6 +481,10 @@ def main():
                    "frames": args.frames, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L, "keep": int(RATIO * L),
                    "input_pool_sets": len(pool), "worker_streams": args.streams, "parallelism": "1 GPU"},
     }
+    # pass 2 computes one column mass per UNMASKED key (the reference overwrites the masked tokens' scores with 1.0,
+    # longvideo_cache.py:272-274): state how many columns that is for this video's DPSelect mask
+    out["config"]["key_patch_mask_rate"] = float(kp_mask.float().mean().item())
+    out["config"]["pass2_live_key_fraction"] = 1.0 - out["config"]["key_patch_mask_rate"]
     if check is not None:
         out["self_check"] = check
     out["cache_checksum"] = checksum   # the sharded runs (--gpus N) print the same fingerprint of the assembled cache

@@ -200,10 +200,17 @@ int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_stride_l,
  * score workspaces (holding q~ from RTK_SCORE_PREPARE / rtk_pivotkv_prepare), their k~ buffers (k_unrot0 == NULL:
  * inside the workspaces) and their partial outputs lie workspace_stride / k_unrot_stride bytes and
  * partial_stride_floats floats apart.  bf16, head_dim 128 (RTK_EUNSUPPORTED otherwise: run the stage per unit).
- * What PivotKVCache runs from after_forward for all layers of a chunk: 28x larger grids, no per-layer tails. */
+ * What PivotKVCache runs from after_forward for all layers of a chunk: 28x larger grids, no per-layer tails.
+ * Live keys (optional; both NULL = every column): key_masks_host is a HOST array of n_units device pointers to the units'
+ * key-patch masks ([L] bytes, entries may be NULL); key_index_ws is device scratch of n_units * (L + 1) int32.  The
+ * reference overwrites the score of every masked token with 1.0 after the scoring (longvideo_cache.py:272-274), so
+ * pass 2 - one column mass per key - runs on the unit's unmasked keys only and leaves the masked columns of `partial`
+ * UNWRITTEN (the selection's mask override never reads them); every other column gets the bits it always got.  The
+ * same mask must be handed to rtk_pivotkv_select_batched.  Ignored for RTK_BF16_REFROUND. */
 int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspace_stride, void* k_unrot0, size_t k_unrot_stride,
                                      float* partial0, size_t partial_stride_floats, int n_units,
-                                     int Hq, int Hkv, int L, int D, int dtype, rtk_stream_t stream);
+                                     int Hq, int Hkv, int L, int D, int dtype,
+                                     const void* const* key_masks_host, int32_t* key_index_ws, rtk_stream_t stream);
 
 /* P6-P7, P9-P10  longvideo_cache.py:272-277, :283-295.
  *   score [L] fp32: entries with mask != 0 are overwritten with 1.0 IN PLACE (masked_fill_, :274);

@@ -690,6 +690,64 @@ def test_pivotkv_benchmarked_batched_path_vs_units_and_oracle(L, layers, n_chunk
     assert cache.num_evicted_tokens == [n_chunks * (L - keep)] * layers
 
 
+@pytest.mark.parametrize("dt_name", ["bf16", "fast"])
+@pytest.mark.parametrize("L", [6272, 1000, 515])
+def test_pass2_live_keys_equal_full_pass_on_unmasked_columns(L, dt_name):
+    """rtk_pivotkv_score_passes_batched with key masks: pass 2 runs on the compacted list of unmasked keys only (the
+    reference discards the masked columns: `score.masked_fill_(mask, 1.0)`, longvideo_cache.py:272-274).  Straight through
+    the ABI, 6 units with DIFFERENT masks - a third masked, nothing masked, everything masked, one live key, all but one,
+    no mask at all: every unmasked column of `partial` must hold exactly the bits of the full pass; masked columns are
+    left untouched (checked through a sentinel)."""
+    import ctypes as C
+
+    import retake._native as nv
+
+    Hq, Hkv, D, units = 28, 4, 128, 6
+    dt = nv.RTK_BF16 if dt_name == "bf16" else nv.RTK_BF16_FAST
+    g = torch.Generator(device=dev()).manual_seed(4200 + L)
+    wsb = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
+    stride = (wsb + 255) & ~255
+    big = torch.empty(units * stride + 256, dtype=torch.uint8, device=dev())
+    base = (big.data_ptr() + 255) & ~255
+    kuns = torch.empty((units, Hkv, L, D), dtype=torch.bfloat16, device=dev())
+    rs_n = C.c_int(0)
+    pf = nv.lib.rtk_pivotkv_score_partials(Hq, Hkv, L, D, dt, C.byref(rs_n))
+    score = torch.empty(L, dtype=torch.float32, device=dev())
+    for u in range(units):
+        q = (1.7 * torch.randn((1, Hq, L, D), generator=g, device=dev())).bfloat16()
+        k = (1.7 * torch.randn((1, Hkv, L, D), generator=g, device=dev())).bfloat16()
+        nv.check(nv.lib.rtk_pivotkv_score_stages(nv.ptr(q), q.stride(1), q.stride(2), nv.ptr(k), k.stride(1), k.stride(2),
+                                                 Hq, Hkv, L, D, dt, None, None, 1.0, nv.ptr(score), nv.ptr(kuns[u]),
+                                                 C.c_void_p(base + u * stride), wsb, nv.SCORE_PREPARE, None, nv.stream()),
+                 "prepare")
+    masks = [torch.rand(L, generator=g, device=dev()) < 0.34, torch.zeros(L, dtype=torch.bool, device=dev()),
+             torch.ones(L, dtype=torch.bool, device=dev()), torch.ones(L, dtype=torch.bool, device=dev()),
+             torch.zeros(L, dtype=torch.bool, device=dev()), None]
+    masks[3][L // 3] = False
+    masks[4][L - 1] = True
+    full = torch.empty((units, pf), dtype=torch.float32, device=dev())
+    nv.check(nv.lib.rtk_pivotkv_score_passes_batched(C.c_void_p(base), stride, nv.ptr(kuns), Hkv * L * D * 2, nv.ptr(full), pf,
+                                                     units, Hq, Hkv, L, D, dt, None, None, nv.stream()), "full")
+    SENT = -12345.0
+    live = torch.full((units, pf), SENT, dtype=torch.float32, device=dev())
+    km = (C.c_void_p * units)(*[m.data_ptr() if m is not None else None for m in masks])
+    kidx = torch.empty((units, L + 1), dtype=torch.int32, device=dev())
+    nv.check(nv.lib.rtk_pivotkv_score_passes_batched(C.c_void_p(base), stride, nv.ptr(kuns), Hkv * L * D * 2, nv.ptr(live), pf,
+                                                     units, Hq, Hkv, L, D, dt, km, nv.ptr(kidx), nv.stream()), "live")
+    torch.cuda.synchronize()
+    full = full.view(units, Hkv, rs_n.value, L)
+    live = live.view(units, Hkv, rs_n.value, L)
+    for u, m in enumerate(masks):
+        if m is None:
+            assert int(kidx[u, L]) == -1 and torch.equal(live[u], full[u])
+            continue
+        n = int((~m).sum())
+        assert int(kidx[u, L]) == n
+        assert torch.equal(kidx[u, :n].long(), (~m).nonzero().flatten())          # ascending live-key list
+        assert torch.equal(live[u][:, :, ~m], full[u][:, :, ~m]), f"unit {u}: an unmasked column differs"
+        assert (live[u][:, :, m] == SENT).all(), f"unit {u}: a masked column was written"
+
+
 @pytest.mark.parametrize("L,layers", [(6272, 4), (2304, 4), (640, 3), (200, 2)])
 def test_pivotkv_fast_rounding_vs_default_and_oracle(L, layers):
     """score_rounding='fast' (RTK_BF16_FAST, opt in): the un-rotated q~ pre-scaled by log2(e)/sqrt(D) and stored as fp16,
@@ -1936,7 +1994,7 @@ def test_pivotkv_score_bf16_ragged_lengths_vs_oracle(L, Hq, Hkv):
                                                  C.c_void_p(base + u * stride), wsb, nv.SCORE_PREPARE, None, nv.stream()),
                  "prepare")
     nv.check(nv.lib.rtk_pivotkv_score_passes_batched(C.c_void_p(base), stride, nv.ptr(kuns), Hkv * L * D * 2, nv.ptr(parts),
-                                                     pf, units, Hq, Hkv, L, D, dt, nv.stream()), "batched")
+                                                     pf, units, Hq, Hkv, L, D, dt, None, None, nv.stream()), "batched")
     torch.cuda.synchronize()
     G = Hq // Hkv
     batched = (parts.view(units, Hkv, rs_n.value, L).sum(2) / G).mean(1)

@@ -62,7 +62,7 @@ def main():
 
         def runb():
             nv.check(nv.lib.rtk_pivotkv_score_passes_batched(C.c_void_p(base), stride, nv.ptr(kuns), Hkv * L * D * kuns.element_size(),
-                                                             nv.ptr(parts), pf, a.units, Hq, Hkv, L, D, dt, st), "batched")
+                                                             nv.ptr(parts), pf, a.units, Hq, Hkv, L, D, dt, None, None, st), "batched")
         for _ in range(2):
             runb()
         torch.cuda.synchronize()

@@ -1103,6 +1103,54 @@ _Pragma("unroll") \
 }
 
 // ------------------------------------------------------------------------------------------------
+// Live keys of pass 2.  The reference overwrites the score of every key-patch token with 1.0 after the scoring
+// (`score.masked_fill_(keypatches_mask_chunk, 1.0)`, longvideo_cache.py:272-274): the column masses of those tokens are
+// computed and thrown away.  A key's column mass depends on its own column only, so pass 2 - whose REGISTER operand is
+// the keys - can run on the compacted list of unmasked keys and leave the masked columns unwritten: identical bits for
+// every column anybody reads, (mask rate) x pass 2 less work (the mask is DPSelect's peak flag: about a third of the
+// tokens).  Pass 1 is untouched: the row normalisers are sums over ALL keys.
+//   key_index[unit][0 .. n)  ascending indices of the unit's unmasked tokens, key_index[unit][L] = n  (-1: no mask, identity)
+// One 1024-thread workgroup per unit: ordered compaction by a block scan of per-thread counts.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAX_MASK_UNITS = 64;
+struct KeyMasks {
+    const uint8_t* m[MAX_MASK_UNITS];
+};
+__global__ __launch_bounds__(1024) void key_compact_kernel(KeyMasks masks, int L, int* __restrict__ key_index) {
+    __shared__ int wsum[16];
+    const uint8_t* __restrict__ mk = masks.m[blockIdx.x];
+    int* __restrict__ out = key_index + (size_t)blockIdx.x * (L + 1);
+    if (!mk) {
+        if (threadIdx.x == 0) out[L] = -1;
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (L + 1023) / 1024;
+    const int b = tid * per, e = min(L, b + per);
+    int cnt = 0;
+    for (int j = b; j < e; ++j) cnt += mk[j] == 0;
+    int inc = cnt;   // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, WAVE);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int v = wsum[w];
+        base += w < wv ? v : 0;
+        total += v;
+    }
+    int at = base + inc - cnt;
+    for (int j = b; j < e; ++j)
+        if (mk[j] == 0) out[at++] = j;
+    if (tid == 0) out[L] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
 // pass 2, LDS-DMA form (bf16, the production kernel): the decomposition of score_pass2_kernel without its in-wave
 // software pipeline (one 32-row block of logits live at a time: ~95 VGPRs -> 4 waves per SIMD), and the streamed
 // query tile goes HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds): no staging registers, no ds_write pass.  A wave's DMA instruction fills
@@ -1115,7 +1163,10 @@ template <int NB, bool FAST = false>
 __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q, const char* __restrict__ k,
                                                      const float* __restrict__ lse, int Hq, int Hkv, int L,
                                                      int rows_per_split, int RS, float* __restrict__ partial, int j_base,
-                                                     int g, int rs) {
+                                                     int g, int rs, const int* __restrict__ kidx, int Lk) {
+    // kidx / Lk: the unit's live keys (ascending token indices, Lk of them; kidx == NULL: all L tokens, Lk == L).  j_base
+    // and the wave's key offsets count positions of THAT list; a position's token index names the k~ row it loads and
+    // the column of `partial` it writes.
     constexpr int DT = RTK_BF16;
     using M = MM<DT>;
     using T = Tile<DT>;
@@ -1139,7 +1190,14 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
     }
     u32x4 kf[NB][M::NREG];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) load_reg_frag<DT>(kg, j0 + 32 * nb, L, lane, kf[nb]);
+    for (int nb = 0; nb < NB; ++nb) {
+        const int jp = j0 + 32 * nb + (lane & 31);           // position in the live-key list
+        const bool ok = jp < Lk;
+        const int row = ok ? (kidx ? kidx[jp] : jp) : 0;      // token index = k~ row
+        const u32x4* p = (const u32x4*)(kg + (size_t)row * HD * M::ESIZE);
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) kf[nb][r] = ok ? p[M::chunk_of(r, hf)] : u32x4{0, 0, 0, 0};
+    }
     const float sqrt_d = sqrtf((float)HD);
     const float c2 = 1.4426950408889634f / sqrt_d;
     float col[NB];
@@ -1272,8 +1330,8 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const float c = col[nb] + __shfl_xor(col[nb], 32, WAVE);
-        const int j = j0 + 32 * nb + (lane_late & 31);
-        if (lane_late < 32 && j < L) partial[((size_t)g * RS + rs) * L + j] = c;
+        const int jp = j0 + 32 * nb + (lane_late & 31);
+        if (lane_late < 32 && jp < Lk) partial[((size_t)g * RS + rs) * L + (kidx ? kidx[jp] : jp)] = c;
     }
 }
 
@@ -1285,11 +1343,22 @@ template <int NB, bool FAST = false>
 __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 2 : 2)))) void score_pass2_dma_kernel(
     const char* __restrict__ q, const char* __restrict__ k, const float* __restrict__ lse, int Hq, int Hkv, int L,
     int rows_per_split, int col_tiles, int RS, int xcd_remap, float* __restrict__ partial, size_t q_unit_bytes,
-    size_t k_unit_bytes, size_t lse_unit_floats, size_t part_unit_floats) {
+    size_t k_unit_bytes, size_t lse_unit_floats, size_t part_unit_floats, const int* __restrict__ key_index = nullptr) {
     q += blockIdx.y * q_unit_bytes;
     k += blockIdx.y * k_unit_bytes;
     lse += blockIdx.y * lse_unit_floats;
     partial += blockIdx.y * part_unit_floats;
+    // the unit's live keys (key_compact_kernel); a workgroup whose key tile lies past them has nothing to do
+    const int* kidx = nullptr;
+    int Lk = L;
+    if (key_index) {
+        const int* ki = key_index + (size_t)blockIdx.y * (L + 1);
+        const int n = ki[L];
+        if (n >= 0) {
+            kidx = ki;
+            Lk = n;
+        }
+    }
     int bx, g, rs;
     {
         int grp;
@@ -1305,13 +1374,14 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
         rs = grp / Hkv;
     }
     const int j_base = bx * (REG_ROWS * NB);
+    if (j_base >= Lk) return;
     if constexpr (NB == 2) {
-        if (L - j_base <= REG_ROWS) {   // uniform per workgroup
-            score_pass2_dma_body<1, FAST>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs);
+        if (Lk - j_base <= REG_ROWS) {   // uniform per workgroup
+            score_pass2_dma_body<1, FAST>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk);
             return;
         }
     }
-    score_pass2_dma_body<NB, FAST>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs);
+    score_pass2_dma_body<NB, FAST>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1714,7 +1784,8 @@ template <int DT>
 static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, int64_t ksh, int64_t ksl, int Hq,
                       int Hkv, int L, int D, const float* cosv, const float* sinv, float a, float* score,
                       void* k_unrot, char* ws, const ScoreWs& w, int stages, float* partial_out, hipStream_t st,
-                      int n_units = 1, size_t ws_stride = 0, size_t k_stride = 0, size_t part_stride = 0) {
+                      int n_units = 1, size_t ws_stride = 0, size_t k_stride = 0, size_t part_stride = 0,
+                      const int* key_index = nullptr) {
     // n_units > 1 (RTK_SCORE_PASSES only): the same passes for n_units units whose workspaces / k~ / partials lie
     // ws_stride / k_stride bytes and part_stride floats apart — one launch per kernel, blockIdx.y = unit
     char* qt = ws + w.q_off;
@@ -1879,12 +1950,12 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                     RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<RTK_P2_NB, true>), dim3(Hkv * rs_n * jt2, n_units), dim3(SC_BLOCK), LDS2, st,
                                (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n,
                                (int)((Hkv * rs_n) % NXCD == 0), part, ws_stride, k_stride, ws_stride / sizeof(float),
-                               part_stride);
+                               part_stride, key_index);
                 else
                 RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<RTK_P2_NB>), dim3(Hkv * rs_n * jt2, n_units), dim3(SC_BLOCK), LDS2, st,
                            (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n,
                            (int)((Hkv * rs_n) % NXCD == 0), part, ws_stride, k_stride, ws_stride / sizeof(float),
-                           part_stride);
+                           part_stride, key_index);
             }
             else
                 RTK_LAUNCH(KID_PASS2, (score_pass2_kernel<DT, NBR>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
@@ -1910,6 +1981,7 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
 extern "C" int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspace_stride, void* k_unrot0,
                                                 size_t k_unrot_stride, float* partial0, size_t partial_stride_floats,
                                                 int n_units, int Hq, int Hkv, int L, int D, int dtype,
+                                                const void* const* key_masks_host, int32_t* key_index_ws,
                                                 rtk_stream_t stream) {
     RTK_CHECK_ARG(workspace0 && partial0 && n_units >= 1, "rtk_pivotkv_score_passes_batched: NULL pointer or no units");
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0 && L >= 1, "rtk_pivotkv_score_passes_batched: bad shape");
@@ -1921,10 +1993,28 @@ extern "C" int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspa
         set_error("rtk_pivotkv_score_passes_batched: bf16 with head_dim %d only (call RTK_SCORE_PASSES per unit)", HD);
         return RTK_EUNSUPPORTED;
     }
+    // live keys of pass 2: units whose key-patch mask is known skip the columns the mask override discards anyway
+    const int* key_index = nullptr;
+    if (key_masks_host && key_index_ws && dtype != RTK_BF16_REFROUND) {
+        bool any = false;
+        for (int u = 0; u < n_units; ++u) any = any || key_masks_host[u];
+        if (any) {
+            for (int u0 = 0; u0 < n_units; u0 += MAX_MASK_UNITS) {
+                KeyMasks km;
+                const int m = std::min(MAX_MASK_UNITS, n_units - u0);
+                for (int u = 0; u < MAX_MASK_UNITS; ++u) km.m[u] = u < m ? (const uint8_t*)key_masks_host[u0 + u] : nullptr;
+                RTK_LAUNCH(KID_FINALIZE, key_compact_kernel, dim3(m), dim3(1024), 0, (hipStream_t)stream, km, L,
+                           key_index_ws + (size_t)u0 * (L + 1));
+            }
+            RTK_LAUNCH_CHECK("key_compact_kernel");
+            key_index = key_index_ws;
+        }
+    }
     float dummy_score = 0.f;  // not touched by RTK_SCORE_PASSES
     return score_impl<RTK_BF16>(workspace0, 0, 0, workspace0, 0, 0, Hq, Hkv, L, D, nullptr, nullptr, 1.0f, &dummy_score,
                                 k_unrot0, (char*)workspace0, w, RTK_SCORE_PASSES, partial0, (hipStream_t)stream, n_units,
-                                workspace_stride, k_unrot0 ? k_unrot_stride : workspace_stride, partial_stride_floats);
+                                workspace_stride, k_unrot0 ? k_unrot_stride : workspace_stride, partial_stride_floats,
+                                key_index);
 }
 
 extern "C" size_t rtk_pivotkv_score_partials(int Hq, int Hkv, int L, int D, int dtype, int* rs_out) {

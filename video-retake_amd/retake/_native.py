@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 RTK_F32, RTK_BF16, RTK_BF16_REFROUND, RTK_BF16_FAST = 0, 1, 2, 3
 SCORE_PREPARE, SCORE_PASSES, SCORE_FINALIZE = 1, 2, 4
@@ -73,7 +73,7 @@ _SIGNATURES = {
                                     _vp, _sz, _vp]),
     "rtk_pivotkv_score_stages": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp,
                                            _vp, _sz, _i, _vp, _vp]),
-    "rtk_pivotkv_score_passes_batched": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]),
+    "rtk_pivotkv_score_passes_batched": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "rtk_pivotkv_score_partials": (C.c_size_t, [_i, _i, _i, _i, _i, C.POINTER(C.c_int)]),
     "rtk_pivotkv_select_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i, _vp]),
     "rtk_pivotkv_prepare": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i,

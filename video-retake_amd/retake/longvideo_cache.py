@@ -215,6 +215,9 @@ class _Batch:
         self.score_ws = torch.empty(slots * self.ws_stride + 256, dtype=torch.uint8, device=device) \
             if self.batched_passes else None
         self.score_ws_base = ((self.score_ws.data_ptr() + 255) & ~255) if self.batched_passes else 0
+        # pass 2's live-key lists (the unmasked tokens of every slot + their count): the columns the mask override
+        # discards (reference :272-274) are not computed
+        self.key_index = torch.empty((slots, L + 1), dtype=torch.int32, device=device) if self.batched_passes else None
         self.v_stage = torch.empty((slots, Hkv, keep, D), dtype=dtype, device=device)
         if reforge:  # kept K is re-rotated from the un-rotated copy straight into the cache: no K staging
             self.k_unrot = torch.empty((slots, Hkv, L, D), dtype=dtype, device=device)
@@ -311,6 +314,9 @@ class PivotKVCache(DynamicCache):
         # the tail append stays on the caller's stream (it is all the layer's attention needs); the flush
         # waits for the workers' events.  Independent updates then overlap on the GPU.
         self.overlap_streams = int(kv_compression_kwargs.get("overlap_streams", 0))
+        # the reference overwrites the score of every key-patch token with 1.0 (:272-274): the batched pass 2 does not
+        # compute those columns.  Same kept set, same scores after the override; False restores the full pass (tests / A/B)
+        self.skip_masked_columns = bool(kv_compression_kwargs.get("skip_masked_columns", True))
         self._sides: List[_Side] = []
         self._side_rr = 0
         self._pos_layers = 0          # len(position_cache) of the reference (skipped layers are padded with [])
@@ -604,10 +610,14 @@ class PivotKVCache(DynamicCache):
                 while j + 1 < len(unscored) and unscored[j + 1] == unscored[j] + 1:
                     j += 1
                 l0, n = unscored[i], j - i + 1
+                mptr = [b.masks.get(l) for l in range(l0, l0 + n)]
+                km = (C.c_void_p * n)(*[m.data_ptr() if m is not None else None for m in mptr]) \
+                    if self.skip_masked_columns and any(m is not None for m in mptr) else None
                 nv.check(nv.lib.rtk_pivotkv_score_passes_batched(
                     C.c_void_p(b.score_ws_base + l0 * b.ws_stride), b.ws_stride,
                     nv.ptr(b.k_unrot[l0]) if b.reforge else None, b.L * D * Hkv * es,
-                    nv.ptr(b.partials[l0]), b.part_floats, n, b.Hq, Hkv, b.L, D, b.score_dt, nv.stream()),
+                    nv.ptr(b.partials[l0]), b.part_floats, n, b.Hq, Hkv, b.L, D, b.score_dt,
+                    km, nv.ptr(b.key_index[l0]) if km is not None else None, nv.stream()),
                     "rtk_pivotkv_score_passes_batched")
                 i = j + 1
             b.scored.clear()
