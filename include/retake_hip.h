@@ -206,7 +206,7 @@ int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_stride_l,
  * reference overwrites the score of every masked token with 1.0 after the scoring (longvideo_cache.py:272-274), so
  * pass 2 - one column mass per key - runs on the unit's unmasked keys only and leaves the masked columns of `partial`
  * UNWRITTEN (the selection's mask override never reads them); every other column gets the bits it always got.  The
- * same mask must be handed to rtk_pivotkv_select_batched.  Ignored for RTK_BF16_REFROUND. */
+ * same mask must be handed to rtk_pivotkv_select_batched. */
 int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspace_stride, void* k_unrot0, size_t k_unrot_stride,
                                      float* partial0, size_t partial_stride_floats, int n_units,
                                      int Hq, int Hkv, int L, int D, int dtype,

@@ -690,7 +690,7 @@ def test_pivotkv_benchmarked_batched_path_vs_units_and_oracle(L, layers, n_chunk
     assert cache.num_evicted_tokens == [n_chunks * (L - keep)] * layers
 
 
-@pytest.mark.parametrize("dt_name", ["bf16", "fast"])
+@pytest.mark.parametrize("dt_name", ["bf16", "fast", "reference"])
 @pytest.mark.parametrize("L", [6272, 1000, 515])
 def test_pass2_live_keys_equal_full_pass_on_unmasked_columns(L, dt_name):
     """rtk_pivotkv_score_passes_batched with key masks: pass 2 runs on the compacted list of unmasked keys only (the
@@ -703,7 +703,7 @@ def test_pass2_live_keys_equal_full_pass_on_unmasked_columns(L, dt_name):
     import retake._native as nv
 
     Hq, Hkv, D, units = 28, 4, 128, 6
-    dt = nv.RTK_BF16 if dt_name == "bf16" else nv.RTK_BF16_FAST
+    dt = {"bf16": nv.RTK_BF16, "fast": nv.RTK_BF16_FAST, "reference": nv.RTK_BF16_REFROUND}[dt_name]
     g = torch.Generator(device=dev()).manual_seed(4200 + L)
     wsb = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
     stride = (wsb + 255) & ~255
@@ -735,8 +735,9 @@ def test_pass2_live_keys_equal_full_pass_on_unmasked_columns(L, dt_name):
     nv.check(nv.lib.rtk_pivotkv_score_passes_batched(C.c_void_p(base), stride, nv.ptr(kuns), Hkv * L * D * 2, nv.ptr(live), pf,
                                                      units, Hq, Hkv, L, D, dt, km, nv.ptr(kidx), nv.stream()), "live")
     torch.cuda.synchronize()
-    full = full.view(units, Hkv, rs_n.value, L)
-    live = live.view(units, Hkv, rs_n.value, L)
+    heads = Hq if dt_name == "reference" else Hkv     # the reference-rounding partials are per head
+    full = full.view(units, heads, rs_n.value, L)
+    live = live.view(units, heads, rs_n.value, L)
     for u, m in enumerate(masks):
         if m is None:
             assert int(kidx[u, L]) == -1 and torch.equal(live[u], full[u])

@@ -1872,7 +1872,7 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                0, st, stat, (size_t)Hq * L, ks_n, w.KS, su);                                                               \
     RTK_LAUNCH(KID_PASS2, (score_pass2_ref_kernel<DIV>), g2, dim3(SC_BLOCK), LDS2, st, (const char*)qt, (const char*)kt,   \
                (const float*)stat, Hq, Hkv, L, rps, jt, rs_n, x2, w.KS, part, ws_stride, k_stride, su, part_stride,        \
-               sqrt_d, rcp_sd)
+               sqrt_d, rcp_sd, key_index)
                 if (rcp_ok) { RTK_REF_PASSES(1); } else { RTK_REF_PASSES(2); }
 #undef RTK_REF_PASSES
                 RTK_LAUNCH_CHECK("score_ref_passes");
@@ -1995,7 +1995,7 @@ extern "C" int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspa
     }
     // live keys of pass 2: units whose key-patch mask is known skip the columns the mask override discards anyway
     const int* key_index = nullptr;
-    if (key_masks_host && key_index_ws && dtype != RTK_BF16_REFROUND) {
+    if (key_masks_host && key_index_ws) {
         bool any = false;
         for (int u = 0; u < n_units; ++u) any = any || key_masks_host[u];
         if (any) {

@@ -179,12 +179,24 @@ __global__ __launch_bounds__(SC_BLOCK, 3) void score_pass2_ref_kernel(
     const char* __restrict__ q, const char* __restrict__ k, const float* __restrict__ stat, int Hq, int Hkv, int L,
     int rows_per_split, int col_tiles, int RS, int xcd_remap, int KS_alloc, float* __restrict__ partial,
     size_t q_unit_bytes, size_t k_unit_bytes, size_t stat_unit_floats, size_t part_unit_floats, float sqrt_d,
-    float rcp_sd) {
+    float rcp_sd, const int* __restrict__ key_index = nullptr) {
     constexpr int DT = RTK_BF16;
     using M = MM<DT>;
     using T = Tile<DT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* m_s = (float*)(smem + 2 * T::BYTES);        // [2][TILE_ROWS]
+    // live keys of the unit (key_compact_kernel, see score_pass2_dma_kernel): positions of the compacted list name the
+    // k~ row a lane loads and the column it writes; key tiles past the list have nothing to do
+    const int* kidx = nullptr;
+    int Lk = L;
+    if (key_index) {
+        const int* ki = key_index + (size_t)blockIdx.y * (L + 1);
+        const int n = ki[L];
+        if (n >= 0) {
+            kidx = ki;
+            Lk = n;
+        }
+    }
     float* r_s = m_s + 2 * TILE_ROWS;                   // [2][TILE_ROWS]
     q += blockIdx.y * q_unit_bytes;
     k += blockIdx.y * k_unit_bytes;
@@ -210,6 +222,7 @@ __global__ __launch_bounds__(SC_BLOCK, 3) void score_pass2_ref_kernel(
         rs = grp / Hkv;
     }
     const int j0 = bx * REG_ROWS + wid * 32;
+    if (bx * REG_ROWS >= Lk) return;   // uniform per workgroup
     const char* kg = k + (size_t)g * L * HD * M::ESIZE;
     const int ib = rs * rows_per_split, ie = min(L, ib + rows_per_split);
     const int nrows = ie - ib;
@@ -222,7 +235,13 @@ __global__ __launch_bounds__(SC_BLOCK, 3) void score_pass2_ref_kernel(
         for (int r = 0; r < M::NREG; ++r) frag_off[r] = row * T::ROWB + ((M::chunk_of(r, hf) ^ (row & 15)) * 16);
     }
     u32x4 kf[M::NREG];
-    load_reg_frag<DT>(kg, j0, L, lane, kf);
+    const int jp = j0 + (lane & 31);                       // position in the live-key list
+    const int jcol = jp < Lk ? (kidx ? kidx[jp] : jp) : -1; // its token index (k~ row, output column)
+    {
+        const u32x4* p = (const u32x4*)(kg + (size_t)max(jcol, 0) * HD * M::ESIZE);
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) kf[r] = jcol >= 0 ? p[M::chunk_of(r, hf)] : u32x4{0, 0, 0, 0};
+    }
     const int drow = 4 * wid + (lane >> 4);
     const int dvoff = drow * T::ROWB + (((lane & 15) ^ (drow & 15)) * 16);
     const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, Hq * L * HD * M::ESIZE, 0x00020000);
@@ -277,8 +296,7 @@ __global__ __launch_bounds__(SC_BLOCK, 3) void score_pass2_ref_kernel(
         if (it + 1 < ntiles && tid < TILE_ROWS) { m_s[(buf ^ 1) * TILE_ROWS + tid] = pm; r_s[(buf ^ 1) * TILE_ROWS + tid] = pr; }
         if (++tcount == tiles_per_head) {   // this head's rows are done: its column sums leave on their own
             const float c = col + __shfl_xor(col, 32, WAVE);
-            const int j = j0 + (lane & 31);
-            if (hf == 0 && j < L) partial[((size_t)(g * G + hh) * RS + rs) * L + j] = c;
+            if (hf == 0 && jcol >= 0) partial[((size_t)(g * G + hh) * RS + rs) * L + jcol] = c;
             col = 0.f;
             tcount = 0;
             ++hh;
