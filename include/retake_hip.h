@@ -180,6 +180,18 @@ int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64_t q_stride
                              float* score, void* k_unrot, void* workspace, size_t workspace_bytes,
                              int stages, float* partial_out /* NULL = inside workspace */, rtk_stream_t stream);
 
+/* The same with the chunk's key-patch mask ([L] bytes, may be NULL) and int32 scratch of L + 1 entries: pass 2 then
+ * computes the column partials of the UNMASKED tokens only (the caller's selection overwrites the masked tokens' score
+ * with 1.0, longvideo_cache.py:272-274) and the masked entries of partial / score hold no meaning until that override.
+ * head_dim 128 kernels; other shapes ignore the mask. */
+int rtk_pivotkv_score_stages_masked(const void* q, int64_t q_stride_h, int64_t q_stride_l,
+                                    const void* k, int64_t k_stride_h, int64_t k_stride_l,
+                                    int Hq, int Hkv, int L, int D, int dtype,
+                                    const float* cos, const float* sin, float attention_scaling,
+                                    float* score, void* k_unrot, void* workspace, size_t workspace_bytes,
+                                    int stages, float* partial_out, const void* key_mask, int32_t* key_index_ws,
+                                    rtk_stream_t stream);
+
 /* Fused form of {rtk_rope_table, RTK_SCORE_PREPARE, rtk_pivotkv_append} for the standard inv_freq rotary
  * modules (longvideo_cache.py:238, :248-259): one pass over the chunk's q, k, v that builds each token's
  * cos/sin in registers (same arithmetic and rounding as rtk_rope_table), writes q~ into `workspace` (where

@@ -749,6 +749,67 @@ def test_pass2_live_keys_equal_full_pass_on_unmasked_columns(L, dt_name):
         assert (live[u][:, :, m] == SENT).all(), f"unit {u}: a masked column was written"
 
 
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("L", [1000, 300, 64])
+def test_pass2_live_keys_per_update_launch(L, tdtype):
+    """rtk_pivotkv_score_stages_masked (what `update` calls for fp32 tensors and for chunks below 512 tokens): with the
+    chunk's key-patch mask pass 2 computes the unmasked columns only - bitwise the columns of the unmasked call - and
+    leaves the masked ones alone.  Through the cache as well: fp32 scores / kept sets with and without
+    `skip_masked_columns` are identical after the mask override."""
+    import ctypes as C
+
+    import retake._native as nv
+    import retake.longvideo_cache as lc
+
+    Hq, Hkv, D = 28, 4, 128
+    g = torch.Generator(device=dev()).manual_seed(77 + L)
+    q = (1.7 * torch.randn((1, Hq, L, D), generator=g, device=dev())).to(tdtype)
+    k = (1.7 * torch.randn((1, Hkv, L, D), generator=g, device=dev())).to(tdtype)
+    mask = torch.rand(L, generator=g, device=dev()) < 0.4
+    dt = nv.dtype_code(q)
+    wsb = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
+    ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev())
+    wsp = C.c_void_p((ws.data_ptr() + 255) & ~255)
+    rs_n = C.c_int(0)
+    pf = nv.lib.rtk_pivotkv_score_partials(Hq, Hkv, L, D, dt, C.byref(rs_n))
+    score = torch.empty(L, dtype=torch.float32, device=dev())
+    stages = nv.SCORE_PREPARE | nv.SCORE_PASSES
+    full = torch.empty(pf, dtype=torch.float32, device=dev())
+    nv.check(nv.lib.rtk_pivotkv_score_stages(nv.ptr(q), q.stride(1), q.stride(2), nv.ptr(k), k.stride(1), k.stride(2), Hq, Hkv,
+                                             L, D, dt, None, None, 1.0, nv.ptr(score), None, wsp, wsb, stages, nv.ptr(full),
+                                             nv.stream()), "full")
+    SENT = -777.0
+    live = torch.full((pf,), SENT, dtype=torch.float32, device=dev())
+    kidx = torch.empty(L + 1, dtype=torch.int32, device=dev())
+    nv.check(nv.lib.rtk_pivotkv_score_stages_masked(nv.ptr(q), q.stride(1), q.stride(2), nv.ptr(k), k.stride(1), k.stride(2),
+                                                    Hq, Hkv, L, D, dt, None, None, 1.0, nv.ptr(score), None, wsp, wsb, stages,
+                                                    nv.ptr(live), nv.ptr(mask), nv.ptr(kidx), nv.stream()), "live")
+    torch.cuda.synchronize()
+    full, live = full.view(Hkv, rs_n.value, L), live.view(Hkv, rs_n.value, L)
+    assert int(kidx[L]) == int((~mask).sum())
+    assert torch.equal(live[:, :, ~mask], full[:, :, ~mask])
+    assert (live[:, :, mask] == SENT).all()
+
+    # and through the cache: the per-update path with and without the skip
+    sec = [16, 24, 24]
+    rot = synth.RotaryStub(synth.inv_freq(D), synth.YARN_FACTOR4_ATTENTION_SCALING, device=dev())
+    res = []
+    for skip in (True, False):
+        cfg = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=1, num_attention_heads=Hq, num_key_value_heads=Hkv,
+                                    longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
+                                        "compression_ratio": 0.25, "compression_method": "pivotkv",
+                                        "pos_embed_reforge": True, "skip_masked_columns": skip}})
+        cache = lc.build_kvcache(cfg)
+        cache.keypatches_mask_chunk = mask
+        gh, gw = (10, 10) if L == 1000 else ((6, 10) if L == 300 else (8, 8))
+        pos = torch.from_numpy(synth.mrope_position_ids(3, L // (gh * gw), gh, gw, hw0=1)).to(dev())
+        v = torch.randn((1, Hkv, L, D), generator=torch.Generator(device=dev()).manual_seed(5), device=dev()).to(tdtype)
+        cache.update(k, v, 0, {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": list(sec)})
+        res.append((cache.last_scores.clone(), cache.last_keep_indices.clone(), cache.key_cache[0].clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("L,layers", [(6272, 4), (2304, 4), (640, 3), (200, 2)])
 def test_pivotkv_fast_rounding_vs_default_and_oracle(L, layers):
     """score_rounding='fast' (RTK_BF16_FAST, opt in): the un-rotated q~ pre-scaled by log2(e)/sqrt(D) and stored as fp16,

@@ -936,12 +936,20 @@ template <int DT, int NB>
 __global__ __launch_bounds__(SC_BLOCK) void score_pass2_kernel(const char* __restrict__ q, const char* __restrict__ k,
                                                                const float* __restrict__ lse, int Hq, int Hkv, int L,
                                                                int rows_per_split, int col_tiles, int RS,
-                                                               int xcd_remap, float* __restrict__ partial) {
+                                                               int xcd_remap, float* __restrict__ partial,
+                                                               const int* __restrict__ key_index = nullptr) {
     using M = MM<DT>;
     using T = Tile<DT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lse_s = (float*)(smem + 2 * T::BYTES);  // [2][TILE_ROWS]
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE, hf = lane >> 5;
+    // live keys (key_compact_kernel, see score_pass2_dma_kernel): list positions name the k~ row and the output column
+    const int* kidx = nullptr;
+    int Lk = L;
+    if (key_index && key_index[L] >= 0) {
+        kidx = key_index;
+        Lk = key_index[L];
+    }
     // XCD-aware decode (block b runs on XCD b % 8): the col_tiles workgroups that stream the same query
     // rows (same KV group, same row split) share an XCD and therefore its L2.
     const int G = Hq / Hkv;
@@ -959,7 +967,8 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass2_kernel(const char* __res
         g = grp % Hkv;
         rs = grp / Hkv;
     }
-    const int j0 = bx * (REG_ROWS * NB) + wid * (32 * NB);   // this wave's NB*32 keys
+    const int j0 = bx * (REG_ROWS * NB) + wid * (32 * NB);   // this wave's NB*32 keys (positions in the live list)
+    if (bx * (REG_ROWS * NB) >= Lk) return;                   // uniform per workgroup
     const char* kg = k + (size_t)g * L * HD * M::ESIZE;
     const int ib = rs * rows_per_split, ie = min(L, ib + rows_per_split);
     const int nrows = ie - ib;
@@ -969,8 +978,15 @@ __global__ __launch_bounds__(SC_BLOCK) void score_pass2_kernel(const char* __res
     Pipe<DT> pp;
     pp.init(tid, lane);
     u32x4 kf[NB][M::NREG];
+    int jcol[NB];   // token index of this lane's key per register block, -1 past the list
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) load_reg_frag<DT>(kg, j0 + 32 * nb, L, lane, kf[nb]);
+    for (int nb = 0; nb < NB; ++nb) {
+        const int jp = j0 + 32 * nb + (lane & 31);
+        jcol[nb] = jp < Lk ? (kidx ? kidx[jp] : jp) : -1;
+        const u32x4* p = (const u32x4*)(kg + (size_t)max(jcol[nb], 0) * HD * M::ESIZE);
+#pragma unroll
+        for (int r = 0; r < M::NREG; ++r) kf[nb][r] = jcol[nb] >= 0 ? p[M::chunk_of(r, hf)] : u32x4{0, 0, 0, 0};
+    }
 
     const float sqrt_d = sqrtf((float)HD);
     const float c2 = 1.4426950408889634f / sqrt_d;
@@ -1097,8 +1113,7 @@ _Pragma("unroll") \
     for (int nb = 0; nb < NB; ++nb) {
         colsum_block<DT>(col[nb], pend[nb], pls, c2, sqrt_d);  // drain the pipeline
         col[nb] += __shfl_xor(col[nb], 32, WAVE);
-        const int j = j0 + 32 * nb + (lane & 31);
-        if (hf == 0 && j < L) partial[((size_t)g * RS + rs) * L + j] = col[nb];
+        if (hf == 0 && jcol[nb] >= 0) partial[((size_t)g * RS + rs) * L + jcol[nb]] = col[nb];
     }
 }
 
@@ -1960,7 +1975,7 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
             else
                 RTK_LAUNCH(KID_PASS2, (score_pass2_kernel<DT, NBR>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
                            (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt, rs_n,
-                           (int)((Hkv * rs_n) % NXCD == 0), part);
+                           (int)((Hkv * rs_n) % NXCD == 0), part, key_index);
             RTK_LAUNCH_CHECK("score_pass2_kernel");
         }
     } else if (stages & RTK_SCORE_PASSES) {
@@ -2029,11 +2044,38 @@ extern "C" size_t rtk_pivotkv_score_partials(int Hq, int Hkv, int L, int D, int 
     return (size_t)(w.ref ? Hq : Hkv) * rs_n * L;
 }
 
+static int score_stages_impl(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k, int64_t k_stride_h,
+                             int64_t k_stride_l, int Hq, int Hkv, int L, int D, int dtype, const float* cosv,
+                             const float* sinv, float attention_scaling, float* score, void* k_unrot, void* workspace,
+                             size_t workspace_bytes, int stages, float* partial_out, const void* key_mask,
+                             int32_t* key_index_ws, rtk_stream_t stream);
+
 extern "C" int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k,
                                         int64_t k_stride_h, int64_t k_stride_l, int Hq, int Hkv, int L, int D, int dtype,
                                         const float* cosv, const float* sinv, float attention_scaling, float* score,
                                         void* k_unrot, void* workspace, size_t workspace_bytes, int stages,
                                         float* partial_out, rtk_stream_t stream) {
+    return score_stages_impl(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, dtype, cosv, sinv,
+                             attention_scaling, score, k_unrot, workspace, workspace_bytes, stages, partial_out, nullptr,
+                             nullptr, stream);
+}
+
+extern "C" int rtk_pivotkv_score_stages_masked(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k,
+                                               int64_t k_stride_h, int64_t k_stride_l, int Hq, int Hkv, int L, int D,
+                                               int dtype, const float* cosv, const float* sinv, float attention_scaling,
+                                               float* score, void* k_unrot, void* workspace, size_t workspace_bytes,
+                                               int stages, float* partial_out, const void* key_mask,
+                                               int32_t* key_index_ws, rtk_stream_t stream) {
+    return score_stages_impl(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, dtype, cosv, sinv,
+                             attention_scaling, score, k_unrot, workspace, workspace_bytes, stages, partial_out, key_mask,
+                             key_index_ws, stream);
+}
+
+static int score_stages_impl(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k, int64_t k_stride_h,
+                             int64_t k_stride_l, int Hq, int Hkv, int L, int D, int dtype, const float* cosv,
+                             const float* sinv, float attention_scaling, float* score, void* k_unrot, void* workspace,
+                             size_t workspace_bytes, int stages, float* partial_out, const void* key_mask,
+                             int32_t* key_index_ws, rtk_stream_t stream) {
     RTK_CHECK_ARG(q && k && score && workspace, "rtk_pivotkv_score: NULL pointer");
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0, "rtk_pivotkv_score: Hq=%d must be a multiple of Hkv=%d", Hq, Hkv);
     RTK_CHECK_ARG(L >= 1 && D >= 2 && D % 2 == 0, "rtk_pivotkv_score: bad shape L=%d D=%d", L, D);
@@ -2048,11 +2090,23 @@ extern "C" int rtk_pivotkv_score_stages(const void* q, int64_t q_stride_h, int64
         return RTK_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
+    // live keys of pass 2 (head_dim 128 kernels only): the columns of masked tokens are not computed, the caller's
+    // selection overwrites their score with 1.0 anyway (longvideo_cache.py:272-274)
+    const int* key_index = nullptr;
+    if (key_mask && key_index_ws && D == HD && (stages & RTK_SCORE_PASSES)) {
+        KeyMasks km;
+        for (int u = 0; u < MAX_MASK_UNITS; ++u) km.m[u] = u == 0 ? (const uint8_t*)key_mask : nullptr;
+        RTK_LAUNCH(KID_FINALIZE, key_compact_kernel, dim3(1), dim3(1024), 0, st, km, L, key_index_ws);
+        RTK_LAUNCH_CHECK("key_compact_kernel");
+        key_index = key_index_ws;
+    }
     if (dtype != RTK_F32)
         return score_impl<RTK_BF16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, cosv, sinv,
-                                    attention_scaling, score, k_unrot, (char*)workspace, w, stages, partial_out, st);
+                                    attention_scaling, score, k_unrot, (char*)workspace, w, stages, partial_out, st, 1, 0, 0, 0,
+                                    key_index);
     return score_impl<RTK_F32>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, Hq, Hkv, L, D, cosv, sinv,
-                               attention_scaling, score, k_unrot, (char*)workspace, w, stages, partial_out, st);
+                               attention_scaling, score, k_unrot, (char*)workspace, w, stages, partial_out, st, 1, 0, 0, 0,
+                               key_index);
 }
 
 extern "C" int rtk_pivotkv_score(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k,

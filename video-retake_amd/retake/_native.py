@@ -73,6 +73,8 @@ _SIGNATURES = {
                                     _vp, _sz, _vp]),
     "rtk_pivotkv_score_stages": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp,
                                            _vp, _sz, _i, _vp, _vp]),
+    "rtk_pivotkv_score_stages_masked": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp,
+                                                  _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp]),
     "rtk_pivotkv_score_passes_batched": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "rtk_pivotkv_score_partials": (C.c_size_t, [_i, _i, _i, _i, _i, C.POINTER(C.c_int)]),
     "rtk_pivotkv_select_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i, _vp]),

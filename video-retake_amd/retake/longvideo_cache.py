@@ -807,12 +807,16 @@ class PivotKVCache(DynamicCache):
             ws_ptr = ws_pointer(ws)
             score = batch.score[layer_idx]
             k_unrot = batch.k_unrot[layer_idx] if reforge else None
-            nv.check(nv.lib.rtk_pivotkv_score_stages(
+            # the matrix passes of a per-update launch know the chunk's key-patch mask: pass 2 skips the columns the
+            # selection overwrites with 1.0 anyway (reference :272-274)
+            live = mask if (stages & nv.SCORE_PASSES) and self.skip_masked_columns else None
+            kidx = self._buf("key_index", (L + 1,), torch.int32, dev, ws) if live is not None else None
+            nv.check(nv.lib.rtk_pivotkv_score_stages_masked(
                 nv.ptr(query_states), query_states.stride(1), query_states.stride(2),
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
                 Hq, Hkv, L, D, batch.score_dt, nv.ptr(shared.get("cos")), nv.ptr(shared.get("sin")), a_scale,
                 nv.ptr(score), nv.ptr(k_unrot), C.c_void_p(ws_ptr), ws_bytes, stages, nv.ptr(batch.partials[layer_idx]),
-                nv.stream()), "rtk_pivotkv_score")
+                nv.ptr(live), nv.ptr(kidx), nv.stream()), "rtk_pivotkv_score")
             return score
 
         def stage_pre(ws, pos_in):
