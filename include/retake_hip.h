@@ -51,7 +51,11 @@ enum rtk_dtype {
      * three.  Scores move by ~1e-5 relative against RTK_BF16 (far inside the reference's own bf16 rounding of the
      * logits); everything downstream of the score is identical.  Opt in: score_rounding="fast".  head_dim 128 only;
      * |k~| beyond fp16's range (65504) saturates. */
-    RTK_BF16_FAST = 3
+    RTK_BF16_FAST = 3,
+    /* fp16 payloads (a float16 model).  Like RTK_BF16, every entry point restates the reference's chain of torch ops
+     * with one rounding to the tensor dtype per op; the score uses exact fp16 products with fp32 accumulation.
+     * Wherever an argument is called `round_bf16`, 2 selects fp16 tables (1 = bf16, 0 = fp32). */
+    RTK_F16 = 4
 };
 
 enum rtk_status {

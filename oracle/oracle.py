@@ -90,9 +90,31 @@ def mallm_compress(x: np.ndarray, tgt: int, sync: bool, hard: bool):
 # ---------------------------------------------------------------------------------------------
 # DPSelect
 # ---------------------------------------------------------------------------------------------
+def dpselect_dis_f16(x16: np.ndarray) -> np.ndarray:
+    """x [T,N,C] numpy float16 -> dis [T,N] float32: visual_compression.py:100-106 on a float16 tensor.  ATen's
+    cosine_similarity is a composite of tensor ops, each rounding to the tensor dtype with fp32 arithmetic inside
+    (verified against the imported reference: equal except for the last bit of ~0.1-0.4 % of the sums, the fp32
+    summation order):  norm = fp16(sqrt(sum x^2)), clamp_min(fp16(1e-8) = 0), xn = fp16(x / norm),
+    cos = fp16(sum fp16(xn_t * xn_t+1)),  dis = 1 - float(cos), row 0 = 1.  numpy's float16 arithmetic rounds every op
+    like torch's CPU half kernels (fp32 operation, then one rounding to half)."""
+    xf = np.ascontiguousarray(x16, dtype=np.float16).astype(np.float32)
+    nrm = np.sqrt((xf * xf).sum(-1, dtype=np.float32)).astype(np.float16)
+    nrm = np.maximum(nrm, np.float16(1e-8))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xn = (xf / nrm.astype(np.float32)[..., None]).astype(np.float16)
+    prod = (xn[:-1].astype(np.float32) * xn[1:].astype(np.float32)).astype(np.float16)
+    cos = prod.astype(np.float32).sum(-1, dtype=np.float32).astype(np.float16)
+    dis = np.empty(xf.shape[:2], dtype=np.float32)
+    dis[0] = 1.0
+    dis[1:] = np.float32(1.0) - cos.astype(np.float32)
+    return dis
+
+
 def dpselect_dis(x: np.ndarray) -> np.ndarray:
-    """x [T,N,C] float32, or uint16 holding bf16 bits -> dis [T,N] float32."""
+    """x [T,N,C] float32, uint16 holding bf16 bits, or numpy float16 -> dis [T,N] float32."""
     x = np.ascontiguousarray(x)
+    if x.dtype == np.float16:
+        return dpselect_dis_f16(x)
     T, N, Cc = x.shape
     dis = np.empty((T, N), dtype=np.float32)
     if x.dtype == np.float32:
@@ -162,6 +184,22 @@ def rope_apply(x: np.ndarray, cos: np.ndarray, sin: np.ndarray, reverse: bool, a
     fn = lib().orc_rope_apply_bf16 if bf16 else lib().orc_rope_apply
     _chk(fn(_p(x), H, L, D, _p(cos), _p(sin), int(reverse), float(attention_scaling), _p(out)), "rope_apply")
     return out
+
+
+def rope_apply_f16(x: np.ndarray, cos: np.ndarray, sin: np.ndarray, reverse: bool, attention_scaling: float = 1.0):
+    """rope_apply on a float16 model: x [H,L,D], cos/sin [L,D] fp32 arrays holding fp16 values; every torch op of
+    longvideo_cache.py:76-81 rounds to fp16 (numpy float16 arithmetic = fp32 operation + one rounding, like torch's CPU
+    half kernels); the division by attention_scaling**2 is tensor / python scalar: fp32 quotient, one rounding."""
+    x16, c16, s16 = (np.ascontiguousarray(a, dtype=np.float32).astype(np.float16) for a in (x, cos, sin))
+    h2 = x16.shape[-1] // 2
+    rot = np.concatenate([-x16[..., h2:], x16[..., :h2]], axis=-1)
+    if reverse:
+        t = (x16 * c16[None]) - (rot * s16[None])
+        a2 = np.float32(float(attention_scaling) ** 2)
+        out = (t.astype(np.float32) / a2).astype(np.float16) if a2 != 1.0 else t
+    else:
+        out = (x16 * c16[None]) + (rot * s16[None])
+    return out.astype(np.float32)
 
 
 def bf16_round(a: np.ndarray) -> np.ndarray:
@@ -234,11 +272,14 @@ class OraclePivotKV:
     """
 
     def __init__(self, num_heads: int, num_kv_heads: int, head_dim: int, compression_ratio: float,
-                 pos_embed_reforge: bool = False, bf16: bool = False, score_rounding: str = "reference"):
+                 pos_embed_reforge: bool = False, bf16: bool = False, score_rounding: str = "reference",
+                 fp16: bool = False):
         """bf16: inputs are fp32 arrays of bf16 values and the RoPE steps round per torch op like the reference on a
         bf16 model; score_rounding 'reference' = the reference's bf16 score chain, 'fp32' = exact products with fp32
         accumulation and fp32 softmax / sums (what the HIP default computes for bf16 inputs)."""
         self.bf16, self.score_rounding = bf16, score_rounding
+        self.fp16 = fp16   # inputs are fp32 arrays of fp16 values, RoPE steps round to fp16, the score is exact ("fp32")
+        assert not (bf16 and fp16)
         self.Hq, self.Hkv, self.D = num_heads, num_kv_heads, head_dim
         self.compression_ratio = compression_ratio
         self.pos_embed_reforge = pos_embed_reforge
@@ -273,7 +314,8 @@ class OraclePivotKV:
         import torch
 
         xt = torch.from_numpy(x)
-        cos, sin = rotary(xt.bfloat16() if self.bf16 else xt, torch.from_numpy(pos))   # tables in the model dtype
+        xt = xt.bfloat16() if self.bf16 else (xt.half() if self.fp16 else xt)
+        cos, sin = rotary(xt, torch.from_numpy(pos))   # tables in the model dtype
         cos, sin = cos.float().numpy(), sin.float().numpy()
         if mrope_section:
             return mrope_merge(cos[:, 0], mrope_section), mrope_merge(sin[:, 0], mrope_section)
@@ -305,8 +347,11 @@ class OraclePivotKV:
         if self.pos_embed_reforge:  # :248-259
             cos, sin = self._tables(rotary, v, position_ids, mrope_section)
             a = rotary.attention_scaling
-            qs = rope_apply(qs, cos, sin, True, a, bf16=self.bf16)
-            ks = rope_apply(ks, cos, sin, True, a, bf16=self.bf16)
+            if self.fp16:
+                qs, ks = rope_apply_f16(qs, cos, sin, True, a), rope_apply_f16(ks, cos, sin, True, a)
+            else:
+                qs = rope_apply(qs, cos, sin, True, a, bf16=self.bf16)
+                ks = rope_apply(ks, cos, sin, True, a, bf16=self.bf16)
         keep = max(1, int(self.compression_ratio * L))  # :263
         if self.bf16 and self.score_rounding == "reference":
             score = pivotkv_score_bf16(qs, ks)
@@ -321,10 +366,10 @@ class OraclePivotKV:
         newpos_t = newpos.reshape((3, 1, keep) if position_ids.ndim == 3 else (1, keep))
         if self.pos_embed_reforge:  # :297-306
             cos, sin = self._tables(rotary, vv[None], newpos_t, mrope_section)
-            kk = rope_apply(kk, cos, sin, False, bf16=self.bf16)
+            kk = rope_apply_f16(kk, cos, sin, False) if self.fp16 else rope_apply(kk, cos, sin, False, bf16=self.bf16)
             self._upd_pos(newpos_t, layer)  # :308-309
         self._upd_evicted(k_len - keep, layer)  # :310
         self.key_cache[layer] = np.concatenate([k_out[:, :, :-L], kk[None]], axis=2)  # :313-318
         self.value_cache[layer] = np.concatenate([v_out[:, :, :-L], vv[None]], axis=2)
-        self.last = dict(score=score, keep_idx=idx, kept_k=kk[None], kept_v=vv[None], pos=newpos_t)
+        self.last = dict(score=score, keep_idx=idx, kept_k=kk[None], kept_v=vv[None], pos=newpos_t, k_unrot=ks)
         return k_out, v_out

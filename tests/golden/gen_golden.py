@@ -659,6 +659,113 @@ def gen_pivotkv_bf16(lc, outdir):
         np.savez_compressed(os.path.join(outdir, f"pivotkv_{name}.npz"), **rec)
 
 
+# --------------------------------------------------------------------------------------
+# fp16 (round 3): the reference run on float16 tensors - DPSelect and PivotKV.  Same recording as the bf16 fixtures;
+# 16-bit payloads are stored as their bit patterns.
+# --------------------------------------------------------------------------------------
+def gen_fp16(vc, lc, outdir):
+    # ---- DPSelect
+    for (name, seed, T, N, C, tgt, sync, raw) in [("video64x16x64_async_r50_fp16", 51, 64, 16, 64, 32, False, True),
+                                                  ("video64x16x64_sync_r50_fp16", 52, 64, 16, 64, 32, True, True),
+                                                  ("video64x196x1280_async_r100_fp16", 53, 64, 196, 1280, 64, False, False),
+                                                  ("video64x196x1280_async_r50_fp16", 54, 64, 196, 1280, 32, False, False),
+                                                  ("video32x144x3584_async_r100_fp16", 55, 32, 144, 3584, 32, False, False)]:
+        x = torch.from_numpy(synth.make_frames("video", seed, T, N, C)).half()
+        d32, d64 = dis_matrices(x)
+        out, mask = vc.memory_bank_compress_keyframe(x.clone(), tgt, 3, sync=sync)
+        xin, outn = x.float().numpy(), out.float().numpy()
+        if sync:
+            idx = recover_frame_idx(xin[:, :, :1], outn[:, :, :1])[:, 0]
+            rows64 = d64.mean(1, keepdims=True).T
+        else:
+            idx = recover_frame_idx(xin, outn)
+            rows64 = d64.T
+        pm = peak_margins(rows64)
+        pk = (rows64 > np.concatenate([np.full((rows64.shape[0], 1), -np.inf), rows64[:, :-1]], 1)) & \
+             (rows64 >= np.concatenate([rows64[:, 1:], np.full((rows64.shape[0], 1), -np.inf)], 1))
+        tm = topk_margin(rows64 + 2.0 * pk, tgt)
+        rec = dict(kind="video", seed=seed, T=T, N=N, C=C, tgt=tgt, sync=sync, window=3, dtype="fp16",
+                   x_crc=synth.checksum(x.view(torch.int16).numpy()), idx=idx, mask=mask.numpy(), dis32=d32, dis64=d64,
+                   out_crc=synth.checksum(out.view(torch.int16).numpy()), min_peak_gap=pm, min_topk_gap=tm)
+        if raw:
+            rec["x"] = x.view(torch.int16).numpy()
+        np.savez_compressed(os.path.join(outdir, f"dpselect_{name}.npz"), **rec)
+        print(f"dpselect_{name}: t={tgt} sync={sync} mask_rate={mask.float().mean():.3f}")
+
+    # ---- PivotKV
+    S = synth.YARN_FACTOR4_ATTENTION_SCALING
+    Hq, Hkv, D, mrope = 28, 4, 128, [16, 24, 24]
+    for (name, gh, gw, gpc, ratio, mrate, seed, raw) in [("fp16_qwen_L256", 8, 8, 4, 0.25, 0.3, 221, True),
+                                                         ("fp16_qwen_L1568", 14, 14, 8, 0.25, 0.3, 222, False)]:
+        L = gpc * gh * gw
+        inv_f = synth.inv_freq(D, 1e6)
+        rotary = synth.RotaryStub(inv_f, S)
+        cache = lc.PivotKVCache(make_config(Hq, Hkv, D, 1, ratio, True))
+        rec = dict(Hq=Hq, Hkv=Hkv, D=D, L=L, gh=gh, gw=gw, grids_per_chunk=gpc, n_chunks=1, ratio=ratio, reforge=True,
+                   mrope_section=np.array(mrope, dtype=np.int64), attention_scaling=S, inv_freq=inv_f, seed=seed, layer=0,
+                   raw=raw, theta=1e6, dtype="fp16")
+        rng = np.random.default_rng(seed + 7)
+        captured = {}
+        orig_topk = torch.Tensor.topk
+
+        def spy_topk(self, *args, **kw):
+            captured["score"] = self.detach().clone()
+            return orig_topk(self, *args, **kw)
+
+        q0, k0, v = map(torch.from_numpy, synth.qkv_chunk(seed * 100, Hq, Hkv, L, D))
+        pos = torch.from_numpy(synth.mrope_position_ids(5, gpc, gh, gw, hw0=5))
+        q = synth.rope_forward(q0, pos, rotary, mrope).half()   # what a float16 model hands to update
+        k = synth.rope_forward(k0, pos, rotary, mrope).half()
+        v = v.half()
+        mask = torch.from_numpy(rng.uniform(size=L) < mrate)
+        cache.keypatches_mask_chunk = mask
+        cache.kvcache_compression = True
+        kw = {"sin": None, "cos": None, "cache_position": None, "query_states": q, "position_ids": pos.clone(),
+              "rotary_emb": rotary, "mrope_section": list(mrope)}
+        torch.Tensor.topk = spy_topk
+        try:
+            cache.update(k, v, 0, kw)
+        finally:
+            torch.Tensor.topk = orig_topk
+        keep = max(1, int(ratio * L))
+        kept_k, kept_v = cache.key_cache[0], cache.value_cache[0]
+        vb, kvb = bf16_bits(v), bf16_bits(kept_v)           # (bit patterns of any 16-bit dtype)
+        idx = np.empty(keep, dtype=np.int64)
+        look = {}
+        for i in range(L):
+            look.setdefault(vb[0, 0, i, :8].tobytes(), []).append(i)
+        for r in range(keep):
+            m = [i for i in look[kvb[0, 0, r, :8].tobytes()] if np.array_equal(vb[0, :, i], kvb[0, :, r])]
+            assert len(m) == 1
+            idx[r] = m[0]
+        assert (np.diff(idx) > 0).all()
+        score_ref = captured["score"]
+        assert score_ref.dtype == torch.float16
+        cos, sin = rotary(v, pos)
+        qt, kt = lc.apply_multimodal_rotary_pos_emb(q, k, cos, sin, mrope, reverse=True, attention_scaling=S)
+        s64 = score_fp64(qt, kt, Hkv)
+        rec["c0_pos"], rec["c0_mask"] = pos.numpy(), mask.numpy()
+        rec["c0_score_bits"] = bf16_bits(score_ref)
+        rec["c0_score64"] = s64
+        rec["c0_keep_idx"] = idx
+        rec["c0_kept_k_bits"] = bf16_bits(kept_k)
+        rec["c0_k_unrot_bits"] = bf16_bits(kt)              # the reference's own un-rotated keys (its helper, fp16)
+        rec["c0_position_cache"] = cache.position_cache[0].numpy().copy()
+        if raw:
+            rec["c0_q_bits"], rec["c0_k_bits"], rec["c0_v_bits"] = bf16_bits(q), bf16_bits(k), vb
+        else:
+            rec["c0_q_crc"], rec["c0_k_crc"] = synth.checksum(bf16_bits(q)), synth.checksum(bf16_bits(k))
+            rec["c0_v_crc"] = synth.checksum(vb)
+        rec["keep"] = keep
+        sr = score_ref.float().numpy()
+        s64m = s64.copy()
+        s64m[mask.numpy()] = 1.0
+        exact = np.sort(np.lexsort((np.arange(L), -s64m))[:keep])
+        print(f"pivotkv_{name}: L={L} keep={keep} distinct fp16 scores {len(np.unique(sr))}, kept-set overlap with exact "
+              f"scoring {np.intersect1d(idx, exact).size}/{keep}, max |score_fp16 - exact| {np.abs(sr - s64m).max():.5f}")
+        np.savez_compressed(os.path.join(outdir, f"pivotkv_{name}.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -674,6 +781,8 @@ def main():
         gen_glue(HERE)
     if args.only in (None, "mallm"):
         gen_mallm(vc, HERE)
+    if args.only in (None, "fp16"):
+        gen_fp16(vc, lc, HERE)
 
 
 if __name__ == "__main__":

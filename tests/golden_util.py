@@ -23,7 +23,7 @@ def dpselect_input(g) -> np.ndarray:
     """[1,T,N,C] float32, or uint16 (bf16 bits) for bf16 fixtures; verified against the stored crc."""
     if "x" in g.files:
         x = g["x"]
-        return x.view(np.uint16) if str(g["dtype"]) == "bf16" else x
+        return x.view(np.uint16) if str(g["dtype"]) in ("bf16", "fp16") else x
     kind, seed = str(g["kind"]), int(g["seed"])
     T, N, C = int(g["T"]), int(g["N"]), int(g["C"])
     if kind == "torch0":
@@ -33,10 +33,11 @@ def dpselect_input(g) -> np.ndarray:
         x = torch.randn(1, T, N, C).numpy()
     else:
         x = synth.make_frames(kind, seed, T, N, C)
-    if str(g["dtype"]) == "bf16":   # the generator cast the fp32 frames with torch's round-to-nearest-even
+    if str(g["dtype"]) in ("bf16", "fp16"):   # the generator cast the fp32 frames with torch's round-to-nearest-even
         import torch
 
-        x = torch.from_numpy(x).bfloat16().view(torch.int16).numpy().view(np.uint16)
+        xt = torch.from_numpy(x)
+        x = (xt.bfloat16() if str(g["dtype"]) == "bf16" else xt.half()).view(torch.int16).numpy().view(np.uint16)
     assert synth.checksum(x) == int(g["x_crc"]), "regenerated input differs from the fixture's"
     return x
 
@@ -204,3 +205,33 @@ def bf16_ulp(x: np.ndarray) -> np.ndarray:
     """Spacing of bf16 numbers at |x| (x fp32 holding bf16 values)."""
     e = np.floor(np.log2(np.maximum(np.abs(x.astype(np.float64)), 2.0 ** -126)))
     return 2.0 ** (e - 7)
+
+
+def pivotkv_fp16_chunk_inputs(g):
+    """(q, k, v) as numpy float16 [1,H,L,D], pos [3,1,L], mask [L] of an fp16 fixture (the reference run on a float16
+    model, one chunk).  Regenerated from the seed for the big cases and verified against the stored crc."""
+    import torch
+
+    pos, mask = g["c0_pos"], g["c0_mask"]
+    if bool(g["raw"]):
+        return tuple(g["c0_" + n + "_bits"].view(np.float16) for n in ("q", "k", "v")) + (pos, mask)
+    Hq, Hkv, D, L = (int(g[k]) for k in ("Hq", "Hkv", "D", "L"))
+    q0, k0, v = synth.qkv_chunk(int(g["seed"]) * 100, Hq, Hkv, L, D)
+    rotary = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]))
+    sec = [int(s) for s in g["mrope_section"]]
+
+    def bits(t):
+        return t.half().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+    q = bits(synth.rope_forward(torch.from_numpy(q0), torch.from_numpy(pos), rotary, sec))
+    k = bits(synth.rope_forward(torch.from_numpy(k0), torch.from_numpy(pos), rotary, sec))
+    vb = bits(torch.from_numpy(v))
+    assert synth.checksum(q) == int(g["c0_q_crc"]) and synth.checksum(k) == int(g["c0_k_crc"])
+    assert synth.checksum(vb) == int(g["c0_v_crc"])
+    return q.view(np.float16), k.view(np.float16), vb.view(np.float16), pos, mask
+
+
+def fp16_ulp(x: np.ndarray) -> np.ndarray:
+    """Spacing of fp16 numbers at |x| (normal range)."""
+    e = np.floor(np.log2(np.maximum(np.abs(np.asarray(x, dtype=np.float64)), 2.0 ** -14)))
+    return 2.0 ** (e - 10)

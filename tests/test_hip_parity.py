@@ -17,9 +17,10 @@ from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-DP_FP32 = [n for n in gu.names("dpselect_") if "edge" not in n and "bf16" not in n]
+DP_FP32 = [n for n in gu.names("dpselect_") if "edge" not in n and "bf16" not in n and "fp16" not in n]
 DP_BF16 = [n for n in gu.names("dpselect_") if "bf16" in n]
-PK = [n for n in gu.names("pivotkv_") if not n.startswith("pivotkv_bf16_")]
+DP_FP16 = [n for n in gu.names("dpselect_") if "fp16" in n]
+PK = [n for n in gu.names("pivotkv_") if not n.startswith(("pivotkv_bf16_", "pivotkv_fp16_"))]
 
 
 def dev():
@@ -94,6 +95,32 @@ def test_dpselect_bf16_golden(name):
         assert torch.equal(out[0], xi)          # ratio 1.0: the identity copy
     out2, mask2 = vc.memory_bank_compress_keyframe(xt, tgt, int(g["window"]), sync=sync)
     assert torch.equal(out2, out) and torch.equal(mask2, mask.flatten())
+
+
+@pytest.mark.parametrize("name", DP_FP16)
+def test_dpselect_fp16_golden(name):
+    """float16 frame banks against the reference's own fp16 run, row by row like the bf16 gate (RTK_F16: the cosine chain
+    rounds to fp16 per torch op, IEEE division)."""
+    import retake.visual_compression as vc
+
+    g = gu.load(name)
+    x = gu.dpselect_input(g)  # uint16 bits
+    xt = torch.from_numpy(x.view(np.int16)).to(dev()).view(torch.float16)
+    tgt, sync = int(g["tgt"]), bool(g["sync"])
+    out, mask, idx, dis, keys = vc.dpselect_stages(xt, tgt, int(g["window"]), sync)
+    disn = dis.cpu().numpy()
+    d = np.abs(disn - g["dis32"])
+    assert d.max() <= 2 ** -9 and (d > 0).mean() < 0.01
+    st = gu.check_dpselect_bf16(g, disn, idx.cpu().numpy(), mask.flatten().cpu().numpy())
+    print(f"\n[{name}] rows {st['rows']}: exact {st['exact']}, tied-boundary {st['tied']}, relaxed {st['relaxed']} "
+          f"({st['flipped_entries']} of {d.size} distances flipped, {st['peak_flags_differing']} peak flags and "
+          f"{st['indices_differing']} picks differ from the reference's)")
+    assert st["exact"] + st["tied"] >= 0.5 * st["rows"] or sync
+    xi = xt[0]
+    ii = idx if not sync else idx[:, None].expand(-1, xi.shape[1])
+    assert torch.equal(out[0], torch.gather(xi, 0, ii[:, :, None].expand(-1, -1, xi.shape[2])))
+    out2, mask2 = vc.memory_bank_compress_keyframe(xt, tgt, int(g["window"]), sync=sync)
+    assert out2.dtype == torch.float16 and torch.equal(out2, out) and torch.equal(mask2, mask.flatten())
 
 
 @pytest.mark.parametrize("sync", [True, False])
@@ -1840,6 +1867,66 @@ def test_pivotkv_bf16_against_reference_bf16(name, rounding):
         if l:   # identical inputs: identical layers, bit for bit
             assert torch.equal(cache._batch.score[l], cache._batch.score[0])
             assert torch.equal(cache.key_cache[l], cache.key_cache[0])
+
+
+@pytest.mark.parametrize("native_rope", [False, True])
+@pytest.mark.parametrize("name", gu.names("pivotkv_fp16_"))
+def test_pivotkv_fp16_against_reference_fp16(name, native_rope):
+    """The HIP cache on float16 tensors (RTK_F16) against the REFERENCE's own fp16 run, three layers (the chunk-batched
+    flush for L >= 512): exact-product scores within 2e-5 of the exact score of the reference's operands, kept set equal
+    up to tokens within one fp16 ulp of its threshold, un-rotated keys and re-rotated kept keys BIT-exact (the fp16
+    rounding chain of longvideo_cache.py:76-81), kept V rows copies.  native_rope: tables from the module (torch's libm
+    values, like the reference) or computed in the kernels (correctly rounded: equal after the fp16 rounding of the table
+    except at fp16 midpoints)."""
+    import retake.longvideo_cache as lc
+    import test_oracle_golden as tog
+
+    g = gu.load(name)
+    Hq, Hkv, D, L, keep = (int(g[k]) for k in ("Hq", "Hkv", "D", "L", "keep"))
+    sec = [int(x) for x in g["mrope_section"]]
+    n_layers = 3
+    llm = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=n_layers, num_attention_heads=Hq, num_key_value_heads=Hkv,
+                                longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
+                                    "compression_ratio": float(g["ratio"]), "compression_method": "pivotkv",
+                                    "pos_embed_reforge": True, "native_rope": native_rope}})
+    cache = lc.build_kvcache(llm)
+    rot = _CpuTablesRotary(g["inv_freq"], float(g["attention_scaling"]), dev())
+    q, k, v, pos, mask = gu.pivotkv_fp16_chunk_inputs(g)
+
+    def dv(a):
+        return torch.from_numpy(a.view(np.int16)).view(torch.float16).to(dev())
+
+    cache.keypatches_mask_chunk = torch.from_numpy(mask).to(dev())
+    cache.kvcache_compression = True
+    qd, kd, vd = dv(q), dv(k), dv(v)
+    for l in range(n_layers):
+        ko, vo = cache.update(kd, vd, l, {"query_states": qd, "position_ids": torch.from_numpy(pos).to(dev()),
+                                          "rotary_emb": rot, "mrope_section": list(sec)})
+        assert ko.dtype == torch.float16 and torch.equal(ko[:, :, -L:], kd)
+    if L >= 512:
+        assert cache._batch.batched_passes and len(cache._batch.pending) == n_layers
+    cache.after_forward()
+    for l in range(n_layers):
+        score = cache._batch.score[l].cpu().numpy()
+        idx = cache._batch.keep_idx[l].cpu().numpy()
+        kk = cache.key_cache[l].cpu().contiguous().view(torch.int16).numpy().view(np.float16)
+        ku = cache._batch.k_unrot[l].cpu().contiguous().view(torch.int16).numpy().view(np.float16)
+        pos_new = cache.position_cache[l].cpu().numpy()
+        if native_rope:   # correctly rounded tables: the bit-exactness claims are checked as a mismatch fraction
+            ref_ku = g["c0_k_unrot_bits"].reshape(-1)
+            frac = float((ku.view(np.uint16).reshape(-1) != ref_ku).mean())
+            assert frac < 1e-4, frac
+            s64 = g["c0_score64"].copy()
+            s64[mask] = 1.0
+            assert np.abs(score - s64).max() < 2e-5
+        else:
+            nxor, err = tog.check_fp16_against_reference(g, score, idx, kk, pos_new, ku, "HIP fp16")
+            if l == 0:
+                print(f"\n[{name}] HIP vs the reference's fp16 run: {nxor // 2} kept tokens differ, max |score - exact| {err:.2e}")
+        assert np.array_equal(cache.value_cache[l].cpu().view(torch.int16).numpy().view(np.uint16)[0],
+                              v.view(np.uint16)[0][:, idx])
+        if l:
+            assert torch.equal(cache._batch.score[l], cache._batch.score[0]) and torch.equal(cache.key_cache[l], cache.key_cache[0])
 
 
 def test_pivotkv_reference_rounding_batched_equals_per_layer():

@@ -11,9 +11,10 @@ import golden_util as gu
 import synth
 from oracle import oracle as orc
 
-DP_FP32 = [n for n in gu.names("dpselect_") if "edge" not in n and "bf16" not in n]
+DP_FP32 = [n for n in gu.names("dpselect_") if "edge" not in n and "bf16" not in n and "fp16" not in n]
 DP_BF16 = [n for n in gu.names("dpselect_") if "bf16" in n]
-PK = [n for n in gu.names("pivotkv_") if not n.startswith("pivotkv_bf16_")]
+DP_FP16 = [n for n in gu.names("dpselect_") if "fp16" in n]
+PK = [n for n in gu.names("pivotkv_") if not n.startswith(("pivotkv_bf16_", "pivotkv_fp16_"))]
 
 
 @pytest.mark.parametrize("name", DP_FP32)
@@ -230,3 +231,73 @@ def test_mallm_matches_reference(name):
         b = (ref.astype(np.uint32) << 16).view(np.float32)
         assert np.abs(a - b).max() <= 2 ** -6                       # at most a bf16 ulp on values of O(1)
         assert (a != b).mean() < 0.02
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp16: the reference run on float16 tensors (fixtures of gen_golden.py --only fp16)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", DP_FP16)
+def test_dpselect_fp16_matches_reference(name):
+    """The numpy-float16 restatement of ATen's fp16 cosine chain against the reference's fp16 run, row by row (the same
+    checker as bf16: rows whose distances equal the reference's must carry its indices and its mask)."""
+    g = gu.load(name)
+    x = gu.dpselect_input(g).view(np.float16)
+    out, mask, idx, dis = orc.dpselect(x, int(g["tgt"]), int(g["window"]), bool(g["sync"]))
+    d = np.abs(dis - g["dis32"])
+    assert d.max() <= 2 ** -9 and (d > 0).mean() < 0.01      # one fp16 ulp of a cosine below 1, rare
+    st = gu.check_dpselect_bf16(g, dis, idx, mask)
+    print(f"\n[{name}] rows {st['rows']}: exact {st['exact']}, tied-boundary {st['tied']}, relaxed {st['relaxed']} "
+          f"({st['flipped_entries']} of {d.size} distances flipped, {st['peak_flags_differing']} peak flags and "
+          f"{st['indices_differing']} picks differ from the reference's)")
+    assert st["exact"] + st["tied"] >= 0.5 * st["rows"] or bool(g["sync"])
+
+
+def check_fp16_against_reference(g, score, keep_idx, kept_k16, pos_new, k_unrot16, what):
+    """Shared by the oracle test (CPU) and the HIP test (GPU).  On float16 tensors the reference rounds the logits, the
+    probabilities and the sums to fp16 (longvideo_cache.py:264-270); the build scores with exact products and fp32
+    accumulation (like its bf16 default), so: the score is the exact score of the reference's own un-rotated operands
+    (<= 2e-5), every token the kept sets disagree on has a reference score within one fp16 ulp of its threshold, the
+    un-rotated keys equal the reference's bit for bit, and so do the re-rotated kept keys of every token both sides
+    kept at the same new position."""
+    L, keep = int(g["L"]), int(g["keep"])
+    mask = g["c0_mask"]
+    s64 = g["c0_score64"].copy()
+    s64[mask] = 1.0
+    err = float(np.abs(score - s64).max())
+    assert err < 2e-5, f"{what}: score differs from the exact score of the reference's operands by {err}"
+    ref = g["c0_score_bits"].view(np.float16).astype(np.float32)
+    ref_idx = g["c0_keep_idx"]
+    thr = np.sort(ref)[::-1][keep - 1]
+    xor = np.setxor1d(keep_idx, ref_idx)
+    assert (np.abs(ref[xor] - thr) <= gu.fp16_ulp(np.full(xor.size, thr))).all(), f"{what}: kept sets differ beyond ties"
+    assert xor.size <= max(4, L // 100)
+    if k_unrot16 is not None:
+        np.testing.assert_array_equal(np.asarray(k_unrot16).view(np.uint16).reshape(-1),
+                                      g["c0_k_unrot_bits"].reshape(-1), err_msg=f"{what}: un-rotated keys")
+    ref_pos = g["c0_position_cache"][..., -keep:].reshape(-1, keep)
+    common, ia, ib = np.intersect1d(keep_idx, ref_idx, return_indices=True)
+    same_pos = (pos_new.reshape(-1, keep)[:, ia] == ref_pos[:, ib]).all(0)
+    assert same_pos.mean() > 0.9
+    a = np.asarray(kept_k16).view(np.uint16).reshape(-1, keep, int(g["D"]))[:, ia[same_pos]]
+    b = g["c0_kept_k_bits"].reshape(-1, keep, int(g["D"]))[:, ib[same_pos]]
+    np.testing.assert_array_equal(a, b, err_msg=f"{what}: re-rotated kept keys")
+    return xor.size, err
+
+
+@pytest.mark.parametrize("name", gu.names("pivotkv_fp16_"))
+def test_pivotkv_fp16_chain_matches_reference(name):
+    g = gu.load(name)
+    Hq, Hkv, D, L = (int(g[k]) for k in ("Hq", "Hkv", "D", "L"))
+    sec = [int(x) for x in g["mrope_section"]]
+    rot = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]))
+    oc = orc.OraclePivotKV(Hq, Hkv, D, float(g["ratio"]), True, fp16=True, score_rounding="fp32")
+    q, k, v, pos, mask = gu.pivotkv_fp16_chunk_inputs(g)
+    oc.keypatches_mask_chunk = mask
+    oc.update(k.astype(np.float32), v.astype(np.float32), 0, q=q.astype(np.float32), position_ids=pos, rotary=rot,
+              mrope_section=sec)
+    last = oc.last
+    nxor, err = check_fp16_against_reference(g, last["score"], last["keep_idx"], last["kept_k"].astype(np.float16),
+                                             last["pos"], last["k_unrot"].astype(np.float16), "oracle")
+    print(f"\n[{name}] oracle vs the reference's fp16 run: {nxor // 2} kept tokens differ (threshold ties), "
+          f"max |score - exact| {err:.2e}")
+    np.testing.assert_array_equal(last["kept_v"].astype(np.float16).view(np.uint16)[0], v.view(np.uint16)[0][:, last["keep_idx"]])

@@ -19,6 +19,53 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 }
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
+// ---- fp16 <-> f32 (IEEE, round to nearest even: v_cvt_f16_f32 / v_cvt_f32_f16, like c10::Half) ---------
+__device__ __forceinline__ float hf2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t f2hf(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ float rhf(float f) { return (float)(_Float16)f; }
+
+// The two 16-bit float formats behind one interface (DT = RTK_BF16 or RTK_F16): torch rounds the result of every
+// elementwise op on such tensors to the tensor's dtype, so the kernels that restate a chain of torch ops need "round
+// two fp32 values into a packed pair", "read a half of a packed pair" and "round trip one value".
+using rtk_f32x2 = __attribute__((ext_vector_type(2))) float;
+using rtk_bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using rtk_f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+template <int DT> struct H16;
+template <> struct H16<RTK_BF16> {
+    static constexpr uint32_t ONE2 = 0x3f803f80u;   // (1.0, 1.0)
+    __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {   // v_cvt_pk_bf16_f32
+        const rtk_f32x2 v = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rtk_bf16x2));
+    }
+    __device__ static __forceinline__ float lo(uint32_t p) { return __uint_as_float(p << 16); }
+    __device__ static __forceinline__ float hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+    __device__ static __forceinline__ float rnd(float x) { return rbf(x); }
+    __device__ static __forceinline__ float ld(const void* p, size_t i) { return bf2f(((const uint16_t*)p)[i]); }
+    __device__ static __forceinline__ void st(void* p, size_t i, float x) { ((uint16_t*)p)[i] = f2bf(x); }
+    // acc + a.lo*b.lo + a.hi*b.hi on packed pairs (products of two 16-bit floats are exact in fp32)
+    __device__ static __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rtk_bf16x2, a), __builtin_bit_cast(rtk_bf16x2, b), acc, false);
+    }
+};
+template <> struct H16<RTK_F16> {
+    static constexpr uint32_t ONE2 = 0x3c003c00u;
+    __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {   // 2 x v_cvt_f16_f32 + pack, RNE, overflow -> inf
+        const rtk_f32x2 v = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rtk_f16x2));
+    }
+    __device__ static __forceinline__ float lo(uint32_t p) { return (float)__builtin_bit_cast(rtk_f16x2, p)[0]; }
+    __device__ static __forceinline__ float hi(uint32_t p) { return (float)__builtin_bit_cast(rtk_f16x2, p)[1]; }
+    __device__ static __forceinline__ float rnd(float x) { return rhf(x); }
+    __device__ static __forceinline__ float ld(const void* p, size_t i) { return hf2f(((const uint16_t*)p)[i]); }
+    __device__ static __forceinline__ void st(void* p, size_t i, float x) { ((uint16_t*)p)[i] = f2hf(x); }
+    __device__ static __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(rtk_f16x2, a), __builtin_bit_cast(rtk_f16x2, b), acc, false);
+    }
+};
+// round x to the 16-bit format named by `mode` (0 = keep fp32, 1 = bf16, 2 = fp16): the dtype a rotary module casts its
+// cos / sin tables to (`.to(x.dtype)`)
+__device__ __forceinline__ float round_to(float x, int mode) { return mode == 1 ? rbf(x) : (mode == 2 ? rhf(x) : x); }
+
 // ---- wave reductions (all 64 lanes participate) -------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -126,7 +173,8 @@ __device__ __forceinline__ void rope_elem(float f, int ra, int rb, const float (
     sincos_cr(p1 * f, sn, cs);
     cs *= scaling;
     sn *= scaling;
-    if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
+    cs = round_to(cs, round_bf16);   // round_bf16: 0 = fp32 tables, 1 = bf16, 2 = fp16 (the model dtype)
+    sn = round_to(sn, round_bf16);
     c1 = cs;
     s1 = sn;
     if (rb != ra) {
@@ -134,7 +182,8 @@ __device__ __forceinline__ void rope_elem(float f, int ra, int rb, const float (
         sincos_cr(p2 * f, sn, cs);
         cs *= scaling;
         sn *= scaling;
-        if (round_bf16) { cs = rbf(cs); sn = rbf(sn); }
+        cs = round_to(cs, round_bf16);
+        sn = round_to(sn, round_bf16);
     }
     c2 = cs;
     s2 = sn;

@@ -30,6 +30,15 @@ template <> struct Elem<RTK_BF16> {
     }
 };
 
+template <> struct Elem<RTK_F16> {
+    static constexpr int PER_VEC = 8;
+    using vec_t = u32x4;
+    __device__ static void unpack(const vec_t& v, float* f) {
+        f[0] = H16<RTK_F16>::lo(v.x); f[1] = H16<RTK_F16>::hi(v.x); f[2] = H16<RTK_F16>::lo(v.y); f[3] = H16<RTK_F16>::hi(v.y);
+        f[4] = H16<RTK_F16>::lo(v.z); f[5] = H16<RTK_F16>::hi(v.z); f[6] = H16<RTK_F16>::lo(v.w); f[7] = H16<RTK_F16>::hi(v.w);
+    }
+};
+
 using bf16x2_dp = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2_dp = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ uint32_t pack2_bf16_dp(float lo, float hi) {   // v_cvt_pk_bf16_f32
@@ -104,13 +113,13 @@ __global__ __launch_bounds__(256) void dis_kernel(const typename Elem<DT>::vec_t
 #pragma unroll
         for (int k = 0; k < VPL; ++k) E::unpack(raw[k], cur + k * PV);
         float ss = 0.f;
-        if constexpr (DT == RTK_BF16) {   // sum of squares straight from the packed words, two elements per instruction
+        if constexpr (DT != RTK_F32) {   // sum of squares straight from the packed words, two elements per instruction
 #pragma unroll
             for (int k = 0; k < VPL; ++k) {
-                ss = dot2_bf16_dp(raw[k].x, raw[k].x, ss);
-                ss = dot2_bf16_dp(raw[k].y, raw[k].y, ss);
-                ss = dot2_bf16_dp(raw[k].z, raw[k].z, ss);
-                ss = dot2_bf16_dp(raw[k].w, raw[k].w, ss);
+                ss = H16<DT>::dot2(raw[k].x, raw[k].x, ss);
+                ss = H16<DT>::dot2(raw[k].y, raw[k].y, ss);
+                ss = H16<DT>::dot2(raw[k].z, raw[k].z, ss);
+                ss = H16<DT>::dot2(raw[k].w, raw[k].w, ss);
             }
         } else {
 #pragma unroll
@@ -118,7 +127,20 @@ __global__ __launch_bounds__(256) void dis_kernel(const typename Elem<DT>::vec_t
         }
         ss = wave_sum_uniform(ss);
         float nrm = sqrtf(ss);
-        if (DT == RTK_BF16) {
+        if constexpr (DT == RTK_F16) {
+            // fp16 tensors: norm -> fp16, clamp_min(eps) with eps = fp16(1e-8) = 0 (a zero vector divides 0 by 0 like the
+            // reference does), the quotient rounded to fp16.  True IEEE division: the reciprocal-product argument below
+            // is a statement about 8-bit significands.
+            nrm = fmaxf(rhf(nrm), rhf(1e-8f));
+#pragma unroll
+            for (int e = 0; e < NE; ++e) cur[e] = __fdiv_rn(cur[e], nrm);
+#pragma unroll
+            for (int e = 0; e < NE; e += 2) {
+                const uint32_t pk = H16<DT>::pack2(cur[e], cur[e + 1]);
+                cur[e] = H16<DT>::lo(pk);
+                cur[e + 1] = H16<DT>::hi(pk);
+            }
+        } else if constexpr (DT == RTK_BF16) {
             nrm = rbf(nrm);
             nrm = fmaxf(nrm, rbf(1e-8f));
             // bf16(fl32(x / nrm)) without a division per element: x and nrm are bf16 values, and the exact quotient
@@ -152,18 +174,18 @@ __global__ __launch_bounds__(256) void dis_kernel(const typename Elem<DT>::vec_t
     // cos / distance of row t (in cur[]) against the previous row (prevn[])
     auto emit = [&](int t, const float* prevn, const float* cur) {
         float dot = 0.f;
-        if (DT == RTK_BF16) {
+        if constexpr (DT != RTK_F32) {
 #pragma unroll
             for (int e = 0; e < NE; e += 2) {
-                const uint32_t pk = pack2_bf16_dp(prevn[e] * cur[e], prevn[e + 1] * cur[e + 1]);
-                dot = dot2_bf16_dp(pk, 0x3f803f80u, dot);   // + bf16(product) for both halves
+                const uint32_t pk = H16<DT>::pack2(prevn[e] * cur[e], prevn[e + 1] * cur[e + 1]);
+                dot = H16<DT>::dot2(pk, H16<DT>::ONE2, dot);   // + round(product) for both halves
             }
         } else {
 #pragma unroll
             for (int e = 0; e < NE; ++e) dot = fmaf(prevn[e], cur[e], dot);
         }
         dot = wave_sum_uniform(dot);
-        if (DT == RTK_BF16) dot = rbf(dot);
+        if constexpr (DT != RTK_F32) dot = H16<DT>::rnd(dot);
         if (lane == t - tb) res = emit_cos ? dot : 1.0f - dot;
     };
 
@@ -206,8 +228,8 @@ __global__ __launch_bounds__(256) void dis_kernel_generic(const void* __restrict
         return;
     }
     auto ld = [&](size_t off) -> float {
-        if (DT == RTK_BF16) return bf2f(((const uint16_t*)xv)[off]);
-        return ((const float*)xv)[off];
+        if constexpr (DT != RTK_F32) return H16<DT>::ld(xv, off);
+        else return ((const float*)xv)[off];
     };
     const size_t a0 = ((size_t)(t - 1) * N + n) * C, b0 = ((size_t)t * N + n) * C;
     float sa = 0.f, sb = 0.f;
@@ -218,11 +240,12 @@ __global__ __launch_bounds__(256) void dis_kernel_generic(const void* __restrict
     }
     float na = sqrtf(wave_sum(sa)), nb = sqrtf(wave_sum(sb));
     float dot = 0.f;
-    if (DT == RTK_BF16) {
-        na = fmaxf(rbf(na), rbf(1e-8f));
-        nb = fmaxf(rbf(nb), rbf(1e-8f));
-        for (int c = lane; c < C; c += WAVE) dot += rbf(rbf(ld(a0 + c) / na) * rbf(ld(b0 + c) / nb));
-        dot = rbf(wave_sum(dot));
+    if constexpr (DT != RTK_F32) {
+        using Hh = H16<DT>;
+        na = fmaxf(Hh::rnd(na), Hh::rnd(1e-8f));
+        nb = fmaxf(Hh::rnd(nb), Hh::rnd(1e-8f));
+        for (int c = lane; c < C; c += WAVE) dot += Hh::rnd(Hh::rnd(ld(a0 + c) / na) * Hh::rnd(ld(b0 + c) / nb));
+        dot = Hh::rnd(wave_sum(dot));
     } else {
         na = fmaxf(na, 1e-8f);
         nb = fmaxf(nb, 1e-8f);
@@ -366,7 +389,7 @@ __global__ __launch_bounds__(256) void mallm_argmax_kernel(const float* __restri
             s = wave_sum(s);
             if (lane == 0) {
                 float m = s / (float)N;
-                mrow[t] = round_bf16 ? rbf(m) : m;
+                mrow[t] = round_to(m, round_bf16);   // 0 = fp32, 1 = bf16, 2 = fp16 (the bank's dtype)
             }
         }
         __syncthreads();
@@ -409,9 +432,18 @@ __global__ __launch_bounds__(256) void mallm_merge_kernel(const void* __restrict
                                                           const int64_t* __restrict__ idx, int T, int N, int C, int hard,
                                                           void* __restrict__ outv, void* __restrict__ sov) {
     const size_t total = (size_t)(T - 1) * N * C;
-    auto ldx = [&](size_t i) -> float { return DT == RTK_BF16 ? bf2f(((const uint16_t*)xv)[i]) : ((const float*)xv)[i]; };
-    auto lds = [&](size_t i) -> float { return DT == RTK_BF16 ? bf2f(((const uint16_t*)sv)[i]) : ((const float*)sv)[i]; };
-    auto rnd = [&](float v) -> float { return DT == RTK_BF16 ? rbf(v) : v; };
+    auto ldx = [&](size_t i) -> float {
+        if constexpr (DT != RTK_F32) return H16<DT>::ld(xv, i);
+        else return ((const float*)xv)[i];
+    };
+    auto lds = [&](size_t i) -> float {
+        if constexpr (DT != RTK_F32) return H16<DT>::ld(sv, i);
+        else return ((const float*)sv)[i];
+    };
+    auto rnd = [&](float v) -> float {
+        if constexpr (DT != RTK_F32) return H16<DT>::rnd(v);
+        else return v;
+    };
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
         const size_t tn = e / C;
@@ -420,7 +452,7 @@ __global__ __launch_bounds__(256) void mallm_merge_kernel(const void* __restrict
         float o;
         if (hard) {
             const int d = t + (t >= ix);
-            if (DT == RTK_BF16) ((uint16_t*)outv)[e] = ((const uint16_t*)xv)[((size_t)d * N + n) * C + c];
+            if (DT != RTK_F32) ((uint16_t*)outv)[e] = ((const uint16_t*)xv)[((size_t)d * N + n) * C + c];
             else ((float*)outv)[e] = ((const float*)xv)[((size_t)d * N + n) * C + c];
             continue;
         }
@@ -436,10 +468,10 @@ __global__ __launch_bounds__(256) void mallm_merge_kernel(const void* __restrict
             den = rnd(__fadd_rn(sd, ss));
             o = rnd(__fdiv_rn(rnd(__fadd_rn(rnd(__fmul_rn(xd, sd)), rnd(__fmul_rn(xs, ss)))), den));
         }
-        if (DT == RTK_BF16) ((uint16_t*)outv)[e] = f2bf(o);
+        if constexpr (DT != RTK_F32) H16<DT>::st(outv, e, o);
         else ((float*)outv)[e] = o;
         if (c == 0) {
-            if (DT == RTK_BF16) ((uint16_t*)sov)[tn] = f2bf(den);
+            if constexpr (DT != RTK_F32) H16<DT>::st(sov, tn, den);
             else ((float*)sov)[tn] = den;
         }
     }
@@ -516,6 +548,7 @@ extern "C" int rtk_dpselect_dis(const void* x, int T, int N, int C, int dtype, f
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RTK_F32) return launch_dis<RTK_F32>(x, T, N, C, 0, dis, st);
     if (dtype == RTK_BF16) return launch_dis<RTK_BF16>(x, T, N, C, 0, dis, st);
+    if (dtype == RTK_F16) return launch_dis<RTK_F16>(x, T, N, C, 0, dis, st);
     set_error("rtk_dpselect_dis: unsupported dtype %d", dtype);
     return RTK_EINVAL;
 }
@@ -526,6 +559,7 @@ extern "C" int rtk_adjacent_cosine(const void* x, int T, int N, int C, int dtype
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RTK_F32) return launch_dis<RTK_F32>(x, T, N, C, 1, cos_out, st);
     if (dtype == RTK_BF16) return launch_dis<RTK_BF16>(x, T, N, C, 1, cos_out, st);
+    if (dtype == RTK_F16) return launch_dis<RTK_F16>(x, T, N, C, 1, cos_out, st);
     set_error("rtk_adjacent_cosine: unsupported dtype %d", dtype);
     return RTK_EINVAL;
 }
@@ -550,12 +584,15 @@ extern "C" int rtk_mallm_merge(const void* x, const void* sizes, const int64_t* 
     RTK_CHECK_ARG(x && idx && out, "rtk_mallm_merge: NULL pointer");
     RTK_CHECK_ARG(hard || (sizes && sizes_out), "rtk_mallm_merge: the soft merge needs sizes and sizes_out");
     RTK_CHECK_ARG(T >= 2 && N >= 1 && C >= 1, "rtk_mallm_merge: bad shape T=%d N=%d C=%d", T, N, C);
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_mallm_merge: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_mallm_merge: unsupported dtype %d", dtype);
     const size_t total = (size_t)(T - 1) * N * C;
     const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65535u * 16u);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RTK_BF16)
         RTK_LAUNCH(KID_GATHER, mallm_merge_kernel<RTK_BF16>, dim3(grid), dim3(256), 0, st, x, sizes, idx, T, N, C, hard, out,
+                   sizes_out);
+    else if (dtype == RTK_F16)
+        RTK_LAUNCH(KID_GATHER, mallm_merge_kernel<RTK_F16>, dim3(grid), dim3(256), 0, st, x, sizes, idx, T, N, C, hard, out,
                    sizes_out);
     else
         RTK_LAUNCH(KID_GATHER, mallm_merge_kernel<RTK_F32>, dim3(grid), dim3(256), 0, st, x, sizes, idx, T, N, C, hard, out,
@@ -583,7 +620,7 @@ extern "C" int rtk_gather_frames(const void* x, int T, int N, int C, int dtype, 
                                  void* out, rtk_stream_t stream) {
     RTK_CHECK_ARG(x && idx && out, "rtk_gather_frames: NULL pointer");
     RTK_CHECK_ARG(T >= 1 && N >= 1 && C >= 1 && tgt >= 1, "rtk_gather_frames: bad shape");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_gather_frames: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_gather_frames: unsupported dtype %d", dtype);
     const size_t esize = dtype == RTK_F32 ? 4 : 2;
     const size_t rowbytes = (size_t)C * esize;
     const size_t rows = (size_t)tgt * N;

@@ -505,6 +505,18 @@ template <> struct Row16<RTK_BF16> {
     }
     __device__ static float rnd(float x) { return rbf(x); }
 };
+template <> struct Row16<RTK_F16> {
+    static constexpr int VE = 8;
+    __device__ static void unpack(const u32x4& v, float* f) {
+        f[0] = H16<RTK_F16>::lo(v.x); f[1] = H16<RTK_F16>::hi(v.x); f[2] = H16<RTK_F16>::lo(v.y); f[3] = H16<RTK_F16>::hi(v.y);
+        f[4] = H16<RTK_F16>::lo(v.z); f[5] = H16<RTK_F16>::hi(v.z); f[6] = H16<RTK_F16>::lo(v.w); f[7] = H16<RTK_F16>::hi(v.w);
+    }
+    __device__ static u32x4 pack(const float* f) {
+        return u32x4{H16<RTK_F16>::pack2(f[0], f[1]), H16<RTK_F16>::pack2(f[2], f[3]), H16<RTK_F16>::pack2(f[4], f[5]),
+                     H16<RTK_F16>::pack2(f[6], f[7])};
+    }
+    __device__ static float rnd(float x) { return rhf(x); }
+};
 
 // Two roles in one launch, so neither waits on the other's dependent loads:
 //   blocks [0, append_blocks)   append: every 16-byte chunk of the chunk's K and V rows -> cache tail
@@ -844,9 +856,9 @@ extern "C" int rtk_pivotkv_commit(const void* k_stage, const void* v_stage, int6
                                   rtk_stream_t stream) {
     RTK_CHECK_ARG(k_stage && v_stage && k_dst && v_dst, "rtk_pivotkv_commit: NULL pointer");
     RTK_CHECK_ARG(H >= 1 && rows >= 0 && D >= 1, "rtk_pivotkv_commit: bad shape");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_commit: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_pivotkv_commit: unsupported dtype %d", dtype);
     if (rows == 0) return RTK_OK;
-    const size_t es = dtype == RTK_BF16 ? 2 : 4;
+    const size_t es = dtype != RTK_F32 ? 2 : 4;
     const size_t blk = (size_t)rows * D * es;
     if (blk % 16 || (stage_stride_h * es) % 16 || (dst_stride_h * es) % 16 ||
         (((uintptr_t)k_stage | (uintptr_t)v_stage | (uintptr_t)k_dst | (uintptr_t)v_dst) & 15)) {
@@ -999,12 +1011,12 @@ extern "C" int rtk_pivotkv_evict(const void* k, int64_t k_stride_h, int64_t k_st
                                  void* v_kept, int64_t kept_stride_h, rtk_stream_t stream) {
     RTK_CHECK_ARG(k && v && keep_idx && k_kept && v_kept, "rtk_pivotkv_evict: NULL pointer");
     RTK_CHECK_ARG(Hkv >= 1 && L >= 1 && keep >= 1 && keep <= L, "rtk_pivotkv_evict: bad shape");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_evict: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_pivotkv_evict: unsupported dtype %d", dtype);
     RTK_CHECK_ARG((cos_new == nullptr) == (sin_new == nullptr), "rtk_pivotkv_evict: cos_new and sin_new go together");
     RTK_CHECK_ARG(!cos_new || k_unrot, "rtk_pivotkv_evict: reforge needs k_unrot");
     RTK_CHECK_ARG((k_tail == nullptr) == (v_tail == nullptr), "rtk_pivotkv_evict: k_tail and v_tail go together");
-    const int ve = dtype == RTK_BF16 ? 8 : 4;
-    const int es = dtype == RTK_BF16 ? 2 : 4;
+    const int ve = dtype != RTK_F32 ? 8 : 4;
+    const int es = dtype != RTK_F32 ? 2 : 4;
     if (D % (2 * ve) != 0) {
         set_error("rtk_pivotkv_evict: head_dim %d must be a multiple of %d for this dtype", D, 2 * ve);
         return RTK_EUNSUPPORTED;
@@ -1027,6 +1039,11 @@ extern "C" int rtk_pivotkv_evict(const void* k, int64_t k_stride_h, int64_t k_st
                    (const char*)k, k_stride_h, k_stride_l, (const char*)v, v_stride_h, v_stride_l, (const char*)k_unrot,
                    Hkv, L, D, keep_idx, keep, cos_new, sin_new, (char*)k_tail, (char*)v_tail, tail_stride_h,
                    (char*)k_kept, (char*)v_kept, kept_stride_h, (int)append_blocks);
+    else if (dtype == RTK_F16)
+        RTK_LAUNCH(KID_EVICT, evict_scan_kernel<RTK_F16>, dim3(append_blocks + kept_blocks), dim3(256), 0, st,
+                   (const char*)k, k_stride_h, k_stride_l, (const char*)v, v_stride_h, v_stride_l, (const char*)k_unrot,
+                   Hkv, L, D, keep_idx, keep, cos_new, sin_new, (char*)k_tail, (char*)v_tail, tail_stride_h,
+                   (char*)k_kept, (char*)v_kept, kept_stride_h, (int)append_blocks);
     else
         RTK_LAUNCH(KID_EVICT, evict_scan_kernel<RTK_F32>, dim3(append_blocks + kept_blocks), dim3(256), 0, st,
                    (const char*)k, k_stride_h, k_stride_l, (const char*)v, v_stride_h, v_stride_l, (const char*)k_unrot,
@@ -1040,9 +1057,9 @@ extern "C" int rtk_copy_rows(const void* src, int64_t src_stride_h, void* dst, i
                              int D, int dtype, rtk_stream_t stream) {
     RTK_CHECK_ARG(src && dst, "rtk_copy_rows: NULL pointer");
     RTK_CHECK_ARG(H >= 1 && rows >= 0 && D >= 1, "rtk_copy_rows: bad shape");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_copy_rows: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_copy_rows: unsupported dtype %d", dtype);
     if (rows == 0) return RTK_OK;
-    const size_t es = dtype == RTK_BF16 ? 2 : 4;
+    const size_t es = dtype != RTK_F32 ? 2 : 4;
     const size_t blk = (size_t)rows * D * es;
     if (blk % 16 || (src_stride_h * es) % 16 || (dst_stride_h * es) % 16 || (((uintptr_t)src | (uintptr_t)dst) & 15)) {
         set_error("rtk_copy_rows: blocks must be 16-byte aligned");
@@ -1061,9 +1078,9 @@ extern "C" int rtk_pivotkv_append(const void* k, int64_t k_stride_h, int64_t k_s
                                   void* k_tail, void* v_tail, int64_t tail_stride_h, rtk_stream_t stream) {
     RTK_CHECK_ARG(k && v && k_tail && v_tail, "rtk_pivotkv_append: NULL pointer");
     RTK_CHECK_ARG(Hkv >= 1 && L >= 1 && D >= 1, "rtk_pivotkv_append: bad shape");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_append: unsupported dtype %d", dtype);
-    const int ve = dtype == RTK_BF16 ? 8 : 4;
-    const int es = dtype == RTK_BF16 ? 2 : 4;
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_pivotkv_append: unsupported dtype %d", dtype);
+    const int ve = dtype != RTK_F32 ? 8 : 4;
+    const int es = dtype != RTK_F32 ? 2 : 4;
     const bool aligned = D % ve == 0 && (k_stride_h * es) % 16 == 0 && (k_stride_l * es) % 16 == 0 &&
                          (v_stride_h * es) % 16 == 0 && (v_stride_l * es) % 16 == 0 && (tail_stride_h * es) % 16 == 0 &&
                          (((uintptr_t)k | (uintptr_t)v | (uintptr_t)k_tail | (uintptr_t)v_tail) & 15) == 0;
@@ -1074,7 +1091,7 @@ extern "C" int rtk_pivotkv_append(const void* k, int64_t k_stride_h, int64_t k_s
     const size_t chunks = (size_t)Hkv * L * (D / ve);
     const unsigned grid = (unsigned)std::min<size_t>((chunks + 4 * 256 - 1) / (4 * 256), 4096);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == RTK_BF16)
+    if (dtype != RTK_F32)   // a pure copy: the 2-byte instantiation serves both 16-bit formats
         RTK_LAUNCH(KID_APPEND, append_kernel<RTK_BF16>, dim3(grid), dim3(256), 0, st, (const char*)k, k_stride_h,
                    k_stride_l, (const char*)v, v_stride_h, v_stride_l, Hkv, L, D, (char*)k_tail, (char*)v_tail,
                    tail_stride_h);
@@ -1095,10 +1112,10 @@ static int evict_batched_impl(const rtk_evict_unit* units, int n_units, int Hkv,
     else for (int d = 0; d < 256; ++d) rs.row[d] = 0;
     RTK_CHECK_ARG(units && n_units >= 1, "rtk_pivotkv_evict_batched: no units");
     RTK_CHECK_ARG(Hkv >= 1 && keep >= 1 && D >= 2, "rtk_pivotkv_evict_batched: bad shape");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_evict_batched: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_pivotkv_evict_batched: unsupported dtype %d", dtype);
     RTK_CHECK_ARG(P == 0 || P == 1 || P == 3, "rtk_pivotkv_evict_batched: P must be 0, 1 or 3, got %d", P);
-    const int ve = dtype == RTK_BF16 ? 8 : 4;
-    const int es = dtype == RTK_BF16 ? 2 : 4;
+    const int ve = dtype != RTK_F32 ? 8 : 4;
+    const int es = dtype != RTK_F32 ? 2 : 4;
     if (D % (2 * ve) != 0) {
         set_error("rtk_pivotkv_evict_batched: head_dim %d must be a multiple of %d for this dtype", D, 2 * ve);
         return RTK_EUNSUPPORTED;
@@ -1133,6 +1150,9 @@ static int evict_batched_impl(const rtk_evict_unit* units, int n_units, int Hkv,
         if (dtype == RTK_BF16) {
             if (native) RTK_EVB(RTK_BF16, 4, true);
             else RTK_EVB(RTK_BF16, 4, false);
+        } else if (dtype == RTK_F16) {
+            if (native) RTK_EVB(RTK_F16, 4, true);
+            else RTK_EVB(RTK_F16, 4, false);
         } else {
             if (native) RTK_EVB(RTK_F32, 2, true);
             else RTK_EVB(RTK_F32, 2, false);
@@ -1165,8 +1185,8 @@ extern "C" int rtk_pivotkv_place_batched(const rtk_place_unit* units, int n_unit
                                          rtk_stream_t stream) {
     RTK_CHECK_ARG(units && n_units >= 1, "rtk_pivotkv_place_batched: no units");
     RTK_CHECK_ARG(H >= 1 && keep >= 1 && D >= 1, "rtk_pivotkv_place_batched: bad shape");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_place_batched: unsupported dtype %d", dtype);
-    const size_t row = (size_t)D * (dtype == RTK_BF16 ? 2 : 4);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_pivotkv_place_batched: unsupported dtype %d", dtype);
+    const size_t row = (size_t)D * (dtype != RTK_F32 ? 2 : 4);
     for (int i = 0; i < n_units; ++i) {
         const rtk_place_unit& u = units[i];
         RTK_CHECK_ARG(u.stage && u.tail && u.keep_idx, "rtk_pivotkv_place_batched: unit %d: NULL pointer", i);
@@ -1193,9 +1213,9 @@ extern "C" int rtk_pivotkv_commit_batched(const rtk_copy_unit* units, int n_unit
                                           rtk_stream_t stream) {
     RTK_CHECK_ARG(units && n_units >= 1, "rtk_pivotkv_commit_batched: no units");
     RTK_CHECK_ARG(H >= 1 && rows >= 0 && D >= 1, "rtk_pivotkv_commit_batched: bad shape");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_pivotkv_commit_batched: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_pivotkv_commit_batched: unsupported dtype %d", dtype);
     if (rows == 0) return RTK_OK;
-    const size_t es = dtype == RTK_BF16 ? 2 : 4;
+    const size_t es = dtype != RTK_F32 ? 2 : 4;
     const size_t blk = (size_t)rows * D * es;
     for (int i = 0; i < n_units; ++i) {
         const rtk_copy_unit& u = units[i];

@@ -74,6 +74,18 @@ template <> struct Vec16<RTK_BF16> {
     }
 };
 
+template <> struct Vec16<RTK_F16> {
+    static constexpr int VE = 8;
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+        f[0] = H16<RTK_F16>::lo(v.x); f[1] = H16<RTK_F16>::hi(v.x); f[2] = H16<RTK_F16>::lo(v.y); f[3] = H16<RTK_F16>::hi(v.y);
+        f[4] = H16<RTK_F16>::lo(v.z); f[5] = H16<RTK_F16>::hi(v.z); f[6] = H16<RTK_F16>::lo(v.w); f[7] = H16<RTK_F16>::hi(v.w);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        return u32x4{H16<RTK_F16>::pack2(f[0], f[1]), H16<RTK_F16>::pack2(f[2], f[3]), H16<RTK_F16>::pack2(f[4], f[5]),
+                     H16<RTK_F16>::pack2(f[6], f[7])};
+    }
+};
+
 constexpr int UNROT_HEADS = 7;
 
 // bf16 pairs through the hardware converter (v_cvt_pk_bf16_f32: round to nearest even, like c10::BFloat16)
@@ -177,25 +189,26 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
         }
         // rotate_half(x)[d] = -x2, rotate_half(x)[d+h2] = x1   (longvideo_cache.py:28-32)
         // x~ = ((x*cos) - (rotate_half(x)*sin)) / a^2, one rounding per torch op (:76-78)
-        if constexpr (DT == RTK_BF16) {
+        if constexpr (DT != RTK_F32) {   // bf16 / fp16: every torch op rounds to the tensor dtype
+            using Hh = H16<DT>;
             const uint32_t wl[4] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w}, wh[4] = {hi[u].x, hi[u].y, hi[u].z, hi[u].w};
             uint32_t r1[4], r2[4];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const float x1a = bf_lo(wl[w]), x1b = bf_hi(wl[w]), x2a = bf_lo(wh[w]), x2b = bf_hi(wh[w]);
+                const float x1a = Hh::lo(wl[w]), x1b = Hh::hi(wl[w]), x2a = Hh::lo(wh[w]), x2b = Hh::hi(wh[w]);
                 const int e = 2 * w;
-                const uint32_t p1 = pack2_bf16(x1a * c1[e], x1b * c1[e + 1]);          // x1*cos
-                const uint32_t n1 = pack2_bf16(x2a * s1[e], x2b * s1[e + 1]);          // -(rotate_half(x)*sin) = x2*sin
-                const uint32_t p2 = pack2_bf16(x2a * c2[e], x2b * c2[e + 1]);          // x2*cos
-                const uint32_t n2 = pack2_bf16(x1a * s2[e], x1b * s2[e + 1]);          // rotate_half(x)*sin = x1*sin
-                uint32_t t1 = pack2_bf16(bf_lo(p1) + bf_lo(n1), bf_hi(p1) + bf_hi(n1));
-                uint32_t t2 = pack2_bf16(bf_lo(p2) - bf_lo(n2), bf_hi(p2) - bf_hi(n2));
+                const uint32_t p1 = Hh::pack2(x1a * c1[e], x1b * c1[e + 1]);          // x1*cos
+                const uint32_t n1 = Hh::pack2(x2a * s1[e], x2b * s1[e + 1]);          // -(rotate_half(x)*sin) = x2*sin
+                const uint32_t p2 = Hh::pack2(x2a * c2[e], x2b * c2[e + 1]);          // x2*cos
+                const uint32_t n2 = Hh::pack2(x1a * s2[e], x1b * s2[e + 1]);          // rotate_half(x)*sin = x1*sin
+                uint32_t t1 = Hh::pack2(Hh::lo(p1) + Hh::lo(n1), Hh::hi(p1) + Hh::hi(n1));
+                uint32_t t2 = Hh::pack2(Hh::lo(p2) - Hh::lo(n2), Hh::hi(p2) - Hh::hi(n2));
                 if constexpr (DIV == 1) {
-                    t1 = pack2_bf16(bf_lo(t1) * rcp_a2, bf_hi(t1) * rcp_a2);
-                    t2 = pack2_bf16(bf_lo(t2) * rcp_a2, bf_hi(t2) * rcp_a2);
+                    t1 = Hh::pack2(Hh::lo(t1) * rcp_a2, Hh::hi(t1) * rcp_a2);
+                    t2 = Hh::pack2(Hh::lo(t2) * rcp_a2, Hh::hi(t2) * rcp_a2);
                 } else if constexpr (DIV == 2) {
-                    t1 = pack2_bf16(__fdiv_rn(bf_lo(t1), a2), __fdiv_rn(bf_hi(t1), a2));
-                    t2 = pack2_bf16(__fdiv_rn(bf_lo(t2), a2), __fdiv_rn(bf_hi(t2), a2));
+                    t1 = Hh::pack2(__fdiv_rn(Hh::lo(t1), a2), __fdiv_rn(Hh::hi(t1), a2));
+                    t2 = Hh::pack2(__fdiv_rn(Hh::lo(t2), a2), __fdiv_rn(Hh::hi(t2), a2));
                 }
                 r1[w] = t1;
                 r2[w] = t2;
@@ -292,25 +305,26 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
     rope_chunk<VE>(inv_freq, rs, d, h2, pid, scaling, round_bf16, c1, s1, c2, s2);
     // x~ = ((x*cos) - (rotate_half(x)*sin)) / a^2 for one head's chunk pair, one rounding per torch op (:76-78)
     auto unrot = [&](const u32x4& lo, const u32x4& hi, u32x4& olo, u32x4& ohi) {
-        if constexpr (DT == RTK_BF16) {
+        if constexpr (DT != RTK_F32) {
+            using Hh = H16<DT>;
             const uint32_t wl[4] = {lo.x, lo.y, lo.z, lo.w}, wh[4] = {hi.x, hi.y, hi.z, hi.w};
             uint32_t r1[4], r2[4];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const float x1a = bf_lo(wl[w]), x1b = bf_hi(wl[w]), x2a = bf_lo(wh[w]), x2b = bf_hi(wh[w]);
+                const float x1a = Hh::lo(wl[w]), x1b = Hh::hi(wl[w]), x2a = Hh::lo(wh[w]), x2b = Hh::hi(wh[w]);
                 const int e = 2 * w;
-                const uint32_t p1 = pack2_bf16(x1a * c1[e], x1b * c1[e + 1]);
-                const uint32_t n1 = pack2_bf16(x2a * s1[e], x2b * s1[e + 1]);
-                const uint32_t p2 = pack2_bf16(x2a * c2[e], x2b * c2[e + 1]);
-                const uint32_t n2 = pack2_bf16(x1a * s2[e], x1b * s2[e + 1]);
-                uint32_t t1 = pack2_bf16(bf_lo(p1) + bf_lo(n1), bf_hi(p1) + bf_hi(n1));
-                uint32_t t2 = pack2_bf16(bf_lo(p2) - bf_lo(n2), bf_hi(p2) - bf_hi(n2));
+                const uint32_t p1 = Hh::pack2(x1a * c1[e], x1b * c1[e + 1]);
+                const uint32_t n1 = Hh::pack2(x2a * s1[e], x2b * s1[e + 1]);
+                const uint32_t p2 = Hh::pack2(x2a * c2[e], x2b * c2[e + 1]);
+                const uint32_t n2 = Hh::pack2(x1a * s2[e], x1b * s2[e + 1]);
+                uint32_t t1 = Hh::pack2(Hh::lo(p1) + Hh::lo(n1), Hh::hi(p1) + Hh::hi(n1));
+                uint32_t t2 = Hh::pack2(Hh::lo(p2) - Hh::lo(n2), Hh::hi(p2) - Hh::hi(n2));
                 if constexpr (DIV == 1) {
-                    t1 = pack2_bf16(bf_lo(t1) * rcp_a2, bf_hi(t1) * rcp_a2);
-                    t2 = pack2_bf16(bf_lo(t2) * rcp_a2, bf_hi(t2) * rcp_a2);
+                    t1 = Hh::pack2(Hh::lo(t1) * rcp_a2, Hh::hi(t1) * rcp_a2);
+                    t2 = Hh::pack2(Hh::lo(t2) * rcp_a2, Hh::hi(t2) * rcp_a2);
                 } else if constexpr (DIV == 2) {
-                    t1 = pack2_bf16(__fdiv_rn(bf_lo(t1), a2), __fdiv_rn(bf_hi(t1), a2));
-                    t2 = pack2_bf16(__fdiv_rn(bf_lo(t2), a2), __fdiv_rn(bf_hi(t2), a2));
+                    t1 = Hh::pack2(__fdiv_rn(Hh::lo(t1), a2), __fdiv_rn(Hh::hi(t1), a2));
+                    t2 = Hh::pack2(__fdiv_rn(Hh::lo(t2), a2), __fdiv_rn(Hh::hi(t2), a2));
                 }
                 r1[w] = t1;
                 r2[w] = t2;
@@ -405,9 +419,9 @@ __global__ __launch_bounds__(256) void unrotate_pack_kernel(const void* __restri
         const size_t src = (size_t)h * stride_h + (size_t)l * stride_l;
         const size_t dst = hl * D;
         float x1, x2;
-        if (DT == RTK_BF16) {
-            x1 = bf2f(((const uint16_t*)xv)[src + d]);
-            x2 = bf2f(((const uint16_t*)xv)[src + d + h2]);
+        if constexpr (DT != RTK_F32) {
+            x1 = H16<DT>::ld(xv, src + d);
+            x2 = H16<DT>::ld(xv, src + d + h2);
         } else {
             x1 = ((const float*)xv)[src + d];
             x2 = ((const float*)xv)[src + d + h2];
@@ -416,17 +430,18 @@ __global__ __launch_bounds__(256) void unrotate_pack_kernel(const void* __restri
         if (cosv) {
             const float c1 = cosv[(size_t)l * D + d], s1 = sinv[(size_t)l * D + d];
             const float c2 = cosv[(size_t)l * D + d + h2], s2 = sinv[(size_t)l * D + d + h2];
-            if (DT == RTK_BF16) {
-                o1 = rbf(rbf(rbf(x1 * c1) - rbf(-x2 * s1)) / a2);
-                o2 = rbf(rbf(rbf(x2 * c2) - rbf(x1 * s2)) / a2);
+            if constexpr (DT != RTK_F32) {
+                using Hh = H16<DT>;
+                o1 = Hh::rnd(Hh::rnd(Hh::rnd(x1 * c1) - Hh::rnd(-x2 * s1)) / a2);
+                o2 = Hh::rnd(Hh::rnd(Hh::rnd(x2 * c2) - Hh::rnd(x1 * s2)) / a2);
             } else {
                 o1 = __fdiv_rn(__fsub_rn(__fmul_rn(x1, c1), __fmul_rn(-x2, s1)), a2);
                 o2 = __fdiv_rn(__fsub_rn(__fmul_rn(x2, c2), __fmul_rn(x1, s2)), a2);
             }
         }
-        if (DT == RTK_BF16) {
-            ((uint16_t*)outv)[dst + d] = f2bf(o1);
-            ((uint16_t*)outv)[dst + d + h2] = f2bf(o2);
+        if constexpr (DT != RTK_F32) {
+            H16<DT>::st(outv, dst + d, o1);
+            H16<DT>::st(outv, dst + d + h2, o2);
         } else {
             ((float*)outv)[dst + d] = o1;
             ((float*)outv)[dst + d + h2] = o2;
@@ -1174,7 +1189,7 @@ __global__ __launch_bounds__(1024) void key_compact_kernel(KeyMasks masks, int L
 // NB = 32-key register blocks per wave (NB = 2: every A fragment read from LDS feeds two MFMAs).
 // ------------------------------------------------------------------------------------------------
 // The work of one workgroup: NB x 32 keys per wave starting at key j_base + wid * 32 * NB, the query rows of split rs.
-template <int NB, bool FAST = false>
+template <int NB, bool FAST = false, bool F16 = false>   // F16: exact softmax on fp16 payloads (RTK_F16)
 __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q, const char* __restrict__ k,
                                                      const float* __restrict__ lse, int Hq, int Hkv, int L,
                                                      int rows_per_split, int RS, float* __restrict__ partial, int j_base,
@@ -1293,6 +1308,7 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
                 _Pragma("unroll")                                                                         \
                 for (int nb = 0; nb < NB; ++nb) {                                                         \
                     if constexpr (FAST) mma16<true>(acc[nb], a[r], kf[nb][r], r == 0 ? lsv : acc[nb]);   \
+                    else if constexpr (F16) mma16<true>(acc[nb], a[r], kf[nb][r], acc[nb]);               \
                     else M::mma(acc[nb], a[r], kf[nb][r]);                                                \
                     __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);            \
                 }                                                                                         \
@@ -1354,7 +1370,7 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
 // REG_ROWS * NB keys (4 waves x NB x 32).  When the LAST tile holds at most half of that (L = 6272 = 24.5 tiles of 256),
 // its workgroups run the one-block body on 32 keys per wave instead of leaving two of four waves without a key: the
 // tile costs half the MFMAs (2 % of the launch's arithmetic was spent on keys past L).
-template <int NB, bool FAST = false>
+template <int NB, bool FAST = false, bool F16 = false>
 __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 2 : 2)))) void score_pass2_dma_kernel(
     const char* __restrict__ q, const char* __restrict__ k, const float* __restrict__ lse, int Hq, int Hkv, int L,
     int rows_per_split, int col_tiles, int RS, int xcd_remap, float* __restrict__ partial, size_t q_unit_bytes,
@@ -1392,11 +1408,11 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
     if (j_base >= Lk) return;
     if constexpr (NB == 2) {
         if (Lk - j_base <= REG_ROWS) {   // uniform per workgroup
-            score_pass2_dma_body<1, FAST>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk);
+            score_pass2_dma_body<1, FAST, F16>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk);
             return;
         }
     }
-    score_pass2_dma_body<NB, FAST>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk);
+    score_pass2_dma_body<NB, FAST, F16>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1405,7 +1421,8 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
 // 32-key block in flight per wave (~100 VGPRs -> 4 waves per SIMD).
 // ------------------------------------------------------------------------------------------------
 // The work of one workgroup: NB x 32 query rows of head h per wave starting at row i_base + wid * 32 * NB, key split ks.
-// MODE: 0 = exact bf16 (RowStatB), 1 = RTK_BF16_FAST production form (RowStatR), 2 = RTK_BF16_FAST fix-up (RowStatF)
+// MODE: 0 = exact bf16 (RowStatB), 1 = RTK_BF16_FAST production form (RowStatR), 2 = RTK_BF16_FAST fix-up (RowStatF),
+//       3 = exact on fp16 payloads (RTK_F16: RowStatB, the fp16 matrix instruction)
 template <int NB, bool LAZY, int MODE = 0>
 __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv,
                                                      int L, int keys_per_split, float* __restrict__ lse_part, int i_base, int h,
@@ -1437,7 +1454,7 @@ __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q,
         for (int r = 0; r < M::NREG; ++r) frag_off[r] = row * T::ROWB + ((M::chunk_of(r, hf) ^ (row & 15)) * 16);
     }
     const float c2 = 1.4426950408889634f / sqrtf((float)HD);
-    constexpr bool FAST = MODE != 0;
+    constexpr bool FAST = MODE == 1 || MODE == 2;
     using Stat = std::conditional_t<MODE == 1, RowStatR, std::conditional_t<MODE == 2, RowStatF, RowStatB>>;
     Stat rs[NB];
     bool primed[NB];       // MODE 2: has this wave re-based its rows yet?  (wave-uniform)
@@ -1486,7 +1503,7 @@ __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q,
             for (int r = 0; r < M::NREG; ++r) {                                                           \
                 _Pragma("unroll")                                                                         \
                 for (int nb = 0; nb < NB; ++nb) {                                                         \
-                    if constexpr (FAST) mma16<true>(acc[nb], a[r], qf[nb][r], acc[nb]);                   \
+                    if constexpr (FAST || MODE == 3) mma16<true>(acc[nb], a[r], qf[nb][r], acc[nb]);      \
                     else M::mma(acc[nb], a[r], qf[nb][r]);                                                \
                     __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);            \
                 }                                                                                         \
@@ -1609,7 +1626,8 @@ namespace rtk {
 // ------------------------------------------------------------------------------------------------
 template <int DT>
 __device__ __forceinline__ float ldx(const void* p, size_t i) {
-    return DT == RTK_BF16 ? bf2f(((const uint16_t*)p)[i]) : ((const float*)p)[i];
+    if constexpr (DT != RTK_F32) return H16<DT>::ld(p, i);
+    else return ((const float*)p)[i];
 }
 
 template <int DT>
@@ -1762,6 +1780,7 @@ struct ScoreWs {
     int RS, KS;
     bool ref;   // RTK_BF16_REFROUND: row statistics are (max, sum) pairs, column partials are per head
     bool fast;  // RTK_BF16_FAST: q~ (pre-scaled) and a second copy of k~ (at k_off) are fp16
+    bool h16;   // RTK_F16: fp16 payloads (un-rotation rounds to fp16, the passes use the fp16 matrix instruction)
 };
 static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
     const size_t es = dtype == RTK_F32 ? 4 : 2;
@@ -1769,6 +1788,7 @@ static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
     ScoreWs w;
     w.ref = dtype == RTK_BF16_REFROUND;
     w.fast = dtype == RTK_BF16_FAST;
+    w.h16 = dtype == RTK_F16;
     const int nbr = REG_ROWS;
     const int reg_tiles = (L + nbr - 1) / nbr, stream_tiles = (L + TILE_ROWS - 1) / TILE_ROWS;
     w.RS = (D == HD) ? pick_splits(reg_tiles, Hkv, stream_tiles, 32, Hkv) : 1;
@@ -1828,6 +1848,15 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
             const float rcp = 1.0f / a2;
             bool done = false;
             if constexpr (DT == RTK_BF16) {
+                if (w.h16) {   // fp16 payloads: the same chain rounded to fp16, IEEE division
+#define RTK_UNROT_H(DIV)                                                                                           \
+    RTK_LAUNCH(KID_UNROT, (unrotate_pack_vec_kernel<RTK_F16, DIV>), grid, dim3(256), 0, st, (const char*)q, qsh, qsl, \
+               (const char*)k, ksh, ksl, Hq, Hkv, L, D, cosv, sinv, a2, rcp, qt, kt)
+                    if (!cosv || a2 == 1.0f) RTK_UNROT_H(0);
+                    else RTK_UNROT_H(2);
+#undef RTK_UNROT_H
+                    done = true;
+                }
                 if (w.fast) {   // q~ -> fp16(q~ * log2(e)/sqrt(D)); k~ -> bf16 (only if the caller wants it) + fp16 at k_off
                     const float qscale = 1.4426950408889634f / sqrtf((float)HD);
 #define RTK_UNROT_F(DIV)                                                                                           \
@@ -1850,10 +1879,14 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
 #undef RTK_UNROT
         } else {
             const size_t nq = (size_t)Hq * L * (D / 2), nk = (size_t)Hkv * L * (D / 2);
-            RTK_LAUNCH(KID_UNROT, unrotate_pack_kernel<DT>, dim3((unsigned)std::min<size_t>((nq + 255) / 256, 8192)),
-                       dim3(256), 0, st, q, qsh, qsl, Hq, L, D, cosv, sinv, a2, (void*)qt);
-            RTK_LAUNCH(KID_UNROT, unrotate_pack_kernel<DT>, dim3((unsigned)std::min<size_t>((nk + 255) / 256, 8192)),
-                       dim3(256), 0, st, k, ksh, ksl, Hkv, L, D, cosv, sinv, a2, (void*)kt);
+            const dim3 gq((unsigned)std::min<size_t>((nq + 255) / 256, 8192)), gk((unsigned)std::min<size_t>((nk + 255) / 256, 8192));
+            if (w.h16) {
+                RTK_LAUNCH(KID_UNROT, unrotate_pack_kernel<RTK_F16>, gq, dim3(256), 0, st, q, qsh, qsl, Hq, L, D, cosv, sinv, a2, (void*)qt);
+                RTK_LAUNCH(KID_UNROT, unrotate_pack_kernel<RTK_F16>, gk, dim3(256), 0, st, k, ksh, ksl, Hkv, L, D, cosv, sinv, a2, (void*)kt);
+            } else {
+                RTK_LAUNCH(KID_UNROT, unrotate_pack_kernel<DT>, gq, dim3(256), 0, st, q, qsh, qsl, Hq, L, D, cosv, sinv, a2, (void*)qt);
+                RTK_LAUNCH(KID_UNROT, unrotate_pack_kernel<DT>, gk, dim3(256), 0, st, k, ksh, ksl, Hkv, L, D, cosv, sinv, a2, (void*)kt);
+            }
         }
         RTK_LAUNCH_CHECK("unrotate_pack_kernel");
     }
@@ -1945,7 +1978,11 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                                dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
                                (int)((Hkv * ks_n) % NXCD == 0), lse, ws_stride, k_stride, ws_stride / sizeof(float),
                                (int)(ks_n == 1));
-                } else
+                } else if (w.h16)
+                    RTK_LAUNCH(KID_PASS1, (score_pass1_dma_kernel<RTK_P1_NB, RTK_P1_LAZY, 3>), dim3(Hkv * ks_n * jt1 * G, n_units),
+                               dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
+                               (int)((Hkv * ks_n) % NXCD == 0), lse, ws_stride, k_stride, ws_stride / sizeof(float));
+                else
                 RTK_LAUNCH(KID_PASS1, (score_pass1_dma_kernel<RTK_P1_NB, RTK_P1_LAZY>), dim3(Hkv * ks_n * jt1 * G, n_units),
                            dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
                            (int)((Hkv * ks_n) % NXCD == 0), lse, ws_stride, k_stride, ws_stride / sizeof(float));
@@ -1966,6 +2003,11 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                                (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n,
                                (int)((Hkv * rs_n) % NXCD == 0), part, ws_stride, k_stride, ws_stride / sizeof(float),
                                part_stride, key_index);
+                else if (w.h16)
+                    RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<RTK_P2_NB, false, true>), dim3(Hkv * rs_n * jt2, n_units), dim3(SC_BLOCK), LDS2, st,
+                               (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n,
+                               (int)((Hkv * rs_n) % NXCD == 0), part, ws_stride, k_stride, ws_stride / sizeof(float),
+                               part_stride, key_index);
                 else
                 RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<RTK_P2_NB>), dim3(Hkv * rs_n * jt2, n_units), dim3(SC_BLOCK), LDS2, st,
                            (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n,
@@ -1979,10 +2021,17 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
             RTK_LAUNCH_CHECK("score_pass2_kernel");
         }
     } else if (stages & RTK_SCORE_PASSES) {
+        if (w.h16) {
+            RTK_LAUNCH(KID_PASS1, score_pass1_generic<RTK_F16>, dim3(L, Hq), dim3(256), D * sizeof(float), st, (const void*)qt,
+                               (const void*)kt, Hq, Hkv, L, D, lse);
+            RTK_LAUNCH(KID_PASS2, score_pass2_generic<RTK_F16>, dim3((L + 255) / 256, Hkv), dim3(256), D * sizeof(float), st,
+                               (const void*)qt, (const void*)kt, lse, Hq, Hkv, L, D, part);
+        } else {
         RTK_LAUNCH(KID_PASS1, score_pass1_generic<DT>, dim3(L, Hq), dim3(256), D * sizeof(float), st, (const void*)qt,
                            (const void*)kt, Hq, Hkv, L, D, lse);
         RTK_LAUNCH(KID_PASS2, score_pass2_generic<DT>, dim3((L + 255) / 256, Hkv), dim3(256), D * sizeof(float), st,
                            (const void*)qt, (const void*)kt, lse, Hq, Hkv, L, D, part);
+        }
         RTK_LAUNCH_CHECK("score_generic");
     }
     if (stages & RTK_SCORE_FINALIZE) {
@@ -2004,7 +2053,7 @@ extern "C" int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspa
                   "rtk_pivotkv_score_passes_batched: workspaces must be 256-byte aligned");
     const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
     RTK_CHECK_ARG(n_units == 1 || workspace_stride >= w.total, "rtk_pivotkv_score_passes_batched: workspace stride too small");
-    if ((dtype != RTK_BF16 && dtype != RTK_BF16_REFROUND && dtype != RTK_BF16_FAST) || D != HD) {
+    if ((dtype != RTK_BF16 && dtype != RTK_BF16_REFROUND && dtype != RTK_BF16_FAST && dtype != RTK_F16) || D != HD) {
         set_error("rtk_pivotkv_score_passes_batched: bf16 with head_dim %d only (call RTK_SCORE_PASSES per unit)", HD);
         return RTK_EUNSUPPORTED;
     }
@@ -2080,8 +2129,8 @@ static int score_stages_impl(const void* q, int64_t q_stride_h, int64_t q_stride
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0, "rtk_pivotkv_score: Hq=%d must be a multiple of Hkv=%d", Hq, Hkv);
     RTK_CHECK_ARG(L >= 1 && D >= 2 && D % 2 == 0, "rtk_pivotkv_score: bad shape L=%d D=%d", L, D);
     RTK_CHECK_ARG((cosv == nullptr) == (sinv == nullptr), "rtk_pivotkv_score: cos and sin must both be given or both NULL");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_BF16_REFROUND || dtype == RTK_BF16_FAST,
-                  "rtk_pivotkv_score: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_BF16_REFROUND || dtype == RTK_BF16_FAST ||
+                      dtype == RTK_F16, "rtk_pivotkv_score: unsupported dtype %d", dtype);
     RTK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "rtk_pivotkv_score: workspace must be 256-byte aligned");
     RTK_CHECK_ARG(stages > 0 && stages <= 7, "rtk_pivotkv_score: stages mask %d out of range", stages);
     const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
@@ -2166,7 +2215,8 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
                                    int64_t* pos_copy, rtk_stream_t stream) {
     RTK_CHECK_ARG(q && k && v && pos && inv_freq && k_unrot && workspace && k_tail && v_tail, "rtk_pivotkv_prepare: NULL pointer");
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && L >= 1 && D >= 2, "rtk_pivotkv_prepare: bad shape");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_BF16_FAST, "rtk_pivotkv_prepare: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_BF16_FAST || dtype == RTK_F16,
+                  "rtk_pivotkv_prepare: unsupported dtype %d", dtype);
     RTK_CHECK_ARG(pos_stride >= L, "rtk_pivotkv_prepare: pos_stride %lld < L %d", (long long)pos_stride, L);
     const bool fast = dtype == RTK_BF16_FAST;
     if (fast && D != HD) {
@@ -2193,6 +2243,10 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
     if (rc) return rc;
     char* qt = (char*)workspace + w.q_off;
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == RTK_F16)
+        return prepare_impl<RTK_F16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv, L,
+                                     D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot, k_tail,
+                                     v_tail, tail_stride_h, P, pos_copy, st);
     if (dtype != RTK_F32)
         return prepare_impl<RTK_BF16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv,
                                       L, D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot,

@@ -13,9 +13,9 @@ __global__ __launch_bounds__(256) void rope_merge_kernel(const void* __restrict_
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int d = (int)(i % D);
         const size_t src = (size_t)rs.row[d] * n + i;
-        if (DT == RTK_BF16) {
-            cos_out[i] = bf2f(((const uint16_t*)cin)[src]);
-            sin_out[i] = bf2f(((const uint16_t*)sin_)[src]);
+        if constexpr (DT != RTK_F32) {
+            cos_out[i] = H16<DT>::ld(cin, src);
+            sin_out[i] = H16<DT>::ld(sin_, src);
         } else {
             cos_out[i] = ((const float*)cin)[src];
             sin_out[i] = ((const float*)sin_)[src];
@@ -38,10 +38,8 @@ __global__ __launch_bounds__(256) void rope_table_kernel(const int64_t* __restri
         sincos_cr(ang, s, c);
         c *= scaling;
         s *= scaling;
-        if (round_bf16) {
-            c = rbf(c);
-            s = rbf(s);
-        }
+        c = round_to(c, round_bf16);   // 0 = fp32 tables, 1 = bf16, 2 = fp16
+        s = round_to(s, round_bf16);
         cos_out[i] = c;
         sin_out[i] = s;
     }
@@ -67,17 +65,17 @@ __global__ __launch_bounds__(256) void rope_shift_kernel(void* __restrict__ kv, 
         float s, c;
         sincos_cr(dl * inv_freq[d], s, c);
         float x1, x2;
-        if (DT == RTK_BF16) {
-            x1 = bf2f(((uint16_t*)kv)[off + d]);
-            x2 = bf2f(((uint16_t*)kv)[off + d + h2]);
+        if constexpr (DT != RTK_F32) {
+            x1 = H16<DT>::ld(kv, off + d);
+            x2 = H16<DT>::ld(kv, off + d + h2);
         } else {
             x1 = ((float*)kv)[off + d];
             x2 = ((float*)kv)[off + d + h2];
         }
         const float o1 = x1 * c - x2 * s, o2 = x2 * c + x1 * s;
-        if (DT == RTK_BF16) {
-            ((uint16_t*)kv)[off + d] = f2bf(o1);
-            ((uint16_t*)kv)[off + d + h2] = f2bf(o2);
+        if constexpr (DT != RTK_F32) {
+            H16<DT>::st(kv, off + d, o1);
+            H16<DT>::st(kv, off + d + h2, o2);
         } else {
             ((float*)kv)[off + d] = o1;
             ((float*)kv)[off + d + h2] = o2;
@@ -127,7 +125,7 @@ extern "C" int rtk_rope_shift(void* k, int64_t stride_h, int H, int n, int D, in
                               const float* inv_freq, int P, const int* sections_host, int nsec, rtk_stream_t stream) {
     RTK_CHECK_ARG(k && delta_dev && inv_freq, "rtk_rope_shift: NULL pointer");
     RTK_CHECK_ARG(H >= 1 && n >= 0 && D >= 2, "rtk_rope_shift: bad shape");
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_rope_shift: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_rope_shift: unsupported dtype %d", dtype);
     if (n == 0) return RTK_OK;
     RowSel rs;
     int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_rope_shift");
@@ -136,6 +134,9 @@ extern "C" int rtk_rope_shift(void* k, int64_t stride_h, int H, int n, int D, in
     const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 8192);
     if (dtype == RTK_BF16)
         RTK_LAUNCH(KID_ROPE, rope_shift_kernel<RTK_BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k, stride_h, H, n,
+                   D, delta_dev, inv_freq, rs);
+    else if (dtype == RTK_F16)
+        RTK_LAUNCH(KID_ROPE, rope_shift_kernel<RTK_F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k, stride_h, H, n,
                    D, delta_dev, inv_freq, rs);
     else
         RTK_LAUNCH(KID_ROPE, rope_shift_kernel<RTK_F32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k, stride_h, H, n,
@@ -149,13 +150,16 @@ extern "C" int rtk_rope_merge(const void* cos_in, const void* sin_in, int P, int
                               rtk_stream_t stream) {
     RTK_CHECK_ARG(cos_in && sin_in && cos_out && sin_out, "rtk_rope_merge: NULL pointer");
     RTK_CHECK_ARG(L >= 1 && D >= 2, "rtk_rope_merge: bad shape L=%d D=%d", L, D);
-    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16, "rtk_rope_merge: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_rope_merge: unsupported dtype %d", dtype);
     RowSel rs;
     int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_rope_merge");
     if (rc) return rc;
     const unsigned grid = (unsigned)std::min<size_t>(((size_t)L * D + 255) / 256, 4096);
     if (dtype == RTK_BF16)
         RTK_LAUNCH(KID_ROPE, rope_merge_kernel<RTK_BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, cos_in, sin_in, L,
+                           D, rs, cos_out, sin_out);
+    else if (dtype == RTK_F16)
+        RTK_LAUNCH(KID_ROPE, rope_merge_kernel<RTK_F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, cos_in, sin_in, L,
                            D, rs, cos_out, sin_out);
     else
         RTK_LAUNCH(KID_ROPE, rope_merge_kernel<RTK_F32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, cos_in, sin_in, L,

@@ -13,9 +13,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
-RTK_F32, RTK_BF16, RTK_BF16_REFROUND, RTK_BF16_FAST = 0, 1, 2, 3
+RTK_F32, RTK_BF16, RTK_BF16_REFROUND, RTK_BF16_FAST, RTK_F16 = 0, 1, 2, 3, 4
 SCORE_PREPARE, SCORE_PASSES, SCORE_FINALIZE = 1, 2, 4
 RTK_EINVAL, RTK_EUNSUPPORTED, RTK_EWORKSPACE, RTK_EHIP, RTK_EREFCRASH = -1, -2, -3, -4, -5
 
@@ -151,7 +151,15 @@ def dtype_code(t: torch.Tensor) -> int:
         return RTK_F32
     if t.dtype == torch.bfloat16:
         return RTK_BF16
-    raise NotImplementedError(f"retake HIP kernels support float32 and bfloat16, got {t.dtype}")
+    if t.dtype == torch.float16:
+        return RTK_F16
+    raise NotImplementedError(f"retake HIP kernels support float32, bfloat16 and float16, got {t.dtype}")
+
+
+def round_mode(dtype: torch.dtype) -> int:
+    """The `round_bf16` argument of the C ABI: which 16-bit format a rotary module's cos / sin tables (and the
+    intermediate results of the model dtype) are rounded to - 0 = none (fp32), 1 = bf16, 2 = fp16."""
+    return 1 if dtype == torch.bfloat16 else (2 if dtype == torch.float16 else 0)
 
 
 def require_device(*tensors: torch.Tensor):

@@ -189,7 +189,7 @@ class _Batch:
         # dtype code of the scoring entry points: bf16 payloads with the reference's bf16 rounding chain, or through the
         # fp16 matrix instruction with pre-scaled queries (score_rounding="fast"), on request
         self.score_dt = ((nv.RTK_BF16_REFROUND if refround else (nv.RTK_BF16_FAST if fast else nv.RTK_BF16))
-                         if dtype == torch.bfloat16 else nv.RTK_F32)
+                         if dtype == torch.bfloat16 else (nv.RTK_F16 if dtype == torch.float16 else nv.RTK_F32))
         self.fast = self.score_dt == nv.RTK_BF16_FAST
         self.Hkv, self.L, self.D, self.dtype, self.device = Hkv, L, D, dtype, device
         self.keep_idx = torch.empty((slots, keep), dtype=torch.int64, device=device)
@@ -211,7 +211,7 @@ class _Batch:
         # one score workspace per slot (q~, lse partials): the matrix passes of all layers run in one launch each
         self.ws_bytes = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, self.score_dt)
         self.ws_stride = (self.ws_bytes + 255) & ~255
-        self.batched_passes = dtype == torch.bfloat16 and D == 128 and L >= 512
+        self.batched_passes = dtype in (torch.bfloat16, torch.float16) and D == 128 and L >= 512
         self.score_ws = torch.empty(slots * self.ws_stride + 256, dtype=torch.uint8, device=device) \
             if self.batched_passes else None
         self.score_ws_base = ((self.score_ws.data_ptr() + 255) & ~255) if self.batched_passes else 0
@@ -555,7 +555,7 @@ class PivotKVCache(DynamicCache):
                 inv = inv.to(device=dev, dtype=torch.float32).contiguous()
             nv.check(nv.lib.rtk_rope_table(nv.ptr(pos2d), pos_ld, P, n, nv.ptr(inv), D,
                                            float(rotary_emb_fn.attention_scaling), sec, nsec,
-                                           int(x_like.dtype == torch.bfloat16), nv.ptr(cos_t), nv.ptr(sin_t), s),
+                                           nv.round_mode(x_like.dtype), nv.ptr(cos_t), nv.ptr(sin_t), s),
                      "rtk_rope_table")
             return
         ids = pos2d.unsqueeze(1) if ndim == 3 else pos2d
@@ -595,7 +595,7 @@ class PivotKVCache(DynamicCache):
         layers, b.pending = b.pending, []
         keep, D, Hkv, P = b.keep, b.D, b.Hkv, b.P
         es = b.v_stage.element_size()
-        dt = nv.RTK_BF16 if b.dtype == torch.bfloat16 else nv.RTK_F32
+        dt = nv.RTK_BF16 if b.dtype == torch.bfloat16 else (nv.RTK_F16 if b.dtype == torch.float16 else nv.RTK_F32)
         with torch.cuda.device(b.device):
             main = torch.cuda.current_stream()
             for l in layers:
@@ -697,7 +697,7 @@ class PivotKVCache(DynamicCache):
                 nv.check(nv.lib.rtk_pivotkv_evict_batched_rope(units, len(layers), Hkv, D, keep, P, dt, nv.ptr(inv),
                                                                float(fn.attention_scaling), sec,
                                                                len(b.mrope_section) if b.mrope_section else 0,
-                                                               int(b.x_like.dtype == torch.bfloat16), 1, s),
+                                                               nv.round_mode(b.x_like.dtype), 1, s),
                          "rtk_pivotkv_evict_batched_rope")
             else:
                 nv.check(nv.lib.rtk_pivotkv_evict_batched(units, len(layers), Hkv, D, keep, P if b.reforge else 0, dt, 1, s),
@@ -885,7 +885,7 @@ class PivotKVCache(DynamicCache):
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
                 nv.ptr(value_states), value_states.stride(1), value_states.stride(2),
                 Hq, Hkv, L, D, batch.score_dt if batch.fast else dt, nv.ptr(pos_in), L, Pn, nv.ptr(inv), a_scale, sec,
-                len(mrope_section) if mrope_section else 0, int(key_states.dtype == torch.bfloat16),
+                len(mrope_section) if mrope_section else 0, nv.round_mode(key_states.dtype),
                 nv.ptr(batch.k_unrot[layer_idx]), C.c_void_p(ws_ptr), ws_bytes, k_tail, v_tail, cap * D,
                 nv.ptr(batch.pos_old[layer_idx]) if defer_select else None, nv.stream())
             if rc == nv.RTK_EUNSUPPORTED:

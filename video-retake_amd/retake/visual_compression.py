@@ -54,7 +54,7 @@ def memory_bank_compress_keyframe(memory_bank: torch.Tensor, tgt_mem_len: int, w
     """DPSelect (reference: visual_compression.py:86-177).
 
     Args:
-        memory_bank: [B=1, T, N, C] frame embeddings (float32 or bfloat16, on the ROCm device)
+        memory_bank: [B=1, T, N, C] frame embeddings (float32, bfloat16 or float16, on the ROCm device)
         tgt_mem_len: number of frames to keep
         window_size: argrelmax window (the callers pass 3)
         sync: True = one frame set for all patch positions; False = per-patch frame sets
@@ -87,7 +87,7 @@ def _mallm_step(memory_bank: torch.Tensor, compression_size, sync: bool, hard: b
                 if not sz.is_contiguous():
                     sz = sz.contiguous()
             nv.check(nv.lib.rtk_adjacent_cosine(nv.ptr(x), T, N, Cc, dt, nv.ptr(cosv), st), "rtk_adjacent_cosine")
-            nv.check(nv.lib.rtk_mallm_argmax(nv.ptr(cosv), T - 1, N, int(bool(sync)), int(dt == nv.RTK_BF16),
+            nv.check(nv.lib.rtk_mallm_argmax(nv.ptr(cosv), T - 1, N, int(bool(sync)), nv.round_mode(memory_bank.dtype),
                                              nv.ptr(idx), st), "rtk_mallm_argmax")
             nv.check(nv.lib.rtk_mallm_merge(nv.ptr(x), nv.ptr(sz), nv.ptr(idx), T, N, Cc, dt, int(hard), nv.ptr(out[b]),
                                             None if hard else nv.ptr(sizes_out[b]), st), "rtk_mallm_merge")
