@@ -35,7 +35,8 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense peaks, MI355X_MICROARCH.md
+TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 
 Hq, Hkv, D = 28, 4, 128
 N_PATCH, C_EMB = 196, 1280
@@ -71,7 +72,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--frames", type=int, default=2048)
     ap.add_argument("--geometry", default="baseline", choices=sorted(GEOMETRIES),
                     help="shape of the HEADLINE measurement (the contract line is 'baseline' = BASELINE configs[2])")
@@ -333,7 +334,7 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
         if geometry is not None:
             set_geometry(geometry)
         SCORE_ROUNDING = score_rounding
-        tdtype = torch.bfloat16 if dtype == "bf16" else torch.float32
+        tdtype = TORCH_DTYPE[dtype]
         rows = frames_total // FRAMES_PER_ROW
         n_chunks = rows // FRAMES_PER_CHUNK
         L = FRAMES_PER_CHUNK * N_PATCH
@@ -356,7 +357,7 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
         nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
         kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in nv.profile_read().items()}
         check = None
-        if dtype == "bf16" and score_rounding == "fp32":
+        if dtype in ("bf16", "fp16") and score_rounding == "fp32":
             check = self_check(cache, pool, kp_mask, n_chunks, layers, rotary)["status"]
         keep = max(1, int(RATIO * L))
         assert cache.key_cache[0].shape[2] == n_chunks * keep
@@ -408,8 +409,8 @@ def main():
 
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    tdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    es = 2 if args.dtype == "bf16" else 4
+    tdtype = TORCH_DTYPE[args.dtype]
+    es = 4 if args.dtype == "fp32" else 2
     T = args.frames // FRAMES_PER_ROW     # rows of the frame bank (= frames; temporal grids of 2 frames for qwen448)
     L = FRAMES_PER_CHUNK * N_PATCH
     n_chunks = T // FRAMES_PER_CHUNK
@@ -596,6 +597,8 @@ def main():
                                                      score_rounding="fast", warmup_chunks=4)
         out["fast_rounding"]["note"] = ("score_rounding='fast' (opt in): q~ pre-scaled and both operands as fp16 on "
                                         "v_mfma_f32_32x32x16_f16, two instructions per logit; scores within ~1e-5 of the default")
+        out["fp16_dtype"] = companion_measurement(dev, args.frames, args.layers, "fp16", 2, 1, args.pool, warmup_chunks=4)
+        out["fp16_dtype"]["note"] = "float16 tensors (RTK_F16): fp16 rounding chains, exact fp16 products on the fp16 matrix instruction"
         out["fp32_parity_dtype"] = companion_measurement(dev, args.frames, args.layers, "fp32", 1, 1, args.pool,
                                                          warmup_chunks=2)
         frames = torch.cat([chunk_frames(c, dev, tdtype) for c in range(min(n_chunks, 4))])[None]

@@ -765,6 +765,22 @@ def gen_fp16(vc, lc, outdir):
               f"scoring {np.intersect1d(idx, exact).size}/{keep}, max |score_fp16 - exact| {np.abs(sr - s64m).max():.5f}")
         np.savez_compressed(os.path.join(outdir, f"pivotkv_{name}.npz"), **rec)
 
+    # ---- MA-LLM / MA-LLM-hard on a float16 bank (the merge loop of qwen2_vl.py:402-410)
+    for (name, seed, T, N, C, tgt, sync, hard) in [("fp16mallm_soft_async_16x6x32_t11", 27, 16, 6, 32, 11, False, False),
+                                                   ("fp16mallm_hard_sync_16x6x32_t11", 28, 16, 6, 32, 11, True, True)]:
+        xt = torch.from_numpy(synth.frames_video(seed, T, N, C)).half()
+        bank = xt.clone()
+        size = torch.ones_like(bank[:, :, :, 0])
+        while bank.shape[1] > tgt:
+            if hard:
+                bank = vc.memory_bank_compress_MALLM_hard(bank, sync=sync)
+            else:
+                bank, size = vc.memory_bank_compress_MALLM(bank, size, sync=sync)
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), x=xt.view(torch.int16).numpy(), dtype="fp16", T=T, N=N, C=C,
+                            tgt=tgt, sync=sync, hard=hard, out=bank.view(torch.int16).numpy(),
+                            size=(size.float().numpy() if not hard else np.zeros((0,), np.float32)))
+        print(name, "out", tuple(bank.shape))
+
 
 def main():
     ap = argparse.ArgumentParser()

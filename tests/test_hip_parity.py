@@ -267,6 +267,23 @@ def test_mallm_golden(name):
         assert np.abs(a - b).max() <= 2 ** -6 and (a != b).mean() < 0.02
 
 
+@pytest.mark.parametrize("name", gu.names("fp16mallm_"))
+def test_mallm_fp16_golden(name):
+    """MA-LLM / MA-LLM-hard merge loops on a float16 bank against the reference's fp16 run (visual_compression.py:5-83):
+    the same pairs merged; merged frames within one fp16 ulp on rare elements (the cosine's fp32 summation order)."""
+    g = gu.load(name)
+    xt = torch.from_numpy(g["x"]).to(dev()).view(torch.float16)
+    bank, size = _mallm_loop(xt, int(g["tgt"]), bool(g["sync"]), bool(g["hard"]))
+    assert bank.shape == tuple(g["out"].shape) and bank.dtype == torch.float16
+    a = bank.float().cpu().numpy()
+    b = g["out"].view(np.float16).astype(np.float32)
+    if bool(g["hard"]):
+        np.testing.assert_array_equal(a, b)
+    else:
+        assert np.abs(a - b).max() <= 2 ** -8 and (a != b).mean() < 0.02
+        np.testing.assert_array_equal(size.float().cpu().numpy(), g["size"])
+
+
 @pytest.mark.parametrize("T,N,C,sync,hard,bf16", [(9, 3, 33, False, False, False), (20, 7, 1280, True, False, False),
                                                   (6, 1, 8, False, True, False), (14, 5, 96, False, False, True),
                                                   (33, 4, 4100, True, True, True)])

@@ -29,7 +29,7 @@ def per_unit_score_select(q, k, pos2d, mask, keep, reforge, inv_freq, attention_
         sin = torch.empty_like(cos)
         sec = (C.c_int * len(sections))(*sections) if sections else None
         nv.check(nv.lib.rtk_rope_table(nv.ptr(pos2d), L, P, L, nv.ptr(inv_freq), D, float(attention_scaling), sec,
-                                       len(sections) if sections else 0, int(q.dtype == torch.bfloat16), nv.ptr(cos),
+                                       len(sections) if sections else 0, nv.round_mode(q.dtype), nv.ptr(cos),
                                        nv.ptr(sin), nv.stream()), "rtk_rope_table")
     wsb = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, dt)
     ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)

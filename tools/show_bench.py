@@ -15,7 +15,7 @@ for k, v in d.get("kernels_timed_region", {}).items():
 for k in ("roofline", "roofline_hbm_kernels", "cpu_baseline", "speedup_vs_cpu_baseline"):
     if k in d:
         print(k, d[k])
-for k in ("real_geometry", "reference_rounding", "fp32_parity_dtype", "fast_rounding"):
+for k in ("real_geometry", "reference_rounding", "fast_rounding", "fp16_dtype", "fp32_parity_dtype"):
     if k in d:
         c = d[k]
         print(f"{k}: {c['value']:.1f} frames/s  ms_per_step={c['ms_per_step']:.1f}  roofline {c['roofline']['kernel']} "

@@ -738,7 +738,7 @@ def bench_main(args, rank: int, world: int, local_rank: int):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     red_dev = torch.device("cpu") if share else dev     # gloo reduces host tensors
     p2p = enable_p2p(device=dev) if transport == "p2p" else None
-    tdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    tdtype = B.TORCH_DTYPE[args.dtype]
     T = args.frames
     n_chunks = T // B.FRAMES_PER_CHUNK
     L = B.FRAMES_PER_CHUNK * B.N_PATCH
