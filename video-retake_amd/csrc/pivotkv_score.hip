@@ -839,7 +839,7 @@ __device__ __forceinline__ void mma16(f32x16& d, const u32x4& a, const u32x4& b,
 // logit, the minimum.  That is exact whenever the row's sum stays inside fp32's comfortable range; a row whose sum
 // left it (a logit beyond ~2^7 in base 2 -> inf, or every logit below ~-60 -> precision lost in subnormals) is
 // detected ONCE, at the end - inf and NaN are sticky in a sum of non-negative terms - and published as NaN; the
-// fix-up launch that follows (score_pass1_dma_kernel<.., FIXUP>) recomputes exactly the workgroups that own a NaN with
+// fix-up launch that follows (score_pass1_fixup_kernel) recomputes exactly the row tiles that own a NaN with
 // RowStatF, the offset-carrying form.  Deterministic: which rows take which path depends on the data only.
 struct RowStatR {
     float sum;
@@ -1601,13 +1601,6 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
         bx = w % row_tiles;
     }
     const int i_base = bx * (REG_ROWS * NB);
-    if constexpr (MODE == 2) {
-        // fix-up launch: only the workgroups that own a row RowStatR published as NaN do anything (normally none)
-        const int i = i_base + (int)threadIdx.x;
-        float v = 0.f;
-        if ((int)threadIdx.x < REG_ROWS * NB && i < L) v = lse_part[((size_t)ks * Hq + h) * L + i];
-        if (!__syncthreads_or(v != v)) return;
-    }
     if constexpr (NB == 2) {
         if (L - i_base <= REG_ROWS) {   // uniform per workgroup
             score_pass1_dma_body<1, LAZY, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
@@ -1615,6 +1608,45 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
         }
     }
     score_pass1_dma_body<NB, LAZY, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
+}
+
+// RTK_BF16_FAST fix-up launch: the row tiles whose plain sums left fp32's range (published as NaN by RowStatR) are
+// recomputed with the offset-carrying form.  Normally there is nothing to fix, so the launch must cost next to nothing: a
+// workgroup looks at FIX_TILES consecutive row tiles at once - one load per thread and tile, all in flight together, one
+// barrier-or per tile - and runs the robust body only for a tile that holds a NaN (1/16 of the main kernel's
+// workgroups: ~4 us per chunk instead of the ~60 us of dispatching 39 200 workgroups that read 1 KB each and leave).
+// Tiles are numbered ((ks * Hq + h) * row_tiles + bx); no XCD-aware decode (nothing streams in the common case).
+constexpr int FIX_TILES = 16;
+template <int NB>
+__global__ __launch_bounds__(SC_BLOCK, 3) void score_pass1_fixup_kernel(
+    const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv, int L, int keys_per_split, int row_tiles,
+    int n_tiles, float* __restrict__ lse_part, size_t q_unit_bytes, size_t k_unit_bytes, size_t lse_unit_floats,
+    int neg_out) {
+    q += blockIdx.y * q_unit_bytes;
+    k += blockIdx.y * k_unit_bytes;
+    lse_part += blockIdx.y * lse_unit_floats;
+    const int t0 = blockIdx.x * FIX_TILES;
+    float v[FIX_TILES];
+#pragma unroll
+    for (int u = 0; u < FIX_TILES; ++u) {
+        const int t = t0 + u;
+        const int bx = t % row_tiles, kh = t / row_tiles;          // kh = ks * Hq + h
+        const int i = bx * (REG_ROWS * NB) + (int)threadIdx.x;
+        v[u] = (t < n_tiles && (int)threadIdx.x < REG_ROWS * NB && i < L) ? lse_part[(size_t)kh * L + i] : 0.f;
+    }
+#pragma unroll 1
+    for (int u = 0; u < FIX_TILES; ++u) {
+        if (!__syncthreads_or(v[u] != v[u])) continue;             // uniform: the whole workgroup takes the same path
+        const int t = t0 + u;
+        const int bx = t % row_tiles, kh = t / row_tiles;
+        const int h = kh % Hq, ks = kh / Hq;
+        const int i_base = bx * (REG_ROWS * NB);
+        if (NB == 2 && L - i_base <= REG_ROWS)
+            score_pass1_dma_body<1, true, 2>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
+        else
+            score_pass1_dma_body<NB, true, 2>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
+        __syncthreads();   // the next tile's prologue writes the LDS buffers this one was still reading
+    }
 }
 
 }  // namespace rtk
@@ -1973,11 +2005,11 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                                dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
                                (int)((Hkv * ks_n) % NXCD == 0), lse, ws_stride, k_stride, ws_stride / sizeof(float),
                                (int)(ks_n == 1));
-                    // rows whose plain sum left fp32's range were published as NaN: their workgroups run again, robustly
-                    RTK_LAUNCH(KID_FINALIZE, (score_pass1_dma_kernel<RTK_P1_NB, true, 2>), dim3(Hkv * ks_n * jt1 * G, n_units),
-                               dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
-                               (int)((Hkv * ks_n) % NXCD == 0), lse, ws_stride, k_stride, ws_stride / sizeof(float),
-                               (int)(ks_n == 1));
+                    // rows whose plain sum left fp32's range were published as NaN: their tiles run again, robustly
+                    const int n_tiles = Hkv * ks_n * jt1 * G;
+                    RTK_LAUNCH(KID_FINALIZE, (score_pass1_fixup_kernel<RTK_P1_NB>), dim3((n_tiles + FIX_TILES - 1) / FIX_TILES, n_units),
+                               dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1, n_tiles,
+                               lse, ws_stride, k_stride, ws_stride / sizeof(float), (int)(ks_n == 1));
                 } else if (w.h16)
                     RTK_LAUNCH(KID_PASS1, (score_pass1_dma_kernel<RTK_P1_NB, RTK_P1_LAZY, 3>), dim3(Hkv * ks_n * jt1 * G, n_units),
                                dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
