@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Randomised differential run of PivotKVCache on the GPU (not a pytest: minutes, not seconds).
+
+For random shapes / dtypes / masks / ratios / RoPE flavours it compresses the same chunks three ways and compares:
+  A  the cache as shipped (live-key pass 2, batched flush where the shape allows)
+  B  the cache with `skip_masked_columns=False` (the full pass 2)          -> caches, scores, kept sets BITWISE equal to A
+  C  the CPU oracle (fp32 runs only)                                        -> scores <= 5e-6, kept sets margin-aware,
+                                                                               kept V exact, kept K <= 1e-5, ids exact
+    python tools/fuzz_gpu.py [--seconds 240] [--seed 0]
+"""
+import argparse
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "video-retake_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+
+import retake.longvideo_cache as lc
+import synth
+from oracle import oracle as orc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(a.seed)
+    t_end = time.time() + a.seconds
+    n_cases = n_oracle = 0
+    worst_score = worst_k = 0.0
+    while time.time() < t_end:
+        Hkv = int(rng.choice([1, 2, 4, 8]))
+        G = int(rng.choice([1, 4, 6, 7]))
+        Hq = Hkv * G
+        D = 128 if rng.uniform() < 0.8 else int(rng.choice([32, 64]))
+        L = int(rng.choice([1, 33, 200, 511, 512, 640, 1000, 2304, 3000]))
+        dtype = [torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 3))]
+        ratio = float(rng.choice([0.01, 0.1, 0.25, 0.5, 0.9]))
+        mrate = float(rng.choice([0.0, 0.0, 0.3, 0.6, 1.0]))
+        reforge = bool(rng.uniform() < 0.8)
+        mrope = bool(rng.uniform() < 0.6)
+        layers = int(rng.integers(1, 4))
+        chunks = int(rng.integers(1, 3))
+        native = bool(rng.uniform() < 0.5)
+        sec = None
+        if mrope:
+            h = D // 2
+            s1 = h // 4
+            sec = [s1, (h - s1) // 2, h - s1 - (h - s1) // 2]
+        S = synth.YARN_FACTOR4_ATTENTION_SCALING if rng.uniform() < 0.7 else 1.0
+        rot = synth.RotaryStub(synth.inv_freq(D), S, device=dev)
+        rot_cpu = synth.RotaryStub(synth.inv_freq(D), S)
+        desc = (f"Hq={Hq} Hkv={Hkv} D={D} L={L} {str(dtype)[6:]} ratio={ratio} mask={mrate} reforge={reforge} mrope={mrope} "
+                f"layers={layers} chunks={chunks} native_rope={native} a={S:.3f}")
+
+        def make(skip):
+            cfg = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=layers, num_attention_heads=Hq,
+                                        num_key_value_heads=Hkv,
+                                        longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
+                                            "compression_ratio": ratio, "compression_method": "pivotkv",
+                                            "pos_embed_reforge": reforge, "native_rope": native, "skip_masked_columns": skip}})
+            return lc.build_kvcache(cfg)
+
+        ca, cb = make(True), make(False)
+        oc = [orc.OraclePivotKV(Hq, Hkv, D, ratio, reforge) for _ in range(layers)] if dtype == torch.float32 and L <= 1000 else None
+        keep = max(1, int(ratio * L))
+        try:
+            for c in range(chunks):
+                seed = int(rng.integers(0, 1 << 30))
+                mask_np = rng.uniform(size=L) < mrate
+                mask = torch.from_numpy(mask_np).to(dev) if mrate > 0 or rng.uniform() < 0.5 else None
+                if mrope:
+                    gw = max(1, int(np.sqrt(L)))
+                    t = (np.arange(L) // max(1, gw * 2)) + 7 * c + 3
+                    pos_np = np.stack([t, (np.arange(L) // gw) % 7 + 2, np.arange(L) % gw + 2]).reshape(3, 1, L).astype(np.int64)
+                else:
+                    pos_np = (np.arange(L) + 11 * c + 5).reshape(1, L).astype(np.int64)
+                for l in range(layers):
+                    q0, k0, v = synth.qkv_chunk(seed + l, Hq, Hkv, L, D)
+                    pos_t = torch.from_numpy(pos_np)
+                    q = synth.rope_forward(torch.from_numpy(q0), pos_t, rot_cpu, sec).to(dtype)
+                    k = synth.rope_forward(torch.from_numpy(k0), pos_t, rot_cpu, sec).to(dtype)
+                    vt = torch.from_numpy(v).to(dtype)
+                    for cache in (ca, cb):
+                        cache.keypatches_mask_chunk = mask
+                        cache.kvcache_compression = True
+                        kw = {"query_states": q.to(dev), "position_ids": pos_t.to(dev).clone(), "rotary_emb": rot}
+                        if sec:
+                            kw["mrope_section"] = list(sec)
+                        cache.update(k.to(dev), vt.to(dev), l, kw)
+                    if oc is not None:
+                        oc[l].keypatches_mask_chunk = mask_np if mask is not None else None
+                        oc[l].update(k.numpy(), v, 0, q=q.numpy(), position_ids=pos_np, rotary=rot_cpu, mrope_section=sec)
+                ca.after_forward()
+                cb.after_forward()
+                for l in range(layers):
+                    sa, sb = ca._batch.score[l], cb._batch.score[l]
+                    assert torch.equal(sa, sb), "scores (after the mask override) differ between live-key and full pass 2"
+                    assert torch.equal(ca._batch.keep_idx[l], cb._batch.keep_idx[l]), "kept sets differ"
+                    assert torch.equal(ca.key_cache[l], cb.key_cache[l]) and torch.equal(ca.value_cache[l], cb.value_cache[l])
+                    if reforge:
+                        assert torch.equal(ca.position_cache[l], cb.position_cache[l])
+                    if oc is not None:
+                        last = oc[l].last
+                        so = last["score"]
+                        err = float(np.abs(sa.cpu().numpy() - so).max())
+                        worst_score = max(worst_score, err)
+                        # the oracle takes the module's tables (torch's libm cos / sin); native_rope computes them
+                        # correctly rounded: one fp32 ulp apart in ~5 % of the entries
+                        bar = (2e-5 if native and reforge else 5e-6) * max(1.0, float(np.abs(so).max()))
+                        assert err < bar, f"score vs oracle {err} (bar {bar})"
+                        idx = ca._batch.keep_idx[l].cpu().numpy()
+                        xor = np.setxor1d(idx, last["keep_idx"])
+                        if xor.size:
+                            thr = np.sort(so)[::-1][keep - 1]
+                            assert np.abs(so[xor] - thr).max() < 4 * bar, "kept sets differ beyond fp32 noise at the threshold"
+                        else:
+                            n0 = ca.key_cache[l].shape[2] - keep
+                            assert np.array_equal(ca.value_cache[l][0, :, n0:].cpu().numpy(), last["kept_v"][0])
+                            kerr = float(np.abs(ca.key_cache[l][0, :, n0:].cpu().numpy() - last["kept_k"][0]).max())
+                            worst_k = max(worst_k, kerr)
+                            assert kerr <= 1e-5 * max(1.0, float(np.abs(last["kept_k"]).max())), f"kept K vs oracle {kerr}"
+                            if reforge:
+                                assert np.array_equal(ca.position_cache[l].cpu().numpy()[..., n0:].reshape(-1, keep),
+                                                      last["pos"].reshape(-1, keep))
+                        n_oracle += 1
+        except Exception as e:   # noqa: BLE001
+            print("FUZZ FAILURE:", desc, "->", type(e).__name__, e, flush=True)
+            raise
+        n_cases += 1
+    print(f"fuzz ok: {n_cases} random configurations (live-key == full pass 2 bitwise), {n_oracle} layer-chunks against the CPU "
+          f"oracle (max score diff {worst_score:.2e}, max kept-K diff {worst_k:.2e})")
+
+
+if __name__ == "__main__":
+    main()
