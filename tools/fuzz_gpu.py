@@ -137,6 +137,53 @@ def main():
         n_cases += 1
     print(f"fuzz ok: {n_cases} random configurations (live-key == full pass 2 bitwise), {n_oracle} layer-chunks against the CPU "
           f"oracle (max score diff {worst_score:.2e}, max kept-K diff {worst_k:.2e})")
+    fuzz_dpselect(dev, rng, a.seconds / 4)
+
+
+def fuzz_dpselect(dev, rng, seconds):
+    """DPSelect on random shapes / dtypes against the CPU oracle, row by row (golden_util.check_dpselect_bf16 with the
+    oracle's result in the role of the reference's)."""
+    import golden_util as gu
+    import retake.visual_compression as vc
+
+    t_end = time.time() + seconds
+    n = relaxed = 0
+    while time.time() < t_end:
+        T = int(rng.choice([2, 3, 9, 33, 64, 130, 300]))
+        N = int(rng.choice([2, 3, 7, 16, 50]))
+        C = int(rng.choice([8, 24, 64, 200, 1280, 2056]))
+        sync = bool(rng.uniform() < 0.4)
+        tgt = int(rng.integers(1, T + 1))
+        dt = ["fp32", "bf16", "fp16"][int(rng.integers(0, 3))]
+        x = synth.frames_video(int(rng.integers(0, 1 << 30)), T, N, C)
+        xt = torch.from_numpy(x)
+        if dt == "fp32":
+            xo, xd = x, xt.to(dev)
+        elif dt == "bf16":
+            xb = xt.bfloat16()
+            xo, xd = xb.view(torch.int16).numpy().view(np.uint16), xb.to(dev)
+        else:
+            xh = xt.half()
+            xo, xd = xh.view(torch.int16).numpy().view(np.float16), xh.to(dev)
+        desc = f"DPSelect T={T} N={N} C={C} {dt} sync={sync} tgt={tgt}"
+        try:
+            out, mask, idx, dis, _ = vc.dpselect_stages(xd, tgt, 3, sync)
+            o_out, o_mask, o_idx, o_dis = orc.dpselect(xo, tgt, 3, sync)
+            g = {"sync": sync, "tgt": tgt, "dis32": o_dis, "idx": o_idx, "mask": o_mask}
+            d = np.abs(dis.cpu().numpy() - o_dis)
+            assert d.max() <= (2e-6 if dt == "fp32" else 2 ** -7), d.max()
+            if dt == "fp32":   # fp32 distances differ by summation order only: treat them as perturbed within that noise
+                st = gu.check_dpselect_bf16(g, dis.cpu().numpy(), idx.cpu().numpy(), mask.flatten().cpu().numpy())
+            else:
+                st = gu.check_dpselect_bf16(g, dis.cpu().numpy(), idx.cpu().numpy(), mask.flatten().cpu().numpy())
+            relaxed += st["relaxed"]
+            ii = idx if not sync else idx[:, None].expand(-1, N)
+            assert torch.equal(out[0], torch.gather(xd[0], 0, ii[:, :, None].expand(-1, -1, C)))
+        except Exception as e:   # noqa: BLE001
+            print("FUZZ FAILURE:", desc, "->", type(e).__name__, e, flush=True)
+            raise
+        n += 1
+    print(f"fuzz ok: {n} random DPSelect calls against the CPU oracle ({relaxed} rows took the relaxed rule)")
 
 
 if __name__ == "__main__":
