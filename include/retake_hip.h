@@ -58,6 +58,14 @@ enum rtk_dtype {
     RTK_F16 = 4
 };
 
+/* Flag for the `dtype` argument of the SCORING entry points (rtk_pivotkv_score_workspace_bytes, _score_partials,
+ * _score, _score_stages[_masked], _score_passes_batched, rtk_pivotkv_prepare, and score_dtype of rtk_pivotkv_select_batched):
+ * the caller batches many (layer, chunk) units per launch, so the key / row splits - which fix the workspace layout, the
+ * partial layout AND the reduction order, i.e. the bits of the score - are chosen for the length of a workgroup's stream
+ * instead of for the workgroup count of one unit (one key split, about eight row tiles per row split).  Every call that
+ * touches the same workspace must carry the same flag. */
+#define RTK_SCORE_MANY_UNITS 0x100
+
 enum rtk_status {
     RTK_OK = 0,
     RTK_EINVAL = -1,      /* bad argument (NULL pointer, non-positive size, unsupported dtype) -> ValueError   */

@@ -64,7 +64,7 @@ def check_batch_against_units(cache, layers, inputs, masks, keep, inv_freq, atte
         q, k = inputs[l]
         pos2d = b.pos_old[l].contiguous()
         s1, i1, p1 = per_unit_score_select(q, k, pos2d, masks[l], keep, b.reforge, inv_freq, attention_scaling, sections,
-                                           score_dt=b.score_dt if getattr(b, "fast", False) else None)
+                                           score_dt=b.score_dt)   # same score arithmetic AND split policy as the batch
         sb, ib = b.score[l], b.keep_idx[l]
         if not torch.equal(sb, s1):
             bad = (sb != s1).nonzero().flatten()

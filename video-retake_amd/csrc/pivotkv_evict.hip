@@ -960,7 +960,7 @@ extern "C" int rtk_pivotkv_select_batched(const rtk_select_unit* units, int n_un
         return RTK_EUNSUPPORTED;
     }
     return select_units(units, n_units, Hkv, RS, G, L, keep, P, reforge, pos_out_stride, (hipStream_t)stream,
-                        score_dtype == RTK_BF16_REFROUND);
+                        (score_dtype & ~RTK_SCORE_MANY_UNITS) == RTK_BF16_REFROUND);
 }
 
 extern "C" int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep, const int64_t* pos, int P,

@@ -1815,6 +1815,8 @@ struct ScoreWs {
     bool h16;   // RTK_F16: fp16 payloads (un-rotation rounds to fp16, the passes use the fp16 matrix instruction)
 };
 static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
+    const bool many = !RTK_IGNORE_MANY_UNITS && (dtype & RTK_SCORE_MANY_UNITS) != 0;   // the caller batches many units per launch
+    dtype &= ~RTK_SCORE_MANY_UNITS;
     const size_t es = dtype == RTK_F32 ? 4 : 2;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     ScoreWs w;
@@ -1828,6 +1830,19 @@ static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
     // bf16 production path: the chunk-batched launches bring their own parallelism (28 layers), so pass 1 prefers
     // longer key streams per workgroup (measured: 2 splits -1.7 % over 4) and half the lse partials
     if (D == HD && dtype != RTK_F32) w.KS = std::min(w.KS, 2);
+    if (many && D == HD && dtype != RTK_F32) {
+        // Launches of many units bring their own parallelism, so the splits are chosen for the length of a workgroup's
+        // stream instead of for the workgroup count of ONE unit (same-box A/Bs at L = 2304 and 6272,
+        // profiles/r06_ab_splits.txt): one key split (pass 1 -1.6 % / -0.4 %, no lse_combine launch), about eight row
+        // tiles per row split (pass 2 -2 % at L = 2304; 14 splits of 7 tiles at L = 6272, what pick_splits gave already).
+        w.KS = 1;
+        const int s0 = std::max(1, (stream_tiles + 7) / 8);
+        w.RS = s0;
+        for (int t = s0; t <= std::min(stream_tiles, s0 + 8); ++t) {
+            const int per = (stream_tiles + t - 1) / t, eff = (stream_tiles + per - 1) / per;
+            if ((Hkv * eff) % NXCD == 0) { w.RS = t; break; }
+        }
+    }
     if (RTK_FORCE_KS > 0 && D == HD && dtype != RTK_F32) w.KS = RTK_FORCE_KS;   // A/B builds only (variants.h)
     if (RTK_FORCE_RS > 0 && D == HD && dtype != RTK_F32) w.RS = RTK_FORCE_RS;
     w.q_off = 0;
@@ -2079,11 +2094,13 @@ extern "C" int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspa
                                                 int n_units, int Hq, int Hkv, int L, int D, int dtype,
                                                 const void* const* key_masks_host, int32_t* key_index_ws,
                                                 rtk_stream_t stream) {
+    const int dtype_full = dtype;              // may carry RTK_SCORE_MANY_UNITS (split policy, see score_ws)
+    dtype &= ~RTK_SCORE_MANY_UNITS;
     RTK_CHECK_ARG(workspace0 && partial0 && n_units >= 1, "rtk_pivotkv_score_passes_batched: NULL pointer or no units");
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0 && L >= 1, "rtk_pivotkv_score_passes_batched: bad shape");
     RTK_CHECK_ARG(((uintptr_t)workspace0 & 255) == 0 && workspace_stride % 256 == 0,
                   "rtk_pivotkv_score_passes_batched: workspaces must be 256-byte aligned");
-    const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
+    const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype_full);
     RTK_CHECK_ARG(n_units == 1 || workspace_stride >= w.total, "rtk_pivotkv_score_passes_batched: workspace stride too small");
     if ((dtype != RTK_BF16 && dtype != RTK_BF16_REFROUND && dtype != RTK_BF16_FAST && dtype != RTK_F16) || D != HD) {
         set_error("rtk_pivotkv_score_passes_batched: bf16 with head_dim %d only (call RTK_SCORE_PASSES per unit)", HD);
@@ -2157,6 +2174,8 @@ static int score_stages_impl(const void* q, int64_t q_stride_h, int64_t q_stride
                              const float* sinv, float attention_scaling, float* score, void* k_unrot, void* workspace,
                              size_t workspace_bytes, int stages, float* partial_out, const void* key_mask,
                              int32_t* key_index_ws, rtk_stream_t stream) {
+    const int dtype_full = dtype;              // may carry RTK_SCORE_MANY_UNITS (split policy, see score_ws)
+    dtype &= ~RTK_SCORE_MANY_UNITS;
     RTK_CHECK_ARG(q && k && score && workspace, "rtk_pivotkv_score: NULL pointer");
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0, "rtk_pivotkv_score: Hq=%d must be a multiple of Hkv=%d", Hq, Hkv);
     RTK_CHECK_ARG(L >= 1 && D >= 2 && D % 2 == 0, "rtk_pivotkv_score: bad shape L=%d D=%d", L, D);
@@ -2165,7 +2184,7 @@ static int score_stages_impl(const void* q, int64_t q_stride_h, int64_t q_stride
                       dtype == RTK_F16, "rtk_pivotkv_score: unsupported dtype %d", dtype);
     RTK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "rtk_pivotkv_score: workspace must be 256-byte aligned");
     RTK_CHECK_ARG(stages > 0 && stages <= 7, "rtk_pivotkv_score: stages mask %d out of range", stages);
-    const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
+    const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype_full);
     if (workspace_bytes < w.total) {
         set_error("rtk_pivotkv_score: workspace %zu < required %zu bytes", workspace_bytes, w.total);
         return RTK_EWORKSPACE;
@@ -2245,6 +2264,8 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
                                    const int* sections_host, int nsec, int round_bf16, void* k_unrot, void* workspace,
                                    size_t workspace_bytes, void* k_tail, void* v_tail, int64_t tail_stride_h,
                                    int64_t* pos_copy, rtk_stream_t stream) {
+    const int dtype_full = dtype;              // may carry RTK_SCORE_MANY_UNITS: the workspace layout follows the split policy
+    dtype &= ~RTK_SCORE_MANY_UNITS;
     RTK_CHECK_ARG(q && k && v && pos && inv_freq && k_unrot && workspace && k_tail && v_tail, "rtk_pivotkv_prepare: NULL pointer");
     RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && L >= 1 && D >= 2, "rtk_pivotkv_prepare: bad shape");
     RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_BF16_FAST || dtype == RTK_F16,
@@ -2256,7 +2277,7 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
         return RTK_EUNSUPPORTED;
     }
     RTK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "rtk_pivotkv_prepare: workspace must be 256-byte aligned");
-    const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
+    const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype_full);
     if (workspace_bytes < w.total) {
         set_error("rtk_pivotkv_prepare: workspace %zu < required %zu bytes", workspace_bytes, w.total);
         return RTK_EWORKSPACE;

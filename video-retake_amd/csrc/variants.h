@@ -19,3 +19,6 @@
 #ifndef RTK_FORCE_RS     // > 0: row splits of pass 2 (bf16 path) instead of score_ws()'s shape rule
 #define RTK_FORCE_RS 0
 #endif
+#ifndef RTK_IGNORE_MANY_UNITS   // 1 = RTK_SCORE_MANY_UNITS changes nothing (A/B of the split policy of batched launches)
+#define RTK_IGNORE_MANY_UNITS 0
+#endif

@@ -191,6 +191,11 @@ class _Batch:
         self.score_dt = ((nv.RTK_BF16_REFROUND if refround else (nv.RTK_BF16_FAST if fast else nv.RTK_BF16))
                          if dtype == torch.bfloat16 else (nv.RTK_F16 if dtype == torch.float16 else nv.RTK_F32))
         self.fast = self.score_dt == nv.RTK_BF16_FAST
+        self.batched_passes = dtype in (torch.bfloat16, torch.float16) and D == 128 and L >= 512
+        if self.batched_passes:   # all layers of a chunk per launch: splits chosen for the stream length (same flag everywhere)
+            self.score_dt |= nv.RTK_SCORE_MANY_UNITS
+        # what rtk_pivotkv_prepare is told: the payload dtype (the reference-rounding mode prepares like plain bf16)
+        self.prep_dt = (nv.RTK_BF16 if refround and dtype == torch.bfloat16 else self.score_dt & 0xFF) | (self.score_dt & ~0xFF)
         self.Hkv, self.L, self.D, self.dtype, self.device = Hkv, L, D, dtype, device
         self.keep_idx = torch.empty((slots, keep), dtype=torch.int64, device=device)
         self.pos_new = torch.empty((P, slots, keep), dtype=torch.int64, device=device) if P else None
@@ -211,7 +216,6 @@ class _Batch:
         # one score workspace per slot (q~, lse partials): the matrix passes of all layers run in one launch each
         self.ws_bytes = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, self.score_dt)
         self.ws_stride = (self.ws_bytes + 255) & ~255
-        self.batched_passes = dtype in (torch.bfloat16, torch.float16) and D == 128 and L >= 512
         self.score_ws = torch.empty(slots * self.ws_stride + 256, dtype=torch.uint8, device=device) \
             if self.batched_passes else None
         self.score_ws_base = ((self.score_ws.data_ptr() + 255) & ~255) if self.batched_passes else 0
@@ -884,7 +888,7 @@ class PivotKVCache(DynamicCache):
                 nv.ptr(query_states), query_states.stride(1), query_states.stride(2),
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
                 nv.ptr(value_states), value_states.stride(1), value_states.stride(2),
-                Hq, Hkv, L, D, batch.score_dt if batch.fast else dt, nv.ptr(pos_in), L, Pn, nv.ptr(inv), a_scale, sec,
+                Hq, Hkv, L, D, batch.prep_dt, nv.ptr(pos_in), L, Pn, nv.ptr(inv), a_scale, sec,
                 len(mrope_section) if mrope_section else 0, nv.round_mode(key_states.dtype),
                 nv.ptr(batch.k_unrot[layer_idx]), C.c_void_p(ws_ptr), ws_bytes, k_tail, v_tail, cap * D,
                 nv.ptr(batch.pos_old[layer_idx]) if defer_select else None, nv.stream())
