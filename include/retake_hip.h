@@ -155,6 +155,14 @@ int rtk_rope_table(const int64_t* pos, int64_t pos_stride, int P, int L, const f
 int rtk_rope_shift(void* k, int64_t stride_h, int H, int n, int D, int dtype, const int64_t* delta_dev,
                    const float* inv_freq, int P, const int* sections_host, int nsec, rtk_stream_t stream);
 
+/* The same for a whole assembled cache in one launch: k [layers, H, world * seg, D] (element strides stride_layer,
+ * stride_h; rows contiguous), the segment of rank r in layer l rotated by table_dev[r * layers + l] temporal steps
+ * (table_dev: device int64 [world, layers], what retake/sharded.exchange_temporal_offsets returns).  Replaces
+ * layers x world calls of rtk_rope_shift in ShardedPivotKV.finalize. */
+int rtk_rope_shift_segments(void* k, int64_t stride_layer, int64_t stride_h, int layers, int H, int world, int seg, int D,
+                            int dtype, const int64_t* table_dev, const float* inv_freq, int P,
+                            const int* sections_host, int nsec, rtk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * PivotKV — replaces retake/longvideo_cache.py:248-318
  * ------------------------------------------------------------------------------------------- */

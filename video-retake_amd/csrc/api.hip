@@ -105,6 +105,6 @@ extern "C" int rtk_profile_read(int kid, long long* count, double* total_ms) {
     return RTK_OK;
 }
 
-extern "C" int rtk_version(void) { return 11; }
+extern "C" int rtk_version(void) { return 12; }
 extern "C" const char* rtk_last_error(void) { return rtk::g_err; }
 extern "C" const char* rtk_arch(void) { return "gfx950"; }

@@ -84,6 +84,48 @@ __global__ __launch_bounds__(256) void rope_shift_kernel(void* __restrict__ kv, 
 }
 
 
+// The same for a whole assembled cache in ONE launch (chunk sharding): k is [layers, H, world * seg, D] and
+// the segment of rank r in layer l is rotated by table[r * layers + l] temporal steps - one launch instead of
+// layers x world launches of rope_shift_kernel (224 at 8 ranks, each a few microseconds of work), same arithmetic.
+template <int DT>
+__global__ __launch_bounds__(256) void rope_shift_segments_kernel(void* __restrict__ kv, int64_t stride_layer, int64_t stride_h,
+                                                                  int layers, int H, int world, int seg, int D,
+                                                                  const int64_t* __restrict__ table,
+                                                                  const float* __restrict__ inv_freq, RowSel rs) {
+    const int h2 = D / 2;
+    const size_t rows = (size_t)world * seg;
+    const size_t total = (size_t)layers * H * rows * h2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % h2);
+        if (rs.row[d] != 0) continue;
+        size_t t = i / h2;
+        const size_t row = t % rows;
+        t /= rows;
+        const int h = (int)(t % H), l = (int)(t / H);
+        const int r = (int)(row / seg);
+        const float dl = (float)table[(size_t)r * layers + l];
+        const size_t off = (size_t)l * stride_layer + (size_t)h * stride_h + row * D;
+        float s, c;
+        sincos_cr(dl * inv_freq[d], s, c);
+        float x1, x2;
+        if constexpr (DT != RTK_F32) {
+            x1 = H16<DT>::ld(kv, off + d);
+            x2 = H16<DT>::ld(kv, off + d + h2);
+        } else {
+            x1 = ((float*)kv)[off + d];
+            x2 = ((float*)kv)[off + d + h2];
+        }
+        const float o1 = x1 * c - x2 * s, o2 = x2 * c + x1 * s;
+        if constexpr (DT != RTK_F32) {
+            H16<DT>::st(kv, off + d, o1);
+            H16<DT>::st(kv, off + d + h2, o2);
+        } else {
+            ((float*)kv)[off + d] = o1;
+            ((float*)kv)[off + d + h2] = o2;
+        }
+    }
+}
+
 // Temporal-id continuity fix of the attention patch (qwen2_vl.py:68-73), on the device: the whole row is
 // shifted so that its first id follows the last id stored for the layer.  One workgroup: the first id is
 // read by everyone before anyone writes.
@@ -142,6 +184,29 @@ extern "C" int rtk_rope_shift(void* k, int64_t stride_h, int H, int n, int D, in
         RTK_LAUNCH(KID_ROPE, rope_shift_kernel<RTK_F32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k, stride_h, H, n,
                    D, delta_dev, inv_freq, rs);
     RTK_LAUNCH_CHECK("rope_shift_kernel");
+    return RTK_OK;
+}
+
+extern "C" int rtk_rope_shift_segments(void* k, int64_t stride_layer, int64_t stride_h, int layers, int H, int world,
+                                       int seg, int D, int dtype, const int64_t* table_dev, const float* inv_freq, int P,
+                                       const int* sections_host, int nsec, rtk_stream_t stream) {
+    RTK_CHECK_ARG(k && table_dev && inv_freq, "rtk_rope_shift_segments: NULL pointer");
+    RTK_CHECK_ARG(layers >= 1 && H >= 1 && world >= 1 && seg >= 0 && D >= 2, "rtk_rope_shift_segments: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_rope_shift_segments: unsupported dtype %d", dtype);
+    if (seg == 0) return RTK_OK;
+    RowSel rs;
+    int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_rope_shift_segments");
+    if (rc) return rc;
+    const size_t total = (size_t)layers * H * world * seg * (D / 2);
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
+#define RTK_RSS(DTV)                                                                                                    \
+    RTK_LAUNCH(KID_ROPE, rope_shift_segments_kernel<DTV>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k, stride_layer, \
+               stride_h, layers, H, world, seg, D, table_dev, inv_freq, rs)
+    if (dtype == RTK_BF16) RTK_RSS(RTK_BF16);
+    else if (dtype == RTK_F16) RTK_RSS(RTK_F16);
+    else RTK_RSS(RTK_F32);
+#undef RTK_RSS
+    RTK_LAUNCH_CHECK("rope_shift_segments_kernel");
     return RTK_OK;
 }
 

@@ -552,14 +552,12 @@ class ShardedPivotKV:
                 kv = g.finish()                                   # [2, layers, Hkv, world*n, D], provisional positions
                 world = table.shape[0]
                 seg = kv.shape[3] // world
-                for layer in range(n_layers):
-                    P = 3 if cache.position_cache[layer].ndim == 3 else 1
-                    for r in range(world):                        # rank r's segment -> its true temporal position
-                        part = kv[0, layer][:, r * seg:(r + 1) * seg]
-                        nv.check(nv.lib.rtk_rope_shift(C.c_void_p(part.data_ptr()), kv.shape[3] * kv.shape[4],
-                                                       kv.shape[2], seg, kv.shape[4], nv.dtype_code(kv),
-                                                       C.c_void_p(table.data_ptr() + (r * n_layers + layer) * 8),
-                                                       nv.ptr(inv), P, sec, nsec, st), "rtk_rope_shift")
+                # every rank's segment of every layer -> its true temporal position, ONE launch (table [world, layers])
+                P = 3 if cache.position_cache[0].ndim == 3 else 1
+                nv.check(nv.lib.rtk_rope_shift_segments(C.c_void_p(kv[0].data_ptr()), kv.stride(1), kv.stride(2), n_layers,
+                                                        kv.shape[2], world, seg, kv.shape[4], nv.dtype_code(kv),
+                                                        nv.ptr(table), nv.ptr(inv), P, sec, nsec, st),
+                         "rtk_rope_shift_segments")
                 keys = [kv[0, layer][None] for layer in range(n_layers)]
                 values = [kv[1, layer][None] for layer in range(n_layers)]
                 pos = all_gather_ids(pos, self.group, counts)
