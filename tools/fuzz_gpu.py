@@ -49,6 +49,7 @@ def main():
         layers = int(rng.integers(1, 4))
         chunks = int(rng.integers(1, 3))
         native = bool(rng.uniform() < 0.5)
+        rounding = str(rng.choice(["fp32", "fp32", "reference", "fast"])) if dtype == torch.bfloat16 and D == 128 else "fp32"
         sec = None
         if mrope:
             h = D // 2
@@ -58,14 +59,15 @@ def main():
         rot = synth.RotaryStub(synth.inv_freq(D), S, device=dev)
         rot_cpu = synth.RotaryStub(synth.inv_freq(D), S)
         desc = (f"Hq={Hq} Hkv={Hkv} D={D} L={L} {str(dtype)[6:]} ratio={ratio} mask={mrate} reforge={reforge} mrope={mrope} "
-                f"layers={layers} chunks={chunks} native_rope={native} a={S:.3f}")
+                f"layers={layers} chunks={chunks} native_rope={native} a={S:.3f} score_rounding={rounding}")
 
         def make(skip):
             cfg = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=layers, num_attention_heads=Hq,
                                         num_key_value_heads=Hkv,
                                         longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
                                             "compression_ratio": ratio, "compression_method": "pivotkv",
-                                            "pos_embed_reforge": reforge, "native_rope": native, "skip_masked_columns": skip}})
+                                            "pos_embed_reforge": reforge, "native_rope": native, "skip_masked_columns": skip,
+                                            "score_rounding": rounding}})
             return lc.build_kvcache(cfg)
 
         ca, cb = make(True), make(False)

@@ -1712,6 +1712,7 @@ __global__ __launch_bounds__(256) void score_pass2_generic(const void* __restric
     float col = 0.f;
     for (int hh = 0; hh < G; ++hh) {
         const int h = g * G + hh;
+        float blk = 0.f;   // two-level sum: 64-row blocks, then blocks (a plain running sum over G * L terms drifts by ~1e-5)
         for (int i = 0; i < L; ++i) {
             __syncthreads();
             for (int d = tid; d < D; d += blockDim.x) qs[d] = ldx<DT>(q, ((size_t)h * L + i) * D + d);
@@ -1719,7 +1720,11 @@ __global__ __launch_bounds__(256) void score_pass2_generic(const void* __restric
             if (j < L) {
                 float s = 0.f;
                 for (int d = 0; d < D; ++d) s = fmaf(qs[d], ldx<DT>(k, ((size_t)g * L + j) * D + d), s);
-                col += expf(__fdiv_rn(s, sqrt_d) - lse[(size_t)h * L + i]);
+                blk += expf(__fdiv_rn(s, sqrt_d) - lse[(size_t)h * L + i]);
+            }
+            if ((i & 63) == 63 || i + 1 == L) {
+                col += blk;
+                blk = 0.f;
             }
         }
     }
