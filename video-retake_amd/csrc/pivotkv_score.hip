@@ -861,6 +861,30 @@ struct RowStatR {
     }
 };
 
+// The same for the exact modes (bf16 / fp16 payloads, un-scaled operands): exp2(dot * c2) added to the row sum, no offset,
+// no per-block test - one multiply more than RowStatR, but none of RowStatB's bookkeeping (the lazy test costs a compare,
+// a ballot and a branch per 32-key block, and the offset a register): same end-of-row check, same fix-up launch, which
+// then runs RowStatB.
+struct RowStatRX {
+    float sum;
+    __device__ __forceinline__ void init() { sum = 0.f; }
+    template <bool RAGGED>
+    __device__ __forceinline__ void update(f32x16& a, int j0, int j_end, int hf, float c2) {
+        if (RAGGED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (j0 + acc_row(r, hf) >= j_end) a[r] = -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(a[r] * c2);
+    }
+    __device__ __forceinline__ float finish() const {
+        const float tot = sum + __shfl_xor(sum, 32, WAVE);
+        const bool fine = tot < 0x1p120f && tot > 0x1p-60f;
+        return fine ? __builtin_amdgcn_logf(tot) : __builtin_nanf("");
+    }
+};
+
 // The robust form (fix-up launch only): sum = sum_j exp2(s_j + off) over the keys this lane has seen, i.e. the true
 // total is sum * 2^-off.  Lazy like RowStatB: the offset is that of the last rescale; when some lane's block sum is
 // not a finite number below 2^96, or nothing has been seen yet (`primed`, wave-uniform), the wave re-bases on the
@@ -1421,8 +1445,11 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
 // 32-key block in flight per wave (~100 VGPRs -> 4 waves per SIMD).
 // ------------------------------------------------------------------------------------------------
 // The work of one workgroup: NB x 32 query rows of head h per wave starting at row i_base + wid * 32 * NB, key split ks.
-// MODE: 0 = exact bf16 (RowStatB), 1 = RTK_BF16_FAST production form (RowStatR), 2 = RTK_BF16_FAST fix-up (RowStatF),
-//       3 = exact on fp16 payloads (RTK_F16: RowStatB, the fp16 matrix instruction)
+// MODE is a set of flags: P1_F16 = the operands are fp16 (fast mode, fp16 payloads), P1_SCALED = q~ was pre-scaled by
+// log2(e)/sqrt(D) (fast mode: the accumulators are base-2 logits), P1_RAW = plain row sums checked once at the end
+// (a fix-up launch with the same flags minus P1_RAW follows).  Statistic: RAW ? (SCALED ? RowStatR : RowStatRX)
+//                                                                              : (SCALED ? RowStatF : RowStatB).
+constexpr int P1_F16 = 1, P1_SCALED = 2, P1_RAW = 4;
 template <int NB, bool LAZY, int MODE = 0>
 __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv,
                                                      int L, int keys_per_split, float* __restrict__ lse_part, int i_base, int h,
@@ -1454,10 +1481,11 @@ __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q,
         for (int r = 0; r < M::NREG; ++r) frag_off[r] = row * T::ROWB + ((M::chunk_of(r, hf) ^ (row & 15)) * 16);
     }
     const float c2 = 1.4426950408889634f / sqrtf((float)HD);
-    constexpr bool FAST = MODE == 1 || MODE == 2;
-    using Stat = std::conditional_t<MODE == 1, RowStatR, std::conditional_t<MODE == 2, RowStatF, RowStatB>>;
+    constexpr bool F16OPS = (MODE & P1_F16) != 0, SCALED = (MODE & P1_SCALED) != 0, RAW = (MODE & P1_RAW) != 0;
+    using Stat = std::conditional_t<RAW, std::conditional_t<SCALED, RowStatR, RowStatRX>,
+                                    std::conditional_t<SCALED, RowStatF, RowStatB>>;
     Stat rs[NB];
-    bool primed[NB];       // MODE 2: has this wave re-based its rows yet?  (wave-uniform)
+    bool primed[NB];       // RowStatF: has this wave re-based its rows yet?  (wave-uniform)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         rs[nb].init();
@@ -1503,7 +1531,7 @@ __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q,
             for (int r = 0; r < M::NREG; ++r) {                                                           \
                 _Pragma("unroll")                                                                         \
                 for (int nb = 0; nb < NB; ++nb) {                                                         \
-                    if constexpr (FAST || MODE == 3) mma16<true>(acc[nb], a[r], qf[nb][r], acc[nb]);      \
+                    if constexpr (F16OPS) mma16<true>(acc[nb], a[r], qf[nb][r], acc[nb]);                 \
                     else M::mma(acc[nb], a[r], qf[nb][r]);                                                \
                     __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);            \
                 }                                                                                         \
@@ -1511,10 +1539,13 @@ __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q,
             __builtin_amdgcn_sched_barrier(0);                                        \
             _Pragma("unroll")                                                                             \
             for (int nb = 0; nb < NB; ++nb) {                                                             \
-                if constexpr (MODE == 1) {                                                                \
+                if constexpr (RAW && SCALED) {                                                            \
                     rs[nb].template update<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf);         \
                     asm volatile("" : "+v"(rs[nb].sum) : : "memory");                                     \
-                } else if constexpr (MODE == 2) {                                                         \
+                } else if constexpr (RAW) {                                                               \
+                    rs[nb].template update<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf, c2);     \
+                    asm volatile("" : "+v"(rs[nb].sum) : : "memory");                                     \
+                } else if constexpr (SCALED) {                                                            \
                     rs[nb].template update<RAG>(acc[nb], (JT) * TILE_ROWS + 32 * blk, nkeys, hf, primed[nb]); \
                     asm volatile("" : "+v"(rs[nb].sum), "+v"(rs[nb].off) : : "memory");                   \
                 } else {                                                                                  \
@@ -1565,7 +1596,7 @@ __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q,
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         float out;
-        if constexpr (FAST) out = rs[nb].finish();
+        if constexpr (RAW || SCALED) out = rs[nb].finish();
         else out = rs[nb].finish(c2);
         const int i = i0 + 32 * nb + (lane & 31);
         if (hf == 0 && i < L) lse_part[((size_t)ks * Hq + h) * L + i] = neg_out ? -out : out;
@@ -1617,7 +1648,7 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
 // workgroups: ~4 us per chunk instead of the ~60 us of dispatching 39 200 workgroups that read 1 KB each and leave).
 // Tiles are numbered ((ks * Hq + h) * row_tiles + bx); no XCD-aware decode (nothing streams in the common case).
 constexpr int FIX_TILES = 16;
-template <int NB>
+template <int NB, int MODE>   // MODE: the robust flags (no P1_RAW) of the launch being repaired
 __global__ __launch_bounds__(SC_BLOCK, 3) void score_pass1_fixup_kernel(
     const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv, int L, int keys_per_split, int row_tiles,
     int n_tiles, float* __restrict__ lse_part, size_t q_unit_bytes, size_t k_unit_bytes, size_t lse_unit_floats,
@@ -1642,9 +1673,9 @@ __global__ __launch_bounds__(SC_BLOCK, 3) void score_pass1_fixup_kernel(
         const int h = kh % Hq, ks = kh / Hq;
         const int i_base = bx * (REG_ROWS * NB);
         if (NB == 2 && L - i_base <= REG_ROWS)
-            score_pass1_dma_body<1, true, 2>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
+            score_pass1_dma_body<1, true, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
         else
-            score_pass1_dma_body<NB, true, 2>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
+            score_pass1_dma_body<NB, true, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
         __syncthreads();   // the next tile's prologue writes the LDS buffers this one was still reading
     }
 }
@@ -2020,24 +2051,24 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
         if (stages & RTK_SCORE_PASSES) {
             if constexpr (dma) {
                 const int jt1 = (L + REG_ROWS * RTK_P1_NB - 1) / (REG_ROWS * RTK_P1_NB);
-                if (w.fast) {   // pass 2 starts its accumulators from -lse: whoever writes the final lse negates it
-                    RTK_LAUNCH(KID_PASS1, (score_pass1_dma_kernel<RTK_P1_NB, true, 1>), dim3(Hkv * ks_n * jt1 * G, n_units),
-                               dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
-                               (int)((Hkv * ks_n) % NXCD == 0), lse, ws_stride, k_stride, ws_stride / sizeof(float),
-                               (int)(ks_n == 1));
-                    // rows whose plain sum left fp32's range were published as NaN: their tiles run again, robustly
-                    const int n_tiles = Hkv * ks_n * jt1 * G;
-                    RTK_LAUNCH(KID_FINALIZE, (score_pass1_fixup_kernel<RTK_P1_NB>), dim3((n_tiles + FIX_TILES - 1) / FIX_TILES, n_units),
-                               dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1, n_tiles,
-                               lse, ws_stride, k_stride, ws_stride / sizeof(float), (int)(ks_n == 1));
-                } else if (w.h16)
-                    RTK_LAUNCH(KID_PASS1, (score_pass1_dma_kernel<RTK_P1_NB, RTK_P1_LAZY, 3>), dim3(Hkv * ks_n * jt1 * G, n_units),
-                               dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
-                               (int)((Hkv * ks_n) % NXCD == 0), lse, ws_stride, k_stride, ws_stride / sizeof(float));
-                else
-                RTK_LAUNCH(KID_PASS1, (score_pass1_dma_kernel<RTK_P1_NB, RTK_P1_LAZY>), dim3(Hkv * ks_n * jt1 * G, n_units),
-                           dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1,
-                           (int)((Hkv * ks_n) % NXCD == 0), lse, ws_stride, k_stride, ws_stride / sizeof(float));
+                // raw row sums + a fix-up launch (1/16 of the grid) for the rows whose sum left fp32's range; the
+                // fast mode's pass 2 starts its accumulators from -lse, so whoever writes the final lse negates it
+                const int n_tiles = Hkv * ks_n * jt1 * G;
+                const dim3 g1(n_tiles, n_units), gf((n_tiles + FIX_TILES - 1) / FIX_TILES, n_units);
+                const int x1 = (int)((Hkv * ks_n) % NXCD == 0), neg = (int)(w.fast && ks_n == 1);
+#define RTK_P1(MODEV)                                                                                                  \
+    RTK_LAUNCH(KID_PASS1, (score_pass1_dma_kernel<RTK_P1_NB, RTK_P1_LAZY, MODEV>), g1, dim3(SC_BLOCK), LDS1, st,           \
+               (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1, x1, lse, ws_stride, k_stride,                     \
+               ws_stride / sizeof(float), neg);                                                                         \
+    if ((MODEV) & P1_RAW)                                                                                               \
+        RTK_LAUNCH(KID_FINALIZE, (score_pass1_fixup_kernel<RTK_P1_NB, (MODEV) & ~P1_RAW>), gf, dim3(SC_BLOCK), LDS1, st,   \
+                   (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1, n_tiles, lse, ws_stride, k_stride,            \
+                   ws_stride / sizeof(float), neg)
+                constexpr int RAWF = RTK_P1_RAW ? P1_RAW : 0;
+                if (w.fast) { RTK_P1(P1_F16 | P1_SCALED | P1_RAW); }
+                else if (w.h16) { RTK_P1(P1_F16 | RAWF); }
+                else { RTK_P1(RAWF); }
+#undef RTK_P1
             }
             else
                 RTK_LAUNCH(KID_PASS1, (score_pass1_kernel<DT, NBR>), dim3(Hkv * ks_n * jt * G), dim3(SC_BLOCK), LDS1, st,

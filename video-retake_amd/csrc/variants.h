@@ -22,3 +22,6 @@
 #ifndef RTK_IGNORE_MANY_UNITS   // 1 = RTK_SCORE_MANY_UNITS changes nothing (A/B of the split policy of batched launches)
 #define RTK_IGNORE_MANY_UNITS 0
 #endif
+#ifndef RTK_P1_RAW        // exact modes' pass 1: 1 = plain row sums + end-of-row check + fix-up launch, 0 = lazy online max (RowStatB)
+#define RTK_P1_RAW 1
+#endif
