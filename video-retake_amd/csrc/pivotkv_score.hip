@@ -1643,13 +1643,13 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
 
 // RTK_BF16_FAST fix-up launch: the row tiles whose plain sums left fp32's range (published as NaN by RowStatR) are
 // recomputed with the offset-carrying form.  Normally there is nothing to fix, so the launch must cost next to nothing: a
-// workgroup looks at FIX_TILES consecutive row tiles at once - one load per thread and tile, all in flight together, one
-// barrier-or per tile - and runs the robust body only for a tile that holds a NaN (1/16 of the main kernel's
-// workgroups: ~4 us per chunk instead of the ~60 us of dispatching 39 200 workgroups that read 1 KB each and leave).
+// workgroup looks at FIX_TILES consecutive row tiles at once - one load per thread and tile, all in flight together, the
+// per-thread NaN bits OR-ed into one LDS word - and runs the robust body only for a tile that holds a NaN (1/32 of the
+// main kernel's workgroups instead of a full-size grid whose 39 200 workgroups read 1 KB each and leave: ~60 us).
 // Tiles are numbered ((ks * Hq + h) * row_tiles + bx); no XCD-aware decode (nothing streams in the common case).
-constexpr int FIX_TILES = 16;
+constexpr int FIX_TILES = 32;   // tiles per workgroup = bits of its NaN mask; 28 units x 700 tiles -> 616 workgroups: one resident round
 template <int NB, int MODE>   // MODE: the robust flags (no P1_RAW) of the launch being repaired
-__global__ __launch_bounds__(SC_BLOCK, 3) void score_pass1_fixup_kernel(
+__global__ __launch_bounds__(SC_BLOCK, 2) void score_pass1_fixup_kernel(   // (2: registers, not occupancy - no spills)
     const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv, int L, int keys_per_split, int row_tiles,
     int n_tiles, float* __restrict__ lse_part, size_t q_unit_bytes, size_t k_unit_bytes, size_t lse_unit_floats,
     int neg_out) {
@@ -1657,6 +1657,8 @@ __global__ __launch_bounds__(SC_BLOCK, 3) void score_pass1_fixup_kernel(
     k += blockIdx.y * k_unit_bytes;
     lse_part += blockIdx.y * lse_unit_floats;
     const int t0 = blockIdx.x * FIX_TILES;
+    __shared__ unsigned nan_tiles;       // bit u: tile t0 + u holds a NaN
+    if (threadIdx.x == 0) nan_tiles = 0;
     float v[FIX_TILES];
 #pragma unroll
     for (int u = 0; u < FIX_TILES; ++u) {
@@ -1665,9 +1667,16 @@ __global__ __launch_bounds__(SC_BLOCK, 3) void score_pass1_fixup_kernel(
         const int i = bx * (REG_ROWS * NB) + (int)threadIdx.x;
         v[u] = (t < n_tiles && (int)threadIdx.x < REG_ROWS * NB && i < L) ? lse_part[(size_t)kh * L + i] : 0.f;
     }
-#pragma unroll 1
-    for (int u = 0; u < FIX_TILES; ++u) {
-        if (!__syncthreads_or(v[u] != v[u])) continue;             // uniform: the whole workgroup takes the same path
+    unsigned mine = 0;                   // (a bit mask, not an indexed array: v[] must stay in registers)
+#pragma unroll
+    for (int u = 0; u < FIX_TILES; ++u) mine |= (v[u] != v[u]) ? (1u << u) : 0u;
+    __syncthreads();
+    if (mine) atomicOr(&nan_tiles, mine);
+    __syncthreads();
+    unsigned todo = nan_tiles;           // uniform: the whole workgroup takes the same path
+    while (todo) {
+        const int u = __builtin_ctz(todo);
+        todo &= todo - 1;
         const int t = t0 + u;
         const int bx = t % row_tiles, kh = t / row_tiles;
         const int h = kh % Hq, ks = kh / Hq;
