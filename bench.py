@@ -590,14 +590,14 @@ def main():
             "real Qwen2-VL-7B geometry at 448 px 16:9: 1024 temporal grids x 144 merged tokens x 3584 channels, "
             "chunk = 16 grids = 2304 tokens (cal_flops.py:8,47; qwen2_vl.py:477-491)")
         out["reference_rounding"] = companion_measurement(dev, args.frames, args.layers, "bf16", 2, 1, args.pool,
-                                                          score_rounding="reference", warmup_chunks=4)
+                                                          score_rounding="reference")
         out["reference_rounding"]["note"] = ("score_rounding='reference': the reference's bf16 logits / probabilities / sums "
                                              "(longvideo_cache.py:264-270) reproduced rounding by rounding")
         out["fast_rounding"] = companion_measurement(dev, args.frames, args.layers, "bf16", 2, 1, args.pool,
-                                                     score_rounding="fast", warmup_chunks=4)
+                                                     score_rounding="fast")
         out["fast_rounding"]["note"] = ("score_rounding='fast' (opt in): q~ pre-scaled and both operands as fp16 on "
                                         "v_mfma_f32_32x32x16_f16, two instructions per logit; scores within ~1e-5 of the default")
-        out["fp16_dtype"] = companion_measurement(dev, args.frames, args.layers, "fp16", 2, 1, args.pool, warmup_chunks=4)
+        out["fp16_dtype"] = companion_measurement(dev, args.frames, args.layers, "fp16", 2, 1, args.pool)
         out["fp16_dtype"]["note"] = "float16 tensors (RTK_F16): fp16 rounding chains, exact fp16 products on the fp16 matrix instruction"
         out["fp32_parity_dtype"] = companion_measurement(dev, args.frames, args.layers, "fp32", 1, 1, args.pool,
                                                          warmup_chunks=2)
