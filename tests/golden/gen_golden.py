@@ -268,6 +268,48 @@ def gen_dpselect(vc, outdir):
     print("dpselect N=1 async ->", crash)
 
 
+def gen_dpselect_degenerate(vc, outdir):
+    """Degenerate calls of visual_compression.py: which exception class each one dies with, and what the calls that do
+    return hand back (tgt_mem_len 0, batch size 2).  One fixture: dpselect_edge_degenerate.npz."""
+    def outcome(f):
+        try:
+            f()
+            return "none"
+        except Exception as e:  # noqa: BLE001
+            return type(e).__name__
+
+    torch.manual_seed(7)
+    x1 = torch.randn(1, 1, 4, 8)
+    x = torch.randn(1, 6, 4, 8)
+    rec = dict(
+        keyframe_T1_sync=outcome(lambda: vc.memory_bank_compress_keyframe(x1.clone(), 1, 3, True)),
+        keyframe_T1_async=outcome(lambda: vc.memory_bank_compress_keyframe(x1.clone(), 1, 3, False)),
+        keyframe_T1_N1_async=outcome(lambda: vc.memory_bank_compress_keyframe(x1[:, :, :1].clone(), 1, 3, False)),
+        keyframe_tgt_gt_T_sync=outcome(lambda: vc.memory_bank_compress_keyframe(x.clone(), 7, 3, True)),
+        keyframe_tgt_gt_T_async=outcome(lambda: vc.memory_bank_compress_keyframe(x.clone(), 7, 3, False)),
+        keyframe_tgt_neg_sync=outcome(lambda: vc.memory_bank_compress_keyframe(x.clone(), -1, 3, True)),
+        keyframe_tgt_gt_T_N1_async=outcome(lambda: vc.memory_bank_compress_keyframe(x[:, :, :1].clone(), 7, 3, False)),
+        mallm_T1=outcome(lambda: vc.memory_bank_compress_MALLM(x1.clone(), torch.ones(1, 1, 4))),
+        mallm_hard_T1=outcome(lambda: vc.memory_bank_compress_MALLM_hard(x1.clone())))
+    for sync in (True, False):
+        tag = "sync" if sync else "async"
+        o, m = vc.memory_bank_compress_keyframe(x.clone(), 0, 3, sync)
+        rec[f"tgt0_{tag}_out_shape"] = np.array(o.shape)
+        rec[f"tgt0_{tag}_mask_shape"] = np.array(m.shape)
+        rec[f"tgt0_{tag}_mask_dtype"] = str(m.dtype)
+    xb = torch.from_numpy(synth.make_frames("video", 71, 12, 5, 24)).repeat(2, 1, 1, 1)
+    xb[1] = torch.from_numpy(synth.make_frames("video", 72, 12, 5, 24))[0]
+    rec["xb"] = xb.numpy()
+    for sync in (True, False):
+        tag = "sync" if sync else "async"
+        o, m = vc.memory_bank_compress_keyframe(xb.clone(), 5, 3, sync)
+        rec[f"b2_{tag}_out"] = o.numpy()
+        rec[f"b2_{tag}_mask"] = m.numpy()
+    np.savez_compressed(os.path.join(outdir, "dpselect_edge_degenerate.npz"), **rec)
+    for k, v in rec.items():
+        print("dpselect_edge_degenerate", k, v if isinstance(v, str) else getattr(v, "shape", v))
+
+
 # --------------------------------------------------------------------------------------
 # PivotKV
 # --------------------------------------------------------------------------------------
@@ -318,6 +360,12 @@ def gen_pivotkv(lc, outdir):
         ("qwen_L256", 28, 4, 128, 8, 8, 4, 2, 0.25, True, [16, 24, 24], S, 0.3, 111, 0, False),
         ("qwen_L2304", 28, 4, 128, 9, 16, 16, 1, 0.25, True, [16, 24, 24], S, 0.3, 112, 0, False),
         ("llava_L392", 28, 4, 128, 14, 14, 2, 2, 0.25, True, None, S, 0.3, 113, 0, False),
+        # compression_ratio 1 - what `dynamic_compression_ratio` sets for every prompt within max_input_length
+        # (qwen2_vl.py:553-554; all shipped configs): the whole chunk is kept, K still goes through the un-rotate /
+        # re-rotate round trip, the id rescale multiplies by 1.0
+        ("small_ratio1_mrope_reforge", 4, 2, 32, 4, 4, 4, 3, 1, True, [4, 6, 6], S, 0.3, 114, 0, True),
+        ("small_ratio1_rope1d_noreforge", 4, 2, 32, 4, 4, 4, 2, 1, False, None, 1.0, 0.2, 115, 0, True),
+        ("qwen_L576_ratio1", 28, 4, 128, 12, 12, 4, 2, 1, True, [16, 24, 24], S, 0.3, 116, 0, False),
     ]
     for (name, Hq, Hkv, D, gh, gw, gpc, nch, ratio, reforge, mrope, a, mrate, seed, layer, raw) in cases:
         for attempt in range(50):
@@ -576,7 +624,8 @@ def gen_pivotkv_bf16(lc, outdir):
     # name, gh, gw, grids per chunk, chunks, ratio, mask rate, seed, raw
     cases = [("bf16_qwen_L256", 8, 8, 4, 2, 0.25, 0.3, 211, True),
              ("bf16_qwen_L1568", 14, 14, 8, 1, 0.25, 0.3, 212, False),
-             ("bf16_qwen_L6272", 14, 14, 32, 1, 0.25, 0.3, 213, False)]
+             ("bf16_qwen_L6272", 14, 14, 32, 1, 0.25, 0.3, 213, False),
+             ("bf16_qwen_L576_ratio1", 12, 12, 4, 2, 1, 0.3, 214, True)]   # dynamic ratio of a short prompt: keep all
     Hq, Hkv, D, mrope = 28, 4, 128, [16, 24, 24]
     for (name, gh, gw, gpc, nch, ratio, mrate, seed, raw) in cases:
         L = gpc * gh * gw
@@ -789,6 +838,8 @@ def main():
     vc, lc = import_reference()
     if args.only in (None, "dpselect"):
         gen_dpselect(vc, HERE)
+    if args.only in (None, "dpselect_degenerate"):
+        gen_dpselect_degenerate(vc, HERE)
     if args.only in (None, "pivotkv"):
         gen_pivotkv(lc, HERE)
     if args.only in (None, "pivotkv_bf16"):

@@ -71,6 +71,35 @@ def test_no_cpu_fallback():
         vc.memory_bank_compress_keyframe(torch.randn(1, 8, 4, 16), 4, 3, True)
 
 
+def test_degenerate_calls_raise_the_reference_exception_classes():
+    """The reference's own failures on degenerate DPSelect / MA-LLM calls (recorded from the imported reference by
+    tests/golden/gen_golden.py::gen_dpselect_degenerate; visual_compression.py:19-23, :100-123, :134, :153-156, :167):
+    the binding raises the same exception class, from the argument checks, before any device work."""
+    import numpy as np
+    import retake.visual_compression as vc
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dpselect_edge_degenerate.npz"), allow_pickle=False)
+    excs = {"RuntimeError": RuntimeError, "IndexError": IndexError}
+    x1, x = torch.randn(1, 1, 4, 8), torch.randn(1, 6, 4, 8)
+    calls = {
+        "keyframe_T1_sync": lambda: vc.memory_bank_compress_keyframe(x1, 1, 3, True),
+        "keyframe_T1_async": lambda: vc.memory_bank_compress_keyframe(x1, 1, 3, False),
+        "keyframe_T1_N1_async": lambda: vc.memory_bank_compress_keyframe(x1[:, :, :1], 1, 3, False),
+        "keyframe_tgt_gt_T_sync": lambda: vc.memory_bank_compress_keyframe(x, 7, 3, True),
+        "keyframe_tgt_gt_T_async": lambda: vc.memory_bank_compress_keyframe(x, 7, 3, False),
+        "keyframe_tgt_neg_sync": lambda: vc.memory_bank_compress_keyframe(x, -1, 3, True),
+        "keyframe_tgt_gt_T_N1_async": lambda: vc.memory_bank_compress_keyframe(x[:, :, :1], 7, 3, False),
+        "mallm_T1": lambda: vc.memory_bank_compress_MALLM(x1, torch.ones(1, 1, 4)),
+        "mallm_hard_T1": lambda: vc.memory_bank_compress_MALLM_hard(x1),
+    }
+    for name, call in calls.items():
+        want = excs[str(g[name])]
+        with pytest.raises(want) as ei:
+            call()
+        assert type(ei.value) is want, (name, type(ei.value))   # not a subclass such as the no-CPU-fallback error's
+        assert "no CPU fallback" not in str(ei.value), name
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "video-retake_amd")
     for dp, _, fns in os.walk(pkg):

@@ -155,6 +155,27 @@ def test_dpselect_async_single_patch_raises_like_reference():
         vc.memory_bank_compress_keyframe(torch.randn(1, 8, 1, 16, device=dev()), 4, 3, sync=False)
 
 
+@pytest.mark.gpu
+def test_dpselect_degenerate_calls_match_reference():
+    """tgt_mem_len 0 (empty selection) and batch size 2 (batch entry 0 chooses the frames; sync gathers every entry,
+    async returns entry 0 only) against the reference's outputs (dpselect_edge_degenerate.npz;
+    visual_compression.py:101, :134-140, :167-175)."""
+    import retake.visual_compression as vc
+
+    g = gu.load("dpselect_edge_degenerate")
+    x = torch.randn(1, 6, 4, 8, device=dev())
+    for sync in (True, False):
+        tag = "sync" if sync else "async"
+        out, mask = vc.memory_bank_compress_keyframe(x, 0, 3, sync)
+        assert tuple(out.shape) == tuple(g[f"tgt0_{tag}_out_shape"]) and out.dtype == x.dtype
+        assert tuple(mask.shape) == tuple(g[f"tgt0_{tag}_mask_shape"]) and mask.dtype == torch.bool
+        xb = torch.from_numpy(g["xb"]).to(dev())
+        out, mask = vc.memory_bank_compress_keyframe(xb, 5, 3, sync)
+        assert out.shape == g[f"b2_{tag}_out"].shape
+        assert np.array_equal(out.cpu().numpy(), g[f"b2_{tag}_out"]), tag
+        assert np.array_equal(mask.cpu().numpy(), g[f"b2_{tag}_mask"]), tag
+
+
 @pytest.mark.parametrize("T,N,C,tgt,sync", [(33, 7, 40, 11, False), (9, 3, 6, 9, True), (3, 2, 1000, 2, False),
                                             (130, 5, 4100, 40, False), (17, 4, 18, 5, True),
                                             (5000, 2, 64, 1234, False), (4097, 1, 32, 4096, True), (8200, 3, 128, 1, False)])
@@ -321,7 +342,7 @@ def test_mallm_step_vs_oracle(T, N, C, sync, hard, bf16):
 # ---------------------------------------------------------------------------------------------------
 # PivotKV
 # ---------------------------------------------------------------------------------------------------
-def _make_cache(g, native_rope=False, overlap_streams=0):
+def _make_cache(g, native_rope=False, overlap_streams=0, **extra):
     import retake.longvideo_cache as lc
 
     Hq, Hkv, D = int(g["Hq"]), int(g["Hkv"]), int(g["D"])
@@ -330,7 +351,7 @@ def _make_cache(g, native_rope=False, overlap_streams=0):
     kw = {"kvcache_compression": True,
           "kvcache_compression_kwargs": {"compression_ratio": float(g["ratio"]), "compression_method": "pivotkv",
                                          "pos_embed_reforge": bool(g["reforge"]), "native_rope": native_rope,
-                                         "overlap_streams": overlap_streams}}
+                                         "overlap_streams": overlap_streams, **extra}}
     sec = [int(s) for s in g["mrope_section"]] or None
     if sec is None:
         cfg = types.SimpleNamespace(text_config=llm, longvideo_kwargs=kw)  # LLaVA-style config
@@ -342,11 +363,21 @@ def _make_cache(g, native_rope=False, overlap_streams=0):
     return cache, sec
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("native_rope,overlap", [(False, 0), (True, 0), (False, 2)])
+@pytest.mark.parametrize("name", [n for n in PK if "ratio1" in n])
+def test_pivotkv_golden_ratio1_scored(name, native_rope, overlap):
+    """compression_ratio 1 with the scoring forced on: the scores equal the reference's too (the default skips them,
+    test_pivotkv_golden covers that route on the same fixtures)."""
+    test_pivotkv_golden(name, native_rope, overlap, score_when_keeping_all=True)
+
+
 @pytest.mark.parametrize("native_rope,overlap", [(False, 0), (True, 0), (False, 2)])
 @pytest.mark.parametrize("name", PK)
-def test_pivotkv_golden(name, native_rope, overlap):
+def test_pivotkv_golden(name, native_rope, overlap, **extra):
     g = gu.load(name)
-    cache, sec = _make_cache(g, native_rope, overlap)
+    cache, sec = _make_cache(g, native_rope, overlap, **extra)
+    unscored = int(g["keep"]) == int(g["L"]) and not extra   # the whole chunk kept: selection is the identity, no scores
     layer, keep, tie = int(g["layer"]), int(g["keep"]), bool(g["tie_case"])
     rotary = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]), device=dev())
     Hkv, D = int(g["Hkv"]), int(g["D"])
@@ -368,9 +399,12 @@ def test_pivotkv_golden(name, native_rope, overlap):
         assert torch.equal(kout[:, :, prev_len:], kt) and torch.equal(vout[:, :, prev_len:], vt)  # uncompressed
         pre = f"c{c}_"
         torch.cuda.synchronize()   # worker streams (overlap > 0) write the diagnostic scratch views
-        score = cache.last_scores.cpu().numpy()
         idx = cache.last_keep_indices.cpu().numpy()
-        assert np.abs(score - g[pre + "score32"]).max() < 5e-6
+        if unscored:
+            assert cache.last_scores is None
+        else:
+            score = cache.last_scores.cpu().numpy()
+            assert np.abs(score - g[pre + "score32"]).max() < 5e-6
         if tie:
             s = g[pre + "score32"]
             np.testing.assert_array_equal(np.sort(s[idx]), np.sort(s[g[pre + "keep_idx"]]))
@@ -1837,7 +1871,8 @@ def test_pivotkv_bf16_against_reference_bf16(name, rounding):
     llm = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=n_layers, num_attention_heads=Hq, num_key_value_heads=Hkv,
                                 longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
                                     "compression_ratio": float(g["ratio"]), "compression_method": "pivotkv",
-                                    "pos_embed_reforge": True, "score_rounding": rounding}})
+                                    "pos_embed_reforge": True, "score_rounding": rounding,
+                                    "score_when_keeping_all": True}})   # (the ratio-1 fixture: scores wanted here)
     cache = lc.build_kvcache(llm)
     rot = _CpuTablesRotary(g["inv_freq"], float(g["attention_scaling"]), dev())
     q, k, v, pos, mask = gu.pivotkv_bf16_chunk_inputs(g, 0)     # later chunks depend on which tied tokens were kept
@@ -1884,6 +1919,74 @@ def test_pivotkv_bf16_against_reference_bf16(name, rounding):
         if l:   # identical inputs: identical layers, bit for bit
             assert torch.equal(cache._batch.score[l], cache._batch.score[0])
             assert torch.equal(cache.key_cache[l], cache.key_cache[0])
+
+
+def test_pivotkv_ratio_above_one_raises_like_reference():
+    """compression_ratio > 1 asks topk for more tokens than the chunk has: RuntimeError (longvideo_cache.py:276)."""
+    g = gu.load("pivotkv_small_ratio1_mrope_reforge")
+    cache, sec = _make_cache(g)
+    cache.compression_ratio = 1.5
+    q, k, v, pos, mask = gu.pivotkv_chunk_inputs(g, 0)
+    kw = {"query_states": torch.from_numpy(q).to(dev()), "position_ids": torch.from_numpy(pos).to(dev()),
+          "rotary_emb": synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]), device=dev()),
+          "mrope_section": list(sec)}
+    with pytest.raises(RuntimeError, match="out of range"):
+        cache.update(torch.from_numpy(k).to(dev()), torch.from_numpy(v).to(dev()), 0, kw)
+
+
+@pytest.mark.parametrize("native_rope", [False, True])
+def test_pivotkv_bf16_ratio1_keeps_all_without_scoring(native_rope):
+    """compression_ratio 1 - the dynamic ratio of every prompt within max_input_length (qwen2_vl.py:553-554) - on bf16
+    tensors against the reference's own run, BOTH chunks, three layers: no scoring launch at all (last_scores is None),
+    every token kept in order, the kept keys equal the reference's un-rotate / re-rotate round trip BIT for bit, V rows
+    are copies, ids and bookkeeping equal."""
+    import retake._native as nv
+    import retake.longvideo_cache as lc
+
+    g = gu.load("pivotkv_bf16_qwen_L576_ratio1")
+    Hq, Hkv, D, L, keep = (int(g[k]) for k in ("Hq", "Hkv", "D", "L", "keep"))
+    assert keep == L
+    sec = [int(x) for x in g["mrope_section"]]
+    n_layers = 3
+    llm = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=n_layers, num_attention_heads=Hq, num_key_value_heads=Hkv,
+                                longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
+                                    "compression_ratio": 1, "compression_method": "pivotkv", "pos_embed_reforge": True,
+                                    "native_rope": native_rope}})
+    cache = lc.build_kvcache(llm)
+    rot = _CpuTablesRotary(g["inv_freq"], float(g["attention_scaling"]), dev())
+
+    def dv(bits):
+        return torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16).to(dev())
+
+    nv.lib.rtk_profile_reset()
+    nv.lib.rtk_profile_enable(1)
+    try:
+        for c in range(int(g["n_chunks"])):
+            q, k, v, pos, mask = gu.pivotkv_bf16_chunk_inputs(g, c)
+            cache.keypatches_mask_chunk = torch.from_numpy(mask).to(dev())
+            cache.kvcache_compression = True
+            for l in range(n_layers):
+                kw = {"query_states": dv(q), "position_ids": torch.from_numpy(pos).to(dev()), "rotary_emb": rot,
+                      "mrope_section": list(sec)}
+                cache.update(dv(k), dv(v), l, kw)
+            cache.after_forward()
+            assert cache.last_scores is None
+            for l in range(n_layers):
+                assert np.array_equal(cache.last_keep_indices.cpu().numpy(), np.arange(L))
+                kk = cache.key_cache[l][:, :, c * L:].cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+                ref = g[f"c{c}_kept_k_bits"]
+                if native_rope:   # correctly rounded tables vs torch's libm: equal except at bf16 midpoints of a table entry
+                    assert (kk != ref).mean() < KEPT_K_MISMATCH_BAR
+                else:
+                    assert np.array_equal(kk, ref)
+                vv = cache.value_cache[l][:, :, c * L:].cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+                assert np.array_equal(vv, v)
+                assert np.array_equal(cache.position_cache[l].cpu().numpy(), g[f"c{c}_position_cache"])
+                assert cache.num_evicted_tokens[l] == 0 and cache.get_seq_length(l) == (c + 1) * L
+        ran = nv.profile_read()
+    finally:
+        nv.lib.rtk_profile_enable(0)
+    assert not [n for n in ran if any(w in n for w in ("pass", "finalize", "select"))], ran   # nothing scored or selected
 
 
 @pytest.mark.parametrize("native_rope", [False, True])

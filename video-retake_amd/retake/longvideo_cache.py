@@ -184,8 +184,10 @@ class _Side:
 class _Batch:
     """Per-chunk batch of pending evictions: slot = layer index.  All units share the chunk geometry."""
 
-    def __init__(self, key, slots, Hq, Hkv, L, D, keep, P, reforge, dtype, device, refround=False, fast=False):
+    def __init__(self, key, slots, Hq, Hkv, L, D, keep, P, reforge, dtype, device, refround=False, fast=False,
+                 keep_all=False):
         self.key, self.slots, self.keep, self.P, self.reforge = key, slots, keep, P, reforge
+        self.keep_all = keep_all   # keep == L and no scoring asked for: the selection is the identity
         # dtype code of the scoring entry points: bf16 payloads with the reference's bf16 rounding chain, or through the
         # fp16 matrix instruction with pre-scaled queries (score_rounding="fast"), on request
         self.score_dt = ((nv.RTK_BF16_REFROUND if refround else (nv.RTK_BF16_FAST if fast else nv.RTK_BF16))
@@ -197,7 +199,8 @@ class _Batch:
         # what rtk_pivotkv_prepare is told: the payload dtype (the reference-rounding mode prepares like plain bf16)
         self.prep_dt = (nv.RTK_BF16 if refround and dtype == torch.bfloat16 else self.score_dt & 0xFF) | (self.score_dt & ~0xFF)
         self.Hkv, self.L, self.D, self.dtype, self.device = Hkv, L, D, dtype, device
-        self.keep_idx = torch.empty((slots, keep), dtype=torch.int64, device=device)
+        self.keep_idx = torch.arange(keep, dtype=torch.int64, device=device).repeat(slots, 1) if keep_all \
+            else torch.empty((slots, keep), dtype=torch.int64, device=device)
         self.pos_new = torch.empty((P, slots, keep), dtype=torch.int64, device=device) if P else None
         # deferred selection (flushed for all layers at once): per-slot column partials of the scoring passes, the
         # final score, a private copy of the chunk's position ids (the caller shifts its tensor in place for the next
@@ -321,6 +324,12 @@ class PivotKVCache(DynamicCache):
         # the reference overwrites the score of every key-patch token with 1.0 (:272-274): the batched pass 2 does not
         # compute those columns.  Same kept set, same scores after the override; False restores the full pass (tests / A/B)
         self.skip_masked_columns = bool(kv_compression_kwargs.get("skip_masked_columns", True))
+        # compression_ratio 1 (what `dynamic_compression_ratio` sets for every prompt within max_input_length,
+        # qwen2_vl.py:553-554): keep == chunk length, so topk(k = L) followed by the ascending sort (:276-277) is the
+        # identity whatever the scores are, and the id rescale (:288-292) multiplies by 1.0.  The scoring passes and the
+        # selection are not run then - the K round trip through the un-rotated frame and the bookkeeping still are.
+        # True restores them (tests, `last_scores`)
+        self.score_when_keeping_all = bool(kv_compression_kwargs.get("score_when_keeping_all", False))
         self._sides: List[_Side] = []
         self._side_rr = 0
         self._pos_layers = 0          # len(position_cache) of the reference (skipped layers are padded with [])
@@ -333,9 +342,10 @@ class PivotKVCache(DynamicCache):
     # ---- diagnostics of the most recent compressed update (the selection may still be deferred: flush first) ----
     @property
     def last_scores(self):
+        """Scores of the most recent compressed update; None if it kept its whole chunk without scoring it."""
         b, l = self._last_slot
         self._flush()
-        return b.score[l]
+        return None if b.keep_all else b.score[l]
 
     @property
     def last_keep_indices(self):
@@ -580,14 +590,16 @@ class PivotKVCache(DynamicCache):
             raise NotImplementedError("score_rounding='reference' needs head_dim 128")
         # "fast" (opt in): bf16 chunks of head_dim 128 on the fp16 matrix instruction; every other shape scores as usual
         fast = self.score_rounding == "fast" and dtype == torch.bfloat16 and D == 128
-        key = (Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast)
+        keep_all = keep == L and not self.score_when_keeping_all
+        key = (Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast, keep_all)
         b = self._batch
         if b is not None and b.key == key and layer_idx < b.slots:
             return b
         self._flush()
         slots = max(int(self.num_hidden_layers), layer_idx + 1, b.slots if b is not None and b.key == key else 0)
         self._batch = None  # release the old buffers before allocating the new ones
-        self._batch = _Batch(key, slots, Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast)
+        self._batch = _Batch(key, slots, Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast,
+                             keep_all)
         return self._batch
 
     def _flush(self):
@@ -771,6 +783,8 @@ class PivotKVCache(DynamicCache):
             if t.stride(-1) != 1:
                 raise ValueError("q/k/v must be contiguous along head_dim")
         keep_len = max(1, int(self.compression_ratio * q_len))  # evict new tokens only (reference :263)
+        if keep_len > q_len:   # compression_ratio > 1: the reference's topk refuses it (:276)
+            raise RuntimeError(f"PivotKVCache.update: selected index k out of range (keep {keep_len} of {q_len} tokens)")
         reforge = bool(self.pos_embed_reforge)
 
         mask = getattr(self, "keypatches_mask_chunk", None)
@@ -836,6 +850,9 @@ class PivotKVCache(DynamicCache):
         def stage_big(ws):
             """the two matrix passes (reference :260-268): deferred to the flush (all layers of the chunk in one
             launch per kernel) whenever the batched form supports the shape"""
+            if batch.keep_all:         # nothing to choose: no scores
+                batch.scored.add(layer_idx)
+                return
             if batch.batched_passes:
                 return
             score_stage(ws, nv.SCORE_PASSES)
@@ -844,6 +861,11 @@ class PivotKVCache(DynamicCache):
         def stage_post(ws, pos_in):
             """small chunks only: column-mass reduction, mask override + top-k + position ids (reference :269-295)
             right away; larger chunks leave this to the batched selection of the flush"""
+            if batch.keep_all:         # keep_idx is the identity (set once per batch); ids x 1.0 = the ids (:288-292)
+                if pos_in is not None:
+                    batch.pos_new[:, layer_idx].copy_(pos_in)
+                batch.selected.add(layer_idx)
+                return
             if defer_select:
                 batch.masks[layer_idx] = mask
                 return

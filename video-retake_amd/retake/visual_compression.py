@@ -23,29 +23,40 @@ def dpselect_stages(memory_bank: torch.Tensor, tgt_mem_len: int, window_size: in
     if memory_bank.ndim != 4:
         raise ValueError(f"memory_bank must be [B,T,N,C], got {tuple(memory_bank.shape)}")
     B, T, N, Cc = memory_bank.shape
-    assert B == 1, "DPSelect uses the first batch entry's similarity only (visual_compression.py:101); bsz must be 1"
-    nv.require_device(memory_bank)
     tgt_mem_len = int(tgt_mem_len)
-    x = memory_bank[0]
-    if not x.is_contiguous():
-        x = x.contiguous()
+    # the reference's failures on degenerate calls, same exception classes, before anything is launched
+    if T < 2:
+        # no adjacent pair: the distance rows are empty and max_pool1d refuses them (visual_compression.py:100-123)
+        raise RuntimeError("memory_bank_compress_keyframe: a single frame (T == 1) has no adjacent-frame distances to pool")
+    if not sync and N == 1:
+        # `.squeeze()` drops the patch axis (visual_compression.py:153-156)
+        raise IndexError("memory_bank_compress_keyframe: sync=False with a single patch position (N == 1)")
+    if not 0 <= tgt_mem_len <= T:
+        raise RuntimeError(f"memory_bank_compress_keyframe: selected index k out of range (tgt_mem_len {tgt_mem_len}, "
+                           f"T {T})")                                      # torch.topk's error (:134 / :167)
+    nv.require_device(memory_bank)
+    # Only the first batch entry's distances choose the frames (visual_compression.py:101).  sync: every batch entry is
+    # gathered at those frames (:138); async: torch.gather with a [1, t, N, C] index returns batch entry 0 only (:173).
+    xs = [memory_bank[b] if memory_bank[b].is_contiguous() else memory_bank[b].contiguous()
+          for b in range(B if sync else 1)]
+    x = xs[0]
     dt = nv.dtype_code(x)
     dev = x.device
-    if not sync and N == 1:
-        # same failure as the reference: `.squeeze()` drops the patch axis (visual_compression.py:153-156)
-        raise IndexError("memory_bank_compress_keyframe: sync=False with a single patch position (N == 1)")
     with torch.cuda.device(dev):
         st = nv.stream()
         dis = torch.empty((T, N), dtype=torch.float32, device=dev)
         nv.check(nv.lib.rtk_dpselect_dis(nv.ptr(x), T, N, Cc, dt, nv.ptr(dis), st), "rtk_dpselect_dis")
         idx = torch.empty((tgt_mem_len,) if sync else (tgt_mem_len, N), dtype=torch.int64, device=dev)
         mask = torch.empty((tgt_mem_len, N), dtype=torch.bool, device=dev)
+        out = torch.empty((len(xs), tgt_mem_len, N, Cc), dtype=x.dtype, device=dev)
+        if tgt_mem_len == 0:  # topk(k=0): empty selections (the callers never ask for it: tgt = max(1, ...))
+            return out, mask, idx, dis, None
         keys = torch.empty((2, T) if sync else (N, T), dtype=torch.float32, device=dev)
         nv.check(nv.lib.rtk_dpselect_select(nv.ptr(dis), T, N, tgt_mem_len, int(window_size), int(bool(sync)),
                                             nv.ptr(idx), nv.ptr(mask), nv.ptr(keys), st), "rtk_dpselect_select")
-        out = torch.empty((1, tgt_mem_len, N, Cc), dtype=x.dtype, device=dev)
-        nv.check(nv.lib.rtk_gather_frames(nv.ptr(x), T, N, Cc, dt, nv.ptr(idx), tgt_mem_len, int(bool(sync)),
-                                          nv.ptr(out), st), "rtk_gather_frames")
+        for b, xb in enumerate(xs):
+            nv.check(nv.lib.rtk_gather_frames(nv.ptr(xb), T, N, Cc, dt, nv.ptr(idx), tgt_mem_len, int(bool(sync)),
+                                              nv.ptr(out[b]), st), "rtk_gather_frames")
     return out, mask, idx, dis, keys
 
 
@@ -54,12 +65,14 @@ def memory_bank_compress_keyframe(memory_bank: torch.Tensor, tgt_mem_len: int, w
     """DPSelect (reference: visual_compression.py:86-177).
 
     Args:
-        memory_bank: [B=1, T, N, C] frame embeddings (float32, bfloat16 or float16, on the ROCm device)
+        memory_bank: [B, T, N, C] frame embeddings (float32, bfloat16 or float16, on the ROCm device); the callers
+            pass B = 1, and like the reference only batch entry 0 chooses the frames
         tgt_mem_len: number of frames to keep
         window_size: argrelmax window (the callers pass 3)
         sync: True = one frame set for all patch positions; False = per-patch frame sets
     Returns:
-        compressed_memory_bank [1, t, N, C] (fresh tensor), keypatches_mask.flatten() [t*N] bool
+        compressed_memory_bank [B, t, N, C] (sync) / [1, t, N, C] (async) (fresh tensor),
+        keypatches_mask.flatten() [t*N] bool
     """
     out, mask, _, _, _ = dpselect_stages(memory_bank, tgt_mem_len, window_size, sync)
     return out, mask.flatten()
@@ -68,8 +81,10 @@ def memory_bank_compress_keyframe(memory_bank: torch.Tensor, tgt_mem_len: int, w
 def _mallm_step(memory_bank: torch.Tensor, compression_size, sync: bool, hard: bool):
     if memory_bank.ndim != 4:
         raise ValueError(f"memory_bank must be [B,T,N,C], got {tuple(memory_bank.shape)}")
-    nv.require_device(memory_bank)
     B, T, N, Cc = memory_bank.shape
+    if T < 2:  # argmax over an empty similarity axis (visual_compression.py:19-23 / :62-66)
+        raise IndexError("memory_bank_compress_MALLM: max(): a single frame (T == 1) has no adjacent pair to merge")
+    nv.require_device(memory_bank)
     dev, dt = memory_bank.device, nv.dtype_code(memory_bank)
     out = torch.empty((B, T - 1, N, Cc), dtype=memory_bank.dtype, device=dev)
     sizes_out = None if hard else torch.empty((B, T - 1, N), dtype=memory_bank.dtype, device=dev)
