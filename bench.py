@@ -350,7 +350,12 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
         nv.check(nv.lib.rtk_profile_enable_mask((1 << ids["score_pass1"]) | (1 << ids["score_pass2"])), "profile_enable")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        cache = kp_mask = None
         for _ in range(steps):
+            # the previous video's cache goes first (as after a finished `generate`): every step then reuses the blocks
+            # the warm-up left in torch's allocator; with both alive, step 2 took fresh hipMallocs - 40-120 ms on a
+            # device whose memory the previous companion had just released
+            cache = kp_mask = None
             _, cache, kp_mask = run_video(frames, pool, None, pos_base, rotary, layers, tdtype)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0

@@ -1,0 +1,12 @@
+import json,sys
+for f in sys.argv[1:]:
+    for line in open(f):
+        line=line.strip()
+        if line.startswith('{'):
+            j=json.loads(line)
+            row=[f.split('/')[-1], round(j['value'])]
+            for k in ('fast_rounding','fp16_dtype','reference_rounding','real_geometry'):
+                if k in j:
+                    c=j[k]; tot=sum(v['total_ms'] for v in c['kernels_timed_region'].values())/c['steps']
+                    row.append((k[:4], round(c['value']), round(c['ms_per_step']-tot,1)))
+            print(row)
