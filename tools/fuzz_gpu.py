@@ -42,7 +42,7 @@ def main():
         D = 128 if rng.uniform() < 0.8 else int(rng.choice([32, 64]))
         L = int(rng.choice([1, 33, 200, 511, 512, 640, 1000, 2304, 3000]))
         dtype = [torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 3))]
-        ratio = float(rng.choice([0.01, 0.1, 0.25, 0.5, 0.9]))
+        ratio = float(rng.choice([0.01, 0.1, 0.25, 0.5, 0.9, 1.0]))
         mrate = float(rng.choice([0.0, 0.0, 0.3, 0.6, 1.0]))
         reforge = bool(rng.uniform() < 0.8)
         mrope = bool(rng.uniform() < 0.6)
@@ -67,7 +67,8 @@ def main():
                                         longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
                                             "compression_ratio": ratio, "compression_method": "pivotkv",
                                             "pos_embed_reforge": reforge, "native_rope": native, "skip_masked_columns": skip,
-                                            "score_rounding": rounding}})
+                                            # ratio 1: `ca` keeps the chunk without scoring it, `cb` scores like the reference
+                                            "score_when_keeping_all": not skip, "score_rounding": rounding}})
             return lc.build_kvcache(cfg)
 
         ca, cb = make(True), make(False)
@@ -104,6 +105,9 @@ def main():
                 cb.after_forward()
                 for l in range(layers):
                     sa, sb = ca._batch.score[l], cb._batch.score[l]
+                    if ca._batch.keep_all:
+                        assert keep == L and ca.last_scores is None
+                        sa = sb   # nothing was scored on the default route; the oracle checks the scored twin
                     assert torch.equal(sa, sb), "scores (after the mask override) differ between live-key and full pass 2"
                     assert torch.equal(ca._batch.keep_idx[l], cb._batch.keep_idx[l]), "kept sets differ"
                     assert torch.equal(ca.key_cache[l], cb.key_cache[l]) and torch.equal(ca.value_cache[l], cb.value_cache[l])
