@@ -201,6 +201,13 @@ __device__ __forceinline__ void rope_chunk(const float* __restrict__ inv_freq, c
             ra[e] = (uint8_t)(wa >> (8 * e));
             rb[e] = (uint8_t)(wb >> (8 * e));
         }
+    } else if constexpr (VE == 2) {
+        const uint16_t wa = *(const uint16_t*)(rs.row + d), wb = *(const uint16_t*)(rs.row + d + h2);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            ra[e] = (uint8_t)(wa >> (8 * e));
+            rb[e] = (uint8_t)(wb >> (8 * e));
+        }
     } else {
         const uint32_t wa = *(const uint32_t*)(rs.row + d), wb = *(const uint32_t*)(rs.row + d + h2);
 #pragma unroll

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "common.cuh"
+#include "variants.h"   // A/B knobs (production builds define none of them)
 
 // LLVM sched_group_barrier masks
 #define SGB_VALU 0x2
@@ -246,7 +247,14 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
 //   three launches become one.  One thread = one token x one 16-byte chunk pair; blockIdx.y splits the heads
 //   in two: y = 0 the first half of the q heads + k (k~ and the k tail), y = 1 the second half + the v tail.
 // ------------------------------------------------------------------------------------------------
-template <int DT, int DIV, bool FAST = false>
+// NW = 32-bit words per thread and row half: 4 (16-byte accesses; fp32) or, for the 16-bit dtypes, 1 (2: A/B builds).  A
+// wave of the 16-byte form issues ~3500 VALU instructions (the per-op rounding chains of 18 heads plus 8 correctly
+// rounded sin / cos pairs) and a chunk of 2304 tokens gives barely half the chip's SIMDs one such wave: that form is bound
+// by the serial instruction stream of its waves.  Narrow chunks split the same work over 4x the waves; what remains is the
+// read + write traffic (45 MB per call at L = 2304) at ~3 TB/s plus the launch ramp.
+template <int NW> struct alignas(4 * NW) WV { uint32_t w[NW]; };
+
+template <int DT, int DIV, bool FAST = false, int NW = 4>
 __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restrict__ q, int64_t q_sh, int64_t q_sl,
                                                             const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
                                                             const char* __restrict__ v, int64_t v_sh, int64_t v_sl,
@@ -259,59 +267,61 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
                                                             int64_t tail_sh, int P, int64_t* __restrict__ pos_copy,
                                                             char* __restrict__ k_fast = nullptr, float qscale = 1.f) {
     using V = Vec16<DT>;
-    constexpr int VE = V::VE;
-    constexpr int ES = 16 / VE;
+    static_assert(NW == 4 || ((NW == 2 || NW == 1) && DT != RTK_F32), "8- / 4-byte chunks: 16-bit dtypes only");
+    constexpr int ES = 16 / V::VE;          // bytes per element
+    constexpr int VE = 4 * NW / ES;         // elements per thread and row half
+    using W = WV<NW>;
     const int h2 = D / 2, lpr = h2 / VE;
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= L * lpr) return;
     const int l = id / lpr, d = (id - l * lpr) * VE;
     if (pos_copy && blockIdx.y == 0 && d == 0)   // the ids the caller may shift in place before the deferred selection runs
         for (int p = 0; p < P; ++p) pos_copy[(size_t)p * L + l] = pos[(size_t)p * pos_ld + l];
-    constexpr int HU = 7;   // heads per batch: all loads of a batch are issued before its arithmetic and stores
-    const int qhalf = (Hq + 1) / 2;
-    const int qb = blockIdx.y == 0 ? 0 : qhalf, qe = blockIdx.y == 0 ? qhalf : Hq;
-    // the KV heads: y = 0 takes k (k~ for the scoring / eviction + the rotated rows for the tail), y = 1 takes v
+    constexpr int HU = RTK_PREP_HU;   // heads per batch: all loads of a batch are issued before its arithmetic and stores
+    const int ny = gridDim.y, qper = (Hq + ny - 1) / ny;
+    const int qb = min((int)blockIdx.y * qper, Hq), qe = min(qb + qper, Hq);
+    // the KV heads: y = 0 takes k (k~ for the scoring / eviction + the rotated rows for the tail), the last y takes v
+    const bool has_kv = blockIdx.y == 0 || (int)blockIdx.y == ny - 1;
     const char* src = blockIdx.y == 0 ? k : v;
     const int64_t sh = blockIdx.y == 0 ? k_sh : v_sh, sl = blockIdx.y == 0 ? k_sl : v_sl;
     char* tail = blockIdx.y == 0 ? k_tail : v_tail;
+    const int nkv = has_kv ? Hkv : 0;
     // Software pipeline over head batches: the rows of batch b+1 (after the last query batch: the first KV batch)
     // are requested before batch b is un-rotated and stored, and the first batch before the table arithmetic
     // (sin / cos are ~25 fp64 operations per value) - with ~1.5 waves per SIMD nothing else hides a round trip.
-    u32x4 lo[HU], hi[HU], lon[HU], hin[HU];
-    auto load_q = [&](u32x4* a, u32x4* b, int hb) {
+    W lo[HU], hi[HU], lon[HU], hin[HU];
+    auto load_q = [&](W* a, W* b, int hb) {
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
             const int h = min(hb + u, qe - 1);
             const char* row = q + ((size_t)h * q_sh + (size_t)l * q_sl) * ES;
-            a[u] = *(const u32x4*)(row + (size_t)d * ES);
-            b[u] = *(const u32x4*)(row + (size_t)(d + h2) * ES);
+            a[u] = *(const W*)(row + (size_t)d * ES);
+            b[u] = *(const W*)(row + (size_t)(d + h2) * ES);
         }
     };
-    auto load_kv = [&](u32x4* a, u32x4* b, int hb) {
+    auto load_kv = [&](W* a, W* b, int hb) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int h = min(hb + u, Hkv - 1);
             const char* row = src + ((size_t)h * sh + (size_t)l * sl) * ES;
-            a[u] = *(const u32x4*)(row + (size_t)d * ES);
-            b[u] = *(const u32x4*)(row + (size_t)(d + h2) * ES);
+            a[u] = *(const W*)(row + (size_t)d * ES);
+            b[u] = *(const W*)(row + (size_t)(d + h2) * ES);
         }
     };
     float pid[3];   // the token's ids (t / h / w rows; a 1-D id fills all three)
 #pragma unroll
     for (int p = 0; p < 3; ++p) pid[p] = (float)pos[(size_t)min(p, P - 1) * pos_ld + l];
     if (qb < qe) load_q(lo, hi, qb);
-    else load_kv(lo, hi, 0);
+    else if (nkv) load_kv(lo, hi, 0);
     float c1[VE], s1[VE], c2[VE], s2[VE];
     rope_chunk<VE>(inv_freq, rs, d, h2, pid, scaling, round_bf16, c1, s1, c2, s2);
     // x~ = ((x*cos) - (rotate_half(x)*sin)) / a^2 for one head's chunk pair, one rounding per torch op (:76-78)
-    auto unrot = [&](const u32x4& lo, const u32x4& hi, u32x4& olo, u32x4& ohi) {
+    auto unrot = [&](const W& lo, const W& hi, W& olo, W& ohi) {
         if constexpr (DT != RTK_F32) {
             using Hh = H16<DT>;
-            const uint32_t wl[4] = {lo.x, lo.y, lo.z, lo.w}, wh[4] = {hi.x, hi.y, hi.z, hi.w};
-            uint32_t r1[4], r2[4];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float x1a = Hh::lo(wl[w]), x1b = Hh::hi(wl[w]), x2a = Hh::lo(wh[w]), x2b = Hh::hi(wh[w]);
+            for (int w = 0; w < NW; ++w) {
+                const float x1a = Hh::lo(lo.w[w]), x1b = Hh::hi(lo.w[w]), x2a = Hh::lo(hi.w[w]), x2b = Hh::hi(hi.w[w]);
                 const int e = 2 * w;
                 const uint32_t p1 = Hh::pack2(x1a * c1[e], x1b * c1[e + 1]);
                 const uint32_t n1 = Hh::pack2(x2a * s1[e], x2b * s1[e + 1]);
@@ -326,44 +336,47 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
                     t1 = Hh::pack2(__fdiv_rn(Hh::lo(t1), a2), __fdiv_rn(Hh::hi(t1), a2));
                     t2 = Hh::pack2(__fdiv_rn(Hh::lo(t2), a2), __fdiv_rn(Hh::hi(t2), a2));
                 }
-                r1[w] = t1;
-                r2[w] = t2;
+                olo.w[w] = t1;
+                ohi.w[w] = t2;
             }
-            olo = u32x4{r1[0], r1[1], r1[2], r1[3]};
-            ohi = u32x4{r2[0], r2[1], r2[2], r2[3]};
         } else {
-            float x1[VE], x2[VE], o1[VE], o2[VE];
-            V::unpack(lo, x1);
-            V::unpack(hi, x2);
+            float o1[VE], o2[VE];
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
-                o1[e] = __fsub_rn(__fmul_rn(x1[e], c1[e]), __fmul_rn(-x2[e], s1[e]));
-                o2[e] = __fsub_rn(__fmul_rn(x2[e], c2[e]), __fmul_rn(x1[e], s2[e]));
+                const float x1 = __uint_as_float(lo.w[e]), x2 = __uint_as_float(hi.w[e]);
+                o1[e] = __fsub_rn(__fmul_rn(x1, c1[e]), __fmul_rn(-x2, s1[e]));
+                o2[e] = __fsub_rn(__fmul_rn(x2, c2[e]), __fmul_rn(x1, s2[e]));
                 if constexpr (DIV != 0) {
                     o1[e] = __fdiv_rn(o1[e], a2);
                     o2[e] = __fdiv_rn(o2[e], a2);
                 }
+                olo.w[e] = __float_as_uint(o1[e]);
+                ohi.w[e] = __float_as_uint(o2[e]);
             }
-            olo = V::pack(o1);
-            ohi = V::pack(o2);
         }
+    };
+    auto to_f16 = [&](const W& x, float scale) {   // bf16 pairs -> fp16 pairs of (value * scale)
+        W o;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) o.w[w] = pack2_f16(bf_lo(x.w[w]) * scale, bf_hi(x.w[w]) * scale);
+        return o;
     };
     for (int hb = qb; hb < qe; hb += HU) {
         if (hb + HU < qe) load_q(lon, hin, hb + HU);
-        else load_kv(lon, hin, 0);
+        else if (nkv) load_kv(lon, hin, 0);
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
             const int h = hb + u;
             if (h >= qe) break;
-            u32x4 olo, ohi;
+            W olo, ohi;
             unrot(lo[u], hi[u], olo, ohi);
             if constexpr (FAST) {   // the score's A / B operand: fp16(q~ * log2(e)/sqrt(D))
-                olo = bf16x8_to_f16x8(olo, qscale);
-                ohi = bf16x8_to_f16x8(ohi, qscale);
+                olo = to_f16(olo, qscale);
+                ohi = to_f16(ohi, qscale);
             }
             char* orow = q_out + ((size_t)h * L + l) * D * ES;
-            *(u32x4*)(orow + (size_t)d * ES) = olo;
-            *(u32x4*)(orow + (size_t)(d + h2) * ES) = ohi;
+            *(W*)(orow + (size_t)d * ES) = olo;
+            *(W*)(orow + (size_t)(d + h2) * ES) = ohi;
         }
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
@@ -371,25 +384,25 @@ __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restri
             hi[u] = hin[u];
         }
     }
-    for (int hb = 0; hb < Hkv; hb += 4) {
-        if (hb + 4 < Hkv) load_kv(lon, hin, hb + 4);
+    for (int hb = 0; hb < nkv; hb += 4) {
+        if (hb + 4 < nkv) load_kv(lon, hin, hb + 4);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int h = hb + u;
-            if (h >= Hkv) break;
+            if (h >= nkv) break;
             char* trow = tail + ((size_t)h * tail_sh + (size_t)l * D) * ES;
-            *(u32x4*)(trow + (size_t)d * ES) = lo[u];
-            *(u32x4*)(trow + (size_t)(d + h2) * ES) = hi[u];
+            *(W*)(trow + (size_t)d * ES) = lo[u];
+            *(W*)(trow + (size_t)(d + h2) * ES) = hi[u];
             if (blockIdx.y == 0) {
-                u32x4 olo, ohi;
+                W olo, ohi;
                 unrot(lo[u], hi[u], olo, ohi);
                 char* orow = k_out + ((size_t)h * L + l) * D * ES;
-                *(u32x4*)(orow + (size_t)d * ES) = olo;
-                *(u32x4*)(orow + (size_t)(d + h2) * ES) = ohi;
+                *(W*)(orow + (size_t)d * ES) = olo;
+                *(W*)(orow + (size_t)(d + h2) * ES) = ohi;
                 if constexpr (FAST) {   // the same k~ as fp16 for the score passes (exact re-encoding)
                     char* frow = k_fast + ((size_t)h * L + l) * D * ES;
-                    *(u32x4*)(frow + (size_t)d * ES) = bf16x8_to_f16x8(olo, 1.f);
-                    *(u32x4*)(frow + (size_t)(d + h2) * ES) = bf16x8_to_f16x8(ohi, 1.f);
+                    *(W*)(frow + (size_t)d * ES) = to_f16(olo, 1.f);
+                    *(W*)(frow + (size_t)(d + h2) * ES) = to_f16(ohi, 1.f);
                 }
             }
         }
@@ -636,7 +649,6 @@ struct RowStat {  // online max / sum of one query row, over the keys this lane 
 //       a block ahead of its MFMAs which alternate strictly between the two accumulators, a last tile that is at most
 //       half full on the one-block body, pass 2's normalisers by LDS-DMA from wave 0.
 // The only compile-time knobs left are the ones variants.h lists (A/B builds; production never defines them).
-#include "variants.h"
 template <int DT> struct RegBlocks {
     static constexpr int NB = 1;
     static constexpr int PF = 1;
@@ -2268,36 +2280,47 @@ static int prepare_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, 
                         int64_t vsh, int64_t vsl, int Hq, int Hkv, int L, int D, const int64_t* pos, int64_t pos_stride,
                         const float* inv_freq, float a, const RowSel& rs, int round_bf16, char* qt, char* kt, void* k_tail,
                         void* v_tail, int64_t tail_sh, int P, int64_t* pos_copy, hipStream_t st, char* k_fast = nullptr) {
-    constexpr int VE = Vec16<DT>::VE;
     const float a2 = (float)((double)a * (double)a);
     const int div = (a2 == 1.0f) ? 0 : ((DT == RTK_BF16 && bf16_rcp_is_exact(a2)) ? 1 : 2);
     const float rcp = 1.0f / a2;
+    // 16-bit dtypes: 4-byte chunks per thread - four times the waves of the 16-byte form, a quarter of the instruction
+    // stream each (same-box A/B, profiles/r11_ab_prepare_chunk_width.txt: 20.0 -> 16.1 us at L = 2304, 29.6 -> 28.4 at 6272)
+    int nw = 4;
+    if constexpr (DT != RTK_F32) nw = RTK_PREP_NW;
+    const int VE = nw * 4 / (DT == RTK_F32 ? 4 : 2);
     const int threads = L * (D / 2 / VE);
-    const dim3 grid((threads + 63) / 64, 2);
-#define RTK_PREP(DIV)                                                                                               \
-    RTK_LAUNCH(KID_UNROT, (prepare_native_kernel<DT, DIV>), grid, dim3(64), 0, st, (const char*)q, qsh, qsl,          \
-               (const char*)k, ksh, ksl, (const char*)v, vsh, vsl, Hq, Hkv, L, D, pos, pos_stride, inv_freq, a, rs,  \
-               round_bf16, a2, rcp, qt, kt, (char*)k_tail, (char*)v_tail, tail_sh, P, pos_copy)
+    const dim3 grid((threads + 63) / 64, RTK_PREP_YSPLIT);
+    char* kf = nullptr;
+    float qscale = 1.f;
+    auto launch = [&](auto kern) {
+        RTK_LAUNCH(KID_UNROT, kern, grid, dim3(64), 0, st, (const char*)q, qsh, qsl, (const char*)k, ksh, ksl, (const char*)v,
+                   vsh, vsl, Hq, Hkv, L, D, pos, pos_stride, inv_freq, a, rs, round_bf16, a2, rcp, qt, kt, (char*)k_tail,
+                   (char*)v_tail, tail_sh, P, pos_copy, kf, qscale);
+    };
+#define RTK_PREP_NWSEL(DIV, FASTV)                                                            \
+    do {                                                                                      \
+        if constexpr (DT != RTK_F32) {                                                        \
+            if (nw == 2) { launch(prepare_native_kernel<DT, DIV, FASTV, 2>); break; }         \
+            if (nw == 1) { launch(prepare_native_kernel<DT, DIV, FASTV, 1>); break; }         \
+        }                                                                                     \
+        launch(prepare_native_kernel<DT, DIV, FASTV, 4>);                                     \
+    } while (0)
     bool done = false;
     if constexpr (DT == RTK_BF16) {
         if (k_fast) {   // RTK_BF16_FAST: q~ as fp16(q~ * log2(e)/sqrt(D)), k~ as bf16 (eviction) and as fp16 (scoring)
-            const float qscale = 1.4426950408889634f / sqrtf((float)D);
-#define RTK_PREP_F(DIV)                                                                                             \
-    RTK_LAUNCH(KID_UNROT, (prepare_native_kernel<DT, DIV, true>), grid, dim3(64), 0, st, (const char*)q, qsh, qsl,    \
-               (const char*)k, ksh, ksl, (const char*)v, vsh, vsl, Hq, Hkv, L, D, pos, pos_stride, inv_freq, a, rs,  \
-               round_bf16, a2, rcp, qt, kt, (char*)k_tail, (char*)v_tail, tail_sh, P, pos_copy, k_fast, qscale)
-            if (div == 0) RTK_PREP_F(0);
-            else if (div == 1) RTK_PREP_F(1);
-            else RTK_PREP_F(2);
-#undef RTK_PREP_F
+            kf = k_fast;
+            qscale = 1.4426950408889634f / sqrtf((float)D);
+            if (div == 0) RTK_PREP_NWSEL(0, true);
+            else if (div == 1) RTK_PREP_NWSEL(1, true);
+            else RTK_PREP_NWSEL(2, true);
             done = true;
         }
     }
     if (done) {}
-    else if (div == 0) RTK_PREP(0);
-    else if (div == 1) RTK_PREP(1);
-    else RTK_PREP(2);
-#undef RTK_PREP
+    else if (div == 0) RTK_PREP_NWSEL(0, false);
+    else if (div == 1) RTK_PREP_NWSEL(1, false);
+    else RTK_PREP_NWSEL(2, false);
+#undef RTK_PREP_NWSEL
     RTK_LAUNCH_CHECK("prepare_native_kernel");
     return RTK_OK;
 }

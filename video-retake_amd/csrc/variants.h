@@ -25,3 +25,12 @@
 #ifndef RTK_P1_RAW        // exact modes' pass 1: 1 = plain row sums + end-of-row check + fix-up launch, 0 = lazy online max (RowStatB)
 #define RTK_P1_RAW 1
 #endif
+#ifndef RTK_PREP_NW       // fused prepare kernel, 16-bit dtypes: 32-bit words per thread and row half (1, 2 or 4)
+#define RTK_PREP_NW 1
+#endif
+#ifndef RTK_PREP_HU       // fused prepare kernel: query heads whose rows are requested together (register batch)
+#define RTK_PREP_HU 7
+#endif
+#ifndef RTK_PREP_YSPLIT   // fused prepare kernel: the query heads are split over this many workgroups per token range (>= 2: k and v go to the first and the last)
+#define RTK_PREP_YSPLIT 2
+#endif
