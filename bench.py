@@ -351,13 +351,16 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         cache = kp_mask = None
+        step_ms = []
         for _ in range(steps):
             # the previous video's cache goes first (as after a finished `generate`): every step then reuses the blocks
             # the warm-up left in torch's allocator; with both alive, step 2 took fresh hipMallocs - 40-120 ms on a
             # device whose memory the previous companion had just released
             cache = kp_mask = None
+            ts = time.perf_counter()
             _, cache, kp_mask = run_video(frames, pool, None, pos_base, rotary, layers, tdtype)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            step_ms.append((time.perf_counter() - ts) * 1e3)
         dt = time.perf_counter() - t0
         nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
         kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in nv.profile_read().items()}
@@ -367,7 +370,8 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
         keep = max(1, int(RATIO * L))
         assert cache.key_cache[0].shape[2] == n_chunks * keep
         del cache
-        res = {"value": frames_total * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+        res = {"value": frames_total * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "step_ms": step_ms,
+               "steps": steps,
                "warmup": warmup, "dtype": dtype, "score_rounding": score_rounding,
                "retained_kv_tokens_per_s": n_chunks * layers * keep * steps / dt,
                "config": {"frames": frames_total, "bank": [1, rows, N_PATCH, C_EMB], "chunks": n_chunks, "layers": layers,

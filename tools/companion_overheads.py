@@ -8,5 +8,5 @@ for f in sys.argv[1:]:
             for k in ('fast_rounding','fp16_dtype','reference_rounding','real_geometry'):
                 if k in j:
                     c=j[k]; tot=sum(v['total_ms'] for v in c['kernels_timed_region'].values())/c['steps']
-                    row.append((k[:4], round(c['value']), round(c['ms_per_step']-tot,1)))
+                    row.append((k[:4], round(c["value"]), round(c["ms_per_step"]-tot,1), [round(x) for x in c.get("step_ms", [])]))
             print(row)
