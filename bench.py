@@ -91,7 +91,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-check", action="store_true")
-    ap.add_argument("--cpu-sample-updates", type=int, default=3, help="timed repetitions of the CPU PivotKV update")
+    ap.add_argument("--cpu-sample-updates", type=int, default=10,
+                    help="timed repetitions of the CPU PivotKV update (~0.7-1 s each on the GPU box's host: ~10 s of CPU work)")
     return ap.parse_args()
 
 
@@ -307,13 +308,14 @@ def cpu_baseline(args, frames_cpu_sample, n_updates):
         oc = orc.OraclePivotKV(Hq, Hkv, D, RATIO, True)
         oc.update(k, v, 0, q=q, position_ids=pos, rotary=rot, mrope_section=MROPE)
 
-    t_up = best_of(one_update, max(1, n_updates))
+    reps_up = max(1, n_updates)
+    t_up = best_of(one_update, reps_up)
     rows = args.frames // FRAMES_PER_ROW
     n_chunks = rows // FRAMES_PER_CHUNK
     total = t_dp * (rows / Ts) + t_up * n_chunks * args.layers
     return {"value": args.frames / total, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle/ (C+OpenMP, fp32): DPSelect on {Ts} of {rows} bank rows ({t_dp:.2f} s) + "
-                      f"one PivotKV update at L={L} ({t_up:.2f} s), each: one warm-up then best of 3; extrapolated to "
+                      f"one PivotKV update at L={L} ({t_up:.2f} s, one warm-up then best of {reps_up}; DPSelect: best of 3); extrapolated to "
                       f"{n_chunks}x{args.layers} updates",
             "dpselect_s_per_2048": t_dp * (rows / Ts), "pivotkv_update_s": t_up}
 
