@@ -1,3 +1,9 @@
+"""Non-pass time of bench.py companions: for every bench JSON given, the headline value and, per companion block,
+(frames/s, ms per step outside the two score passes, per-step wall times).  A companion whose non-pass time is far above
+~70 ms (BASELINE geometry) / ~40 ms (real geometry) carried host or allocator stalls.
+
+    python tools/companion_overheads.py gpurun_out/b1.json [...]
+"""
 import json,sys
 for f in sys.argv[1:]:
     for line in open(f):
