@@ -52,6 +52,8 @@ def gen_qwen_forward(qv, outdir):
         "base": dict(cfg=dict(ratio=0.5), inp=dict(grid_t=24)),
         "fcs_sync": dict(cfg=dict(ratio=1.0, sync=True, frame_chunk_size=5, chunk_frames=6), inp=dict(grid_t=16, seed=79)),
         "dynamic": dict(cfg=dict(ratio=0.5, dynamic=40), inp=dict(grid_t=24, seed=80)),
+        # the prompt fits max_input_length: the dynamic ratio becomes the integer 1 (qwen2_vl.py:553-554)
+        "dynamic_fits": dict(cfg=dict(ratio=0.5, dynamic=100000), inp=dict(grid_t=24, seed=83)),
     }
     for name, c in cases.items():
         cfg = gs.qwen_config(**c["cfg"])
@@ -80,6 +82,7 @@ def gen_llava(lo, outdir):
         "base": dict(cfg=dict(ratio=0.5), inp=dict(T=12)),
         "fcs_sync": dict(cfg=dict(ratio=1.0, sync=True, frame_chunk_size=5, chunk_frames=3), inp=dict(T=10, seed=81)),
         "dynamic_odd": dict(cfg=dict(ratio=0.5, dynamic=30, side=5), inp=dict(T=8, side=5, seed=82)),
+        "dynamic_fits": dict(cfg=dict(ratio=0.5, dynamic=100000), inp=dict(T=12, seed=84)),
     }
     for name, c in cases.items():
         cfg = gs.llava_config(**c["cfg"])
@@ -135,16 +138,17 @@ def gen_llava(lo, outdir):
 # --------------------------------------------------------------------------------------
 # attention prologue + cache over a realistic call sequence
 # --------------------------------------------------------------------------------------
-def attention_scenario(lc, forward, llava, seed):
+def attention_scenario(lc, forward, llava, seed, ratio=0.5):
     """text(5) -> video chunk (32) -> video chunk (32) -> text(3) -> decode(1), two layers sharing one reference
-    PivotKVCache (reforge on, ratio 0.5).  Returns the record or None when a top-k decision is fragile."""
+    PivotKVCache (reforge on, ratio 0.5; or 1 - what the dynamic ratio gives a prompt that fits, qwen2_vl.py:553-554).
+    Returns the record or None when a top-k decision is fragile."""
     hidden, heads, kvh, D = 64, 4, 2, 16
     S = 1.1386
     layers = [gs.StubAttention(l, hidden, heads, kvh, None if llava else (2, 3, 3), S, seed=seed) for l in range(2)]
-    cfg = G.make_config(heads, kvh, D, 2, 0.5, True, llava=llava)
+    cfg = G.make_config(heads, kvh, D, 2, ratio, True, llava=llava)
     cache = lc.PivotKVCache(cfg)
     g = torch.Generator().manual_seed(seed)
-    rec = {"llava": llava, "seed": seed, "attention_scaling": S}
+    rec = {"llava": llava, "seed": seed, "attention_scaling": S, "ratio": float(ratio)}
     for l, a in enumerate(layers):
         for i, w in enumerate(a.weights()):
             rec[f"w{l}_{i}"] = w
@@ -197,8 +201,8 @@ def attention_scenario(lc, forward, llava, seed):
             if kind == "video":
                 sc = captured.pop().numpy().astype(np.float64)
                 srt = -np.sort(-sc)
-                keep = max(1, int(0.5 * n))
-                if srt[keep - 1] - srt[keep] < 1e-4:
+                keep = max(1, int(ratio * n))
+                if keep < n and srt[keep - 1] - srt[keep] < 1e-4:
                     return None
         if hasattr(cache, "after_forward"):
             cache.after_forward()
@@ -223,6 +227,10 @@ def gen_attention(lc, qv, lo, outdir):
             raise RuntimeError(name)
         np.savez_compressed(os.path.join(outdir, f"glue_attention_{name}.npz"), **rec)
         print(f"glue_attention_{name}: seed {rec['seed']}, cache lengths {[rec[f'cache_k{l}'].shape[2] for l in range(2)]}, "
+              f"evicted {rec['num_evicted'].tolist()}")
+        rec = attention_scenario(lc, fwd, llava, 400, ratio=1)
+        np.savez_compressed(os.path.join(outdir, f"glue_attention_{name}_ratio1.npz"), **rec)
+        print(f"glue_attention_{name}_ratio1: cache lengths {[rec[f'cache_k{l}'].shape[2] for l in range(2)]}, "
               f"evicted {rec['num_evicted'].tolist()}")
 
 

@@ -198,10 +198,12 @@ def _oracle_keyframe(memory_bank, tgt_mem_len, window_size=3, sync=True):
 
 QWEN_FWD = {"base": (dict(ratio=0.5), dict(grid_t=24)),
             "fcs_sync": (dict(ratio=1.0, sync=True, frame_chunk_size=5, chunk_frames=6), dict(grid_t=16, seed=79)),
-            "dynamic": (dict(ratio=0.5, dynamic=40), dict(grid_t=24, seed=80))}
+            "dynamic": (dict(ratio=0.5, dynamic=40), dict(grid_t=24, seed=80)),
+            "dynamic_fits": (dict(ratio=0.5, dynamic=100000), dict(grid_t=24, seed=83))}   # ratio becomes the integer 1
 LLAVA_FWD = {"base": (dict(ratio=0.5), dict(T=12)),
              "fcs_sync": (dict(ratio=1.0, sync=True, frame_chunk_size=5, chunk_frames=3), dict(T=10, seed=81)),
-             "dynamic_odd": (dict(ratio=0.5, dynamic=30, side=5), dict(T=8, side=5, seed=82))}
+             "dynamic_odd": (dict(ratio=0.5, dynamic=30, side=5), dict(T=8, side=5, seed=82)),
+             "dynamic_fits": (dict(ratio=0.5, dynamic=100000), dict(T=12, seed=84))}
 
 
 def run_qwen_forward(name, device="cpu"):

@@ -1762,38 +1762,41 @@ def test_pivotkv_full_size_invariants():
 # glue on the device: the reference-recorded model-forward scenarios with the HIP DPSelect inside, and the patched
 # attention forwards over text -> video chunks -> text -> decode with the HIP PivotKV cache
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["base", "fcs_sync", "dynamic"])
+@pytest.mark.parametrize("name", ["base", "fcs_sync", "dynamic", "dynamic_fits"])
 def test_qwen2vl_forward_driver_on_gpu(name):
     import test_glue_cpu as tg
 
     tg.run_qwen_forward(name, device=dev())
 
 
-@pytest.mark.parametrize("name", ["base", "fcs_sync", "dynamic_odd"])
+@pytest.mark.parametrize("name", ["base", "fcs_sync", "dynamic_odd", "dynamic_fits"])
 def test_llava_forward_driver_on_gpu(name):
     import test_glue_cpu as tg
 
     tg.run_llava_forward(name, device=dev())
 
 
-@pytest.mark.parametrize("model", ["qwen2vl", "llava"])
+@pytest.mark.parametrize("model", ["qwen2vl", "llava", "qwen2vl_ratio1", "llava_ratio1"])
 def test_attention_patch_with_pivotkv_cache_matches_reference(model):
     """G1 (qwen2_vl.py:42-122 / llava_onevision.py:59-141) + P1-P15: two patched attention layers sharing one HIP
     PivotKVCache through text(5) -> video chunk(32) -> video chunk(32) -> text(3) -> decode(1), against the reference's
     attention outputs, the ids after the continuity shift (in place for Qwen2-VL, cloned for LLaVA) and the final
-    compressed cache / position cache / eviction counters recorded with the reference's own PivotKVCache."""
+    compressed cache / position cache / eviction counters recorded with the reference's own PivotKVCache.  `_ratio1`:
+    compression_ratio 1 (the dynamic ratio of a prompt that fits): every chunk token kept, nothing scored."""
     import glue_stubs as gs
     import retake.llava_onevision as lo
     import retake.longvideo_cache as lc
     import retake.qwen2_vl as q
 
     g = gu.load("glue_attention_" + model)
+    ratio = 1 if "ratio1" in model else 0.5
+    assert float(g["ratio"]) == ratio
     llava = bool(g["llava"])
     S = float(g["attention_scaling"])
     layers = [gs.StubAttention(l, 64, 4, 2, None if llava else (2, 3, 3), S,
                                weights=[g[f"w{l}_{i}"] for i in range(7)]).to_device(dev()).eval() for l in range(2)]
     llm = types.SimpleNamespace(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2)
-    kw = {"kvcache_compression": True, "kvcache_compression_kwargs": {"compression_ratio": 0.5,
+    kw = {"kvcache_compression": True, "kvcache_compression_kwargs": {"compression_ratio": ratio,
                                                                       "compression_method": "pivotkv",
                                                                       "pos_embed_reforge": True}}
     if llava:
