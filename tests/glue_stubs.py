@@ -6,6 +6,7 @@ the cache were handed.
 """
 from __future__ import annotations
 
+import math
 import types
 
 import numpy as np
@@ -239,6 +240,7 @@ class StubAttention(torch.nn.Module):
         self.hidden_size, self.layer_idx, self.attention_dropout = hidden, layer_idx, 0.0
         self.scaling = self.head_dim ** -0.5
         self.is_causal = True
+        self._flash_attn_uses_top_left_mask = False
         self.q_proj = torch.nn.Linear(hidden, hidden)
         self.k_proj = torch.nn.Linear(hidden, kv_heads * self.head_dim)
         self.v_proj = torch.nn.Linear(hidden, kv_heads * self.head_dim)
@@ -272,6 +274,28 @@ def causal_mask(q_len, total, dtype=torch.float32):
     m = torch.zeros(q_len, total, dtype=dtype)
     m[torch.arange(total)[None, :] > qpos] = float("-inf")
     return m[None, None]
+
+
+def flash_attention_forward_stub(query_states, key_states, value_states, attention_mask, query_length, is_causal=True,
+                                 dropout=0.0, sliding_window=None, use_top_left_mask=False, **kwargs):
+    """Stand-in for transformers' `_flash_attention_forward` (third-party; needs the flash-attn package): the same
+    contract on plain torch - inputs [b, s, heads, d], no padding mask (HF hands the FA2 path attention_mask=None for an
+    all-ones mask), causal mask aligned bottom-right when the keys are longer than the queries, output
+    [b, q_len, heads, d].  Used on BOTH sides: by the generator around the reference's FA2 patch and by the tests
+    around this repo's."""
+    assert attention_mask is None and sliding_window is None and not use_top_left_mask and dropout == 0.0
+    q, k, v = (t.transpose(1, 2) for t in (query_states, key_states, value_states))
+    ql, kl = q.shape[2], k.shape[2]
+    assert ql == query_length
+    mask = None
+    if is_causal and ql > 1:
+        qpos = torch.arange(kl - ql, kl, device=q.device)[:, None]
+        mask = torch.arange(kl, device=q.device)[None, :] <= qpos
+    w = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(q.shape[-1])
+    if mask is not None:
+        w = w.masked_fill(~mask, float("-inf"))
+    w = torch.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+    return torch.matmul(w, v).transpose(1, 2)
 
 
 def eager_attention_forward_448(module, query, key, value, attention_mask, scaling, dropout=0.0, **kwargs):

@@ -138,7 +138,7 @@ def gen_llava(lo, outdir):
 # --------------------------------------------------------------------------------------
 # attention prologue + cache over a realistic call sequence
 # --------------------------------------------------------------------------------------
-def attention_scenario(lc, forward, llava, seed, ratio=0.5):
+def attention_scenario(lc, forward, llava, seed, ratio=0.5, fa2=False):
     """text(5) -> video chunk (32) -> video chunk (32) -> text(3) -> decode(1), two layers sharing one reference
     PivotKVCache (reforge on, ratio 0.5; or 1 - what the dynamic ratio gives a prompt that fits, qwen2_vl.py:553-554).
     Returns the record or None when a top-k decision is fragile."""
@@ -148,7 +148,7 @@ def attention_scenario(lc, forward, llava, seed, ratio=0.5):
     cfg = G.make_config(heads, kvh, D, 2, ratio, True, llava=llava)
     cache = lc.PivotKVCache(cfg)
     g = torch.Generator().manual_seed(seed)
-    rec = {"llava": llava, "seed": seed, "attention_scaling": S, "ratio": float(ratio)}
+    rec = {"llava": llava, "seed": seed, "attention_scaling": S, "ratio": float(ratio), "fa2": fa2}
     for l, a in enumerate(layers):
         for i, w in enumerate(a.weights()):
             rec[f"w{l}_{i}"] = w
@@ -192,8 +192,8 @@ def attention_scenario(lc, forward, llava, seed, ratio=0.5):
                 with torch.no_grad():
                     if llava:
                         o = forward(att, x, None, mask4, cache, cp, position_ids=pos_shared)
-                    else:
-                        o = forward(att, x, mask4, pos_shared, cache, False, True, cp)
+                    else:   # the FA2 path gets no mask from HF when nothing is padded (bsz 1)
+                        o = forward(att, x, None if fa2 else mask4, pos_shared, cache, False, True, cp)
             finally:
                 torch.Tensor.topk = orig_topk
             rec[f"s{si}_l{l}_out"] = o[0].numpy()
@@ -232,6 +232,18 @@ def gen_attention(lc, qv, lo, outdir):
         np.savez_compressed(os.path.join(outdir, f"glue_attention_{name}_ratio1.npz"), **rec)
         print(f"glue_attention_{name}_ratio1: cache lengths {[rec[f'cache_k{l}'].shape[2] for l in range(2)]}, "
               f"evicted {rec['num_evicted'].tolist()}")
+    # the FlashAttention-2 patch (qwen2_vl.py:224-363) - the attention every shipped config selects - around a plain-torch
+    # stand-in for transformers' `_flash_attention_forward` (the flash-attn package is not in this image)
+    qv._flash_attention_forward = gs.flash_attention_forward_stub
+    for attempt in range(3000):   # four tie-free top-k boundaries in a row (the 1.0 ties of the key patches) are rare
+        rec = attention_scenario(lc, qv.retake_Qwen2VLFlashAttention2_forward, False, 500 + attempt, fa2=True)
+        if rec is not None:
+            break
+    else:
+        raise RuntimeError("fa2")
+    np.savez_compressed(os.path.join(outdir, "glue_attention_qwen2vl_fa2.npz"), **rec)
+    print(f"glue_attention_qwen2vl_fa2: seed {rec['seed']}, cache lengths {[rec[f'cache_k{l}'].shape[2] for l in range(2)]}, "
+          f"evicted {rec['num_evicted'].tolist()}")
 
 
 def main():

@@ -71,6 +71,18 @@ class DynamicCache448:
             self.value_cache[layer_idx] = torch.cat([self.value_cache[layer_idx], value_states], dim=-2)
         return self.key_cache[layer_idx], self.value_cache[layer_idx]
 
+    # what the FlashAttention-2 patch asks the cache (qwen2_vl.py:245-252, :270): 4.48's DynamicCache answers
+    def get_seq_length(self, layer_idx=0):
+        if len(self.key_cache) <= layer_idx or len(self.key_cache[layer_idx]) == 0:
+            return 0
+        return self.key_cache[layer_idx].shape[-2]
+
+    def get_max_cache_shape(self):
+        return None
+
+    def get_usable_length(self, new_seq_length, layer_idx=0):
+        return self.get_seq_length(layer_idx)   # no maximum length: the previous length
+
 
 def import_reference():
     import transformers.cache_utils as cu

@@ -1776,13 +1776,16 @@ def test_llava_forward_driver_on_gpu(name):
     tg.run_llava_forward(name, device=dev())
 
 
-@pytest.mark.parametrize("model", ["qwen2vl", "llava", "qwen2vl_ratio1", "llava_ratio1"])
-def test_attention_patch_with_pivotkv_cache_matches_reference(model):
+@pytest.mark.parametrize("model", ["qwen2vl", "llava", "qwen2vl_ratio1", "llava_ratio1", "qwen2vl_fa2"])
+def test_attention_patch_with_pivotkv_cache_matches_reference(model, monkeypatch):
     """G1 (qwen2_vl.py:42-122 / llava_onevision.py:59-141) + P1-P15: two patched attention layers sharing one HIP
     PivotKVCache through text(5) -> video chunk(32) -> video chunk(32) -> text(3) -> decode(1), against the reference's
     attention outputs, the ids after the continuity shift (in place for Qwen2-VL, cloned for LLaVA) and the final
     compressed cache / position cache / eviction counters recorded with the reference's own PivotKVCache.  `_ratio1`:
-    compression_ratio 1 (the dynamic ratio of a prompt that fits): every chunk token kept, nothing scored."""
+    compression_ratio 1 (the dynamic ratio of a prompt that fits): every chunk token kept, nothing scored.  `_fa2`: the
+    FlashAttention-2 patch (qwen2_vl.py:224-363; what every shipped config selects) with transformers'
+    `_flash_attention_forward` replaced on both sides by the same plain-torch stand-in (no flash-attn package here) and,
+    as HF does for an unpadded batch of one, no attention mask."""
     import glue_stubs as gs
     import retake.llava_onevision as lo
     import retake.longvideo_cache as lc
@@ -1791,6 +1794,11 @@ def test_attention_patch_with_pivotkv_cache_matches_reference(model):
     g = gu.load("glue_attention_" + model)
     ratio = 1 if "ratio1" in model else 0.5
     assert float(g["ratio"]) == ratio
+    fa2 = bool(g["fa2"])
+    if fa2:
+        import transformers.modeling_flash_attention_utils as fau
+
+        monkeypatch.setattr(fau, "_flash_attention_forward", gs.flash_attention_forward_stub)
     llava = bool(g["llava"])
     S = float(g["attention_scaling"])
     layers = [gs.StubAttention(l, 64, 4, 2, None if llava else (2, 3, 3), S,
@@ -1821,6 +1829,8 @@ def test_attention_patch_with_pivotkv_cache_matches_reference(model):
             with torch.no_grad():
                 if llava:
                     o = lo.retake_Qwen2Attention_forward(att, x, None, mask4, cache, cp, position_ids=pos_shared)
+                elif fa2:
+                    o = q.retake_Qwen2VLFlashAttention2_forward(att, x, None, pos_shared, cache, False, True, cp)
                 else:
                     o = q.retake_Qwen2VLAttention_forward(att, x, mask4, pos_shared, cache, False, True, cp)
             ref = g[f"s{si}_l{l}_out"]

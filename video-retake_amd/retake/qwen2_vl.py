@@ -124,6 +124,20 @@ def retake_Qwen2VLFlashAttention2_forward(self, hidden_states, attention_mask=No
     from transformers.modeling_flash_attention_utils import _flash_attention_forward  # third-party
 
     bsz, q_len, _ = hidden_states.size()
+    if past_key_value is not None and getattr(self.config, "use_sliding_window", False) \
+            and getattr(self.config, "sliding_window", None) is not None:
+        # sliding-window models (Qwen2-VL ships use_sliding_window = false): the reference trims the padding mask to the
+        # window before the cache update when the cache already holds tokens (reference :268-294; the sliced past
+        # keys / values themselves are not used there either, only their length is checked)
+        prev_len = past_key_value.get_seq_length(self.layer_idx)
+        if q_len + prev_len > self.config.sliding_window and prev_len > 0:
+            slicing_tokens = 1 - self.config.sliding_window
+            if min(prev_len, -slicing_tokens) != self.config.sliding_window - 1:
+                raise ValueError("past key must have a shape of (`batch_size, num_heads, self.config.sliding_window-1, "
+                                 f"head_dim`), got a past length of {prev_len}")
+            if attention_mask is not None:
+                attention_mask = attention_mask[:, slicing_tokens:]
+                attention_mask = torch.cat([attention_mask, torch.ones_like(attention_mask[:, -1:])], dim=-1)
     query_states, key_states, value_states = _qkv_and_cache_update(self, hidden_states, position_ids, past_key_value,
                                                                    cache_position)
     key_states = repeat_kv(key_states, self.num_key_value_groups)
