@@ -242,6 +242,16 @@ def gen_attention(lc, qv, lo, outdir):
     else:
         raise RuntimeError("fa2")
     np.savez_compressed(os.path.join(outdir, "glue_attention_qwen2vl_fa2.npz"), **rec)
+    # the SDPA patch (qwen2_vl.py:125-221): torch's own kernel on both sides, the 4-D mask sliced to the key length
+    for attempt in range(3000):
+        rec2 = attention_scenario(lc, qv.retake_Qwen2VLSdpaAttention_forward, False, 4000 + attempt)
+        if rec2 is not None:
+            break
+    else:
+        raise RuntimeError("sdpa")
+    rec2["sdpa"] = True
+    np.savez_compressed(os.path.join(outdir, "glue_attention_qwen2vl_sdpa.npz"), **rec2)
+    print(f"glue_attention_qwen2vl_sdpa: seed {rec2['seed']}, cache lengths {[rec2[f'cache_k{l}'].shape[2] for l in range(2)]}")
     print(f"glue_attention_qwen2vl_fa2: seed {rec['seed']}, cache lengths {[rec[f'cache_k{l}'].shape[2] for l in range(2)]}, "
           f"evicted {rec['num_evicted'].tolist()}")
 

@@ -1776,7 +1776,7 @@ def test_llava_forward_driver_on_gpu(name):
     tg.run_llava_forward(name, device=dev())
 
 
-@pytest.mark.parametrize("model", ["qwen2vl", "llava", "qwen2vl_ratio1", "llava_ratio1", "qwen2vl_fa2"])
+@pytest.mark.parametrize("model", ["qwen2vl", "llava", "qwen2vl_ratio1", "llava_ratio1", "qwen2vl_fa2", "qwen2vl_sdpa"])
 def test_attention_patch_with_pivotkv_cache_matches_reference(model, monkeypatch):
     """G1 (qwen2_vl.py:42-122 / llava_onevision.py:59-141) + P1-P15: two patched attention layers sharing one HIP
     PivotKVCache through text(5) -> video chunk(32) -> video chunk(32) -> text(3) -> decode(1), against the reference's
@@ -1831,6 +1831,8 @@ def test_attention_patch_with_pivotkv_cache_matches_reference(model, monkeypatch
                     o = lo.retake_Qwen2Attention_forward(att, x, None, mask4, cache, cp, position_ids=pos_shared)
                 elif fa2:
                     o = q.retake_Qwen2VLFlashAttention2_forward(att, x, None, pos_shared, cache, False, True, cp)
+                elif "sdpa" in model:   # (qwen2_vl.py:125-221)
+                    o = q.retake_Qwen2VLSdpaAttention_forward(att, x, mask4, pos_shared, cache, False, True, cp)
                 else:
                     o = q.retake_Qwen2VLAttention_forward(att, x, mask4, pos_shared, cache, False, True, cp)
             ref = g[f"s{si}_l{l}_out"]
