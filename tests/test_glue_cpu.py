@@ -184,6 +184,40 @@ def test_patch_rebinds_hf_classes():
                 setattr(m.Qwen2VLForConditionalGeneration, k, v)
 
 
+def test_patch_llava_rebinds_hf_classes_and_adds_rotary_module():
+    """patch_llava_onevision on the installed transformers: the model class gets the five glue methods, Qwen2Attention the
+    patched forward and an __init__ that gives every layer its own rotary module (llava_onevision.py:48-56) - checked by
+    constructing a real (tiny) HF Qwen2Attention."""
+    import transformers.models.llava_onevision.modeling_llava_onevision as ml
+    import transformers.models.qwen2.modeling_qwen2 as m2
+    from transformers import Qwen2Config
+
+    import retake.llava_onevision as lo
+    import retake.monkeypatch as mp
+
+    names = ("forward", "compress_video_tokens", "segment_input_ids", "get_chunk_size", "forge_input_chunks")
+    saved = {k: ml.LlavaOnevisionForConditionalGeneration.__dict__.get(k) for k in names}
+    att_saved = (m2.Qwen2Attention.__init__, m2.Qwen2Attention.forward)
+    try:
+        mp.patch_llava_onevision("retake")
+        assert ml.LlavaOnevisionForConditionalGeneration.forward is lo.retake_LlavaOnevisionForConditionalGeneration_forward
+        assert ml.LlavaOnevisionForConditionalGeneration.get_chunk_size is lo.retake_LlavaOnevisionForConditionalGeneration_get_chunk_size
+        assert m2.Qwen2Attention.forward is lo.retake_Qwen2Attention_forward
+        cfg = Qwen2Config(hidden_size=64, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=1,
+                          intermediate_size=128, vocab_size=32, max_position_embeddings=256)
+        att = m2.Qwen2Attention(cfg, layer_idx=0)
+        assert isinstance(att.rotary_emb, m2.Qwen2RotaryEmbedding)
+        cos, sin = att.rotary_emb(torch.zeros(1, 5, 64), torch.arange(5)[None])
+        assert cos.shape == (1, 5, 16) and float(getattr(att.rotary_emb, "attention_scaling", 1.0)) == 1.0
+    finally:
+        m2.Qwen2Attention.__init__, m2.Qwen2Attention.forward = att_saved
+        for k, v in saved.items():
+            if v is None:
+                delattr(ml.LlavaOnevisionForConditionalGeneration, k)
+            else:
+                setattr(ml.LlavaOnevisionForConditionalGeneration, k, v)
+
+
 # ---------------------------------------------------------------------------------------------------
 # model forwards driven with stub modules against goldens recorded from the reference (tests/golden/gen_glue_golden.py).
 # On CPU the DPSelect call inside compress_video_tokens is served by the CPU oracle (the product has no CPU path);
