@@ -215,6 +215,53 @@ def attention_scenario(lc, forward, llava, seed, ratio=0.5, fa2=False):
     return rec
 
 
+def gen_fa2_sliding_window(lc, qv, outdir):
+    """The sliding-window branch of the FA2 patch (qwen2_vl.py:268-294; dead in the shipped configs, Qwen2-VL has
+    use_sliding_window = false): what reaches `_flash_attention_forward` - the trimmed padding mask, the window - over two
+    text steps on a cache that already holds tokens, and the ValueError of a past shorter than the window."""
+    calls = []
+
+    def recording_stub(q, k, v, attention_mask, query_length, **kw):
+        calls.append((None if attention_mask is None else attention_mask.clone(), kw.get("sliding_window")))
+        kw.pop("sliding_window", None)
+        return gs.flash_attention_forward_stub(q, k, v, None, query_length, **kw)
+
+    qv._flash_attention_forward = recording_stub
+    rec = {}
+    for case, (n0, n1, window) in {"trim": (6, 5, 7), "short_past": (3, 6, 7)}.items():
+        att = gs.StubAttention(0, 64, 4, 2, (2, 3, 3), 1.0, seed=77)
+        att.config.use_sliding_window, att.config.sliding_window, att.config.max_window_layers = True, window, 0
+        cache = lc.PivotKVCache(G.make_config(4, 2, 16, 1, 0.5, True))
+        cache.kvcache_compression = False
+        g = torch.Generator().manual_seed(91)
+        rec[f"{case}_w"] = np.array([0])  # placeholder so that the key order is stable
+        for i, w in enumerate(att.weights()):
+            rec[f"{case}_w{i}"] = w
+        total = 0
+        del calls[:]
+        for si, n in enumerate((n0, n1)):
+            x = torch.randn(1, n, 64, generator=g)
+            pos = (torch.arange(n) + total)[None, None].repeat(3, 1, 1)
+            total += n
+            am = torch.ones(1, total, dtype=torch.int64)
+            am[0, 0] = 0
+            rec[f"{case}_s{si}_x"] = x.numpy()
+            try:
+                with torch.no_grad():
+                    o = qv.retake_Qwen2VLFlashAttention2_forward(att, x, am, pos, cache, False, True, torch.arange(total - n, total))
+                rec[f"{case}_s{si}_out"] = o[0].numpy()
+                rec[f"{case}_s{si}_exc"] = "none"
+                m, sw = calls[-1]
+                rec[f"{case}_s{si}_mask_to_fa"] = m.numpy()
+                rec[f"{case}_s{si}_window_to_fa"] = -1 if sw is None else int(sw)
+            except Exception as e:  # noqa: BLE001
+                rec[f"{case}_s{si}_exc"] = type(e).__name__
+        rec[f"{case}_shape"] = np.array([n0, n1, window])
+    np.savez_compressed(os.path.join(outdir, "glue_attention_qwen2vl_fa2_sliding.npz"), **rec)
+    print("glue_attention_qwen2vl_fa2_sliding:", {k: (str(v) if k.endswith("exc") else getattr(v, "shape", v))
+                                                  for k, v in rec.items() if "mask_to_fa" in k or k.endswith("exc") or "window_to" in k})
+
+
 def gen_attention(lc, qv, lo, outdir):
     for name, fwd, llava in (("qwen2vl", qv.retake_Qwen2VLAttention_forward, False),
                              ("llava", lo.retake_Qwen2Attention_forward, True)):
@@ -267,6 +314,7 @@ def main():
     gen_qwen_forward(qv, HERE)
     gen_llava(lo, HERE)
     gen_attention(lc, qv, lo, HERE)
+    gen_fa2_sliding_window(lc, qv, HERE)
 
 
 if __name__ == "__main__":

@@ -80,6 +80,9 @@ class DynamicCache448:
     def get_max_cache_shape(self):
         return None
 
+    def __getitem__(self, layer_idx):
+        return self.key_cache[layer_idx], self.value_cache[layer_idx]
+
     def get_usable_length(self, new_seq_length, layer_idx=0):
         return self.get_seq_length(layer_idx)   # no maximum length: the previous length
 

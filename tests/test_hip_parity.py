@@ -1848,6 +1848,55 @@ def test_attention_patch_with_pivotkv_cache_matches_reference(model, monkeypatch
     assert cache.num_evicted_tokens == g["num_evicted"].tolist()
 
 
+def test_fa2_patch_sliding_window_branch_matches_reference(monkeypatch):
+    """The sliding-window branch of the FA2 patch (qwen2_vl.py:268-294; Qwen2-VL ships use_sliding_window = false): the
+    padding mask and window that reach `_flash_attention_forward`, the outputs, and the ValueError of a past shorter than
+    the window - as recorded from the reference's patch (glue_attention_qwen2vl_fa2_sliding.npz)."""
+    import glue_stubs as gs
+    import retake.longvideo_cache as lc
+    import retake.qwen2_vl as q
+    import transformers.modeling_flash_attention_utils as fau
+
+    g = gu.load("glue_attention_qwen2vl_fa2_sliding")
+    calls = []
+
+    def recording_stub(qs, ks, vs, attention_mask, query_length, **kw):
+        calls.append((None if attention_mask is None else attention_mask.clone(), kw.get("sliding_window")))
+        kw.pop("sliding_window", None)
+        return gs.flash_attention_forward_stub(qs, ks, vs, None, query_length, **kw)
+
+    monkeypatch.setattr(fau, "_flash_attention_forward", recording_stub)
+    for case in ("trim", "short_past"):
+        n0, n1, window = (int(v) for v in g[f"{case}_shape"])
+        att = gs.StubAttention(0, 64, 4, 2, (2, 3, 3), 1.0, weights=[g[f"{case}_w{i}"] for i in range(7)]).to_device(dev()).eval()
+        att.config.use_sliding_window, att.config.sliding_window, att.config.max_window_layers = True, window, 0
+        llm = types.SimpleNamespace(hidden_size=64, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2,
+                                    longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
+                                        "compression_ratio": 0.5, "compression_method": "pivotkv", "pos_embed_reforge": True}})
+        cache = lc.build_kvcache(llm)
+        cache.kvcache_compression = False
+        total = 0
+        for si, n in enumerate((n0, n1)):
+            x = torch.from_numpy(g[f"{case}_s{si}_x"]).to(dev())
+            pos = (torch.arange(n, device=dev()) + total)[None, None].repeat(3, 1, 1)
+            total += n
+            am = torch.ones(1, total, dtype=torch.int64, device=dev())
+            am[0, 0] = 0
+            want = str(g[f"{case}_s{si}_exc"])
+            if want != "none":
+                with pytest.raises({"ValueError": ValueError}[want]):
+                    q.retake_Qwen2VLFlashAttention2_forward(att, x, am, pos, cache, False, True, torch.arange(total - n, total, device=dev()))
+                continue
+            with torch.no_grad():
+                o = q.retake_Qwen2VLFlashAttention2_forward(att, x, am, pos, cache, False, True,
+                                                            torch.arange(total - n, total, device=dev()))
+            m, sw = calls[-1]
+            np.testing.assert_array_equal(m.cpu().numpy(), g[f"{case}_s{si}_mask_to_fa"])
+            assert (-1 if sw is None else int(sw)) == int(g[f"{case}_s{si}_window_to_fa"])
+            ref = g[f"{case}_s{si}_out"]
+            assert np.abs(o[0].cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max()) < 2e-5
+
+
 # ---------------------------------------------------------------------------------------------------
 # bf16 (production dtype) against the reference run on bf16 tensors (fixtures pivotkv_bf16_*)
 # ---------------------------------------------------------------------------------------------------
