@@ -298,6 +298,19 @@ def flash_attention_forward_stub(query_states, key_states, value_states, attenti
     return torch.matmul(w, v).transpose(1, 2)
 
 
+INTERFACE_CALLS = []
+
+
+def attention_interface_stub(module, query, key, value, attention_mask, dropout=0.0, scaling=None, sliding_window=None,
+                             **kwargs):
+    """An attention function to register in transformers' ALL_ATTENTION_FUNCTIONS under a test-only name: pins the
+    non-eager dispatch of the LLaVA attention patch (llava_onevision.py:118-139) - what it is handed is recorded in
+    INTERFACE_CALLS, the arithmetic is the 4.48 eager function's."""
+    INTERFACE_CALLS.append((float(dropout), float(scaling), -1 if sliding_window is None else int(sliding_window),
+                            sorted(kwargs)))
+    return eager_attention_forward_448(module, query, key, value, attention_mask, scaling, dropout)
+
+
 def eager_attention_forward_448(module, query, key, value, attention_mask, scaling, dropout=0.0, **kwargs):
     """transformers==4.48 `eager_attention_forward` of modeling_qwen2 (third-party, restated from its published source;
     the reference pins 4.48, environment.yaml:9): unlike 5.x it slices the 4-D mask to the key length, which is what

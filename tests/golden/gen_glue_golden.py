@@ -138,13 +138,16 @@ def gen_llava(lo, outdir):
 # --------------------------------------------------------------------------------------
 # attention prologue + cache over a realistic call sequence
 # --------------------------------------------------------------------------------------
-def attention_scenario(lc, forward, llava, seed, ratio=0.5, fa2=False):
+def attention_scenario(lc, forward, llava, seed, ratio=0.5, fa2=False, attn_impl=None):
     """text(5) -> video chunk (32) -> video chunk (32) -> text(3) -> decode(1), two layers sharing one reference
     PivotKVCache (reforge on, ratio 0.5; or 1 - what the dynamic ratio gives a prompt that fits, qwen2_vl.py:553-554).
     Returns the record or None when a top-k decision is fragile."""
     hidden, heads, kvh, D = 64, 4, 2, 16
     S = 1.1386
     layers = [gs.StubAttention(l, hidden, heads, kvh, None if llava else (2, 3, 3), S, seed=seed) for l in range(2)]
+    if attn_impl:
+        for a in layers:
+            a.config._attn_implementation = attn_impl
     cfg = G.make_config(heads, kvh, D, 2, ratio, True, llava=llava)
     cache = lc.PivotKVCache(cfg)
     g = torch.Generator().manual_seed(seed)
@@ -213,6 +216,28 @@ def attention_scenario(lc, forward, llava, seed, ratio=0.5, fa2=False):
     rec["num_evicted"] = np.array(cache.num_evicted_tokens, dtype=np.int64)
     rec["n_steps"] = len(steps)
     return rec
+
+
+def gen_llava_interface(lc, lo, outdir):
+    """The non-eager dispatch of the LLaVA attention patch (llava_onevision.py:118-139): an attention function registered
+    in transformers' ALL_ATTENTION_FUNCTIONS under a test-only name, the same scenario as glue_attention_llava."""
+    from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+
+    ALL_ATTENTION_FUNCTIONS["retake_test_stub"] = gs.attention_interface_stub
+    for attempt in range(3000):
+        del gs.INTERFACE_CALLS[:]
+        rec = attention_scenario(lc, lo.retake_Qwen2Attention_forward, True, 7000 + attempt, attn_impl="retake_test_stub")
+        if rec is not None:
+            break
+    else:
+        raise RuntimeError("llava interface")
+    calls = list(gs.INTERFACE_CALLS)
+    rec["interface_dropout"] = np.array([c[0] for c in calls])
+    rec["interface_scaling"] = np.array([c[1] for c in calls])
+    rec["interface_window"] = np.array([c[2] for c in calls])
+    rec["interface_kwargs"] = np.array([",".join(c[3]) for c in calls])
+    np.savez_compressed(os.path.join(outdir, "glue_attention_llava_interface.npz"), **rec)
+    print(f"glue_attention_llava_interface: seed {rec['seed']}, {len(calls)} interface calls, kwargs {calls[0][3]}")
 
 
 def gen_fa2_sliding_window(lc, qv, outdir):
@@ -315,6 +340,7 @@ def main():
     gen_llava(lo, HERE)
     gen_attention(lc, qv, lo, HERE)
     gen_fa2_sliding_window(lc, qv, HERE)
+    gen_llava_interface(lc, lo, HERE)
 
 
 if __name__ == "__main__":

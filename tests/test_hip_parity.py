@@ -1776,7 +1776,8 @@ def test_llava_forward_driver_on_gpu(name):
     tg.run_llava_forward(name, device=dev())
 
 
-@pytest.mark.parametrize("model", ["qwen2vl", "llava", "qwen2vl_ratio1", "llava_ratio1", "qwen2vl_fa2", "qwen2vl_sdpa"])
+@pytest.mark.parametrize("model", ["qwen2vl", "llava", "qwen2vl_ratio1", "llava_ratio1", "qwen2vl_fa2", "qwen2vl_sdpa",
+                                   "llava_interface"])
 def test_attention_patch_with_pivotkv_cache_matches_reference(model, monkeypatch):
     """G1 (qwen2_vl.py:42-122 / llava_onevision.py:59-141) + P1-P15: two patched attention layers sharing one HIP
     PivotKVCache through text(5) -> video chunk(32) -> video chunk(32) -> text(3) -> decode(1), against the reference's
@@ -1799,10 +1800,19 @@ def test_attention_patch_with_pivotkv_cache_matches_reference(model, monkeypatch
         import transformers.modeling_flash_attention_utils as fau
 
         monkeypatch.setattr(fau, "_flash_attention_forward", gs.flash_attention_forward_stub)
+    interface = "interface" in model   # `_interface`: the non-eager dispatch (llava_onevision.py:118-139) through an attention
+    if interface:                      # function registered under a test-only name, as on the reference's side
+        from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+
+        ALL_ATTENTION_FUNCTIONS["retake_test_stub"] = gs.attention_interface_stub
+        del gs.INTERFACE_CALLS[:]
     llava = bool(g["llava"])
     S = float(g["attention_scaling"])
     layers = [gs.StubAttention(l, 64, 4, 2, None if llava else (2, 3, 3), S,
                                weights=[g[f"w{l}_{i}"] for i in range(7)]).to_device(dev()).eval() for l in range(2)]
+    if interface:
+        for a in layers:
+            a.config._attn_implementation = "retake_test_stub"
     llm = types.SimpleNamespace(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2)
     kw = {"kvcache_compression": True, "kvcache_compression_kwargs": {"compression_ratio": ratio,
                                                                       "compression_method": "pivotkv",
@@ -1846,6 +1856,12 @@ def test_attention_patch_with_pivotkv_cache_matches_reference(model, monkeypatch
         assert np.abs(cache.value_cache[l].cpu().numpy() - g[f"cache_v{l}"]).max() <= 1e-5
         np.testing.assert_array_equal(cache.position_cache[l].cpu().numpy(), g[f"cache_pos{l}"])
     assert cache.num_evicted_tokens == g["num_evicted"].tolist()
+    if interface:   # the registered function was handed what the reference hands it
+        calls = list(gs.INTERFACE_CALLS)
+        assert [c[0] for c in calls] == g["interface_dropout"].tolist()
+        assert np.allclose([c[1] for c in calls], g["interface_scaling"])
+        assert [c[2] for c in calls] == g["interface_window"].tolist()
+        assert [",".join(c[3]) for c in calls] == g["interface_kwargs"].tolist()
 
 
 def test_fa2_patch_sliding_window_branch_matches_reference(monkeypatch):
