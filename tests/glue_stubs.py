@@ -155,6 +155,28 @@ def qwen_inputs(grid_t=16, gh=4, gw=4, n_pre=5, n_post=7, d=24, seed=77, device=
     return {k: v.to(device) for k, v in kw.items()}
 
 
+def qwen_generate_steps(mod, cfg, device="cpu", grid_t=24, seed=85, n_decode=2):
+    """A `generate`-shaped call sequence on the stub model: the prefill forward WITHOUT position ids (they come from
+    `get_rope_index`, stubbed to return the ids of qwen_inputs and their delta; qwen2_vl.py:573-590), then `n_decode`
+    one-token forwards with the returned cache, no ids, cache_position continuing the UNCOMPRESSED prompt length like HF's
+    generate does (ids = cache_position + rope_deltas), the last one with return_dict=True.  Returns (model, outputs)."""
+    me = make_qwen_model(mod, cfg)
+    kw = qwen_inputs(grid_t=grid_t, seed=seed, device=device)
+    pos = kw.pop("position_ids")
+    S = kw["input_ids"].shape[1]
+    deltas = (pos.max() + 1 - S).reshape(1, 1)
+    me.get_rope_index = lambda input_ids, image_grid_thw, video_grid_thw, attention_mask: (pos.clone(), deltas.clone())
+    fwd = getattr(mod, "retake_Qwen2VLForConditionalGeneration_forward")
+    outs = [fwd(me, return_dict=False, **kw)]
+    cache = outs[0][1]
+    for i in range(n_decode):
+        ids = torch.tensor([[TXT + 2 + i]], device=device)
+        am = torch.ones(1, S + i + 1, dtype=torch.long, device=device)
+        outs.append(fwd(me, input_ids=ids, attention_mask=am, past_key_values=cache, use_cache=True,
+                        cache_position=torch.tensor([S + i], device=device), return_dict=(i == n_decode - 1)))
+    return me, outs
+
+
 # ---------------------------------------------------------------------------------------------------
 # LLaVA-OneVision model stub (reference: llava_onevision.py:306-583)
 # ---------------------------------------------------------------------------------------------------
@@ -225,6 +247,25 @@ def llava_inputs(T=12, side=4, n_pre=3, n_post=5, C=32, seed=78, device="cpu", p
     kw = dict(input_ids=ids, attention_mask=am, position_ids=torch.arange(S)[None], pixel_values_videos=pix,
               cache_position=torch.arange(S))
     return {k: v.to(device) for k, v in kw.items()}, bank
+
+
+def llava_generate_steps(mod, cfg, device="cpu", T=12, seed=86, n_decode=2):
+    """A `generate`-shaped call sequence on the LLaVA stub model: the chunked prefill, then `n_decode` one-token forwards
+    (input_ids.shape[1] == 1 selects the decode branch, llava_onevision.py:330-353, :548-560) with the returned cache, the
+    ids HF's generate would hand over, the last one with return_dict=True.  Returns (model, outputs)."""
+    kw, bank = llava_inputs(T=T, seed=seed, device=device)
+    me = make_llava_model(mod, cfg, bank.to(device))
+    me.image_newline = me.image_newline.to(device)
+    S = kw["input_ids"].shape[1]
+    fwd = getattr(mod, "retake_LlavaOnevisionForConditionalGeneration_forward")
+    outs = [fwd(me, return_dict=False, **kw)]
+    cache = outs[0][1]
+    for i in range(n_decode):
+        outs.append(fwd(me, input_ids=torch.tensor([[TXT + 2 + i]], device=device),
+                        attention_mask=torch.ones(1, S + i + 1, dtype=torch.long, device=device),
+                        position_ids=torch.tensor([[S + i]], device=device), past_key_values=cache, use_cache=True,
+                        cache_position=torch.tensor([S + i], device=device), return_dict=(i == n_decode - 1)))
+    return me, outs
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -77,6 +77,25 @@ def gen_qwen_forward(qv, outdir):
               f"kv ratio {rec['kv_ratio_after']:.4f}, margin {m:.2e}")
 
 
+def gen_qwen_generate(qv, outdir):
+    """Prefill without position ids + two decode forwards (qwen2_vl.py:543-590, :721-733): glue_stubs.qwen_generate_steps."""
+    cfg = gs.qwen_config(ratio=0.5)
+    me, outs = gs.qwen_generate_steps(qv, cfg)
+    rec = gs.calls_to_record(me.model.calls, "call")
+    rec["prefill_logits"] = outs[0][0].numpy()
+    for i, o in enumerate(outs[1:-1]):
+        rec[f"decode{i}_logits"] = o[0].numpy()
+    last = outs[-1]
+    rec["last_logits"] = last.logits.numpy()
+    rec["last_rope_deltas"] = last.rope_deltas.numpy()
+    rec["last_class"] = type(last).__name__
+    rec["last_cache_is_prefill_cache"] = last.past_key_values is outs[0][1]
+    rec["rope_deltas_attr"] = me.rope_deltas.numpy()
+    np.savez_compressed(os.path.join(outdir, "glue_qwen2vl_generate.npz"), **rec)
+    print(f"glue_qwen2vl_generate: {len(me.model.calls)} model calls, decode ids "
+          f"{[c['position_ids'].reshape(3, -1)[:, 0].tolist() for c in me.model.calls[-2:]]}, deltas {rec['rope_deltas_attr'].tolist()}")
+
+
 def gen_llava(lo, outdir):
     cases = {
         "base": dict(cfg=dict(ratio=0.5), inp=dict(T=12)),
@@ -240,6 +259,25 @@ def gen_llava_interface(lc, lo, outdir):
     print(f"glue_attention_llava_interface: seed {rec['seed']}, {len(calls)} interface calls, kwargs {calls[0][3]}")
 
 
+def gen_llava_generate(lo, outdir):
+    """Chunked prefill + two decode forwards of the LLaVA glue (llava_onevision.py:330-353, :548-583):
+    glue_stubs.llava_generate_steps."""
+    cfg = gs.llava_config(ratio=0.5)
+    me, outs = gs.llava_generate_steps(lo, cfg)
+    rec = gs.calls_to_record(me.language_model.calls, "call")
+    rec["prefill_logits"] = outs[0][0].numpy()
+    for i, o in enumerate(outs[1:-1]):
+        rec[f"decode{i}_logits"] = o[0].numpy()
+    last = outs[-1]
+    rec["last_logits"] = last.logits.numpy()
+    rec["last_class"] = type(last).__name__
+    rec["last_cache_is_prefill_cache"] = last.past_key_values is outs[0][1]
+    rec["last_video_hidden_states_is_none"] = last.video_hidden_states is None
+    rec["last_image_hidden_states_is_none"] = last.image_hidden_states is None
+    np.savez_compressed(os.path.join(outdir, "glue_llava_generate.npz"), **rec)
+    print(f"glue_llava_generate: {len(me.language_model.calls)} LM calls, class {rec['last_class']}")
+
+
 def gen_fa2_sliding_window(lc, qv, outdir):
     """The sliding-window branch of the FA2 patch (qwen2_vl.py:268-294; dead in the shipped configs, Qwen2-VL has
     use_sliding_window = false): what reaches `_flash_attention_forward` - the trimmed padding mask, the window - over two
@@ -337,7 +375,9 @@ def main():
     assert lo.__file__.startswith(G.REF)
     lo.eager_attention_forward = gs.eager_attention_forward_448   # the 4.48 function the reference was written against
     gen_qwen_forward(qv, HERE)
+    gen_qwen_generate(qv, HERE)
     gen_llava(lo, HERE)
+    gen_llava_generate(lo, HERE)
     gen_attention(lc, qv, lo, HERE)
     gen_fa2_sliding_window(lc, qv, HERE)
     gen_llava_interface(lc, lo, HERE)

@@ -259,6 +259,63 @@ def run_qwen_forward(name, device="cpu"):
     assert out[1].kvcache_compression is False and out[1].keypatches_mask_chunk is None   # off for decoding
 
 
+def run_qwen_generate(device="cpu"):
+    """Prefill without position ids (get_rope_index) + two decode forwards on the returned cache (qwen2_vl.py:543-590,
+    :721-733) against the reference's call record: ids from cache_position + rope_deltas, cache passed through, output
+    class and fields of the return_dict form."""
+    import glue_stubs as gs
+    import retake.qwen2_vl as q
+
+    g = gu.load("glue_qwen2vl_generate")
+    me, outs = gs.qwen_generate_steps(q, gs.qwen_config(ratio=0.5), device=device)
+    tol = 0.0 if device == "cpu" else 1e-6
+    gs.assert_calls_equal(me.model.calls, g, "call", emb_tol=tol)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), g["prefill_logits"], rtol=0, atol=tol)
+    for i, o in enumerate(outs[1:-1]):
+        np.testing.assert_allclose(o[0].cpu().numpy(), g[f"decode{i}_logits"], rtol=0, atol=tol)
+    last = outs[-1]
+    np.testing.assert_allclose(last.logits.cpu().numpy(), g["last_logits"], rtol=0, atol=tol)
+    np.testing.assert_array_equal(last.rope_deltas.cpu().numpy(), g["last_rope_deltas"])
+    assert type(last).__name__ == str(g["last_class"])
+    assert (last.past_key_values is outs[0][1]) == bool(g["last_cache_is_prefill_cache"])
+    np.testing.assert_array_equal(me.rope_deltas.cpu().numpy(), g["rope_deltas_attr"])
+
+
+def test_qwen2vl_generate_sequence_matches_reference(monkeypatch):
+    import retake.qwen2_vl as q
+
+    monkeypatch.setattr(q, "memory_bank_compress_keyframe", _oracle_keyframe)
+    run_qwen_generate()
+
+
+def run_llava_generate(device="cpu"):
+    """Chunked prefill + two decode forwards of the LLaVA glue (llava_onevision.py:330-353, :548-583) against the
+    reference's call record; the return_dict form carries the reference's class and None-ness of its fields."""
+    import glue_stubs as gs
+    import retake.llava_onevision as lo
+
+    g = gu.load("glue_llava_generate")
+    me, outs = gs.llava_generate_steps(lo, gs.llava_config(ratio=0.5), device=device)
+    tol = 0.0 if device == "cpu" else 1e-6
+    gs.assert_calls_equal(me.language_model.calls, g, "call", emb_tol=tol)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), g["prefill_logits"], rtol=0, atol=tol)
+    for i, o in enumerate(outs[1:-1]):
+        np.testing.assert_allclose(o[0].cpu().numpy(), g[f"decode{i}_logits"], rtol=0, atol=tol)
+    last = outs[-1]
+    np.testing.assert_allclose(last.logits.cpu().numpy(), g["last_logits"], rtol=0, atol=tol)
+    assert type(last).__name__ == str(g["last_class"])
+    assert (last.past_key_values is outs[0][1]) == bool(g["last_cache_is_prefill_cache"])
+    assert (last.video_hidden_states is None) == bool(g["last_video_hidden_states_is_none"])
+    assert (last.image_hidden_states is None) == bool(g["last_image_hidden_states_is_none"])
+
+
+def test_llava_generate_sequence_matches_reference(monkeypatch):
+    import retake.qwen2_vl as q
+
+    monkeypatch.setattr(q, "memory_bank_compress_keyframe", _oracle_keyframe)
+    run_llava_generate()
+
+
 def run_llava_forward(name, device="cpu"):
     import glue_stubs as gs
     import retake.llava_onevision as lo

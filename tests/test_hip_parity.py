@@ -1769,6 +1769,18 @@ def test_qwen2vl_forward_driver_on_gpu(name):
     tg.run_qwen_forward(name, device=dev())
 
 
+def test_qwen2vl_generate_sequence_on_gpu():
+    import test_glue_cpu as tg
+
+    tg.run_qwen_generate(device=dev())
+
+
+def test_llava_generate_sequence_on_gpu():
+    import test_glue_cpu as tg
+
+    tg.run_llava_generate(device=dev())
+
+
 @pytest.mark.parametrize("name", ["base", "fcs_sync", "dynamic_odd", "dynamic_fits"])
 def test_llava_forward_driver_on_gpu(name):
     import test_glue_cpu as tg
