@@ -155,6 +155,17 @@ def qwen_inputs(grid_t=16, gh=4, gw=4, n_pre=5, n_post=7, d=24, seed=77, device=
     return {k: v.to(device) for k, v in kw.items()}
 
 
+def qwen_inputs_with_image(n_img=4, rows_per_token=4, device="cpu", **kw):
+    """qwen_inputs with `n_img` image tokens inside the leading text segment and their pixel rows (the image branch of
+    the forward, qwen2_vl.py:593-596, :631-645); rows_per_token != 4 makes features and tokens disagree."""
+    out = qwen_inputs(n_pre=9, device=device, **kw)
+    out["input_ids"][0, 2:2 + n_img] = IMG
+    g = torch.Generator().manual_seed(5)
+    out["pixel_values"] = torch.randn(n_img * rows_per_token, out["pixel_values_videos"].shape[-1], generator=g).to(device)
+    out["image_grid_thw"] = torch.tensor([[1, 4, n_img * rows_per_token // 4]], device=device)
+    return out
+
+
 def qwen_generate_steps(mod, cfg, device="cpu", grid_t=24, seed=85, n_decode=2):
     """A `generate`-shaped call sequence on the stub model: the prefill forward WITHOUT position ids (they come from
     `get_rope_index`, stubbed to return the ids of qwen_inputs and their delta; qwen2_vl.py:573-590), then `n_decode`

@@ -77,6 +77,27 @@ def gen_qwen_forward(qv, outdir):
               f"kv ratio {rec['kv_ratio_after']:.4f}, margin {m:.2e}")
 
 
+def gen_qwen_image(qv, outdir):
+    """Image tokens beside the video (qwen2_vl.py:593-596, :631-645): features scattered into the text segment; the
+    ValueError when features and tokens disagree."""
+    cfg = gs.qwen_config(ratio=0.5)
+    me = gs.make_qwen_model(qv, cfg)
+    kw = gs.qwen_inputs_with_image(grid_t=16, seed=87)
+    out = qv.retake_Qwen2VLForConditionalGeneration_forward(me, return_dict=False, **{k: v.clone() for k, v in kw.items()})
+    rec = gs.calls_to_record(me.model.calls, "call")
+    rec["logits"] = out[0].numpy()
+    rec["visual_calls"] = np.array(me.visual.calls, dtype=np.int64)
+    me = gs.make_qwen_model(qv, gs.qwen_config(ratio=0.5))
+    try:
+        qv.retake_Qwen2VLForConditionalGeneration_forward(me, return_dict=False, **gs.qwen_inputs_with_image(grid_t=16, seed=87, rows_per_token=3))
+        rec["mismatch_exc"], rec["mismatch_msg"] = "none", ""
+    except Exception as e:  # noqa: BLE001
+        rec["mismatch_exc"], rec["mismatch_msg"] = type(e).__name__, str(e)
+    np.savez_compressed(os.path.join(outdir, "glue_qwen2vl_forward_image.npz"), **rec)
+    print(f"glue_qwen2vl_forward_image: {len(me.model.calls)} calls after the failed forward, visual calls "
+          f"{rec['visual_calls'].tolist()}, mismatch -> {rec['mismatch_exc']}: {rec['mismatch_msg']}")
+
+
 def gen_qwen_generate(qv, outdir):
     """Prefill without position ids + two decode forwards (qwen2_vl.py:543-590, :721-733): glue_stubs.qwen_generate_steps."""
     cfg = gs.qwen_config(ratio=0.5)
@@ -376,6 +397,7 @@ def main():
     lo.eager_attention_forward = gs.eager_attention_forward_448   # the 4.48 function the reference was written against
     gen_qwen_forward(qv, HERE)
     gen_qwen_generate(qv, HERE)
+    gen_qwen_image(qv, HERE)
     gen_llava(lo, HERE)
     gen_llava_generate(lo, HERE)
     gen_attention(lc, qv, lo, HERE)

@@ -259,6 +259,35 @@ def run_qwen_forward(name, device="cpu"):
     assert out[1].kvcache_compression is False and out[1].keypatches_mask_chunk is None   # off for decoding
 
 
+def run_qwen_image(device="cpu"):
+    """Image tokens beside the video (qwen2_vl.py:593-596, :631-645): features scattered into the text segment, and the
+    reference's ValueError - class and message - when features and tokens disagree."""
+    import glue_stubs as gs
+    import retake.qwen2_vl as q
+
+    g = gu.load("glue_qwen2vl_forward_image")
+    me = gs.make_qwen_model(q, gs.qwen_config(ratio=0.5))
+    out = q.retake_Qwen2VLForConditionalGeneration_forward(me, return_dict=False,
+                                                           **gs.qwen_inputs_with_image(grid_t=16, seed=87, device=device))
+    tol = 0.0 if device == "cpu" else 1e-6
+    gs.assert_calls_equal(me.model.calls, g, "call", emb_tol=tol)
+    np.testing.assert_allclose(out[0].cpu().numpy(), g["logits"], rtol=0, atol=tol)
+    np.testing.assert_array_equal(np.array(me.visual.calls, dtype=np.int64), g["visual_calls"])
+    me = gs.make_qwen_model(q, gs.qwen_config(ratio=0.5))
+    with pytest.raises(ValueError) as ei:
+        q.retake_Qwen2VLForConditionalGeneration_forward(
+            me, return_dict=False, **gs.qwen_inputs_with_image(grid_t=16, seed=87, rows_per_token=3, device=device))
+    assert str(g["mismatch_exc"]) == "ValueError" and str(ei.value) == str(g["mismatch_msg"])
+    assert not me.model.calls
+
+
+def test_qwen2vl_forward_with_image_tokens_matches_reference(monkeypatch):
+    import retake.qwen2_vl as q
+
+    monkeypatch.setattr(q, "memory_bank_compress_keyframe", _oracle_keyframe)
+    run_qwen_image()
+
+
 def run_qwen_generate(device="cpu"):
     """Prefill without position ids (get_rope_index) + two decode forwards on the returned cache (qwen2_vl.py:543-590,
     :721-733) against the reference's call record: ids from cache_position + rope_deltas, cache passed through, output
