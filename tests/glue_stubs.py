@@ -155,6 +155,27 @@ def qwen_inputs(grid_t=16, gh=4, gw=4, n_pre=5, n_post=7, d=24, seed=77, device=
     return {k: v.to(device) for k, v in kw.items()}
 
 
+def bare_hf_qwen2vl(cfg):
+    """An instance of the installed transformers' Qwen2VLForConditionalGeneration WITHOUT running its __init__ (no
+    weights): only `.config` set - what forge_input_chunks' prompt-guided branch asks of `self` (isinstance + config)."""
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLForConditionalGeneration
+
+    me = Qwen2VLForConditionalGeneration.__new__(Qwen2VLForConditionalGeneration)
+    me.__dict__["config"] = cfg
+    return me
+
+
+def prompt_guided_case():
+    """Inputs of the prompt-guided forge_input_chunks scenario: 3 text + 12 video + 5 text tokens, chunk [3, 7)."""
+    S = 20
+    seg = [(0, 3, "text"), (3, 15, "video"), (15, 20, "text")]
+    pos = torch.arange(S)[None, None].repeat(3, 1, 1) + 100
+    pos[1] += 7
+    am = torch.ones(1, S, dtype=torch.long)
+    am[0, 0] = 0
+    return seg, torch.arange(S), pos, am, torch.arange(S * 2, dtype=torch.float32).reshape(1, S, 2)
+
+
 def qwen_inputs_with_image(n_img=4, rows_per_token=4, device="cpu", **kw):
     """qwen_inputs with `n_img` image tokens inside the leading text segment and their pixel rows (the image branch of
     the forward, qwen2_vl.py:593-596, :631-645); rows_per_token != 4 makes features and tokens disagree."""

@@ -98,6 +98,28 @@ def gen_qwen_image(qv, outdir):
           f"{rec['visual_calls'].tolist()}, mismatch -> {rec['mismatch_exc']}: {rec['mismatch_msg']}")
 
 
+def gen_qwen_prompt_guided(qv, outdir):
+    """Prompt-guided forge_input_chunks of Qwen2-VL (qwen2_vl.py:500-517): on an instance of the HF class (the branch
+    checks isinstance) and the NotImplementedError for any other `self`."""
+    cfg = gs.qwen_config(ratio=0.5, prompt_guided=True)
+    seg, cp, pos, am, ie = gs.prompt_guided_case()
+    out = qv.retake_Qwen2VLForConditionalGeneration_forge_input_chunks(gs.bare_hf_qwen2vl(cfg), 3, 7, seg, cp, pos, am, None, ie)
+    rec = {"cp": out[0].numpy(), "pos": out[1].numpy(), "am": out[2].numpy(), "ie": out[3].numpy(),
+           "prompt_length": int(out[4])}
+    try:
+        qv.retake_Qwen2VLForConditionalGeneration_forge_input_chunks(types.SimpleNamespace(config=cfg), 3, 7, seg, cp, pos, am, None, ie)
+        rec["other_class_exc"] = "none"
+    except Exception as e:  # noqa: BLE001
+        rec["other_class_exc"] = type(e).__name__
+    cfg1 = gs.qwen_config(ratio=0.5, kv_ratio=1, prompt_guided=True)   # ratio 1: the branch is off (:502)
+    out = qv.retake_Qwen2VLForConditionalGeneration_forge_input_chunks(types.SimpleNamespace(config=cfg1), 3, 7, seg, cp, pos, am, None, ie)
+    rec["ratio1_prompt_length_is_none"] = out[4] is None
+    rec["ratio1_cp"] = out[0].numpy()
+    np.savez_compressed(os.path.join(outdir, "glue_qwen2vl_prompt_guided.npz"), **rec)
+    print(f"glue_qwen2vl_prompt_guided: prompt_length {rec['prompt_length']}, other class -> {rec['other_class_exc']}, "
+          f"ratio 1 -> prompt_length None: {rec['ratio1_prompt_length_is_none']}")
+
+
 def gen_qwen_generate(qv, outdir):
     """Prefill without position ids + two decode forwards (qwen2_vl.py:543-590, :721-733): glue_stubs.qwen_generate_steps."""
     cfg = gs.qwen_config(ratio=0.5)
@@ -398,6 +420,7 @@ def main():
     gen_qwen_forward(qv, HERE)
     gen_qwen_generate(qv, HERE)
     gen_qwen_image(qv, HERE)
+    gen_qwen_prompt_guided(qv, HERE)
     gen_llava(lo, HERE)
     gen_llava_generate(lo, HERE)
     gen_attention(lc, qv, lo, HERE)

@@ -61,21 +61,26 @@ def test_forge_input_chunks_matches_reference():
 
 
 def test_forge_input_chunks_prompt_guided():
+    """Prompt-guided mode (qwen2_vl.py:500-517) against the reference: the trailing text segment appended to the chunk
+    on an instance of the HF model class, NotImplementedError for any other `self`, off at compression_ratio 1."""
+    import glue_stubs as gs
     import retake.qwen2_vl as q
 
-    cfg = _glue_cfg()
-    cfg.longvideo_kwargs["kvcache_compression_kwargs"]["prompt_guided_compression"] = True
-    S = 20
-    seg = [(0, 3, "text"), (3, 15, "video"), (15, 20, "text")]
-    pos = torch.arange(S)[None, None].repeat(3, 1, 1) + 100
-    am = torch.ones(1, S, dtype=torch.long)
-    cp = torch.arange(S)
-    ie = torch.arange(S, dtype=torch.float32).reshape(1, S, 1)
-    cpc, posc, amc, iec, pl = q.retake_Qwen2VLForConditionalGeneration_forge_input_chunks(_me(cfg), 3, 7, seg, cp, pos,
-                                                                                        am, None, ie)
-    assert pl == 5 and iec.shape[1] == 4 + 5 and amc.shape[1] == 7 + 5 and cpc.shape[0] == 7 + 5
-    # prompt ids continue right after the chunk's last temporal id (reference :509-510)
-    assert posc[0, 0, 4].item() == posc[0, 0, 3].item() + 1
+    g = gu.load("glue_qwen2vl_prompt_guided")
+    cfg = gs.qwen_config(ratio=0.5, prompt_guided=True)
+    seg, cp, pos, am, ie = gs.prompt_guided_case()
+    out = q.retake_Qwen2VLForConditionalGeneration_forge_input_chunks(gs.bare_hf_qwen2vl(cfg), 3, 7, seg, cp, pos, am, None, ie)
+    for name, t in zip(["cp", "pos", "am", "ie"], out[:4]):
+        np.testing.assert_array_equal(t.numpy(), g[name], err_msg=name)
+    assert int(out[4]) == int(g["prompt_length"]) == 5
+    assert out[1][0, 0, 4].item() == out[1][0, 0, 3].item() + 1   # prompt ids continue after the chunk's last temporal id
+    assert str(g["other_class_exc"]) == "NotImplementedError"
+    with pytest.raises(NotImplementedError):
+        q.retake_Qwen2VLForConditionalGeneration_forge_input_chunks(_me(cfg), 3, 7, seg, cp, pos, am, None, ie)
+    cfg1 = gs.qwen_config(ratio=0.5, kv_ratio=1, prompt_guided=True)
+    out = q.retake_Qwen2VLForConditionalGeneration_forge_input_chunks(_me(cfg1), 3, 7, seg, cp, pos, am, None, ie)
+    assert (out[4] is None) == bool(g["ratio1_prompt_length_is_none"])
+    np.testing.assert_array_equal(out[0].numpy(), g["ratio1_cp"])
 
 
 def test_llava_helpers():

@@ -261,6 +261,12 @@ def retake_Qwen2VLForConditionalGeneration_forge_input_chunks(self, ss, ee, moda
     prompt_length = None
     if _prefill.prompt_guided(self.config):
         s_p, e_p, t_p = modality_segments[-1]
+        # only '<|vision_pad|>' counts as vision for Qwen2-VL, so the trailing segment starts at '<|vision_end|>'; any
+        # other model class is refused (reference :506-511)
+        from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLForConditionalGeneration  # third-party
+
+        if not isinstance(self, Qwen2VLForConditionalGeneration):
+            raise NotImplementedError
         assert t_p == "text"
         pos_offset = position_ids[0, 0, s_p] - position_ids_chunk[0, 0, -1] - 1
         position_ids_chunk = torch.cat([position_ids_chunk, position_ids[:, :, s_p:e_p] - pos_offset], dim=2)
