@@ -111,16 +111,29 @@ class Rotary:
 
 
 OVERLAP_STREAMS = 0
+CACHE_EXTRA = {}               # build-specific cache options of a companion measurement (the headline sets none)
+MAX_INPUT_LENGTH = 32000       # configs/retake_demo.yaml:23
+
+
+def cache_kwargs():
+    """kvcache_compression_kwargs of the measured cache: the reference's own YAML keys (configs/retake_demo.yaml:18-24)
+    plus the `compression_ratio` its dynamic rule writes into the same dict before the cache is built
+    (qwen2_vl.py:553-557; here the 4x of BASELINE configs[2]).  Build-specific options appear only when a flag / a
+    companion asks for them - the headline runs on the product defaults."""
+    kw = {"dynamic_compression_ratio": True, "compression_method": "pivotkv", "pos_embed_reforge": True,
+          "max_input_length": MAX_INPUT_LENGTH, "compression_ratio": RATIO}
+    if SCORE_ROUNDING != "fp32":
+        kw["score_rounding"] = SCORE_ROUNDING
+    if OVERLAP_STREAMS:
+        kw["overlap_streams"] = OVERLAP_STREAMS
+    kw.update(CACHE_EXTRA)
+    return kw
 
 
 def make_cache_config(layers):
     return types.SimpleNamespace(
         hidden_size=Hq * D, num_hidden_layers=layers, num_attention_heads=Hq, num_key_value_heads=Hkv,
-        longvideo_kwargs={"kvcache_compression": True,
-                          "kvcache_compression_kwargs": {"compression_ratio": RATIO, "compression_method": "pivotkv",
-                                                         "pos_embed_reforge": True, "native_rope": True,
-                                                         "score_rounding": SCORE_ROUNDING,
-                                                         "overlap_streams": OVERLAP_STREAMS}})
+        longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": cache_kwargs()})
 
 
 def chunk_position_ids(c, device):
@@ -138,10 +151,15 @@ def chunk_frames(c, dev, tdtype):
     return torch.randn((FRAMES_PER_CHUNK, N_PATCH, C_EMB), generator=g, device=dev, dtype=torch.float32).to(tdtype)
 
 
-def pool_set(i, dev, tdtype):
-    """Resident (q, k, v) set i; update (chunk c, layer l) of ANY run uses set (c * layers + l) % pool size."""
+def pool_set(i, dev, tdtype, projection_layout=False):
+    """Resident (q, k, v) set i; update (chunk c, layer l) of ANY run uses set (c * layers + l) % pool size.
+    projection_layout: the memory layout q_proj / k_proj / v_proj produce ([1, L, H*D], handed on as the transposed
+    [1, H, L, D] view, qwen2_vl.py:55-57) instead of head-major tensors."""
     g = torch.Generator(device=dev).manual_seed(9000 + i)
     L = FRAMES_PER_CHUNK * N_PATCH
+    if projection_layout:
+        return tuple((1.7 * torch.randn((1, L, h, D), generator=g, device=dev, dtype=torch.float32)).to(tdtype).transpose(1, 2)
+                     for h in (Hq, Hkv, Hkv))
     return tuple((1.7 * torch.randn((1, h, L, D), generator=g, device=dev, dtype=torch.float32)).to(tdtype)
                  for h in (Hq, Hkv, Hkv))
 
@@ -160,8 +178,11 @@ def cache_checksum(keys, values, pos):
             "k_abs_sum": kabs}
 
 
-def run_video(frames, pool, masks, pos_base, rotary, layers, tdtype):
-    """One step on one GPU: DPSelect + all (chunk, layer) PivotKV updates.  Returns retained tokens."""
+def run_video(frames, pool, masks, pos_base, rotary, layers, tdtype, pre_rope=False):
+    """One step on one GPU: DPSelect + all (chunk, layer) PivotKV updates.  Returns retained tokens.
+    pre_rope: the pool holds PRE-RoPE projections and every update is the attention patch's fused prologue
+    (PivotKVCache.update_pre_rope: continuity shift + RoPE of q / k + append + scoring operands in one kernel; the
+    rotated queries overwrite the pool's q, as they overwrite q_proj's output in the model)."""
     import retake.longvideo_cache as lc
     import retake.visual_compression as vc
 
@@ -180,6 +201,10 @@ def run_video(frames, pool, masks, pos_base, rotary, layers, tdtype):
         for layer in range(layers):
             q, k, v = pool[call % len(pool)]
             call += 1
+            if pre_rope:
+                if cache.update_pre_rope(q, k, v, layer, pos, rotary, MROPE) is None:
+                    raise RuntimeError("update_pre_rope declined a video chunk of the benchmark geometry")
+                continue
             # what the attention patch does (qwen2_vl.py:68-73): the ids tensor is shared by the layers of
             # the chunk and shifted in place, on the device (no host sync)
             cache.shift_temporal_ids_(pos, layer)
@@ -258,23 +283,34 @@ def score_roofline(kern, dtype, L, T, n_updates):
 
 
 def hbm_achievable(dev):
-    """What a plain device-to-device copy reaches on this GPU, beside the nominal 8 TB/s every HBM roofline fraction
-    above is quoted against (state both): a 2 GiB buffer, far beyond L2 + MALL, timed with HIP events
-    outside the timed region; read + write bytes counted."""
+    """What a device-to-device copy reaches on this GPU, beside the nominal 8 TB/s every HBM roofline fraction above
+    is quoted against (state both): a 2 GiB buffer, far beyond L2 + MALL, timed with HIP events outside
+    the timed region; read + write bytes counted.  Two copies: the library's non-temporal 16-byte-vector kernel
+    (rtk_profile_copy - the float4 copy MI355X_MICROARCH.md quotes 6.29 TB/s for) and torch's copy_."""
+    import retake._native as nv
+
     n = 1 << 30   # bf16 elements: 2 GiB
     src = torch.empty(n, dtype=torch.bfloat16, device=dev).normal_()
     dst = torch.empty_like(src)
-    dst.copy_(src)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        dst.copy_(src)
-    e1.record()
-    torch.cuda.synchronize()
-    gbs = 2 * n * 2 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return 2 * n * 2 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    nt = timed(lambda: nv.check(nv.lib.rtk_profile_copy(nv.ptr(dst), nv.ptr(src), 2 * n, nv.stream()), "rtk_profile_copy"))
+    tc = timed(lambda: dst.copy_(src))
     del src, dst
-    return {"copy_GBps": gbs, "frac_of_nominal": gbs / HBM_PEAK_GBS, "note": "torch copy_ of 2 GiB (read + write bytes)"}
+    best = max(nt, tc)
+    return {"copy_GBps": best, "frac_of_nominal": best / HBM_PEAK_GBS, "nt_vector_copy_GBps": nt, "torch_copy_GBps": tc,
+            "guide_float4_copy_GBps": 6290.0,
+            "note": "2 GiB device copy, read + write bytes; best of the library's non-temporal 16-byte copy and torch copy_"}
 
 
 def cpu_baseline(args, frames_cpu_sample, n_updates):
@@ -321,32 +357,33 @@ def cpu_baseline(args, frames_cpu_sample, n_updates):
 
 
 def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_n, geometry=None, score_rounding="fp32",
-                          warmup_chunks=None):
+                          warmup_chunks=None, pre_rope=False, cache_extra=None, time_all_kernels=False):
     """The same step measured again in another configuration, AFTER (and outside) the timed region `value` comes from:
     another geometry, another score arithmetic or the parity dtype.  Same protocol in small: resident inputs, `warmup`
     untimed steps (optionally shortened to `warmup_chunks` chunks - enough to build every buffer and touch every
     kernel), then `steps` timed steps between synchronisations, HIP events around the two score passes.  Returns
     {value, ms_per_step, roofline, ...}; restores the module's geometry / rounding afterwards."""
-    global SCORE_ROUNDING, N_PATCH, C_EMB, GRID_H, GRID_W, FRAMES_PER_CHUNK, FRAMES_PER_ROW
+    global SCORE_ROUNDING, N_PATCH, C_EMB, GRID_H, GRID_W, FRAMES_PER_CHUNK, FRAMES_PER_ROW, CACHE_EXTRA
     import retake._native as nv
 
     saved_geo = (N_PATCH, C_EMB, GRID_H, GRID_W, FRAMES_PER_CHUNK, FRAMES_PER_ROW)
-    saved_round = SCORE_ROUNDING
+    saved_round, saved_extra = SCORE_ROUNDING, CACHE_EXTRA
     try:
         if geometry is not None:
             set_geometry(geometry)
         SCORE_ROUNDING = score_rounding
+        CACHE_EXTRA = dict(cache_extra or {})
         tdtype = TORCH_DTYPE[dtype]
         rows = frames_total // FRAMES_PER_ROW
         n_chunks = rows // FRAMES_PER_CHUNK
         L = FRAMES_PER_CHUNK * N_PATCH
         frames = torch.cat([chunk_frames(c, dev, tdtype) for c in range(n_chunks)])[None]
-        pool = [pool_set(i, dev, tdtype) for i in range(min(pool_n, n_chunks * layers))]
+        pool = [pool_set(i, dev, tdtype, projection_layout=pre_rope) for i in range(min(pool_n, n_chunks * layers))]
         pos_base = [chunk_position_ids(c, dev) for c in range(n_chunks)]
         rotary = Rotary(dev)
         for _ in range(warmup):
             fr = frames if warmup_chunks is None else frames[:, : warmup_chunks * FRAMES_PER_CHUNK]
-            run_video(fr, pool, None, pos_base, rotary, layers, tdtype)
+            run_video(fr, pool, None, pos_base, rotary, layers, tdtype, pre_rope)
         ids = nv.profile_kernel_ids()
         nv.check(nv.lib.rtk_profile_reset(), "profile_reset")
         nv.check(nv.lib.rtk_profile_enable_mask((1 << ids["score_pass1"]) | (1 << ids["score_pass2"])), "profile_enable")
@@ -360,14 +397,23 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
             # device whose memory the previous companion had just released
             cache = kp_mask = None
             ts = time.perf_counter()
-            _, cache, kp_mask = run_video(frames, pool, None, pos_base, rotary, layers, tdtype)
+            _, cache, kp_mask = run_video(frames, pool, None, pos_base, rotary, layers, tdtype, pre_rope)
             torch.cuda.synchronize()
             step_ms.append((time.perf_counter() - ts) * 1e3)
         dt = time.perf_counter() - t0
         nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
         kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in nv.profile_read().items()}
+        kern_all = None
+        if time_all_kernels:   # untimed extra pass with every kernel bracketed: the per-update share of the step
+            cache = kp_mask = None
+            nv.check(nv.lib.rtk_profile_reset(), "profile_reset")
+            nv.check(nv.lib.rtk_profile_enable(1), "profile_enable")
+            _, cache, kp_mask = run_video(frames, pool, None, pos_base, rotary, layers, tdtype, pre_rope)
+            torch.cuda.synchronize()
+            nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
+            kern_all = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in nv.profile_read().items()}
         check = None
-        if dtype in ("bf16", "fp16") and score_rounding == "fp32":
+        if dtype in ("bf16", "fp16") and score_rounding == "fp32" and not pre_rope:
             check = self_check(cache, pool, kp_mask, n_chunks, layers, rotary)["status"]
         keep = max(1, int(RATIO * L))
         assert cache.key_cache[0].shape[2] == n_chunks * keep
@@ -380,12 +426,21 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
                           "chunk_tokens": L, "keep": keep, "key_patch_mask_rate": float(kp_mask.float().mean().item())},
                "kernels_timed_region": kern,
                "roofline": score_roofline(kern, dtype, L, rows, n_chunks * layers * steps)}
+        res["config"]["cache_kwargs"] = cache_kwargs()
+        if pre_rope:
+            res["config"]["update_call"] = "PivotKVCache.update_pre_rope (pre-RoPE projections, [L, H*D] layout)"
+        if kern_all is not None:
+            res["kernels_untimed_single_stream"] = kern_all
+            per_update = sum(v["total_ms"] for k, v in kern_all.items()
+                             if k in ("prologue", "unrotate_pack", "position_shift", "append", "rope_table"))
+            total = sum(v["total_ms"] for k, v in kern_all.items() if not k.startswith(("dpselect", "gather_frames")))
+            res["per_update_kernels_share_of_gpu_time"] = per_update / total if total else None
         if check is not None:
             res["self_check"] = check
         return res
     finally:
         N_PATCH, C_EMB, GRID_H, GRID_W, FRAMES_PER_CHUNK, FRAMES_PER_ROW = saved_geo
-        SCORE_ROUNDING = saved_round
+        SCORE_ROUNDING, CACHE_EXTRA = saved_round, saved_extra
         torch.cuda.empty_cache()
 
 
@@ -490,6 +545,10 @@ def main():
                                f"L={L}, Hq={Hq}, Hkv={Hkv}, D={D}, reforge+M-RoPE "
                                + ("(BASELINE configs[2])" if args.geometry == "baseline" else f"({GEOMETRIES[args.geometry][6]})"),
                    "geometry": args.geometry, "score_rounding": args.score_rounding,
+                   "cache_kwargs": cache_kwargs(),
+                   "native_rope": "product default: on for inv_freq rotary modules (no config key set)",
+                   "update_call": "PivotKVCache.update (rotated q / k, the reference's cache_kwargs protocol) after "
+                                  "shift_temporal_ids_, as the attention patch calls them",
                    "frames": args.frames, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L, "keep": int(RATIO * L),
                    "input_pool_sets": len(pool), "worker_streams": args.streams, "parallelism": "1 GPU"},
     }
@@ -596,10 +655,24 @@ def main():
         del frames, pool
         torch.cuda.empty_cache()
         out["real_geometry"] = companion_measurement(dev, args.frames, args.layers, "bf16", max(2, args.steps), 1, args.pool,
-                                                     geometry="qwen448")
+                                                     geometry="qwen448", time_all_kernels=True)
         out["real_geometry"]["config"]["workload"] = (
             "real Qwen2-VL-7B geometry at 448 px 16:9: 1024 temporal grids x 144 merged tokens x 3584 channels, "
             "chunk = 16 grids = 2304 tokens (cal_flops.py:8,47; qwen2_vl.py:477-491)")
+        # the attention patch's fused prologue: the same step fed with PRE-RoPE projections in the projection layout
+        # (what the patched HF attention hands over on the GPU), at both geometries
+        out["pre_rope_prologue"] = {
+            "note": "PivotKVCache.update_pre_rope: continuity shift + rotary tables + RoPE of q / k + cache append + "
+                    "scoring operands in ONE kernel per update (replaces position_shift + HF's eager RoPE ops + "
+                    "prepare); the rotated queries overwrite the pool's q like they overwrite q_proj's output",
+            "real_geometry": companion_measurement(dev, args.frames, args.layers, "bf16", 2, 1, args.pool,
+                                                   geometry="qwen448", pre_rope=True, time_all_kernels=True),
+            "baseline_geometry": companion_measurement(dev, args.frames, args.layers, "bf16", 2, 1, args.pool,
+                                                       pre_rope=True, time_all_kernels=True)}
+        # the bit-faithful opt-out of the native RoPE: the rotary module is CALLED for the tables (reference :249, :298)
+        out["rotary_module_called"] = companion_measurement(dev, args.frames, args.layers, "bf16", 2, 1, args.pool,
+                                                            cache_extra={"native_rope": False})
+        out["rotary_module_called"]["note"] = "native_rope: False - the opt-out; tables from the rotary module + merge kernel"
         out["reference_rounding"] = companion_measurement(dev, args.frames, args.layers, "bf16", 2, 1, args.pool,
                                                           score_rounding="reference")
         out["reference_rounding"]["note"] = ("score_rounding='reference': the reference's bf16 logits / probabilities / sums "

@@ -65,6 +65,10 @@ enum rtk_dtype {
  * instead of for the workgroup count of one unit (one key split, about eight row tiles per row split).  Every call that
  * touches the same workspace must carry the same flag. */
 #define RTK_SCORE_MANY_UNITS 0x100
+/* Flag for the `dtype` argument of rtk_pivotkv_prepare only: the chunk keeps every token (compression_ratio 1, what
+ * `dynamic_compression_ratio` gives every prompt within max_input_length, qwen2_vl.py:553-554) and is not scored, so
+ * the un-rotated queries are not produced - k~ (for the re-rotation) and the cache tail still are. */
+#define RTK_PREPARE_K_ONLY 0x200
 
 enum rtk_status {
     RTK_OK = 0,
@@ -349,9 +353,10 @@ typedef struct rtk_evict_unit {
     const int64_t* keep_idx;  /* [keep] ascending, from rtk_pivotkv_select */
     const float* cos_new;     /* fp32 [keep,D] tables of the NEW positions of the kept rows, or NULL (no reforge) */
     const float* sin_new;
-    void* k_dst;              /* kept row (h,r) at h*k_dst_stride_h + r*D; must not alias k_src */
+    void* k_dst;              /* kept row (h,r) at h*k_dst_stride_h + r*D; must not alias k_src.  NULL: K is left alone */
     int64_t k_dst_stride_h;
-    void* v_dst;              /* kept row (h,r) at h*v_dst_stride_h + r*D; must not alias v_src */
+    void* v_dst;              /* kept row (h,r) at h*v_dst_stride_h + r*D; must not alias v_src.  NULL: V is left alone
+                                 (keep == L: every row already sits where the append put it) */
     int64_t v_dst_stride_h;
     const int64_t* pos_src;   /* optional: ids of the kept rows [P,keep] (row stride pos_src_stride) ... */
     int64_t pos_src_stride;
@@ -409,6 +414,107 @@ typedef struct rtk_place_unit {
 int rtk_pivotkv_place_batched(const rtk_place_unit* units, int n_units, int H, int keep, int D, int dtype,
                               rtk_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * One-call update and one-call flush (ABI 13).  PivotKVCache.update runs 1,792 times per 2048-frame video and
+ * the reference calls cache.after_forward() once per chunk (qwen2_vl.py:715-716): on MI355X the per-call HOST work
+ * around the launches decides the real-geometry step, so the argument blocks are bound ONCE per chunk geometry
+ * (rtk_pivotkv_batch, HOST memory owned by the caller) and per layer (rtk_layer_state, HOST memory owned by the
+ * caller, updated by the library), and each update / flush is ONE call that fills in the launches the
+ * entry points above would have been handed one by one.  Nothing new is computed here:
+ *   rtk_pivotkv_update  = rtk_pivotkv_prepare (rotated q, k)  or the attention prologue (pre-RoPE q, k; below)
+ *   rtk_pivotkv_flush   = rtk_pivotkv_score_passes_batched + rtk_pivotkv_select_batched +
+ *                         rtk_pivotkv_evict_batched[_rope] + rtk_pivotkv_place_batched for the pending layers
+ * ------------------------------------------------------------------------------------------- */
+
+/* One layer's pre-allocated cache (longvideo_cache.py: key_cache[l] / value_cache[l] / position_cache[l]). */
+typedef struct rtk_layer_state {
+    void* k;                 /* [1, Hkv, cap, D] keys   (element (h, r, d) at (h*cap + r)*D + d) */
+    void* v;                 /* [1, Hkv, cap, D] values */
+    int64_t cap;             /* rows allocated per head */
+    int64_t length;          /* committed (compressed) rows                                  - advanced by rtk_pivotkv_flush */
+    int64_t pending;         /* uncompressed chunk rows at [length, length + pending)        - set by update, cleared by flush */
+    int64_t pending_keep;    /* rows of them that survive                                                                      */
+    int64_t* pos;            /* [P, pos_cap] position ids of the cached rows (pos_embed_reforge) or NULL */
+    int64_t pos_cap;
+    int64_t pos_len;         /*                                                              - advanced by rtk_pivotkv_flush */
+    const uint8_t* mask;     /* the pending chunk's key-patch mask [L] or NULL (cache.keypatches_mask_chunk, :272-274) */
+} rtk_layer_state;
+
+/* The per-chunk batch: geometry + the slot-strided scratch of all layers (slot = layer index).  Every buffer is
+ * caller-allocated device memory; sizes as the per-stage entry points document them. */
+typedef struct rtk_pivotkv_batch {
+    int32_t Hq, Hkv, L, D, keep, P, slots;
+    int32_t dtype;            /* payload: RTK_F32 / RTK_BF16 / RTK_F16 */
+    int32_t score_dtype;      /* what the scoring entry points are told (may carry RTK_SCORE_MANY_UNITS) */
+    int32_t prep_dtype;       /* what rtk_pivotkv_prepare is told */
+    int32_t reforge;          /* pos_embed_reforge */
+    int32_t keep_all;         /* keep == L and no scores wanted: selection is the identity, no score passes */
+    int32_t round_mode;       /* 0 fp32 / 1 bf16 / 2 fp16 rotary tables */
+    int32_t nsec;
+    int32_t sections[8];      /* mrope_section (nsec entries; nsec = 0: plain RoPE) */
+    int32_t rs_n;             /* row splits of the column partials (rtk_pivotkv_score_partials) */
+    int32_t skip_masked;      /* pass 2 on the unmasked keys only */
+    float attention_scaling;
+    int32_t pad0;
+    const float* inv_freq;    /* [D/2] fp32 */
+    void* score_ws;           /* slot s at score_ws + s*score_ws_stride (256-byte aligned): q~, lse, ... */
+    uint64_t score_ws_stride, score_ws_bytes;
+    void* k_unrot;            /* [slots, Hkv, L, D] un-rotated keys */
+    float* partials;          /* [slots, partial_floats] */
+    uint64_t partial_floats;
+    float* score;             /* [slots, L] */
+    int64_t* pos_old;         /* [slots, P, L] ids of the pending chunks (after the continuity shift) */
+    int64_t* keep_idx;        /* [slots, keep] */
+    int64_t* pos_new;         /* [P, slots, keep] */
+    void* sel_ws;             /* slot s at sel_ws + s*sel_ws_stride */
+    uint64_t sel_ws_stride;
+    int32_t* key_index;       /* [slots, L + 1] */
+    void* v_stage;            /* [slots, Hkv, keep, D] */
+    void* k_stage;            /* [slots, Hkv, keep, D] (no reforge only, else NULL) */
+    int64_t* shift_row;       /* RTK_UPDATE_PRE_ROPE: the caller's temporal-id row; rtk_pivotkv_flush applies the last
+                                 pending layer's continuity shift to it in place (qwen2_vl.py:73), then clears this field */
+    int32_t pre_rope;         /* the pending units were appended from pre-RoPE projections: k~ == k0 */
+    int32_t batched_passes;   /* 1: the score passes of all pending layers run from rtk_pivotkv_flush, one launch per kernel
+                                 (16-bit payloads, head_dim 128); 0: rtk_pivotkv_update runs them per unit */
+} rtk_pivotkv_batch;
+
+/* The tensors of one update call.  Strides in elements; element (h, l, d) at h*stride_h + l*stride_l + d. */
+typedef struct rtk_update_io {
+    const void* q; int64_t q_stride_h, q_stride_l;   /* [Hq, L, D] */
+    const void* k; int64_t k_stride_h, k_stride_l;   /* [Hkv, L, D] */
+    const void* v; int64_t v_stride_h, v_stride_l;   /* [Hkv, L, D] */
+    const int64_t* pos; int64_t pos_stride;          /* [P, L] ids of the chunk, row p at pos + p*pos_stride */
+    void* q_rot; int64_t qr_stride_h, qr_stride_l;   /* RTK_UPDATE_PRE_ROPE: rotated queries out (may alias q) */
+    int32_t flags;
+    int32_t pad0;
+} rtk_update_io;
+enum rtk_update_flags {
+    /* q, k are the PRE-RoPE projections (what q_proj / k_proj return).  One launch then does the whole prologue of the
+     * attention patch (qwen2_vl.py:55-86, llava_onevision.py:59-141) and of PivotKVCache.update (:238, :248-259):
+     *   continuity shift  t' = t + (prev + 1 - t[0]) on the temporal row, prev = the layer's last cached temporal id
+     *                     (qwen2_vl.py:68-73; applied to the ids the kernel uses and to pos_old - the caller's tensor is
+     *                     shifted in place by rtk_pivotkv_flush, see rtk_pivotkv_batch.shift_row);
+     *   rotary tables     cos / sin of the shifted ids (rtk_rope_table's arithmetic, M-RoPE section merge :68-74);
+     *   q_rot             = (q*cos) + (rotate_half(q)*sin), one rounding per torch op  -> the layer's attention;
+     *   k tail, v tail    rotated k and v appended to the cache (:238);
+     *   q~, k~            the un-rotated operands of the score passes are the inputs themselves (un-rotating
+     *                     a rotation returns the pre-RoPE value up to rounding), copied to the score workspace / k_unrot.
+     * Needs pos_embed_reforge and an inv_freq rotary (batch.inv_freq). */
+    RTK_UPDATE_PRE_ROPE = 1
+};
+/* longvideo_cache.py:217-310 up to the deferred selection, for layer slot `slot`.  Rows go to the layer's tail
+ * (ls->k/v + length rows; the caller has made sure length + L <= cap), ls->pending / pending_keep are set. */
+int rtk_pivotkv_update(const rtk_pivotkv_batch* batch, rtk_layer_state* layer, int slot, const rtk_update_io* io,
+                       rtk_stream_t stream);
+
+/* longvideo_cache.py:260-318 for the n pending layers slots[0..n) (ascending) of one chunk: score passes (unless
+ * keep_all), selection, eviction (re-rotated K straight into the cache, V compacted in place) and the bookkeeping of
+ * rtk_layer_state (length, pos_len, pending).  layers[i] is the state of slot slots[i].  Native RoPE (batch.inv_freq)
+ * when reforging.  RTK_EUNSUPPORTED when the shape needs the per-stage entry points (L < 512, head_dim != 128 for the
+ * batched passes). */
+int rtk_pivotkv_flush(rtk_pivotkv_batch* batch, rtk_layer_state* const* layers, const int32_t* slots, int n,
+                      rtk_stream_t stream);
+
 /* G1  qwen2_vl.py:68-73 / llava_onevision.py:68-72, without the host round trip of the reference's
  * `if position_ids[0,0,0] != prev + 1`:  t[0:n] += (prev + 1) - t[0]  in place, where t is the temporal
  * row of the chunk's position ids and prev = *prev_dev (device memory: the last temporal id the layer's
@@ -463,6 +569,9 @@ int rtk_profile_reset(void);
 int rtk_profile_num_kernels(void);
 const char* rtk_profile_kernel_name(int kernel_id);
 int rtk_profile_read(int kernel_id, long long* launches, double* total_ms);
+/* Calibration for the HBM rooflines: dst = src over 16-byte vectors with non-temporal loads and stores - the device
+ * copy the "achievable" bandwidth beside the nominal 8 TB/s is measured with (bench.py: hbm_achievable). */
+int rtk_profile_copy(void* dst, const void* src, size_t bytes, rtk_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,340 @@
+"""The one-call entry points (rtk_pivotkv_update / rtk_pivotkv_flush, ABI 13) and the attention prologue
+(PivotKVCache.update_pre_rope) against the stage-by-stage route, torch restatements and the CPU oracle.
+
+Reference rows: longvideo_cache.py:217-323 (update), qwen2_vl.py:55-86 / llava_onevision.py:59-141 (attention prologue).
+"""
+import ctypes as C
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+Hq, Hkv, D = 28, 4, 128
+SEC = [16, 24, 24]
+A = synth.YARN_FACTOR4_ATTENTION_SCALING
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def cfg(layers, ratio=0.25, reforge=True, **extra):
+    kw = {"compression_ratio": ratio, "compression_method": "pivotkv", "pos_embed_reforge": reforge}
+    kw.update(extra)
+    return types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=layers, num_attention_heads=Hq,
+                                 num_key_value_heads=Hkv,
+                                 longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": kw})
+
+
+def rot_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def native_tables(pos, rot, dtype, mrope=True):
+    """[L, D] cos / sin of `pos` ([3, 1, L] or [1, L]) exactly as the kernels compute them (rtk_rope_table), rounded to
+    `dtype` like a rotary module's `.to(x.dtype)`."""
+    import retake._native as nv
+
+    P, L = (3, pos.shape[-1]) if pos.ndim == 3 else (1, pos.shape[-1])
+    p2 = pos.reshape(P, L).contiguous()
+    cos = torch.empty((L, D), dtype=torch.float32, device=dev())
+    sin = torch.empty_like(cos)
+    sec = (C.c_int * 3)(*SEC) if P == 3 else None
+    nv.check(nv.lib.rtk_rope_table(nv.ptr(p2), L, P, L, nv.ptr(rot.inv_freq), D, rot.attention_scaling, sec,
+                                   3 if P == 3 else 0, nv.round_mode(dtype), nv.ptr(cos), nv.ptr(sin), nv.stream()),
+             "rtk_rope_table")
+    return cos.to(dtype), sin.to(dtype)
+
+
+def projections(seed, L, dtype):
+    """q0, k0, v0 as q_proj / k_proj / v_proj hand them over: [1, L, H*D] memory, transposed [1, H, L, D] views."""
+    g = torch.Generator(device=dev()).manual_seed(seed)
+    return tuple((1.7 * torch.randn((1, L, h, D), generator=g, device=dev())).to(dtype).transpose(1, 2) for h in (Hq, Hkv, Hkv))
+
+
+def chunk_ids(c, L, mrope=True):
+    if mrope:
+        return torch.from_numpy(synth.mrope_position_ids(10 + 7 * c, L // 64, 8, 8, hw0=2)).to(dev())
+    return (torch.arange(L, device=dev()) + 100 + 9 * c * L).view(1, L)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("ratio", [0.25, 1])
+def test_one_call_update_and_flush_equal_the_staged_route(dtype, ratio):
+    """3 chunks x 3 layers at L = 640 (over the L >= 512 gate of the deferred selection): the cache driven through
+    rtk_pivotkv_update / rtk_pivotkv_flush holds bitwise what the stage-by-stage route leaves - keys, values, ids,
+    evicted-token counts, scores and kept indices of the last unit."""
+    import retake.longvideo_cache as lc
+
+    layers, n_chunks, L = 3, 3, 640
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+
+    def run(cache):
+        calls = 0
+        for c in range(n_chunks):
+            pos = chunk_ids(c, L)
+            cache.keypatches_mask_chunk = torch.from_numpy(np.random.default_rng(c).uniform(size=L) < 0.3).to(dev())
+            cache.kvcache_compression = True
+            for l in range(layers):
+                q0, k0, v = synth.qkv_chunk(700 + 10 * c + l, Hq, Hkv, L, D)
+                cache.shift_temporal_ids_(pos, l)
+                q = synth.rope_forward(torch.from_numpy(q0).to(dev()), pos, rot, SEC).to(dtype)
+                k = synth.rope_forward(torch.from_numpy(k0).to(dev()), pos, rot, SEC).to(dtype)
+                vt = torch.from_numpy(v).to(dev()).to(dtype)
+                kw = {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": SEC, "sin": None}
+                ko, vo = cache.update(k, vt, l, kw)
+                assert set(kw) == {"sin"}       # the reference's pops (:235, :241-243)
+                assert torch.equal(ko[:, :, -L:], k) and torch.equal(vo[:, :, -L:], vt)
+                calls += cache._batch.c_pending
+            if c == n_chunks - 1:
+                last = (cache.last_scores, cache.last_keep_indices.clone())
+            cache.after_forward()
+        return calls, last
+
+    one, staged = lc.build_kvcache(cfg(layers, ratio)), lc.build_kvcache(cfg(layers, ratio, one_call_update=False))
+    n_one, last_one = run(one)
+    n_staged, last_staged = run(staged)
+    assert n_staged == 0 and n_one > 0, "the one-call route was not taken"
+    keep = max(1, int(ratio * L))
+    for l in range(layers):
+        assert one.key_cache[l].shape == (1, Hkv, n_chunks * keep, D)
+        assert torch.equal(one.key_cache[l], staged.key_cache[l])
+        assert torch.equal(one.value_cache[l], staged.value_cache[l])
+        assert torch.equal(one.position_cache[l], staged.position_cache[l])
+    assert one.num_evicted_tokens == staged.num_evicted_tokens == [n_chunks * (L - keep)] * layers
+    if ratio != 1:
+        assert torch.equal(last_one[0], last_staged[0])
+    assert torch.equal(last_one[1], last_staged[1])
+
+
+@pytest.mark.parametrize("mrope", [True, False])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+def test_prologue_outputs_bitwise(dtype, mrope):
+    """update_pre_rope on two chunks x two layers: the rotated queries, the cache tail, the ids and the scoring operands
+    are bit for bit what torch computes op by op (one rounding per op, like the reference's eager chain) from the
+    kernels' own tables: q_rot = (q0*cos) + (rotate_half(q0)*sin) over the shifted ids; tail K the same of k0, tail V = v0;
+    q~ = q0 and k~ = k0; the caller's ids are shifted in place by the flush (Qwen2-VL) or left alone (LLaVA)."""
+    import retake.longvideo_cache as lc
+
+    layers, L = 2, 640
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    cache = lc.build_kvcache(cfg(layers))
+    sec = SEC if mrope else None
+    es = 4 if dtype == torch.float32 else 2
+    for c in range(2):
+        pos = chunk_ids(c, L, mrope)
+        pos_in = pos.clone()
+        cache.kvcache_compression = True
+        cache.keypatches_mask_chunk = None
+        for l in range(layers):
+            q0, k0, v0 = projections(40 + 10 * c + l, L, dtype)
+            q_keep, k_keep = q0.clone(), k0.clone()
+            prev = cache.get_prev_temporal_idx(l)
+            prev = int(prev) if not isinstance(prev, int) else prev
+            P0 = cache.get_seq_length(l)
+            out = cache.update_pre_rope(q0, k0, v0, l, pos, rot, sec, shift_ids_in_place=mrope)
+            assert out is not None, "the prologue declined a plain video chunk"
+            q_rot, K, V = out
+            assert q_rot.data_ptr() == q0.data_ptr() and K.shape[2] == P0 + L
+            want_ids = pos_in.clone()
+            if mrope:
+                want_ids[0, 0] += prev + 1 - want_ids[0, 0, 0]
+            else:
+                want_ids[0] += prev + 1 - want_ids[0, 0]
+            cos, sin = native_tables(want_ids, rot, dtype)
+            want_q = (q_keep * cos) + (rot_half(q_keep) * sin)
+            want_k = (k_keep * cos) + (rot_half(k_keep) * sin)
+            assert torch.equal(q_rot, want_q), f"q_rot differs in {(q_rot != want_q).sum().item()} entries"
+            assert torch.equal(K[:, :, P0:], want_k) and torch.equal(V[:, :, P0:], v0)
+            b = cache._batch
+            assert torch.equal(b.pos_old[l].reshape(want_ids.shape), want_ids)
+            assert torch.equal(b.k_unrot[l], k_keep[0])
+            ws = b.score_ws[(b.score_ws_base - b.score_ws.data_ptr()) + l * b.ws_stride:][: Hq * L * D * es]
+            assert torch.equal(ws.view(dtype).view(Hq, L, D), q_keep[0])
+            assert torch.equal(pos, pos_in), "the caller's ids move at the flush, not before"
+        last_prev = cache.get_prev_temporal_idx(layers - 1)   # (flushes: read it the way the reference would, then undo)
+        cache.after_forward()
+        if mrope:   # the flush applied the LAST layer's shift, what the reference's layer loop leaves in the tensor
+            assert pos[0, 0, 0].item() >= 0 and torch.equal(pos[1:], pos_in[1:])
+            assert torch.equal(pos[0, 0] - pos[0, 0, 0], pos_in[0, 0] - pos_in[0, 0, 0])
+        else:
+            assert torch.equal(pos, pos_in)
+        del last_prev
+
+
+@pytest.mark.parametrize("L", [640, 2304])
+def test_prologue_cache_against_oracle_fp32(L):
+    """fp32, M-RoPE, reforge, two chunks: the cache the prologue route builds against the CPU oracle fed with the ROTATED
+    tensors the reference's attention patch would have produced - kept indices bit-exact on tie-free boundaries, kept K
+    within 1e-5, kept V and ids exact (north_star's bar; SURVEY A8: pre-RoPE operands are allowed inside it)."""
+    import retake.longvideo_cache as lc
+
+    ratio = 0.25
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    rot_cpu = synth.RotaryStub(synth.inv_freq(D), A)
+    cache = lc.build_kvcache(cfg(1, ratio))
+    oc = orc.OraclePivotKV(Hq, Hkv, D, ratio, True)
+    keep = int(ratio * L)
+    fragile = 0
+    for c in range(2):
+        q0, k0, v = synth.qkv_chunk(900 + c, Hq, Hkv, L, D)
+        pos = torch.from_numpy(synth.mrope_position_ids(5 + 40 * c, L // 64, 8, 8, hw0=2))
+        prev = oc.get_prev_temporal_idx(0)
+        pos_sh = pos.clone()
+        pos_sh[0, 0] += prev + 1 - pos_sh[0, 0, 0]
+        q = synth.rope_forward(torch.from_numpy(q0), pos_sh, rot_cpu, SEC)
+        k = synth.rope_forward(torch.from_numpy(k0), pos_sh, rot_cpu, SEC)
+        oc.update(k.numpy(), v, 0, q=q.numpy(), position_ids=pos_sh.numpy(), rotary=rot_cpu, mrope_section=SEC)
+        qd = torch.from_numpy(q0).to(dev()).transpose(1, 2).contiguous().transpose(1, 2)
+        kd = torch.from_numpy(k0).to(dev()).transpose(1, 2).contiguous().transpose(1, 2)
+        cache.kvcache_compression = True
+        out = cache.update_pre_rope(qd, kd, torch.from_numpy(v).to(dev()), 0, pos.to(dev()), rot, SEC)
+        assert out is not None
+        score = cache.last_scores.cpu().numpy()
+        idx = cache.last_keep_indices.cpu().numpy()
+        cache.after_forward()
+        so = oc.last["score"]
+        assert np.abs(score - so).max() < 5e-6
+        srt = np.sort(so)[::-1]
+        if srt[keep - 1] - srt[keep] > 2e-5:
+            assert np.array_equal(idx, oc.last["keep_idx"])
+            assert np.abs(cache.key_cache[0][:, :, -keep:].cpu().numpy() - oc.last["kept_k"]).max() <= 1e-5
+            assert np.array_equal(cache.value_cache[0][:, :, -keep:].cpu().numpy(), oc.last["kept_v"])
+            assert np.array_equal(cache.position_cache[0][..., -keep:].cpu().numpy(), oc.last["pos"])
+        else:
+            fragile += 1
+    assert fragile < 2, "both chunks had a fragile k-th boundary: pick another seed"
+
+
+def test_prologue_keep_all_leaves_the_appended_rows():
+    """compression_ratio 1 through the prologue: nothing is scored, staged or copied - the cache holds the rotated keys
+    and the values the append wrote, and the (shifted) ids; the staged route builds the same ids / values and keys that
+    differ only by the rounding of the reference's un-rotate / re-rotate round trip."""
+    import retake.longvideo_cache as lc
+
+    layers, L, dtype = 2, 640, torch.bfloat16
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    cache = lc.build_kvcache(cfg(layers, 1))
+    eager = lc.build_kvcache(cfg(layers, 1, one_call_update=False))
+    for c in range(2):
+        pos, pos_e = chunk_ids(c, L), chunk_ids(c, L)
+        for l in range(layers):
+            q0, k0, v0 = projections(60 + 10 * c + l, L, dtype)
+            qe, ke = q0.clone(), k0.clone()
+            cache.kvcache_compression = eager.kvcache_compression = True
+            assert cache.update_pre_rope(q0, k0, v0, l, pos, rot, SEC) is not None
+            assert cache._batch.keep_all and cache._batch.partials is None, "a keep-all batch allocated scoring scratch"
+            eager.shift_temporal_ids_(pos_e, l)
+            cos, sin = rot(v0, pos_e)
+            qr, kr = lc.apply_multimodal_rotary_pos_emb(qe, ke, cos, sin, SEC)
+            eager.update(kr, v0, l, {"query_states": qr, "position_ids": pos_e, "rotary_emb": rot, "mrope_section": SEC})
+            assert torch.equal(q0, qr) or (q0 != qr).float().mean().item() < 1e-4   # module vs kernel tables: <= 1 ulp, rare
+        cache.after_forward()
+        eager.after_forward()
+        assert torch.equal(pos, pos_e)
+    for l in range(layers):
+        assert torch.equal(cache.value_cache[l], eager.value_cache[l])
+        assert torch.equal(cache.position_cache[l], eager.position_cache[l])
+        a, b = cache.key_cache[l].float(), eager.key_cache[l].float()
+        assert a.shape == b.shape == (1, Hkv, 2 * L, D)
+        assert ((a - b).abs() <= 2.0 ** -6 * b.abs().clamp_min(1e-3)).all()    # two bf16 roundings of a round trip
+    assert cache.last_scores is None
+
+
+def test_prologue_declines_what_it_cannot_serve():
+    """None - and nothing touched - for text segments (compression off), small chunks, rotary modules that have to be
+    called, CPU tensors and score_rounding='reference'."""
+    import retake.longvideo_cache as lc
+
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+
+    class Opaque:   # no inv_freq: has to be called
+        attention_scaling = 1.0
+
+        def __call__(self, x, ids):
+            return rot(x, ids)
+
+    L = 640
+    pos = chunk_ids(0, L)
+    for kw, rotary, n in (({}, rot, 128), ({}, Opaque(), L), ({"score_rounding": "reference"}, rot, L),
+                          ({"native_rope": False}, rot, L)):
+        cache = lc.build_kvcache(cfg(1, **kw))
+        q0, k0, v0 = projections(1, n, torch.bfloat16)
+        qk = q0.clone()
+        p = chunk_ids(0, n)
+        assert cache.update_pre_rope(q0, k0, v0, 0, p, rotary, SEC) is None
+        assert torch.equal(q0, qk) and cache.get_seq_length(0) == 0
+    cache = lc.build_kvcache(cfg(1))
+    cache.kvcache_compression = False
+    q0, k0, v0 = projections(1, L, torch.bfloat16)
+    assert cache.update_pre_rope(q0, k0, v0, 0, pos, rot, SEC) is None
+
+
+def test_qwen_attention_patch_takes_the_prologue():
+    """The patched Qwen2-VL SDPA attention on a stand-in module (projections + rotary), two chunks of 640 tokens and a
+    reforging PivotKV cache: the fused prologue route and the op-by-op route (one_call_update off) give the same
+    attention output to bf16 rounding noise and the same cache ids / values."""
+    import retake.longvideo_cache as lc
+    import retake.qwen2_vl as rq
+
+    hidden, L = Hq * D, 640
+    torch.manual_seed(0)
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj = torch.nn.Linear(hidden, Hq * D, bias=True)
+            self.k_proj = torch.nn.Linear(hidden, Hkv * D, bias=True)
+            self.v_proj = torch.nn.Linear(hidden, Hkv * D, bias=True)
+            self.o_proj = torch.nn.Linear(Hq * D, hidden, bias=False)
+            self.num_heads, self.num_key_value_heads, self.head_dim = Hq, Hkv, D
+            self.num_key_value_groups, self.hidden_size = Hq // Hkv, hidden
+            self.rope_scaling = {"mrope_section": SEC}
+            self.attention_dropout, self.layer_idx, self.is_causal = 0.0, 0, True
+            self.rotary_emb = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+
+    attn = Attn().to(dev()).to(torch.bfloat16)
+    caches = [lc.build_kvcache(cfg(1)), lc.build_kvcache(cfg(1, one_call_update=False))]
+    outs = [[], []]
+    with torch.no_grad():
+        for c in range(2):
+            x = torch.randn((1, L, hidden), device=dev(), dtype=torch.bfloat16) * 0.5
+            for i, cache in enumerate(caches):
+                cache.kvcache_compression = True
+                cache.before_forward()
+                y, _, _ = rq.retake_Qwen2VLSdpaAttention_forward(attn, x, attention_mask=None, position_ids=chunk_ids(c, L),
+                                                                 past_key_value=cache)
+                cache.after_forward()
+                outs[i].append(y.float())
+    assert caches[0]._batch.c_pending == 0 and caches[0]._layers[0].length == 2 * (L // 4)
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 0.05 * b.abs().max().item()
+    assert torch.equal(caches[0].position_cache[0], caches[1].position_cache[0])
+    assert torch.equal(caches[0].value_cache[0], caches[1].value_cache[0])
+
+
+def test_layer_state_block_tracks_the_store():
+    """rtk_layer_state mirrors _LayerStore: the library sees the buffers only when both are dense blocks of one capacity,
+    and the numbers Python reads are the ones the library advanced."""
+    import retake.longvideo_cache as lc
+
+    L = 640
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    cache = lc.build_kvcache(cfg(1))
+    for c in range(2):
+        q0, k0, v0 = projections(c, L, torch.bfloat16)
+        cache.kvcache_compression = True
+        assert cache.update_pre_rope(q0, k0, v0, 0, chunk_ids(c, L), rot, SEC) is not None
+        st = cache._layers[0]
+        assert st.c.pending == L and st.pending_keep == L // 4 and st.c.k == st.k.data_ptr() and st.c.cap == st.k.shape[2]
+        cache.after_forward()
+        assert st.pending == 0 and st.length == (c + 1) * (L // 4) == st.pos_len and st.c.mask is None
+    cache.key_cache[0] = cache.key_cache[0][:, :, ::2]      # an external writer hands over a strided view
+    assert cache._layers[0].c.cap == 0                       # ... which the library must not touch

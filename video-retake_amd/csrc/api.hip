@@ -1,4 +1,5 @@
 // api.hip — ABI bookkeeping: version, architecture, thread-local error string.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 
@@ -28,7 +29,8 @@ namespace rtk {
 static const char* const kKernelNames[KID_COUNT] = {"dpselect_dis", "dpselect_select", "gather_frames", "rope_table",
                                                     "unrotate_pack", "score_pass1", "score_pass2", "score_finalize",
                                                     "pivotkv_select", "evict_scan", "copy_rows", "append",
-                                                    "evict_batched", "commit_batched", "position_shift", "pivotkv_emit"};
+                                                    "evict_batched", "commit_batched", "position_shift", "pivotkv_emit",
+                                                    "prologue"};
 struct ProfRec { int kid; hipEvent_t a, b; };
 static std::mutex g_pm;
 static std::atomic<unsigned> g_prof{0};  // bit k set = time kernel id k
@@ -105,6 +107,37 @@ extern "C" int rtk_profile_read(int kid, long long* count, double* total_ms) {
     return RTK_OK;
 }
 
-extern "C" int rtk_version(void) { return 12; }
+// ---- calibration copy for the HBM rooflines ------------------------------------------------------------
+namespace rtk {
+// dst[i] = src[i] over 16-byte vectors, non-temporal on both sides (no L2 / MALL residue between repetitions), four
+// independent vectors in flight per thread: the "float4 copy" MI355X_MICROARCH.md quotes 6.29 TB/s for.
+__global__ __launch_bounds__(256) void copy_nt_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
+                    c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride);
+        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+}  // namespace rtk
+
+extern "C" int rtk_profile_copy(void* dst, const void* src, size_t bytes, rtk_stream_t stream) {
+    RTK_CHECK_ARG(dst && src && bytes % 16 == 0 && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0,
+                  "rtk_profile_copy: 16-byte aligned buffers of a multiple of 16 bytes");
+    if (bytes == 0) return RTK_OK;
+    const size_t n = bytes / 16;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 4 * 256 - 1) / (4 * 256), 256 * 32);
+    hipLaunchKernelGGL(rtk::copy_nt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const rtk::u32x4*)src,
+                       (rtk::u32x4*)dst, n);
+    RTK_LAUNCH_CHECK("copy_nt_kernel");
+    return RTK_OK;
+}
+
+extern "C" int rtk_version(void) { return 13; }
 extern "C" const char* rtk_last_error(void) { return rtk::g_err; }
 extern "C" const char* rtk_arch(void) { return "gfx950"; }

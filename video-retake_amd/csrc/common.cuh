@@ -147,6 +147,46 @@ __device__ __forceinline__ float finalize_ref_column(const float* __restrict__ p
 // llvm.memcpy, which keeps register staging arrays in scratch memory)
 using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
 
+// ---- 16-byte chunks of a row as fp32 lanes (un-rotate / rotate kernels) ----------------------------------------
+template <int DT> struct Vec16;
+template <> struct Vec16<RTK_F32> {
+    static constexpr int VE = 4;
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+    }
+};
+template <> struct Vec16<RTK_BF16> {
+    static constexpr int VE = 8;
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        return u32x4{(uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16), (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
+                     (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16), (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16)};
+    }
+};
+
+template <> struct Vec16<RTK_F16> {
+    static constexpr int VE = 8;
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+        f[0] = H16<RTK_F16>::lo(v.x); f[1] = H16<RTK_F16>::hi(v.x); f[2] = H16<RTK_F16>::lo(v.y); f[3] = H16<RTK_F16>::hi(v.y);
+        f[4] = H16<RTK_F16>::lo(v.z); f[5] = H16<RTK_F16>::hi(v.z); f[6] = H16<RTK_F16>::lo(v.w); f[7] = H16<RTK_F16>::hi(v.w);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        return u32x4{H16<RTK_F16>::pack2(f[0], f[1]), H16<RTK_F16>::pack2(f[2], f[3]), H16<RTK_F16>::pack2(f[4], f[5]),
+                     H16<RTK_F16>::pack2(f[6], f[7])};
+    }
+};
+
+// NW 32-bit words of a row as one aligned load / store (the narrow-chunk forms of the per-update kernels)
+template <int NW> struct alignas(4 * NW) WV { uint32_t w[NW]; };
+
 }  // namespace rtk
 
 // ---- host-side error plumbing --------------------------------------------------------------------
@@ -253,7 +293,7 @@ inline int make_rowsel(RowSel& rs, int P, int D, const int* sections, int nsec, 
 namespace rtk {
 enum KernelId {
     KID_DIS = 0, KID_DPSEL, KID_GATHER, KID_ROPE, KID_UNROT, KID_PASS1, KID_PASS2, KID_FINALIZE, KID_PSEL, KID_EVICT,
-    KID_COPY, KID_APPEND, KID_EVICTB, KID_COMMITB, KID_SHIFT, KID_PEMIT, KID_COUNT
+    KID_COPY, KID_APPEND, KID_EVICTB, KID_COMMITB, KID_SHIFT, KID_PEMIT, KID_PROLOGUE, KID_COUNT
 };
 bool profile_on(int kid);
 void profile_begin(int kid, hipStream_t st);

@@ -707,14 +707,16 @@ __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, in
     if (r >= keep) return;
     const int d = (id - r * lpr) * VE;
     const int l = (int)un.keep_idx[r];
-    const bool reforge = NATIVE || un.cos_new != nullptr;
-    // low_only: rows copied verbatim (V; K without reforge) are staged only when their source lies inside the
-    // destination range [0, keep) of the tail they will overwrite; the others are moved in place by place_batched_kernel
-    const bool copy_rows = !low_only || l < keep;
     const char* ks = (const char*)un.k_src;
     const char* vs = (const char*)un.v_src;
     char* kd = (char*)un.k_dst;
     char* vd = (char*)un.v_dst;
+    // a NULL destination skips the tensor: keep-all chunks leave V (and an unchanged K) where the append put them
+    const bool reforge = (NATIVE || un.cos_new != nullptr) && kd != nullptr;
+    // low_only: rows copied verbatim (V; K without reforge) are staged only when their source lies inside the
+    // destination range [0, keep) of the tail they will overwrite; the others are moved in place by place_batched_kernel
+    const bool stage_row = !low_only || l < keep;
+    const bool copy_k = kd != nullptr && !reforge && stage_row, copy_rows = vd != nullptr && stage_row;
     u32x4 k_lo[HU], k_hi[HU], v_lo[HU], v_hi[HU];
     auto load_batch = [&](int hb) {
 #pragma unroll
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, in
             const int h = min(hb + u, Hkv - 1);
             const char* kr = ks + ((size_t)h * un.k_src_stride_h + (size_t)l * D) * ES;
             const char* vr = vs + ((size_t)h * un.v_src_stride_h + (size_t)l * D) * ES;
-            if (reforge || copy_rows) {
+            if (reforge || copy_k) {
                 k_lo[u] = *(const u32x4*)(kr + (size_t)d * ES);
                 k_hi[u] = *(const u32x4*)(kr + (size_t)(d + h2) * ES);
             }
@@ -732,9 +734,10 @@ __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, in
             }
         }
     };
+    if (!reforge && !copy_k && !copy_rows) return;
     load_batch(0);   // the rows are requested before the table arithmetic / table reads below
     float c1[VE], s1[VE], c2[VE], s2[VE];
-    if (NATIVE) {
+    if (NATIVE && reforge) {
         float pid[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) pid[p] = (float)un.pos_src[(size_t)min(p, P - 1) * un.pos_src_stride + r];
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, in
                 }
                 *(u32x4*)(ko + (size_t)d * ES) = R::pack(o1);
                 *(u32x4*)(ko + (size_t)(d + h2) * ES) = R::pack(o2);
-            } else if (copy_rows) {   // torch.gather(key_states, 2, keep)  (:279)
+            } else if (copy_k) {   // torch.gather(key_states, 2, keep)  (:279)
                 *(u32x4*)(ko + (size_t)d * ES) = k_lo[u];
                 *(u32x4*)(ko + (size_t)(d + h2) * ES) = k_hi[u];
             }
@@ -1122,7 +1125,7 @@ static int evict_batched_impl(const rtk_evict_unit* units, int n_units, int Hkv,
     }
     for (int i = 0; i < n_units; ++i) {
         const rtk_evict_unit& u = units[i];
-        RTK_CHECK_ARG(u.k_src && u.v_src && u.keep_idx && u.k_dst && u.v_dst, "rtk_pivotkv_evict_batched: unit %d: NULL pointer", i);
+        RTK_CHECK_ARG(u.k_src && u.v_src && u.keep_idx, "rtk_pivotkv_evict_batched: unit %d: NULL pointer", i);
         RTK_CHECK_ARG((u.cos_new == nullptr) == (u.sin_new == nullptr), "rtk_pivotkv_evict_batched: unit %d: cos_new and sin_new go together", i);
         RTK_CHECK_ARG((u.pos_dst == nullptr) || (u.pos_src != nullptr && P > 0), "rtk_pivotkv_evict_batched: unit %d: pos_dst needs pos_src and P", i);
         RTK_CHECK_ARG(!native || (u.pos_src != nullptr && P > 0 && u.cos_new == nullptr),

@@ -51,42 +51,6 @@ constexpr int NXCD = 8;      // MI355X: 8 XCDs, workgroup b is dispatched to XCD
 // One thread owns a 16-byte chunk of the first half of a token row plus its rotation partner in the
 // second half, keeps that token's cos/sin in registers and walks UNROT_HEADS heads with it.
 // ------------------------------------------------------------------------------------------------
-template <int DT> struct Vec16;
-template <> struct Vec16<RTK_F32> {
-    static constexpr int VE = 4;
-    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
-        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
-    }
-    __device__ static __forceinline__ u32x4 pack(const float* f) {
-        return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
-    }
-};
-template <> struct Vec16<RTK_BF16> {
-    static constexpr int VE = 8;
-    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
-        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
-    }
-    __device__ static __forceinline__ u32x4 pack(const float* f) {
-        return u32x4{(uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16), (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
-                     (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16), (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16)};
-    }
-};
-
-template <> struct Vec16<RTK_F16> {
-    static constexpr int VE = 8;
-    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
-        f[0] = H16<RTK_F16>::lo(v.x); f[1] = H16<RTK_F16>::hi(v.x); f[2] = H16<RTK_F16>::lo(v.y); f[3] = H16<RTK_F16>::hi(v.y);
-        f[4] = H16<RTK_F16>::lo(v.z); f[5] = H16<RTK_F16>::hi(v.z); f[6] = H16<RTK_F16>::lo(v.w); f[7] = H16<RTK_F16>::hi(v.w);
-    }
-    __device__ static __forceinline__ u32x4 pack(const float* f) {
-        return u32x4{H16<RTK_F16>::pack2(f[0], f[1]), H16<RTK_F16>::pack2(f[2], f[3]), H16<RTK_F16>::pack2(f[4], f[5]),
-                     H16<RTK_F16>::pack2(f[6], f[7])};
-    }
-};
-
 constexpr int UNROT_HEADS = 7;
 
 // bf16 pairs through the hardware converter (v_cvt_pk_bf16_f32: round to nearest even, like c10::BFloat16)
@@ -252,7 +216,6 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
 // rounded sin / cos pairs) and a chunk of 2304 tokens gives barely half the chip's SIMDs one such wave: that form is bound
 // by the serial instruction stream of its waves.  Narrow chunks split the same work over 4x the waves; what remains is the
 // read + write traffic (45 MB per call at L = 2304) at ~3 TB/s plus the launch ramp.
-template <int NW> struct alignas(4 * NW) WV { uint32_t w[NW]; };
 
 template <int DT, int DIV, bool FAST = false, int NW = 4>
 __global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restrict__ q, int64_t q_sh, int64_t q_sl,
@@ -2289,6 +2252,7 @@ static int prepare_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, 
     if constexpr (DT != RTK_F32) nw = RTK_PREP_NW;
     const int VE = nw * 4 / (DT == RTK_F32 ? 4 : 2);
     const int threads = L * (D / 2 / VE);
+    static_assert(RTK_PREP_YSPLIT >= 2, "the first y-slice takes k and the LAST one v: one slice would never append v");
     const dim3 grid((threads + 63) / 64, RTK_PREP_YSPLIT);
     char* kf = nullptr;
     float qscale = 1.f;
@@ -2332,6 +2296,8 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
                                    const int* sections_host, int nsec, int round_bf16, void* k_unrot, void* workspace,
                                    size_t workspace_bytes, void* k_tail, void* v_tail, int64_t tail_stride_h,
                                    int64_t* pos_copy, rtk_stream_t stream) {
+    const bool k_only = (dtype & RTK_PREPARE_K_ONLY) != 0;   // keep-all chunk: no q~
+    dtype &= ~RTK_PREPARE_K_ONLY;
     const int dtype_full = dtype;              // may carry RTK_SCORE_MANY_UNITS: the workspace layout follows the split policy
     dtype &= ~RTK_SCORE_MANY_UNITS;
     RTK_CHECK_ARG(q && k && v && pos && inv_freq && k_unrot && workspace && k_tail && v_tail, "rtk_pivotkv_prepare: NULL pointer");
@@ -2339,17 +2305,18 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
     RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_BF16_FAST || dtype == RTK_F16,
                   "rtk_pivotkv_prepare: unsupported dtype %d", dtype);
     RTK_CHECK_ARG(pos_stride >= L, "rtk_pivotkv_prepare: pos_stride %lld < L %d", (long long)pos_stride, L);
-    const bool fast = dtype == RTK_BF16_FAST;
+    const bool fast = dtype == RTK_BF16_FAST && !k_only;
     if (fast && D != HD) {
         set_error("rtk_pivotkv_prepare: RTK_BF16_FAST needs head_dim %d", HD);
         return RTK_EUNSUPPORTED;
     }
     RTK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "rtk_pivotkv_prepare: workspace must be 256-byte aligned");
     const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype_full);
-    if (workspace_bytes < w.total) {
+    if (!k_only && workspace_bytes < w.total) {
         set_error("rtk_pivotkv_prepare: workspace %zu < required %zu bytes", workspace_bytes, w.total);
         return RTK_EWORKSPACE;
     }
+    if (k_only) Hq = 0;   // the kernel's query loop is empty; k / v take the same path
     const int ve = dtype != RTK_F32 ? 8 : 4, es = dtype != RTK_F32 ? 2 : 4;
     const bool ok = (D % (2 * ve) == 0) && D <= 256 && (q_stride_h * es) % 16 == 0 && (q_stride_l * es) % 16 == 0 &&
                     (k_stride_h * es) % 16 == 0 && (k_stride_l * es) % 16 == 0 && (v_stride_h * es) % 16 == 0 &&

@@ -1,0 +1,504 @@
+// pivotkv_update.hip — PivotKVCache.update and the per-chunk flush as ONE call each (include/retake_hip.h, ABI 13),
+// and the attention prologue: the one kernel that takes a layer's pre-RoPE projections to everything the layer's
+// attention and the deferred PivotKV scoring need.
+//
+// Why: a 2048-frame video is 1,792 updates (qwen2_vl.py:670-720 calls the decoder once per chunk, every layer calls
+// cache.update, longvideo_cache.py:217).  At the real Qwen2-VL geometry (L = 2304) the GPU work of one update is ~20 us;
+// ~50 us of host work per update (argument marshalling for a 30-argument launch, view construction, dict bookkeeping)
+// made the step host-bound.  The argument blocks are bound once per chunk geometry (rtk_pivotkv_batch) and per layer
+// (rtk_layer_state); an update is then four pointer stores and one call.
+#include <algorithm>
+#include <vector>
+
+#include "common.cuh"
+#include "variants.h"
+
+namespace rtk {
+
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+using f16x2_t = __attribute__((ext_vector_type(2))) _Float16;
+__device__ __forceinline__ uint32_t upd_pack2_f16(float lo, float hi) {   // saturating, like pivotkv_score.hip's pack2_f16
+    const f32x2_t v = {__builtin_fminf(__builtin_fmaxf(lo, -65504.f), 65504.f),
+                       __builtin_fminf(__builtin_fmaxf(hi, -65504.f), 65504.f)};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention prologue (qwen2_vl.py:55-86 / llava_onevision.py:59-141 + longvideo_cache.py:238, :248-259), from the
+// PRE-RoPE projections q0 [Hq,L,D], k0, v0 [Hkv,L,D] (strided: the [L, H*D] layout the projections produce):
+//   ids      t' = t + (prev + 1 - t[0]) on the temporal row (the continuity shift, qwen2_vl.py:68-73); a copy of the
+//            shifted ids goes to pos_copy for the deferred selection
+//   tables   cos / sin of the token's ids in registers: rope_chunk (= rtk_rope_table's arithmetic: fp32 id * inv_freq,
+//            correctly rounded sin / cos, * attention_scaling, rounded to the model dtype like the rotary module's
+//            `.to(x.dtype)`), M-RoPE rows picked per channel (:68-74)
+//   q_rot    (q0*cos) + (rotate_half(q0)*sin), one rounding per torch op (apply_multimodal_rotary_pos_emb :80-81)
+//            -> the layer's attention; may alias q0 (every address is read and written by one thread only)
+//   k tail   the same rotation of k0, appended to the cache tail; v tail: v0 (:238)
+//   q~, k~   the score passes' operands.  The reference un-rotates the rotated tensors (:248-259); un-rotating a
+//            rotation returns the pre-RoPE value up to the rounding of the round trip, so q~ := q0 and
+//            k~ := k0 - copies into the contiguous [H,L,D] layout the matrix passes stream.
+// One thread = one token x one NW-word chunk pair (d, d + D/2); blockIdx.y splits the query heads, y = 0 also takes
+// k, the last y takes v.  Same software pipeline as prepare_native_kernel: the rows of head batch b+1 are requested
+// before batch b is rotated and stored, and the first batch before the table arithmetic.
+// ------------------------------------------------------------------------------------------------
+template <int DT, bool FAST, int NW>
+__global__ __launch_bounds__(64) void prologue_kernel(const char* q, int64_t q_sh, int64_t q_sl,
+                                                      const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
+                                                      const char* __restrict__ v, int64_t v_sh, int64_t v_sl,
+                                                      int Hq, int Hkv, int L, int D,
+                                                      const int64_t* __restrict__ pos, int64_t pos_ld,
+                                                      const int64_t* __restrict__ prev,
+                                                      const float* __restrict__ inv_freq, float scaling, RowSel rs,
+                                                      int round_mode, char* q_rot, int64_t qr_sh, int64_t qr_sl,
+                                                      char* __restrict__ q_out, char* __restrict__ k_out,
+                                                      char* __restrict__ k_tail, char* __restrict__ v_tail,
+                                                      int64_t tail_sh, int P, int64_t* __restrict__ pos_copy,
+                                                      char* __restrict__ k_fast, float qscale) {
+    using V = Vec16<DT>;
+    static_assert(NW == 4 || ((NW == 2 || NW == 1) && DT != RTK_F32), "8- / 4-byte chunks: 16-bit dtypes only");
+    constexpr int ES = 16 / V::VE;          // bytes per element
+    constexpr int VE = 4 * NW / ES;         // elements per thread and row half
+    using W = WV<NW>;
+    const int h2 = D / 2, lpr = h2 / VE;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= L * lpr) return;
+    const int l = id / lpr, d = (id - l * lpr) * VE;
+    // continuity shift: the whole temporal row moves so that its first id follows the layer's last cached id
+    const long long delta = (prev ? (long long)prev[0] : -1ll) + 1 - (long long)pos[0];
+    long long ids[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int pr = min(p, P - 1);
+        ids[p] = (long long)pos[(size_t)pr * pos_ld + l] + (pr == 0 ? delta : 0ll);
+    }
+    if (pos_copy && blockIdx.y == 0 && d == 0)
+        for (int p = 0; p < P; ++p) pos_copy[(size_t)p * L + l] = ids[p];
+    constexpr int HU = RTK_PREP_HU;
+    const int ny = gridDim.y, qper = (Hq + ny - 1) / ny;
+    const int qb = min((int)blockIdx.y * qper, Hq), qe = min(qb + qper, Hq);
+    const bool is_k = blockIdx.y == 0;
+    const bool has_kv = is_k || (int)blockIdx.y == ny - 1;
+    const char* src = is_k ? k : v;
+    const int64_t sh = is_k ? k_sh : v_sh, sl = is_k ? k_sl : v_sl;
+    char* tail = is_k ? k_tail : v_tail;
+    const int nkv = has_kv ? Hkv : 0;
+    W lo[HU], hi[HU], lon[HU], hin[HU];
+    auto load_q = [&](W* a, W* b, int hb) {
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int h = min(hb + u, qe - 1);
+            const char* row = q + ((size_t)h * q_sh + (size_t)l * q_sl) * ES;
+            a[u] = *(const W*)(row + (size_t)d * ES);
+            b[u] = *(const W*)(row + (size_t)(d + h2) * ES);
+        }
+    };
+    auto load_kv = [&](W* a, W* b, int hb) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int h = min(hb + u, Hkv - 1);
+            const char* row = src + ((size_t)h * sh + (size_t)l * sl) * ES;
+            a[u] = *(const W*)(row + (size_t)d * ES);
+            b[u] = *(const W*)(row + (size_t)(d + h2) * ES);
+        }
+    };
+    float pid[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pid[p] = (float)ids[p];   // position_ids.float() inside the rotary module
+    if (qb < qe) load_q(lo, hi, qb);
+    else if (nkv) load_kv(lo, hi, 0);
+    float c1[VE], s1[VE], c2[VE], s2[VE];
+    rope_chunk<VE>(inv_freq, rs, d, h2, pid, scaling, round_mode, c1, s1, c2, s2);
+    // (x*cos) + (rotate_half(x)*sin) for one head's chunk pair, one rounding per torch op, no fma contraction;
+    // rotate_half(x)[d] = -x2, rotate_half(x)[d + h2] = x1
+    auto rot = [&](const W& lo, const W& hi, W& olo, W& ohi) {
+        if constexpr (DT != RTK_F32) {
+            using Hh = H16<DT>;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float x1a = Hh::lo(lo.w[w]), x1b = Hh::hi(lo.w[w]), x2a = Hh::lo(hi.w[w]), x2b = Hh::hi(hi.w[w]);
+                const int e = 2 * w;
+                const uint32_t p1 = Hh::pack2(x1a * c1[e], x1b * c1[e + 1]);
+                const uint32_t n1 = Hh::pack2(-x2a * s1[e], -x2b * s1[e + 1]);
+                const uint32_t p2 = Hh::pack2(x2a * c2[e], x2b * c2[e + 1]);
+                const uint32_t n2 = Hh::pack2(x1a * s2[e], x1b * s2[e + 1]);
+                olo.w[w] = Hh::pack2(Hh::lo(p1) + Hh::lo(n1), Hh::hi(p1) + Hh::hi(n1));
+                ohi.w[w] = Hh::pack2(Hh::lo(p2) + Hh::lo(n2), Hh::hi(p2) + Hh::hi(n2));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float x1 = __uint_as_float(lo.w[e]), x2 = __uint_as_float(hi.w[e]);
+                olo.w[e] = __float_as_uint(__fadd_rn(__fmul_rn(x1, c1[e]), __fmul_rn(-x2, s1[e])));
+                ohi.w[e] = __float_as_uint(__fadd_rn(__fmul_rn(x2, c2[e]), __fmul_rn(x1, s2[e])));
+            }
+        }
+    };
+    auto to_f16 = [&](const W& x, float scale) {   // bf16 pairs -> fp16 pairs of (value * scale): RTK_BF16_FAST operands
+        W o;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            o.w[w] = upd_pack2_f16(__uint_as_float(x.w[w] << 16) * scale, __uint_as_float(x.w[w] & 0xffff0000u) * scale);
+        return o;
+    };
+    for (int hb = qb; hb < qe; hb += HU) {
+        if (hb + HU < qe) load_q(lon, hin, hb + HU);
+        else if (nkv) load_kv(lon, hin, 0);
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int h = hb + u;
+            if (h >= qe) break;
+            if (q_out) {   // q~ := q0 (keep-all chunks are not scored: no q~)
+                char* orow = q_out + ((size_t)h * L + l) * D * ES;
+                if constexpr (FAST) {
+                    *(W*)(orow + (size_t)d * ES) = to_f16(lo[u], qscale);
+                    *(W*)(orow + (size_t)(d + h2) * ES) = to_f16(hi[u], qscale);
+                } else {
+                    *(W*)(orow + (size_t)d * ES) = lo[u];
+                    *(W*)(orow + (size_t)(d + h2) * ES) = hi[u];
+                }
+            }
+            W olo, ohi;
+            rot(lo[u], hi[u], olo, ohi);
+            char* rrow = q_rot + ((size_t)h * qr_sh + (size_t)l * qr_sl) * ES;
+            *(W*)(rrow + (size_t)d * ES) = olo;
+            *(W*)(rrow + (size_t)(d + h2) * ES) = ohi;
+        }
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            lo[u] = lon[u];
+            hi[u] = hin[u];
+        }
+    }
+    for (int hb = 0; hb < nkv; hb += 4) {
+        if (hb + 4 < nkv) load_kv(lon, hin, hb + 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int h = hb + u;
+            if (h >= nkv) break;
+            char* trow = tail + ((size_t)h * tail_sh + (size_t)l * D) * ES;
+            if (is_k) {
+                char* orow = k_out + ((size_t)h * L + l) * D * ES;   // k~ := k0
+                *(W*)(orow + (size_t)d * ES) = lo[u];
+                *(W*)(orow + (size_t)(d + h2) * ES) = hi[u];
+                if constexpr (FAST) {
+                    char* frow = k_fast + ((size_t)h * L + l) * D * ES;
+                    *(W*)(frow + (size_t)d * ES) = to_f16(lo[u], 1.f);
+                    *(W*)(frow + (size_t)(d + h2) * ES) = to_f16(hi[u], 1.f);
+                }
+                W olo, ohi;
+                rot(lo[u], hi[u], olo, ohi);
+                *(W*)(trow + (size_t)d * ES) = olo;
+                *(W*)(trow + (size_t)(d + h2) * ES) = ohi;
+            } else {
+                *(W*)(trow + (size_t)d * ES) = lo[u];
+                *(W*)(trow + (size_t)(d + h2) * ES) = hi[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            lo[u] = lon[u];
+            hi[u] = hin[u];
+        }
+    }
+}
+
+template <int DT>
+static int prologue_launch(const rtk_pivotkv_batch* b, const rtk_update_io* io, const RowSel& rs, const int64_t* prev,
+                           char* q_out, char* k_out, char* k_tail, char* v_tail, int64_t tail_sh, int64_t* pos_copy,
+                           char* k_fast, hipStream_t st) {
+    int nw = 4;
+    if constexpr (DT != RTK_F32) nw = RTK_PREP_NW;
+    const int VE = nw * 4 / (DT == RTK_F32 ? 4 : 2);
+    const int threads = b->L * (b->D / 2 / VE);
+    const dim3 grid((threads + 63) / 64, RTK_PREP_YSPLIT);
+    const float qscale = k_fast ? 1.4426950408889634f / sqrtf((float)b->D) : 1.f;
+    auto launch = [&](auto kern) {
+        RTK_LAUNCH(KID_PROLOGUE, kern, grid, dim3(64), 0, st, (const char*)io->q, io->q_stride_h, io->q_stride_l,
+                   (const char*)io->k, io->k_stride_h, io->k_stride_l, (const char*)io->v, io->v_stride_h, io->v_stride_l,
+                   b->Hq, b->Hkv, b->L, b->D, io->pos, io->pos_stride, prev, b->inv_freq, b->attention_scaling, rs,
+                   b->round_mode, (char*)io->q_rot, io->qr_stride_h, io->qr_stride_l, q_out, k_out, k_tail, v_tail, tail_sh,
+                   b->P, pos_copy, k_fast, qscale);
+    };
+#define RTK_PRO_NWSEL(FASTV)                                                              \
+    do {                                                                                  \
+        if constexpr (DT != RTK_F32) {                                                    \
+            if (nw == 2) { launch(prologue_kernel<DT, FASTV, 2>); break; }                \
+            if (nw == 1) { launch(prologue_kernel<DT, FASTV, 1>); break; }                \
+        }                                                                                 \
+        launch(prologue_kernel<DT, FASTV, 4>);                                            \
+    } while (0)
+    bool done = false;
+    if constexpr (DT == RTK_BF16) {
+        if (k_fast) {
+            RTK_PRO_NWSEL(true);
+            done = true;
+        }
+    }
+    if (!done) RTK_PRO_NWSEL(false);
+#undef RTK_PRO_NWSEL
+    RTK_LAUNCH_CHECK("prologue_kernel");
+    return RTK_OK;
+}
+
+static inline size_t esize(int dtype) { return dtype == RTK_F32 ? 4 : 2; }
+
+}  // namespace rtk
+
+using namespace rtk;
+
+static int check_batch(const rtk_pivotkv_batch* b, const char* who) {
+    RTK_CHECK_ARG(b, "%s: NULL batch", who);
+    RTK_CHECK_ARG(b->Hq >= 1 && b->Hkv >= 1 && b->Hq % b->Hkv == 0 && b->L >= 1 && b->D >= 2 && b->slots >= 1,
+                  "%s: bad geometry", who);
+    RTK_CHECK_ARG(b->keep >= 1 && b->keep <= b->L, "%s: keep=%d out of range for L=%d", who, b->keep, b->L);
+    RTK_CHECK_ARG(b->P == 0 || b->P == 1 || b->P == 3, "%s: P must be 0, 1 or 3, got %d", who, b->P);
+    RTK_CHECK_ARG(b->dtype == RTK_F32 || b->dtype == RTK_BF16 || b->dtype == RTK_F16, "%s: unsupported dtype %d", who, b->dtype);
+    RTK_CHECK_ARG(b->nsec >= 0 && b->nsec <= 8, "%s: nsec %d out of range", who, b->nsec);
+    RTK_CHECK_ARG(b->keep_idx && (b->keep_all || b->v_stage), "%s: NULL batch buffer", who);
+    RTK_CHECK_ARG(b->keep_all || (b->score_ws && b->partials && b->score && b->sel_ws), "%s: NULL scoring buffer", who);
+    return RTK_OK;
+}
+
+extern "C" int rtk_pivotkv_update(const rtk_pivotkv_batch* b, rtk_layer_state* ls, int slot, const rtk_update_io* io,
+                                  rtk_stream_t stream) {
+    int rc = check_batch(b, "rtk_pivotkv_update");
+    if (rc) return rc;
+    RTK_CHECK_ARG(ls && io, "rtk_pivotkv_update: NULL layer state or io block");
+    RTK_CHECK_ARG(slot >= 0 && slot < b->slots, "rtk_pivotkv_update: slot %d outside the batch (%d slots)", slot, b->slots);
+    RTK_CHECK_ARG(io->q && io->k && io->v, "rtk_pivotkv_update: NULL q / k / v");
+    RTK_CHECK_ARG(ls->k && ls->v && ls->length >= 0 && ls->length + b->L <= ls->cap,
+                  "rtk_pivotkv_update: the layer's cache has no room for the chunk (length %lld + %d > cap %lld)",
+                  (long long)ls->length, b->L, (long long)ls->cap);
+    RTK_CHECK_ARG(ls->pending == 0, "rtk_pivotkv_update: the layer still has a pending chunk (flush first)");
+    if (!b->reforge || !b->inv_freq || b->P == 0 || !io->pos || !b->k_unrot || !b->score_ws) {
+        set_error("rtk_pivotkv_update: needs pos_embed_reforge, position ids and an inv_freq rotary (use the per-stage calls)");
+        return RTK_EUNSUPPORTED;
+    }
+    const size_t es = esize(b->dtype);
+    const int L = b->L, D = b->D, Hkv = b->Hkv;
+    char* k_tail = (char*)ls->k + (size_t)ls->length * D * es;
+    char* v_tail = (char*)ls->v + (size_t)ls->length * D * es;
+    const int64_t tail_sh = ls->cap * D;
+    char* ws = (char*)b->score_ws + (size_t)slot * b->score_ws_stride;
+    char* k_unrot = (char*)b->k_unrot + (size_t)slot * Hkv * L * D * es;
+    int64_t* pos_copy = b->pos_old ? b->pos_old + (size_t)slot * b->P * L : nullptr;
+    const int score_base = b->score_dtype & 0xFF;
+    hipStream_t st = (hipStream_t)stream;
+    if (io->flags & RTK_UPDATE_PRE_ROPE) {
+        RTK_CHECK_ARG(io->q_rot, "rtk_pivotkv_update: RTK_UPDATE_PRE_ROPE needs q_rot");
+        if (score_base == RTK_BF16_REFROUND) {
+            set_error("rtk_pivotkv_update: score_rounding='reference' scores the reference's round-tripped q~ / k~ "
+                      "(rotate first, then update without RTK_UPDATE_PRE_ROPE)");
+            return RTK_EUNSUPPORTED;
+        }
+        const int ve = b->dtype != RTK_F32 ? 8 : 4;
+        const bool ok = (D % (2 * ve) == 0) && D <= 256 && (io->q_stride_h * es) % 16 == 0 && (io->q_stride_l * es) % 16 == 0 &&
+                        (io->k_stride_h * es) % 16 == 0 && (io->k_stride_l * es) % 16 == 0 && (io->v_stride_h * es) % 16 == 0 &&
+                        (io->v_stride_l * es) % 16 == 0 && (io->qr_stride_h * es) % 16 == 0 && (io->qr_stride_l * es) % 16 == 0 &&
+                        (tail_sh * es) % 16 == 0 &&
+                        (((uintptr_t)io->q | (uintptr_t)io->k | (uintptr_t)io->v | (uintptr_t)io->q_rot | (uintptr_t)k_unrot |
+                          (uintptr_t)k_tail | (uintptr_t)v_tail | (uintptr_t)ws) & 15) == 0;
+        if (!ok) {
+            set_error("rtk_pivotkv_update: the prologue needs 16-byte aligned pointers / strides and head_dim a multiple of %d", 2 * ve);
+            return RTK_EUNSUPPORTED;
+        }
+        RTK_CHECK_ARG(io->pos_stride >= L, "rtk_pivotkv_update: pos_stride %lld < L %d", (long long)io->pos_stride, L);
+        const size_t need = rtk_pivotkv_score_workspace_bytes(b->Hq, Hkv, L, D, b->score_dtype);
+        if (!b->keep_all && b->score_ws_bytes < need) {
+            set_error("rtk_pivotkv_update: workspace %zu < required %zu bytes", (size_t)b->score_ws_bytes, need);
+            return RTK_EWORKSPACE;
+        }
+        RowSel rs;
+        rc = make_rowsel(rs, b->P, D, b->nsec ? b->sections : nullptr, b->nsec, "rtk_pivotkv_update");
+        if (rc) return rc;
+        const int64_t* prev = (ls->pos && ls->pos_len > 0) ? ls->pos + (ls->pos_len - 1) : nullptr;
+        char* q_out = b->keep_all ? nullptr : ws;   // q~ at offset 0 of the slot's score workspace
+        // RTK_BF16_FAST: a second, fp16 copy of k~ inside the workspace, right behind q~ (score_ws: k_off)
+        char* k_fast = nullptr;
+        if (score_base == RTK_BF16_FAST && !b->keep_all)
+            k_fast = ws + (((size_t)b->Hq * L * D * es + 255) & ~(size_t)255);
+        if (b->dtype == RTK_F16)
+            rc = prologue_launch<RTK_F16>(b, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, nullptr, st);
+        else if (b->dtype == RTK_BF16)
+            rc = prologue_launch<RTK_BF16>(b, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, k_fast, st);
+        else
+            rc = prologue_launch<RTK_F32>(b, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, nullptr, st);
+        if (rc) return rc;
+    } else {
+        const int dt = b->prep_dtype | (b->keep_all ? RTK_PREPARE_K_ONLY : 0);
+        rc = rtk_pivotkv_prepare(io->q, io->q_stride_h, io->q_stride_l, io->k, io->k_stride_h, io->k_stride_l, io->v,
+                                 io->v_stride_h, io->v_stride_l, b->Hq, Hkv, L, D, dt, io->pos, io->pos_stride, b->P,
+                                 b->inv_freq, b->attention_scaling, b->nsec ? b->sections : nullptr, b->nsec, b->round_mode,
+                                 k_unrot, ws, b->score_ws_bytes, k_tail, v_tail, tail_sh, pos_copy, stream);
+        if (rc) return rc;
+    }
+    if (!b->keep_all && !b->batched_passes) {
+        // shapes outside the chunk-batched passes (fp32 payloads, other head dims): the unit's two matrix passes now
+        float* part = b->partials + (size_t)slot * b->partial_floats;
+        const bool live = b->skip_masked && ls->mask && b->key_index;
+        rc = rtk_pivotkv_score_stages_masked(ws, 0, 0, ws, 0, 0, b->Hq, Hkv, L, D, b->score_dtype, nullptr, nullptr, 1.0f,
+                                             b->score + (size_t)slot * L, k_unrot, ws, b->score_ws_bytes, RTK_SCORE_PASSES,
+                                             part, live ? ls->mask : nullptr,
+                                             live ? b->key_index + (size_t)slot * (L + 1) : nullptr, stream);
+        if (rc) return rc;
+    }
+    ls->pending = L;
+    ls->pending_keep = b->keep;
+    return RTK_OK;
+}
+
+extern "C" int rtk_pivotkv_flush(rtk_pivotkv_batch* b, rtk_layer_state* const* layers, const int32_t* slots, int n,
+                                 rtk_stream_t stream) {
+    int rc = check_batch(b, "rtk_pivotkv_flush");
+    if (rc) return rc;
+    RTK_CHECK_ARG(layers && slots && n >= 1 && n <= b->slots, "rtk_pivotkv_flush: bad layer list");
+    const int L = b->L, D = b->D, Hkv = b->Hkv, keep = b->keep, P = b->P;
+    const size_t es = esize(b->dtype);
+    const bool reforge = b->reforge != 0;
+    if (reforge && (!b->inv_freq || P == 0 || !b->k_unrot || !b->pos_old || !b->pos_new)) {
+        set_error("rtk_pivotkv_flush: pos_embed_reforge needs position ids and an inv_freq rotary (use the per-stage calls)");
+        return RTK_EUNSUPPORTED;
+    }
+    if (!reforge && !b->keep_all && !b->k_stage) {
+        set_error("rtk_pivotkv_flush: no K staging buffer");
+        return RTK_EINVAL;
+    }
+    for (int i = 0; i < n; ++i) {
+        const rtk_layer_state* ls = layers[i];
+        RTK_CHECK_ARG(ls && ls->k && ls->v, "rtk_pivotkv_flush: layer %d: NULL state", i);
+        RTK_CHECK_ARG(slots[i] >= 0 && slots[i] < b->slots && (i == 0 || slots[i] > slots[i - 1]),
+                      "rtk_pivotkv_flush: slots must be ascending and inside the batch");
+        RTK_CHECK_ARG(ls->pending == L && ls->pending_keep == keep && ls->length + L <= ls->cap,
+                      "rtk_pivotkv_flush: layer %d has no pending chunk of this batch", i);
+        RTK_CHECK_ARG(!(reforge && P) || (ls->pos && ls->pos_len + keep <= ls->pos_cap),
+                      "rtk_pivotkv_flush: layer %d: position cache has no room for %d ids", i, keep);
+    }
+    if (b->shift_row) {
+        // the attention patch shifts the ids tensor it was handed in place (qwen2_vl.py:73); the prologue left that to
+        // here: one launch per chunk, with the last layer's rule - what the reference's loop leaves behind
+        const rtk_layer_state* last = layers[n - 1];
+        const int64_t* prev = (last->pos && last->pos_len > 0) ? last->pos + (last->pos_len - 1) : nullptr;
+        rc = rtk_position_shift(b->shift_row, L, prev, stream);
+        if (rc) return rc;
+        b->shift_row = nullptr;
+    }
+    if (!b->keep_all) {
+        if (b->batched_passes) {
+            std::vector<const void*> masks((size_t)n);
+            int i = 0;
+            while (i < n) {   // every run of consecutive slots in one launch per kernel (:260-268)
+                int j = i;
+                while (j + 1 < n && slots[j + 1] == slots[j] + 1) ++j;
+                const int l0 = slots[i], cnt = j - i + 1;
+                bool any = false;
+                for (int u = 0; u < cnt; ++u) {
+                    masks[u] = b->skip_masked ? layers[i + u]->mask : nullptr;
+                    any = any || masks[u];
+                }
+                rc = rtk_pivotkv_score_passes_batched(
+                    (char*)b->score_ws + (size_t)l0 * b->score_ws_stride, b->score_ws_stride,
+                    reforge ? (char*)b->k_unrot + (size_t)l0 * Hkv * L * D * es : nullptr, (size_t)Hkv * L * D * es,
+                    b->partials + (size_t)l0 * b->partial_floats, b->partial_floats, cnt, b->Hq, Hkv, L, D, b->score_dtype,
+                    (any && b->key_index) ? masks.data() : nullptr,
+                    (any && b->key_index) ? b->key_index + (size_t)l0 * (L + 1) : nullptr, stream);
+                if (rc) return rc;
+                i = j + 1;
+            }
+        }
+        std::vector<rtk_select_unit> su((size_t)n);
+        for (int i = 0; i < n; ++i) {   // mask override + top-k + id gather / rescale (:269-295)
+            const int l = slots[i];
+            rtk_select_unit& u = su[i];
+            u.partial = b->partials + (size_t)l * b->partial_floats;
+            u.score = b->score + (size_t)l * L;
+            u.mask = layers[i]->mask;
+            u.pos = P ? b->pos_old + (size_t)l * P * L : nullptr;
+            u.keep_idx = b->keep_idx + (size_t)l * keep;
+            u.rank = nullptr;
+            u.pos_out = P ? b->pos_new + (size_t)l * keep : nullptr;
+            u.workspace = (char*)b->sel_ws + (size_t)l * b->sel_ws_stride;
+        }
+        rc = rtk_pivotkv_select_batched(su.data(), n, Hkv, b->rs_n, b->Hq / Hkv, L, keep, P, (int)reforge,
+                                        (int64_t)b->slots * keep, b->score_dtype, stream);
+        if (rc) return rc;
+    }
+    std::vector<rtk_evict_unit> eu((size_t)n);
+    std::vector<rtk_place_unit> pl((size_t)2 * n);
+    int nc = 0;
+    for (int i = 0; i < n; ++i) {
+        const int l = slots[i];
+        rtk_layer_state* ls = layers[i];
+        const size_t tail = (size_t)ls->length * D * es;
+        rtk_evict_unit& u = eu[i];
+        u.cos_new = u.sin_new = nullptr;
+        const int64_t* kidx = b->keep_idx + (size_t)l * keep;
+        if (reforge) {   // kept K = k~ re-rotated at the NEW ids, straight into the cache (:297-306)
+            u.k_src = (char*)b->k_unrot + (size_t)l * Hkv * L * D * es;
+            u.k_src_stride_h = (int64_t)L * D;
+            // keep-all chunks of pre-RoPE units: new ids == old ids and k~ == k0, so the tail already holds the result
+            u.k_dst = (b->keep_all && b->pre_rope) ? nullptr : (char*)ls->k + tail;
+            u.k_dst_stride_h = ls->cap * D;
+        } else {
+            u.k_src = (char*)ls->k + tail;
+            u.k_src_stride_h = ls->cap * D;
+            if (b->keep_all) {
+                u.k_dst = nullptr;
+                u.k_dst_stride_h = 0;
+            } else {
+                u.k_dst = (char*)b->k_stage + (size_t)l * Hkv * keep * D * es;
+                u.k_dst_stride_h = (int64_t)keep * D;
+                pl[nc].stage = u.k_dst;
+                pl[nc].stage_stride_h_bytes = (int64_t)keep * D * es;
+                pl[nc].tail = (char*)ls->k + tail;
+                pl[nc].tail_stride_h_bytes = ls->cap * D * es;
+                pl[nc].keep_idx = kidx;
+                ++nc;
+            }
+        }
+        u.v_src = (char*)ls->v + tail;
+        u.v_src_stride_h = ls->cap * D;
+        if (b->keep_all) {   // every V row already sits where it belongs
+            u.v_dst = nullptr;
+            u.v_dst_stride_h = 0;
+        } else {
+            u.v_dst = (char*)b->v_stage + (size_t)l * Hkv * keep * D * es;
+            u.v_dst_stride_h = (int64_t)keep * D;
+            pl[nc].stage = u.v_dst;
+            pl[nc].stage_stride_h_bytes = (int64_t)keep * D * es;
+            pl[nc].tail = (char*)ls->v + tail;
+            pl[nc].tail_stride_h_bytes = ls->cap * D * es;
+            pl[nc].keep_idx = kidx;
+            ++nc;
+        }
+        u.keep_idx = kidx;
+        if (reforge && P) {   // bookkeeping (:308-309).  keep-all: the ids x 1.0 are the ids (:288-292)
+            u.pos_src = b->keep_all ? b->pos_old + (size_t)l * P * L : b->pos_new + (size_t)l * keep;
+            u.pos_src_stride = b->keep_all ? (int64_t)L : (int64_t)b->slots * keep;
+            u.pos_dst = ls->pos + ls->pos_len;
+            u.pos_dst_stride = ls->pos_cap;
+        } else {
+            u.pos_src = u.pos_dst = nullptr;
+            u.pos_src_stride = u.pos_dst_stride = 0;
+        }
+    }
+    if (reforge)
+        rc = rtk_pivotkv_evict_batched_rope(eu.data(), n, Hkv, D, keep, P, b->dtype, b->inv_freq, b->attention_scaling,
+                                            b->nsec ? b->sections : nullptr, b->nsec, b->round_mode, 1, stream);
+    else if (!b->keep_all)
+        rc = rtk_pivotkv_evict_batched(eu.data(), n, Hkv, D, keep, 0, b->dtype, 1, stream);
+    if (rc) return rc;
+    if (nc) {
+        rc = rtk_pivotkv_place_batched(pl.data(), nc, Hkv, keep, D, b->dtype, stream);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < n; ++i) {
+        rtk_layer_state* ls = layers[i];
+        ls->length += keep;
+        ls->pending = 0;
+        ls->pending_keep = 0;
+        ls->mask = nullptr;
+        if (reforge && P) ls->pos_len += keep;
+    }
+    b->pre_rope = 0;
+    return RTK_OK;
+}

@@ -13,10 +13,12 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 RTK_F32, RTK_BF16, RTK_BF16_REFROUND, RTK_BF16_FAST, RTK_F16 = 0, 1, 2, 3, 4
 RTK_SCORE_MANY_UNITS = 0x100   # flag for the dtype argument of the scoring entry points (split policy of batched launches)
+RTK_PREPARE_K_ONLY = 0x200     # flag for the dtype argument of rtk_pivotkv_prepare: keep-all chunk, no q~
+RTK_UPDATE_PRE_ROPE = 1        # rtk_update_io.flags: q / k are the pre-RoPE projections (attention prologue)
 SCORE_PREPARE, SCORE_PASSES, SCORE_FINALIZE = 1, 2, 4
 RTK_EINVAL, RTK_EUNSUPPORTED, RTK_EWORKSPACE, RTK_EHIP, RTK_EREFCRASH = -1, -2, -3, -4, -5
 
@@ -54,6 +56,35 @@ class P2PPeers(C.Structure):
 class CopyUnit(C.Structure):
     """rtk_copy_unit (include/retake_hip.h)."""
     _fields_ = [("src", _vp), ("src_stride_h_bytes", _i64), ("dst", _vp), ("dst_stride_h_bytes", _i64)]
+
+
+_u64, _i32 = C.c_uint64, C.c_int32
+
+
+class LayerState(C.Structure):
+    """rtk_layer_state (include/retake_hip.h): one layer's pre-allocated cache, shared with the library."""
+    _fields_ = [("k", _vp), ("v", _vp), ("cap", _i64), ("length", _i64), ("pending", _i64), ("pending_keep", _i64),
+                ("pos", _vp), ("pos_cap", _i64), ("pos_len", _i64), ("mask", _vp)]
+
+
+class PivotKVBatch(C.Structure):
+    """rtk_pivotkv_batch (include/retake_hip.h)."""
+    _fields_ = [("Hq", _i32), ("Hkv", _i32), ("L", _i32), ("D", _i32), ("keep", _i32), ("P", _i32), ("slots", _i32),
+                ("dtype", _i32), ("score_dtype", _i32), ("prep_dtype", _i32), ("reforge", _i32), ("keep_all", _i32),
+                ("round_mode", _i32), ("nsec", _i32), ("sections", _i32 * 8), ("rs_n", _i32), ("skip_masked", _i32),
+                ("attention_scaling", _f), ("pad0", _i32), ("inv_freq", _vp),
+                ("score_ws", _vp), ("score_ws_stride", _u64), ("score_ws_bytes", _u64),
+                ("k_unrot", _vp), ("partials", _vp), ("partial_floats", _u64), ("score", _vp), ("pos_old", _vp),
+                ("keep_idx", _vp), ("pos_new", _vp), ("sel_ws", _vp), ("sel_ws_stride", _u64), ("key_index", _vp),
+                ("v_stage", _vp), ("k_stage", _vp), ("shift_row", _vp), ("pre_rope", _i32), ("batched_passes", _i32)]
+
+
+class UpdateIO(C.Structure):
+    """rtk_update_io (include/retake_hip.h)."""
+    _fields_ = [("q", _vp), ("q_stride_h", _i64), ("q_stride_l", _i64), ("k", _vp), ("k_stride_h", _i64),
+                ("k_stride_l", _i64), ("v", _vp), ("v_stride_h", _i64), ("v_stride_l", _i64), ("pos", _vp),
+                ("pos_stride", _i64), ("q_rot", _vp), ("qr_stride_h", _i64), ("qr_stride_l", _i64), ("flags", _i32),
+                ("pad0", _i32)]
 
 
 _SIGNATURES = {
@@ -94,6 +125,8 @@ _SIGNATURES = {
     "rtk_pivotkv_place_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp]),
     "rtk_pivotkv_commit_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp]),
     "rtk_position_shift": (C.c_int, [_vp, _i, _vp, _vp]),
+    "rtk_pivotkv_update": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
+    "rtk_pivotkv_flush": (C.c_int, [_vp, _vp, _vp, _i, _vp]),
     "rtk_p2p_alloc": (C.c_int, [_sz, _i, C.POINTER(_vp)]),
     "rtk_p2p_free": (C.c_int, [_vp]),
     "rtk_p2p_export": (C.c_int, [_vp, _vp, C.POINTER(_sz)]),
@@ -108,6 +141,7 @@ _SIGNATURES = {
     "rtk_profile_num_kernels": (C.c_int, []),
     "rtk_profile_kernel_name": (C.c_char_p, [_i]),
     "rtk_profile_read": (C.c_int, [_i, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    "rtk_profile_copy": (C.c_int, [_vp, _vp, _sz, _vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -177,6 +211,26 @@ def ptr(t):
 
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+try:  # the raw handle of the current stream without building a torch.cuda.Stream object (hot path of update)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+    _cur_device = torch._C._cuda_getDevice
+except AttributeError:  # a torch without these private helpers: the public route
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+    def _cur_device():
+        return torch.cuda.current_device()
+
+
+def raw_stream(index: int) -> int:
+    """hipStream_t of torch's current stream on device `index`, as an int."""
+    return _raw_stream(index)
+
+
+def current_device() -> int:
+    return _cur_device()
 
 
 def profile_kernel_ids() -> dict:

@@ -63,7 +63,17 @@ def retake_Qwen2Attention_forward(self, hidden_states, position_embeddings, atte
     # current chunk's ids follow the reforged ids of the earlier chunks (reference :76-88); the ids are
     # cloned first so the shift of one layer does not leak into the next one
     position_ids = None
-    if past_key_value is not None and getattr(past_key_value, "pos_embed_reforge", False):
+    fused = None
+    reforge = past_key_value is not None and getattr(past_key_value, "pos_embed_reforge", False)
+    if reforge and query_states.is_cuda and query_states.shape[0] == 1 and kwargs.get("position_ids") is not None \
+            and getattr(past_key_value, "kvcache_compression", False) and hasattr(past_key_value, "update_pre_rope"):
+        # video chunks on the GPU: the whole prologue in one kernel (see qwen2_vl._qkv_and_cache_update); the ids the
+        # caller handed over stay as they are, like the reference's clone
+        fused = past_key_value.update_pre_rope(query_states, key_states, value_states, self.layer_idx,
+                                               kwargs["position_ids"], self.rotary_emb, None, shift_ids_in_place=False)
+    if fused is not None:
+        query_states, key_states, value_states = fused
+    elif reforge:
         position_ids = kwargs.get("position_ids")
         if position_ids.is_cuda and hasattr(past_key_value, "shift_temporal_ids_"):
             # same rule on the device, no host sync (a zero shift leaves the clone equal to the ids)
@@ -75,13 +85,14 @@ def retake_Qwen2Attention_forward(self, hidden_states, position_embeddings, atte
                 position_ids = position_ids.clone()
                 position_ids[0, :] += prev_tempo_idx + 1 - cur_tempo_idx
         position_embeddings = None  # must be recomputed from the shifted ids
-    if position_embeddings is None:
-        cos, sin = self.rotary_emb(value_states, position_ids)
-    else:
-        cos, sin = position_embeddings
-    query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)
+    if fused is None:
+        if position_embeddings is None:
+            cos, sin = self.rotary_emb(value_states, position_ids)
+        else:
+            cos, sin = position_embeddings
+        query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)
 
-    if past_key_value is not None:
+    if fused is None and past_key_value is not None:
         cache_kwargs = {"sin": sin, "cos": cos, "cache_position": cache_position,
                         "query_states": query_states, "position_ids": position_ids, "rotary_emb": self.rotary_emb}
         key_states, value_states = past_key_value.update(key_states, value_states, self.layer_idx, cache_kwargs)

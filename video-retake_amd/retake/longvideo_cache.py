@@ -158,19 +158,86 @@ DynamicCache = _HFDynamicCache if _hf_dynamic_cache_is_legacy() else _ListDynami
 
 
 class _LayerStore:
-    """One layer's pre-allocated K/V buffers [1, Hkv, cap, D] and position ids [P, cap]."""
+    """One layer's pre-allocated K/V buffers [1, Hkv, cap, D] and position ids [P, cap].  The numbers live in a
+    rtk_layer_state block (`c`) the library reads and advances itself (rtk_pivotkv_update / rtk_pivotkv_flush)."""
 
-    __slots__ = ("k", "v", "length", "pending", "pending_keep", "pending_event", "pos", "pos_len", "pos_ndim")
+    __slots__ = ("c", "cref", "_k", "_v", "_pos", "pending_event", "pos_ndim")
 
     def __init__(self):
-        self.k = self.v = None
-        self.length = 0          # committed tokens
-        self.pending = 0         # uncompressed chunk tokens sitting at [length, length+pending)
-        self.pending_keep = 0
+        self.c = nv.LayerState()
+        self.cref = C.addressof(self.c)
+        self._k = self._v = self._pos = None
         self.pending_event = None  # worker-stream completion of this layer's scoring (overlap_streams > 0)
-        self.pos = None          # int64 [P, cap]: position ids of the cached tokens (pos_embed_reforge)
-        self.pos_len = 0
-        self.pos_ndim = 0        # 3: ids are [3, 1, n] (M-RoPE), 2: [1, n]
+        self.pos_ndim = 0          # 3: ids are [3, 1, n] (M-RoPE), 2: [1, n]
+
+    def _sync(self):
+        k, v, c = self._k, self._v, self.c
+        c.k = k.data_ptr() if k is not None else None
+        c.v = v.data_ptr() if v is not None else None
+        # the library may only use the buffers when both are dense [1, Hkv, cap, D] blocks of one capacity
+        ok = (k is not None and v is not None and k.ndim == 4 and k.shape == v.shape and k.is_contiguous()
+              and v.is_contiguous())
+        c.cap = k.shape[2] if ok else 0
+
+    @property
+    def k(self):
+        return self._k
+
+    @k.setter
+    def k(self, t):
+        self._k = t
+        self._sync()
+
+    @property
+    def v(self):
+        return self._v
+
+    @v.setter
+    def v(self, t):
+        self._v = t
+        self._sync()
+
+    @property
+    def pos(self):           # int64 [P, cap]: position ids of the cached tokens (pos_embed_reforge)
+        return self._pos
+
+    @pos.setter
+    def pos(self, t):
+        self._pos = t
+        self.c.pos = t.data_ptr() if t is not None else None
+        self.c.pos_cap = t.shape[1] if t is not None else 0
+
+    @property
+    def length(self):        # committed tokens
+        return self.c.length
+
+    @length.setter
+    def length(self, n):
+        self.c.length = n
+
+    @property
+    def pending(self):       # uncompressed chunk tokens sitting at [length, length + pending)
+        return self.c.pending
+
+    @pending.setter
+    def pending(self, n):
+        self.c.pending = n
+
+    @property
+    def pending_keep(self):
+        return self.c.pending_keep
+
+    @pending_keep.setter
+    def pending_keep(self, n):
+        self.c.pending_keep = n
+
+    @property
+    def pos_len(self):
+        return self.c.pos_len
+
+    @pos_len.setter
+    def pos_len(self, n):
+        self.c.pos_len = n
 
 
 class _Side:
@@ -181,11 +248,21 @@ class _Side:
         self.ws: Dict[str, torch.Tensor] = {}
 
 
+class _Rotary:
+    """What the kernels need of an inv_freq * position rotary module (native RoPE): its inv_freq on the device and
+    attention_scaling.  HF builds one rotary module per attention layer; modules with equal contents share an entry."""
+
+    __slots__ = ("inv", "scaling", "device")
+
+    def __init__(self, inv, scaling, device):
+        self.inv, self.scaling, self.device = inv, scaling, device
+
+
 class _Batch:
     """Per-chunk batch of pending evictions: slot = layer index.  All units share the chunk geometry."""
 
     def __init__(self, key, slots, Hq, Hkv, L, D, keep, P, reforge, dtype, device, refround=False, fast=False,
-                 keep_all=False):
+                 keep_all=False, skip_masked=True):
         self.key, self.slots, self.keep, self.P, self.reforge = key, slots, keep, P, reforge
         self.keep_all = keep_all   # keep == L and no scoring asked for: the selection is the identity
         # dtype code of the scoring entry points: bf16 payloads with the reference's bf16 rounding chain, or through the
@@ -199,6 +276,7 @@ class _Batch:
         # what rtk_pivotkv_prepare is told: the payload dtype (the reference-rounding mode prepares like plain bf16)
         self.prep_dt = (nv.RTK_BF16 if refround and dtype == torch.bfloat16 else self.score_dt & 0xFF) | (self.score_dt & ~0xFF)
         self.Hkv, self.L, self.D, self.dtype, self.device = Hkv, L, D, dtype, device
+        self.Hq = Hq
         self.keep_idx = torch.arange(keep, dtype=torch.int64, device=device).repeat(slots, 1) if keep_all \
             else torch.empty((slots, keep), dtype=torch.int64, device=device)
         self.pos_new = torch.empty((P, slots, keep), dtype=torch.int64, device=device) if P else None
@@ -207,37 +285,93 @@ class _Batch:
         # layer), the key-patch mask of the update and the selection scratch
         self.rs_n = C.c_int(0)
         self.part_floats = nv.lib.rtk_pivotkv_score_partials(Hq, Hkv, L, D, self.score_dt, C.byref(self.rs_n))
-        self.partials = torch.empty((slots, self.part_floats), dtype=torch.float32, device=device)
-        self.score = torch.empty((slots, L), dtype=torch.float32, device=device)
         self.pos_old = torch.empty((slots, P, L), dtype=torch.int64, device=device) if P else None
         self.sel_bytes = nv.lib.rtk_pivotkv_select_workspace_bytes(L)
-        self.sel_ws = torch.empty((slots, self.sel_bytes), dtype=torch.uint8, device=device)
         self.masks: Dict[int, Optional[torch.Tensor]] = {}
         self.selected = set()      # layers whose selection already ran inside update (small chunks)
         self.scored = set()        # layers whose matrix passes already ran inside update
-        self.Hq = Hq
         # one score workspace per slot (q~, lse partials): the matrix passes of all layers run in one launch each
         self.ws_bytes = nv.lib.rtk_pivotkv_score_workspace_bytes(Hq, Hkv, L, D, self.score_dt)
         self.ws_stride = (self.ws_bytes + 255) & ~255
-        self.score_ws = torch.empty(slots * self.ws_stride + 256, dtype=torch.uint8, device=device) \
-            if self.batched_passes else None
-        self.score_ws_base = ((self.score_ws.data_ptr() + 255) & ~255) if self.batched_passes else 0
-        # pass 2's live-key lists (the unmasked tokens of every slot + their count): the columns the mask override
-        # discards (reference :272-274) are not computed
-        self.key_index = torch.empty((slots, L + 1), dtype=torch.int32, device=device) if self.batched_passes else None
-        self.v_stage = torch.empty((slots, Hkv, keep, D), dtype=dtype, device=device)
+        self.partials = self.score = self.sel_ws = self.score_ws = self.key_index = None
+        self.score_ws_base = 0
+        self.v_stage = None
         if reforge:  # kept K is re-rotated from the un-rotated copy straight into the cache: no K staging
             self.k_unrot = torch.empty((slots, Hkv, L, D), dtype=dtype, device=device)
-            self.cos_new = torch.empty((slots * keep, D), dtype=torch.float32, device=device)
-            self.sin_new = torch.empty((slots * keep, D), dtype=torch.float32, device=device)
             self.k_stage = None
         else:
-            self.k_unrot = self.cos_new = self.sin_new = None
-            self.k_stage = torch.empty((slots, Hkv, keep, D), dtype=dtype, device=device)
+            self.k_unrot = None
+            self.k_stage = None if keep_all else torch.empty((slots, Hkv, keep, D), dtype=dtype, device=device)
+        self.cos_new = self.sin_new = None   # tables of a third-party rotary module, allocated when one is used
         self.pending: List[int] = []
+        self.c_pending = 0         # how many of them were appended by rtk_pivotkv_update (the one-call path)
         self.rotary_emb_fn = None
+        self.rot: Optional[_Rotary] = None
         self.mrope_section = None
         self.x_like = None
+        self.mask_obj = None       # the last key-patch mask tensor that passed validation, and its address
+        self.mask_ptr = None
+        self.shift_ids = None      # pre-RoPE units: the caller's ids tensor, shifted in place by the flush
+        self.qshape, self.kshape = torch.Size((1, Hq, L, D)), torch.Size((1, Hkv, L, D))
+        self.dev_index = device.index if device.index is not None else torch.cuda.current_device()
+        # the one-call path (rtk_pivotkv_update / rtk_pivotkv_flush): argument blocks bound once per batch
+        self.c = nv.PivotKVBatch()
+        self.cref = C.addressof(self.c)
+        self.io = nv.UpdateIO()
+        self.ioref = C.addressof(self.io)
+        c = self.c
+        c.Hq, c.Hkv, c.L, c.D, c.keep, c.P, c.slots = Hq, Hkv, L, D, keep, P, slots
+        c.dtype = nv.RTK_BF16 if dtype == torch.bfloat16 else (nv.RTK_F16 if dtype == torch.float16 else nv.RTK_F32)
+        c.score_dtype, c.prep_dtype = self.score_dt, self.prep_dt
+        c.reforge, c.keep_all, c.round_mode = int(reforge), int(keep_all), nv.round_mode(dtype)
+        c.rs_n, c.skip_masked, c.batched_passes = self.rs_n.value, int(skip_masked), int(self.batched_passes)
+        c.partial_floats = self.part_floats
+        c.keep_idx = self.keep_idx.data_ptr()
+        c.pos_new = self.pos_new.data_ptr() if P else None
+        c.pos_old = self.pos_old.data_ptr() if P else None
+        c.k_unrot = self.k_unrot.data_ptr() if reforge else None
+        c.k_stage = self.k_stage.data_ptr() if self.k_stage is not None else None
+        # the one-call path serves the deferred chip-wide selection (L >= 512) of reforging caches with position ids
+        self.c_capable = bool(reforge and P and L >= 512)
+        if not keep_all:
+            self.ensure_scoring()
+            self.ensure_staging()
+        else:  # nothing is scored or staged: the scratch is allocated only if a route that needs it comes along
+            self._dummy = torch.empty(512, dtype=torch.uint8, device=device)
+            c.score_ws = (self._dummy.data_ptr() + 255) & ~255
+            c.score_ws_stride, c.score_ws_bytes = 0, 0
+
+    def ensure_scoring(self):
+        """Scoring scratch of every slot (q~ / lse workspace, column partials, scores, selection scratch, live-key
+        lists); keep-all batches get it only on the routes that still un-rotate the queries."""
+        if self.partials is not None:
+            return
+        slots, L, device, c = self.slots, self.L, self.device, self.c
+        self.partials = torch.empty((slots, self.part_floats), dtype=torch.float32, device=device)
+        self.score = torch.empty((slots, L), dtype=torch.float32, device=device)
+        self.sel_ws = torch.empty((slots, self.sel_bytes), dtype=torch.uint8, device=device)
+        self.score_ws = torch.empty(slots * self.ws_stride + 256, dtype=torch.uint8, device=device)
+        self.score_ws_base = (self.score_ws.data_ptr() + 255) & ~255
+        # pass 2's live-key lists (the unmasked tokens of every slot + their count): the columns the mask override
+        # discards (reference :272-274) are not computed
+        self.key_index = torch.empty((slots, L + 1), dtype=torch.int32, device=device)
+        c.partials, c.score, c.sel_ws = self.partials.data_ptr(), self.score.data_ptr(), self.sel_ws.data_ptr()
+        c.sel_ws_stride = self.sel_bytes
+        c.score_ws, c.score_ws_stride, c.score_ws_bytes = self.score_ws_base, self.ws_stride, self.ws_bytes
+        c.key_index = self.key_index.data_ptr()
+
+    def ensure_staging(self):
+        if self.v_stage is None:
+            self.v_stage = torch.empty((self.slots, self.Hkv, self.keep, self.D), dtype=self.dtype, device=self.device)
+            self.c.v_stage = self.v_stage.data_ptr()
+            if not self.reforge and self.k_stage is None:
+                self.k_stage = torch.empty_like(self.v_stage)
+                self.c.k_stage = self.k_stage.data_ptr()
+
+    def ensure_tables(self):
+        if self.cos_new is None:
+            self.cos_new = torch.empty((self.slots * self.keep, self.D), dtype=torch.float32, device=self.device)
+            self.sin_new = torch.empty((self.slots * self.keep, self.D), dtype=torch.float32, device=self.device)
 
 
 class _CacheView:
@@ -308,9 +442,14 @@ class PivotKVCache(DynamicCache):
         self.compression_ratio = kv_compression_kwargs["compression_ratio"]  # captured at construction (P0b)
         self.compression_method = kv_compression_kwargs["compression_method"]
         self.pos_embed_reforge = kv_compression_kwargs.get("pos_embed_reforge", False)
-        # MI355X build option: compute cos/sin tables in a HIP kernel from rotary_emb.inv_freq instead of
-        # calling the rotary module (valid for the default / YaRN inv_freq*position rotary modules)
-        self.native_rope = bool(kv_compression_kwargs.get("native_rope", False))
+        # cos/sin of the position ids are computed inside the HIP kernels from rotary_emb.inv_freq / attention_scaling
+        # whenever the rotary module is of the static inv_freq * position kind (HF's default / linear / YaRN / llama3
+        # rope types, which is every shipped config: configs/*.yaml patch YaRN, monkeypatch.py:24-48) - correctly
+        # rounded sin / cos, within one fp32 ulp of the module's, kept keys inside the 1e-5 bar.  Any other module
+        # (dynamic / longrope types, no inv_freq) is CALLED, exactly as the reference does (:249, :298).
+        # native_rope: False forces the call for every module (the bit-faithful opt-out).
+        self.native_rope = bool(kv_compression_kwargs.get("native_rope", True))
+        self._rotaries: Dict[int, Tuple[Any, Optional[_Rotary]]] = {}
         # MI355X build option for bf16 models: "fp32" (default) scores with exact bf16 products, fp32 accumulation, softmax
         # and sums; "reference" reproduces the reference's own bf16 roundings of the logits, probabilities, per-head
         # sums and means (longvideo_cache.py:264-270 on bf16 tensors) - coarser, but what the reference computes
@@ -330,6 +469,9 @@ class PivotKVCache(DynamicCache):
         # selection are not run then - the K round trip through the un-rotated frame and the bookkeeping still are.
         # True restores them (tests, `last_scores`)
         self.score_when_keeping_all = bool(kv_compression_kwargs.get("score_when_keeping_all", False))
+        # MI355X build option (tests / A-B): False sends every update and flush through the stage-by-stage route
+        # instead of the one-call entry points rtk_pivotkv_update / rtk_pivotkv_flush - same kernels, same results
+        self.one_call_update = bool(kv_compression_kwargs.get("one_call_update", True))
         self._sides: List[_Side] = []
         self._side_rr = 0
         self._pos_layers = 0          # len(position_cache) of the reference (skipped layers are padded with [])
@@ -495,21 +637,32 @@ class PivotKVCache(DynamicCache):
         host round trip of the comparison."""
         if not self.pos_embed_reforge:
             return position_ids
-        nv.require_device(position_ids)
-        row = position_ids[0, 0] if position_ids.ndim == 3 else position_ids[0]
-        if position_ids.dtype != torch.int64 or row.stride(-1) != 1:
+        return self._shift_row(position_ids, layer_idx)
+
+    def _shift_row(self, position_ids: torch.Tensor, layer_idx: int):
+        if not position_ids.is_cuda:
+            nv.require_device(position_ids)
+        if position_ids.dtype is not torch.int64 or position_ids.stride(-1) != 1:
+            row = position_ids[0, 0] if position_ids.ndim == 3 else position_ids[0]
             prev = self.get_prev_temporal_idx(layer_idx)
             row += prev + 1 - row[0].clone()
             return position_ids
         prev_ptr = None
         if len(self._layers) > layer_idx:
-            st = self._layers[layer_idx]
-            if st.pending:
+            c = self._layers[layer_idx].c
+            if c.pending:
                 self._flush()
-            if layer_idx < self._pos_layers and st.pos is not None and st.pos_len:
-                prev_ptr = C.c_void_p(st.pos.data_ptr() + 8 * (st.pos_len - 1))
-        with torch.cuda.device(position_ids.device):
-            nv.check(nv.lib.rtk_position_shift(nv.ptr(row), row.shape[0], prev_ptr, nv.stream()), "rtk_position_shift")
+            if layer_idx < self._pos_layers and c.pos and c.pos_len:
+                prev_ptr = c.pos + 8 * (c.pos_len - 1)
+        # the temporal row ([0, 0, :] of [3, 1, n] ids, [0, :] of [1, n] ids) starts at the tensor's first element
+        idx = position_ids.get_device()
+        if nv.current_device() == idx:
+            rc = nv.lib.rtk_position_shift(position_ids.data_ptr(), position_ids.shape[-1], prev_ptr, nv.raw_stream(idx))
+        else:
+            with torch.cuda.device(idx):
+                rc = nv.lib.rtk_position_shift(position_ids.data_ptr(), position_ids.shape[-1], prev_ptr,
+                                               nv.raw_stream(idx))
+        nv.check(rc, "rtk_position_shift")
         return position_ids
 
     # ---- storage -------------------------------------------------------------------------------
@@ -555,6 +708,31 @@ class PivotKVCache(DynamicCache):
             ws[name] = t
         return t[:n].view(*shape)
 
+    _STATIC_ROPE_TYPES = ("default", "linear", "yarn", "llama3", "mrope")
+
+    def _rotary(self, rotary_emb_fn, device) -> Optional[_Rotary]:
+        """The native-RoPE view of a rotary module, or None when the module has to be called (reference :249, :298).
+        Memoised per module object; modules with equal inv_freq / attention_scaling (HF: one per layer) share one
+        entry, so a chunk's layers stay in one batch."""
+        hit = self._rotaries.get(id(rotary_emb_fn))
+        if hit is not None and hit[0] is rotary_emb_fn and (hit[1] is None or hit[1].device == device):
+            return hit[1]
+        entry = None
+        inv = getattr(rotary_emb_fn, "inv_freq", None)
+        if (self.native_rope and isinstance(inv, torch.Tensor) and hasattr(rotary_emb_fn, "attention_scaling")
+                and getattr(rotary_emb_fn, "rope_type", "default") in self._STATIC_ROPE_TYPES):
+            inv = inv.detach().to(device=device, dtype=torch.float32).contiguous()
+            scaling = float(rotary_emb_fn.attention_scaling)
+            for _, other in self._rotaries.values():
+                if (other is not None and other.device == device and other.scaling == scaling
+                        and other.inv.shape == inv.shape and torch.equal(other.inv, inv)):
+                    entry = other
+                    break
+            if entry is None:
+                entry = _Rotary(inv, scaling, device)
+        self._rotaries[id(rotary_emb_fn)] = (rotary_emb_fn, entry)   # the strong reference pins the id
+        return entry
+
     def _rope_tables(self, cos_t, sin_t, rotary_emb_fn, x_like, pos2d, pos_ld, ndim, mrope_section, n, D):
         """fp32 [n, D] cos/sin tables of the ids pos2d [P, n] (row stride pos_ld), section-merged
         (reference :249 / :298 + :68-74), written into cos_t / sin_t."""
@@ -563,12 +741,9 @@ class PivotKVCache(DynamicCache):
         sec = (C.c_int * len(mrope_section))(*mrope_section) if mrope_section else None
         nsec = len(mrope_section) if mrope_section else 0
         s = nv.stream()
-        if self.native_rope and hasattr(rotary_emb_fn, "inv_freq"):
-            inv = rotary_emb_fn.inv_freq
-            if inv.device != dev or inv.dtype != torch.float32 or not inv.is_contiguous():
-                inv = inv.to(device=dev, dtype=torch.float32).contiguous()
-            nv.check(nv.lib.rtk_rope_table(nv.ptr(pos2d), pos_ld, P, n, nv.ptr(inv), D,
-                                           float(rotary_emb_fn.attention_scaling), sec, nsec,
+        rot = self._rotary(rotary_emb_fn, dev)
+        if rot is not None:
+            nv.check(nv.lib.rtk_rope_table(nv.ptr(pos2d), pos_ld, P, n, nv.ptr(rot.inv), D, rot.scaling, sec, nsec,
                                            nv.round_mode(x_like.dtype), nv.ptr(cos_t), nv.ptr(sin_t), s),
                      "rtk_rope_table")
             return
@@ -599,18 +774,75 @@ class PivotKVCache(DynamicCache):
         slots = max(int(self.num_hidden_layers), layer_idx + 1, b.slots if b is not None and b.key == key else 0)
         self._batch = None  # release the old buffers before allocating the new ones
         self._batch = _Batch(key, slots, Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast,
-                             keep_all)
+                             keep_all, self.skip_masked_columns)
         return self._batch
 
     def _flush(self):
-        """Evict every pending (layer, chunk) unit: one batched gather / re-rotate launch and one batched
-        commit launch (reference :278-318 for all layers of the chunk)."""
+        """Evict every pending (layer, chunk) unit (reference :260-318 for all layers of the chunk): the score passes,
+        the selection, one batched gather / re-rotate launch and one batched placement launch."""
         b = self._batch
         if b is None or not b.pending:
             return
+        if b.c_pending == len(b.pending) and self._flush_c(b):
+            return
+        self._flush_general(b)
+
+    def _flush_c(self, b: _Batch) -> bool:
+        """rtk_pivotkv_flush: the whole chain in one call (units appended by rtk_pivotkv_update only)."""
+        layers = b.pending
+        if any(layers[i] >= layers[i + 1] for i in range(len(layers) - 1)):
+            layers = sorted(set(layers))
+        L_ = self._layers
+        n = len(layers)
+        if b.reforge and b.P:
+            for l in layers:
+                st = L_[l]
+                if st.c.pos_len + b.keep > st.c.pos_cap:
+                    self._pos_reserve(st, b.P, 3 if b.P == 3 else 2, b.keep, b.device)
+                elif st.pos_ndim == 0:
+                    st.pos_ndim = 3 if b.P == 3 else 2
+        states = (C.c_void_p * n)(*[L_[l].cref for l in layers])
+        slots = (C.c_int32 * n)(*layers)
+        idx = b.dev_index
+        if nv.current_device() == idx:
+            rc = nv.lib.rtk_pivotkv_flush(b.cref, states, slots, n, nv.raw_stream(idx))
+        else:
+            with torch.cuda.device(b.device):
+                rc = nv.lib.rtk_pivotkv_flush(b.cref, states, slots, n, nv.raw_stream(idx))
+        if rc == nv.RTK_EUNSUPPORTED:
+            return False
+        nv.check(rc, "rtk_pivotkv_flush")
+        b.pending = []
+        b.c_pending = 0
+        b.masks.clear()
+        b.scored.clear()
+        b.selected.clear()
+        b.shift_ids = None
+        if b.reforge and b.P:
+            self._pos_layers = max(self._pos_layers, layers[-1] + 1)
+        return True
+
+    def _flush_general(self, b: _Batch):
+        """The same chain launched stage by stage: worker streams, small chunks (selection inside update), rotary
+        modules that have to be called for the tables of the new ids."""
         layers, b.pending = b.pending, []
+        b.c_pending = 0
+        if b.shift_ids is not None:   # pre-RoPE units: the caller's ids tensor takes the last layer's shift now
+            ids, b.shift_ids = b.shift_ids, None
+            b.c.shift_row = None
+            self._shift_row(ids, layers[-1])
+        if not b.keep_all:
+            b.ensure_scoring()
+            b.ensure_staging()
         keep, D, Hkv, P = b.keep, b.D, b.Hkv, b.P
-        es = b.v_stage.element_size()
+        if b.keep_all:   # units of the one-call path carry their ids in pos_old only: ids x 1.0 = the ids (:288-292)
+            for l in layers:
+                if l not in b.selected:
+                    if P:
+                        b.pos_new[:, l].copy_(b.pos_old[l])
+                    b.selected.add(l)
+                    b.scored.add(l)
+        es = 4 if b.dtype == torch.float32 else 2
         dt = nv.RTK_BF16 if b.dtype == torch.bfloat16 else (nv.RTK_F16 if b.dtype == torch.float16 else nv.RTK_F32)
         with torch.cuda.device(b.device):
             main = torch.cuda.current_stream()
@@ -660,8 +892,10 @@ class PivotKVCache(DynamicCache):
             # reforge: K is re-rotated at the NEW ids (reference :297-306).  With the native RoPE the eviction kernel
             # computes their cos/sin itself; a third-party rotary module is called once for every pending slot and its
             # section-merged fp32 tables are handed over.
-            rope_in_kernel = bool(b.reforge and P and self.native_rope and hasattr(b.rotary_emb_fn, "inv_freq"))
+            rot = self._rotary(b.rotary_emb_fn, b.device) if (b.reforge and P) else None
+            rope_in_kernel = rot is not None
             if b.reforge and not rope_in_kernel:
+                b.ensure_tables()
                 n = (hi - lo + 1) * keep
                 pos2d, ld = b.pos_new[:, lo:hi + 1].reshape(P, n), n  # a copy when the slot range is partial
                 self._rope_tables(b.cos_new[lo * keep:], b.sin_new[lo * keep:], b.rotary_emb_fn, b.x_like, pos2d, ld,
@@ -682,6 +916,9 @@ class PivotKVCache(DynamicCache):
                         u.cos_new = b.cos_new.data_ptr() + l * keep * D * 4
                         u.sin_new = b.sin_new.data_ptr() + l * keep * D * 4
                     u.k_dst, u.k_dst_stride_h = st.k.data_ptr() + tail, cap * D  # straight into the cache
+                elif b.keep_all:   # every row already sits where the append put it
+                    u.k_src, u.k_src_stride_h = st.k.data_ptr() + tail, cap * D
+                    u.cos_new = u.sin_new = u.k_dst = None
                 else:
                     u.k_src, u.k_src_stride_h = st.k.data_ptr() + tail, cap * D
                     u.cos_new = u.sin_new = None
@@ -691,11 +928,14 @@ class PivotKVCache(DynamicCache):
                     places[nc].keep_idx = b.keep_idx[l].data_ptr()
                     nc += 1
                 u.v_src, u.v_src_stride_h = st.v.data_ptr() + tail, cap * D
-                u.v_dst, u.v_dst_stride_h = b.v_stage[l].data_ptr(), keep * D
-                places[nc].stage, places[nc].stage_stride_h_bytes = b.v_stage[l].data_ptr(), keep * D * es
-                places[nc].tail, places[nc].tail_stride_h_bytes = st.v.data_ptr() + tail, cap * D * es
-                places[nc].keep_idx = b.keep_idx[l].data_ptr()
-                nc += 1
+                if b.keep_all:
+                    u.v_dst = None
+                else:
+                    u.v_dst, u.v_dst_stride_h = b.v_stage[l].data_ptr(), keep * D
+                    places[nc].stage, places[nc].stage_stride_h_bytes = b.v_stage[l].data_ptr(), keep * D * es
+                    places[nc].tail, places[nc].tail_stride_h_bytes = st.v.data_ptr() + tail, cap * D * es
+                    places[nc].keep_idx = b.keep_idx[l].data_ptr()
+                    nc += 1
                 u.keep_idx = b.keep_idx[l].data_ptr()
                 if b.reforge and P:  # bookkeeping (reference :308-309)
                     self._pos_reserve(st, P, 3 if P == 3 else 2, keep, b.device)
@@ -705,33 +945,215 @@ class PivotKVCache(DynamicCache):
                     u.pos_src = u.pos_dst = None
             s = nv.stream()
             if rope_in_kernel:
-                fn = b.rotary_emb_fn
-                inv = fn.inv_freq
-                if inv.device != b.device or inv.dtype != torch.float32 or not inv.is_contiguous():
-                    inv = inv.to(device=b.device, dtype=torch.float32).contiguous()
                 sec = (C.c_int * len(b.mrope_section))(*b.mrope_section) if b.mrope_section else None
-                nv.check(nv.lib.rtk_pivotkv_evict_batched_rope(units, len(layers), Hkv, D, keep, P, dt, nv.ptr(inv),
-                                                               float(fn.attention_scaling), sec,
+                nv.check(nv.lib.rtk_pivotkv_evict_batched_rope(units, len(layers), Hkv, D, keep, P, dt, nv.ptr(rot.inv),
+                                                               rot.scaling, sec,
                                                                len(b.mrope_section) if b.mrope_section else 0,
                                                                nv.round_mode(b.x_like.dtype), 1, s),
                          "rtk_pivotkv_evict_batched_rope")
-            else:
+            elif b.reforge or not b.keep_all:
                 nv.check(nv.lib.rtk_pivotkv_evict_batched(units, len(layers), Hkv, D, keep, P if b.reforge else 0, dt, 1, s),
                          "rtk_pivotkv_evict_batched")
             # kept rows -> head of the tail: in place, except the ~ratio of them whose source lies inside the destination
             # range (parked in the staging rows by the launch above) - reference :313-318 without a full second copy
-            nv.check(nv.lib.rtk_pivotkv_place_batched(places, nc, Hkv, keep, D, dt, s), "rtk_pivotkv_place_batched")
+            if nc:
+                nv.check(nv.lib.rtk_pivotkv_place_batched(places, nc, Hkv, keep, D, dt, s), "rtk_pivotkv_place_batched")
         for l in layers:
             st = self._layers[l]
             st.length += keep
             st.pending = 0
             st.pending_keep = 0
+            st.c.mask = None
             if b.reforge and P:
                 st.pos_len += keep
                 self._pos_layers = max(self._pos_layers, l + 1)
 
     # ---- the hot path ---------------------------------------------------------------------------
     def update(
+        self,
+        key_states: torch.Tensor,
+        value_states: torch.Tensor,
+        layer_idx: int,
+        cache_kwargs: Optional[Dict[str, Any]] = None,
+    ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """
+        Input
+            query_states: [bsz, num_heads, q_len, d]      (cache_kwargs['query_states'], post-RoPE)
+            key_states:   [bsz, num_key_value_heads, q_len, d]
+            position_ids: [3, bsz, q_len] / [bsz, q_len]  (cache_kwargs['position_ids'])
+        Output
+            key_states_output, value_states_output: the layer's UNCOMPRESSED keys/values
+            ([prefix | whole current chunk]) for this layer's self attention (reference :217-323).
+
+        A chunk whose geometry matches the current batch goes through ONE library call (rtk_pivotkv_update: argument
+        blocks bound once per batch and per layer); everything else - the first update of a geometry, text / decode
+        appends, worker streams, small chunks, rotary modules that must be called - through `_update_general`.
+        """
+        b = self._batch
+        if b is not None and b.c_capable and cache_kwargs is not None and self.kvcache_compression \
+                and self.overlap_streams <= 0 and self.one_call_update:
+            out = self._update_c(b, key_states, value_states, layer_idx, cache_kwargs, None)
+            if out is not None:
+                return out
+        return self._update_general(key_states, value_states, layer_idx, cache_kwargs)
+
+    def _update_c(self, b: _Batch, key_states, value_states, layer_idx, ck, q0, shift_ids_in_place=True):
+        """One rtk_pivotkv_update call.  q0 None: `ck["query_states"]` / key_states are rotated (the reference's
+        protocol); else q0 / key_states are the pre-RoPE projections and the rotated queries are written over q0.
+        Returns None - having changed nothing - when the call does not fit the batch."""
+        q = ck.get("query_states") if q0 is None else q0
+        pos = ck.get("position_ids")
+        if q is None or pos is None or layer_idx >= b.slots or layer_idx >= len(self._layers):
+            return None
+        rot_fn = ck.get("rotary_emb")
+        hit = self._rotaries.get(id(rot_fn))
+        if hit is None or hit[0] is not rot_fn or hit[1] is None or hit[1] is not b.rot \
+                or ck.get("mrope_section") != b.mrope_section:
+            return None
+        dt = b.dtype
+        if q.shape != b.qshape or key_states.shape != b.kshape or value_states.shape != b.kshape \
+                or q.dtype is not dt or key_states.dtype is not dt or value_states.dtype is not dt:
+            return None
+        idx = b.dev_index
+        if not (q.is_cuda and q.get_device() == idx and key_states.get_device() == idx
+                and value_states.get_device() == idx and pos.is_cuda and pos.get_device() == idx
+                and nv.current_device() == idx):
+            return None
+        L, P = b.L, b.P
+        if pos.dtype is not torch.int64 or pos.shape[-1] != L or pos.shape[0] != P or pos.ndim != (3 if P == 3 else 2) \
+                or pos.stride(-1) != 1 or (pos.ndim == 3 and pos.shape[1] != 1):
+            return None
+        mask = self.keypatches_mask_chunk
+        if mask is None:
+            mptr = None
+        elif mask is b.mask_obj:
+            mptr = b.mask_ptr
+        else:
+            if not (mask.is_cuda and mask.dtype is torch.bool and mask.numel() == L and mask.is_contiguous()
+                    and mask.get_device() == idx):
+                return None
+            b.mask_obj, b.mask_ptr = mask, mask.data_ptr()
+            mptr = b.mask_ptr
+        st = self._layers[layer_idx]
+        c = st.c
+        if c.pending:
+            self._flush()
+        P0 = c.length
+        if P0 + L > c.cap:   # (cap is 0 for buffers the library may not use)
+            return None
+        pre = q0 is not None
+        if b.pending and bool(b.c.pre_rope) != pre:
+            self._flush()
+        qs, ks, vs = q.stride(), key_states.stride(), value_states.stride()
+        if qs[3] != 1 or ks[3] != 1 or vs[3] != 1:
+            return None
+        io = b.io
+        io.q, io.q_stride_h, io.q_stride_l = q.data_ptr(), qs[1], qs[2]
+        io.k, io.k_stride_h, io.k_stride_l = key_states.data_ptr(), ks[1], ks[2]
+        io.v, io.v_stride_h, io.v_stride_l = value_states.data_ptr(), vs[1], vs[2]
+        io.pos, io.pos_stride = pos.data_ptr(), pos.stride(0)
+        if pre:
+            io.q_rot, io.qr_stride_h, io.qr_stride_l, io.flags = io.q, qs[1], qs[2], nv.RTK_UPDATE_PRE_ROPE
+        else:
+            io.q_rot, io.flags = None, 0
+        c.mask = mptr
+        rc = nv.lib.rtk_pivotkv_update(b.cref, st.cref, layer_idx, b.ioref, nv.raw_stream(idx))
+        if rc:
+            c.mask = None
+            if rc == nv.RTK_EUNSUPPORTED:
+                return None
+            nv.check(rc, "rtk_pivotkv_update")
+        if not self._warned:  # the reference's logger.warning_once (:232)
+            self._warned = True
+            _warn_once("Enable PivotKVCache compression: length after compression %.2f" % (self.compression_ratio))
+        if not pre:  # the reference's cache_kwargs protocol (:235, :241-243)
+            ck.pop("position_ids", None)
+            ck.pop("query_states", None)
+            ck.pop("rotary_emb", None)
+            ck.pop("mrope_section", None)
+        else:
+            b.c.pre_rope = 1
+            if shift_ids_in_place:     # the flush shifts the caller's ids in place (qwen2_vl.py:73)
+                b.shift_ids = pos
+                b.c.shift_row = io.pos
+        nev = self.num_evicted_tokens
+        if len(nev) > layer_idx:
+            nev[layer_idx] += L - b.keep   # reference :310
+        else:
+            self.update_num_evicted_tokens(L - b.keep, layer_idx)
+        if mask is not None:
+            b.masks[layer_idx] = mask
+        if b.keep_all:
+            b.scored.add(layer_idx)
+        elif not b.batched_passes:
+            b.scored.add(layer_idx)
+        b.pending.append(layer_idx)
+        b.c_pending += 1
+        self._last_slot = (b, layer_idx)
+        n = P0 + L
+        return st._k.narrow(2, 0, n), st._v.narrow(2, 0, n)
+
+    def update_pre_rope(self, query_states, key_states, value_states, layer_idx, position_ids, rotary_emb,
+                        mrope_section=None, shift_ids_in_place=True):
+        """The attention patch's whole prologue as ONE kernel (not in the reference: there it is the continuity shift,
+        the rotary module, apply_multimodal_rotary_pos_emb and PivotKVCache.update, qwen2_vl.py:68-86 + :217-259).
+        query_states [1, Hq, L, D], key_states / value_states [1, Hkv, L, D] are the PRE-RoPE projections of a video
+        chunk.  Returns (rotated queries - written over `query_states` -, keys, values) with keys / values as `update`
+        returns them, or None - nothing touched - when this call has to take the eager route (first chunk of a
+        geometry, text segments, score_rounding="reference", rotary modules that must be called, small chunks).
+        shift_ids_in_place: the Qwen2-VL patch shifts the ids tensor it was handed (qwen2_vl.py:73; done here by the
+        chunk's flush, with the last layer's rule - what the reference's layer loop leaves behind); the LLaVA patch
+        shifts a private clone (llava_onevision.py:76-88), i.e. leaves the caller's tensor alone."""
+        if not (self.kvcache_compression and self.pos_embed_reforge and self.one_call_update) or self.overlap_streams > 0 \
+                or position_ids is None or not key_states.is_cuda or key_states.shape[0] != 1 \
+                or (torch.is_grad_enabled() and query_states.requires_grad):
+            return None
+        L = key_states.shape[2]
+        b = self._batch
+        hit = self._rotaries.get(id(rotary_emb))
+        if b is None or b.L != L or hit is None or hit[0] is not rotary_emb or hit[1] is None or hit[1] is not b.rot \
+                or layer_idx >= b.slots or layer_idx >= len(self._layers) \
+                or self._layers[layer_idx].c.length + L > self._layers[layer_idx].c.cap:
+            # not the steady state: find / build the batch of this geometry, bind the rotary, make room
+            dev = key_states.device
+            rot = self._rotary(rotary_emb, dev)
+            keep_len = max(1, int(self.compression_ratio * L))
+            if rot is None or L < 512 or keep_len > L or (self.score_rounding == "reference"
+                                                         and key_states.dtype == torch.bfloat16):
+                return None
+            Hq, D = query_states.shape[1], query_states.shape[3]
+            b = self._get_batch(layer_idx, Hq, key_states.shape[1], L, D, keep_len, 3 if position_ids.ndim == 3 else 1,
+                                key_states.dtype, dev)
+            if not b.c_capable:
+                return None
+            self._bind_rotary(b, rotary_emb, mrope_section, rot)
+            b.x_like = value_states[:, :, :1]
+            self.reserve(layer_idx, L, key_states)
+        ck = {"position_ids": position_ids, "rotary_emb": rotary_emb, "mrope_section": mrope_section}
+        out = self._update_c(b, key_states, value_states, layer_idx, ck, query_states, shift_ids_in_place)
+        if out is None:
+            return None
+        return query_states, out[0], out[1]
+
+    def _bind_rotary(self, b: _Batch, rotary_emb_fn, mrope_section, rot: Optional[_Rotary]):
+        """The rotary module / M-RoPE sections the batch's pending units were (and its next units will be) rotated
+        with; units of different rotaries never share a flush."""
+        same_fn = b.rotary_emb_fn is rotary_emb_fn or (rot is not None and b.rot is rot)
+        if b.pending and (not same_fn or b.mrope_section != mrope_section):
+            self._flush()
+        b.rotary_emb_fn, b.rot = rotary_emb_fn, rot
+        if b.mrope_section != mrope_section or b.c.inv_freq != (rot.inv.data_ptr() if rot is not None else None):
+            b.mrope_section = list(mrope_section) if mrope_section is not None else None
+            c = b.c
+            c.nsec = len(mrope_section) if mrope_section else 0
+            if c.nsec > 8:
+                raise ValueError("mrope_section has more than 8 entries")
+            for i in range(c.nsec):
+                c.sections[i] = int(mrope_section[i])
+            c.inv_freq = rot.inv.data_ptr() if rot is not None else None
+            c.attention_scaling = rot.scaling if rot is not None else 1.0
+
+    def _update_general(
         self,
         key_states: torch.Tensor,
         value_states: torch.Tensor,
@@ -798,9 +1220,10 @@ class PivotKVCache(DynamicCache):
             nv.require_device(position_ids)
             Pn = 3 if position_ids.ndim == 3 else 1
         batch = self._get_batch(layer_idx, Hq, Hkv, L, D, keep_len, Pn, key_states.dtype, dev)
-        if batch.pending and (batch.rotary_emb_fn is not rotary_emb_fn or batch.mrope_section != mrope_section):
+        rot = self._rotary(rotary_emb_fn, dev) if reforge else None
+        self._bind_rotary(batch, rotary_emb_fn, mrope_section, rot)
+        if batch.pending and batch.c.pre_rope:   # units of the prologue route are flushed among themselves
             self._flush()
-        batch.rotary_emb_fn, batch.mrope_section = rotary_emb_fn, mrope_section
         batch.x_like = value_states[:, :, :1]
         st = self.reserve(layer_idx, n_new, key_states)
         P0 = st.length
@@ -839,6 +1262,7 @@ class PivotKVCache(DynamicCache):
 
         def stage_pre(ws, pos_in):
             """RoPE tables of the chunk's ids + un-rotate / pack (reference :248-259), on the CURRENT stream."""
+            batch.ensure_scoring()
             if reforge:
                 cos_t = self._buf("old_cos", (L, D), torch.float32, dev, ws)
                 sin_t = self._buf("old_sin", (L, D), torch.float32, dev, ws)
@@ -899,18 +1323,19 @@ class PivotKVCache(DynamicCache):
         def fused_prepare(ws, pos_in) -> bool:
             """append + native RoPE tables + un-rotate in ONE launch (k read once); False if the shape needs the
             separate kernels."""
-            if not (reforge and self.native_rope and hasattr(rotary_emb_fn, "inv_freq") and pos_in is not None):
+            if not (reforge and rot is not None and pos_in is not None):
                 return False
-            inv = rotary_emb_fn.inv_freq
-            if inv.device != dev or inv.dtype != torch.float32 or not inv.is_contiguous():
-                inv = inv.to(device=dev, dtype=torch.float32).contiguous()
-            ws_ptr = ws_pointer(ws)
+            inv = rot.inv
+            # keep-all chunks are not scored: no q~, no score workspace (any aligned address will do)
+            k_only = batch.keep_all and batch.partials is None
+            ws_ptr = batch.c.score_ws if k_only else ws_pointer(ws)
             sec = (C.c_int * len(mrope_section))(*mrope_section) if mrope_section else None
             rc = nv.lib.rtk_pivotkv_prepare(
                 nv.ptr(query_states), query_states.stride(1), query_states.stride(2),
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
                 nv.ptr(value_states), value_states.stride(1), value_states.stride(2),
-                Hq, Hkv, L, D, batch.prep_dt, nv.ptr(pos_in), L, Pn, nv.ptr(inv), a_scale, sec,
+                Hq, Hkv, L, D, batch.prep_dt | (nv.RTK_PREPARE_K_ONLY if k_only else 0), nv.ptr(pos_in), L, Pn,
+                nv.ptr(inv), a_scale, sec,
                 len(mrope_section) if mrope_section else 0, nv.round_mode(key_states.dtype),
                 nv.ptr(batch.k_unrot[layer_idx]), C.c_void_p(ws_ptr), ws_bytes, k_tail, v_tail, cap * D,
                 nv.ptr(batch.pos_old[layer_idx]) if defer_select else None, nv.stream())
