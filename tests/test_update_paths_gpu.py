@@ -244,7 +244,9 @@ def test_prologue_keep_all_leaves_the_appended_rows():
         assert torch.equal(cache.position_cache[l], eager.position_cache[l])
         a, b = cache.key_cache[l].float(), eager.key_cache[l].float()
         assert a.shape == b.shape == (1, Hkv, 2 * L, D)
-        assert ((a - b).abs() <= 2.0 ** -6 * b.abs().clamp_min(1e-3)).all()    # two bf16 roundings of a round trip
+        # the round trip mixes a channel with its rotation partner: its bf16 roundings scale with the pair's norm
+        pair = (b[..., : D // 2] ** 2 + b[..., D // 2:] ** 2).sqrt()
+        assert ((a - b).abs() <= 2.0 ** -5 * torch.cat((pair, pair), -1).clamp_min(1e-3)).all()
     assert cache.last_scores is None
 
 
@@ -279,8 +281,9 @@ def test_prologue_declines_what_it_cannot_serve():
 
 def test_qwen_attention_patch_takes_the_prologue():
     """The patched Qwen2-VL SDPA attention on a stand-in module (projections + rotary), two chunks of 640 tokens and a
-    reforging PivotKV cache: the fused prologue route and the op-by-op route (one_call_update off) give the same
-    attention output to bf16 rounding noise and the same cache ids / values."""
+    reforging PivotKV cache, fp32 (the parity dtype: kept sets are decided by margins far above the arithmetic's noise):
+    the fused prologue route and the op-by-op route (one_call_update off) give the same attention output and the same
+    cache - ids and values exactly, keys to the 1e-5 bar."""
     import retake.longvideo_cache as lc
     import retake.qwen2_vl as rq
 
@@ -300,12 +303,12 @@ def test_qwen_attention_patch_takes_the_prologue():
             self.attention_dropout, self.layer_idx, self.is_causal = 0.0, 0, True
             self.rotary_emb = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
 
-    attn = Attn().to(dev()).to(torch.bfloat16)
+    attn = Attn().to(dev())
     caches = [lc.build_kvcache(cfg(1)), lc.build_kvcache(cfg(1, one_call_update=False))]
     outs = [[], []]
     with torch.no_grad():
         for c in range(2):
-            x = torch.randn((1, L, hidden), device=dev(), dtype=torch.bfloat16) * 0.5
+            x = torch.randn((1, L, hidden), device=dev()) * 0.5
             for i, cache in enumerate(caches):
                 cache.kvcache_compression = True
                 cache.before_forward()
@@ -315,9 +318,10 @@ def test_qwen_attention_patch_takes_the_prologue():
                 outs[i].append(y.float())
     assert caches[0]._batch.c_pending == 0 and caches[0]._layers[0].length == 2 * (L // 4)
     for a, b in zip(*outs):
-        assert (a - b).abs().max().item() <= 0.05 * b.abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
     assert torch.equal(caches[0].position_cache[0], caches[1].position_cache[0])
     assert torch.equal(caches[0].value_cache[0], caches[1].value_cache[0])
+    assert (caches[0].key_cache[0] - caches[1].key_cache[0]).abs().max().item() <= 1e-5
 
 
 def test_layer_state_block_tracks_the_store():

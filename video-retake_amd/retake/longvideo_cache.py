@@ -1111,7 +1111,8 @@ class PivotKVCache(DynamicCache):
         L = key_states.shape[2]
         b = self._batch
         hit = self._rotaries.get(id(rotary_emb))
-        if b is None or b.L != L or hit is None or hit[0] is not rotary_emb or hit[1] is None or hit[1] is not b.rot \
+        if b is None or b.L != L or not b.c_capable or hit is None or hit[0] is not rotary_emb or hit[1] is None \
+                or hit[1] is not b.rot \
                 or layer_idx >= b.slots or layer_idx >= len(self._layers) \
                 or self._layers[layer_idx].c.length + L > self._layers[layer_idx].c.cap:
             # not the steady state: find / build the batch of this geometry, bind the rotary, make room
