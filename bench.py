@@ -88,6 +88,9 @@ def parse():
                          "(reported under 'overlap'; 0 = skip)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "p2p"],
                     help="N > 1: torch.distributed collectives over RCCL, or the direct peer-to-peer pushes of retake/p2p.py")
+    ap.add_argument("--pre-rope", action="store_true",
+                    help="measure the attention patch's fused prologue instead (PivotKVCache.update_pre_rope on pre-RoPE "
+                         "projections in the projection layout); not the contract line")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-check", action="store_true")
@@ -181,8 +184,9 @@ def cache_checksum(keys, values, pos):
 def run_video(frames, pool, masks, pos_base, rotary, layers, tdtype, pre_rope=False):
     """One step on one GPU: DPSelect + all (chunk, layer) PivotKV updates.  Returns retained tokens.
     pre_rope: the pool holds PRE-RoPE projections and every update is the attention patch's fused prologue
-    (PivotKVCache.update_pre_rope: continuity shift + RoPE of q / k + append + scoring operands in one kernel; the
-    rotated queries overwrite the pool's q, as they overwrite q_proj's output in the model)."""
+    (PivotKVCache.update_pre_rope: continuity shift + RoPE of q / k + append + scoring operands in one kernel).  In the
+    model the rotated queries overwrite q_proj's fresh output; the pool's tensors are reused, so here they go to a
+    scratch tensor of the same layout instead (rotating in place would scale a set by attention_scaling per use)."""
     import retake.longvideo_cache as lc
     import retake.visual_compression as vc
 
@@ -194,6 +198,7 @@ def run_video(frames, pool, masks, pos_base, rotary, layers, tdtype, pre_rope=Fa
     cache = lc.build_kvcache(make_cache_config(layers), reserve_tokens=n_chunks * max(1, int(RATIO * L)) + L)
     retained = 0
     call = 0
+    q_rot = torch.empty_like(pool[0][0]) if pre_rope else None
     for c in range(n_chunks):
         cache.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
         cache.kvcache_compression = True
@@ -202,7 +207,7 @@ def run_video(frames, pool, masks, pos_base, rotary, layers, tdtype, pre_rope=Fa
             q, k, v = pool[call % len(pool)]
             call += 1
             if pre_rope:
-                if cache.update_pre_rope(q, k, v, layer, pos, rotary, MROPE) is None:
+                if cache.update_pre_rope(q, k, v, layer, pos, rotary, MROPE, query_out=q_rot) is None:
                     raise RuntimeError("update_pre_rope declined a video chunk of the benchmark geometry")
                 continue
             # what the attention patch does (qwen2_vl.py:68-73): the ids tensor is shared by the layers of
@@ -481,13 +486,16 @@ def main():
     L = FRAMES_PER_CHUNK * N_PATCH
     n_chunks = T // FRAMES_PER_CHUNK
     frames = torch.cat([chunk_frames(c, dev, tdtype) for c in range(n_chunks)])[None]
-    pool = [pool_set(i, dev, tdtype) for i in range(min(args.pool, n_chunks * args.layers))]
+    pool = [pool_set(i, dev, tdtype, projection_layout=args.pre_rope) for i in range(min(args.pool, n_chunks * args.layers))]
     pos_base = [chunk_position_ids(c, dev) for c in range(n_chunks)]
     rotary = Rotary(dev)
     masks = None
+    if args.pre_rope:
+        args.no_self_check = True   # the self-check replays rotated inputs through one-unit launches
+        args.no_extras = True
 
     for _ in range(args.warmup):
-        run_video(frames, pool, masks, pos_base, rotary, args.layers, tdtype)
+        run_video(frames, pool, masks, pos_base, rotary, args.layers, tdtype, args.pre_rope)
     torch.cuda.synchronize()
     # HIP events bracket the dominant kernels (the two score passes) on their launch streams INSIDE the timed
     # region; timing every small kernel as well costs ~9 % of wall time, so the full per-kernel table comes
@@ -501,7 +509,7 @@ def main():
     t0 = time.perf_counter()
     retained = 0
     for _ in range(args.steps):
-        r, cache, kp_mask = run_video(frames, pool, masks, pos_base, rotary, args.layers, tdtype)
+        r, cache, kp_mask = run_video(frames, pool, masks, pos_base, rotary, args.layers, tdtype, args.pre_rope)
         retained += r
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -520,7 +528,7 @@ def main():
         OVERLAP_STREAMS = 0
         nv.check(nv.lib.rtk_profile_reset(), "profile_reset")
         nv.check(nv.lib.rtk_profile_enable(1), "profile_enable")
-        run_video(frames[:, : min(T, 64 * FRAMES_PER_CHUNK)], pool, masks, pos_base, rotary, args.layers, tdtype)
+        run_video(frames[:, : min(T, 64 * FRAMES_PER_CHUNK)], pool, masks, pos_base, rotary, args.layers, tdtype, args.pre_rope)
         torch.cuda.synchronize()
         dp_names = ("dpselect_dis", "dpselect_select", "gather_frames")
         prof_all = {k: v for k, v in nv.profile_read().items() if k not in dp_names}
@@ -547,8 +555,9 @@ def main():
                    "geometry": args.geometry, "score_rounding": args.score_rounding,
                    "cache_kwargs": cache_kwargs(),
                    "native_rope": "product default: on for inv_freq rotary modules (no config key set)",
-                   "update_call": "PivotKVCache.update (rotated q / k, the reference's cache_kwargs protocol) after "
-                                  "shift_temporal_ids_, as the attention patch calls them",
+                   "update_call": ("PivotKVCache.update_pre_rope (pre-RoPE projections, projection layout)" if args.pre_rope else
+                                   "PivotKVCache.update (rotated q / k, the reference's cache_kwargs protocol) after "
+                                   "shift_temporal_ids_, as the attention patch calls them"),
                    "frames": args.frames, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L, "keep": int(RATIO * L),
                    "input_pool_sets": len(pool), "worker_streams": args.streams, "parallelism": "1 GPU"},
     }
@@ -664,7 +673,7 @@ def main():
         out["pre_rope_prologue"] = {
             "note": "PivotKVCache.update_pre_rope: continuity shift + rotary tables + RoPE of q / k + cache append + "
                     "scoring operands in ONE kernel per update (replaces position_shift + HF's eager RoPE ops + "
-                    "prepare); the rotated queries overwrite the pool's q like they overwrite q_proj's output",
+                    "prepare); the rotated queries go to a scratch tensor of the projection layout",
             "real_geometry": companion_measurement(dev, args.frames, args.layers, "bf16", 2, 1, args.pool,
                                                    geometry="qwen448", pre_rope=True, time_all_kernels=True),
             "baseline_geometry": companion_measurement(dev, args.frames, args.layers, "bf16", 2, 1, args.pool,

@@ -139,10 +139,12 @@ def test_prologue_outputs_bitwise(dtype, mrope):
             prev = cache.get_prev_temporal_idx(l)
             prev = int(prev) if not isinstance(prev, int) else prev
             P0 = cache.get_seq_length(l)
-            out = cache.update_pre_rope(q0, k0, v0, l, pos, rot, sec, shift_ids_in_place=mrope)
+            qo = torch.empty_like(q0) if l == 1 else None     # layer 1: rotated queries to a tensor of their own
+            out = cache.update_pre_rope(q0, k0, v0, l, pos, rot, sec, shift_ids_in_place=mrope, query_out=qo)
             assert out is not None, "the prologue declined a plain video chunk"
             q_rot, K, V = out
-            assert q_rot.data_ptr() == q0.data_ptr() and K.shape[2] == P0 + L
+            assert q_rot.data_ptr() == (q0 if qo is None else qo).data_ptr() and K.shape[2] == P0 + L
+            assert qo is None or torch.equal(q0, q_keep)
             want_ids = pos_in.clone()
             if mrope:
                 want_ids[0, 0] += prev + 1 - want_ids[0, 0, 0]

@@ -997,7 +997,7 @@ class PivotKVCache(DynamicCache):
                 return out
         return self._update_general(key_states, value_states, layer_idx, cache_kwargs)
 
-    def _update_c(self, b: _Batch, key_states, value_states, layer_idx, ck, q0, shift_ids_in_place=True):
+    def _update_c(self, b: _Batch, key_states, value_states, layer_idx, ck, q0, shift_ids_in_place=True, q_out=None):
         """One rtk_pivotkv_update call.  q0 None: `ck["query_states"]` / key_states are rotated (the reference's
         protocol); else q0 / key_states are the pre-RoPE projections and the rotated queries are written over q0.
         Returns None - having changed nothing - when the call does not fit the batch."""
@@ -1053,7 +1053,11 @@ class PivotKVCache(DynamicCache):
         io.v, io.v_stride_h, io.v_stride_l = value_states.data_ptr(), vs[1], vs[2]
         io.pos, io.pos_stride = pos.data_ptr(), pos.stride(0)
         if pre:
-            io.q_rot, io.qr_stride_h, io.qr_stride_l, io.flags = io.q, qs[1], qs[2], nv.RTK_UPDATE_PRE_ROPE
+            if q_out is None:
+                io.q_rot, io.qr_stride_h, io.qr_stride_l, io.flags = io.q, qs[1], qs[2], nv.RTK_UPDATE_PRE_ROPE
+            else:
+                io.q_rot, io.qr_stride_h, io.qr_stride_l = q_out.data_ptr(), q_out.stride(1), q_out.stride(2)
+                io.flags = nv.RTK_UPDATE_PRE_ROPE
         else:
             io.q_rot, io.flags = None, 0
         c.mask = mptr
@@ -1094,7 +1098,7 @@ class PivotKVCache(DynamicCache):
         return st._k.narrow(2, 0, n), st._v.narrow(2, 0, n)
 
     def update_pre_rope(self, query_states, key_states, value_states, layer_idx, position_ids, rotary_emb,
-                        mrope_section=None, shift_ids_in_place=True):
+                        mrope_section=None, shift_ids_in_place=True, query_out=None):
         """The attention patch's whole prologue as ONE kernel (not in the reference: there it is the continuity shift,
         the rotary module, apply_multimodal_rotary_pos_emb and PivotKVCache.update, qwen2_vl.py:68-86 + :217-259).
         query_states [1, Hq, L, D], key_states / value_states [1, Hkv, L, D] are the PRE-RoPE projections of a video
@@ -1103,7 +1107,9 @@ class PivotKVCache(DynamicCache):
         geometry, text segments, score_rounding="reference", rotary modules that must be called, small chunks).
         shift_ids_in_place: the Qwen2-VL patch shifts the ids tensor it was handed (qwen2_vl.py:73; done here by the
         chunk's flush, with the last layer's rule - what the reference's layer loop leaves behind); the LLaVA patch
-        shifts a private clone (llava_onevision.py:76-88), i.e. leaves the caller's tensor alone."""
+        shifts a private clone (llava_onevision.py:76-88), i.e. leaves the caller's tensor alone.
+        query_out: where the rotated queries go instead of over `query_states` (same shape and dtype, head_dim
+        contiguous); it is then the first element of the returned tuple."""
         if not (self.kvcache_compression and self.pos_embed_reforge and self.one_call_update) or self.overlap_streams > 0 \
                 or position_ids is None or not key_states.is_cuda or key_states.shape[0] != 1 \
                 or (torch.is_grad_enabled() and query_states.requires_grad):
@@ -1131,10 +1137,13 @@ class PivotKVCache(DynamicCache):
             b.x_like = value_states[:, :, :1]
             self.reserve(layer_idx, L, key_states)
         ck = {"position_ids": position_ids, "rotary_emb": rotary_emb, "mrope_section": mrope_section}
-        out = self._update_c(b, key_states, value_states, layer_idx, ck, query_states, shift_ids_in_place)
+        if query_out is not None and (query_out.shape != query_states.shape or query_out.dtype is not query_states.dtype
+                                      or query_out.device != query_states.device or query_out.stride(-1) != 1):
+            raise ValueError("query_out must match query_states in shape, dtype and device, with a contiguous head_dim")
+        out = self._update_c(b, key_states, value_states, layer_idx, ck, query_states, shift_ids_in_place, query_out)
         if out is None:
             return None
-        return query_states, out[0], out[1]
+        return (query_states if query_out is None else query_out), out[0], out[1]
 
     def _bind_rotary(self, b: _Batch, rotary_emb_fn, mrope_section, rot: Optional[_Rotary]):
         """The rotary module / M-RoPE sections the batch's pending units were (and its next units will be) rotated
