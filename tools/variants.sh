@@ -6,11 +6,11 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=${RTK_SRC:-$ROOT/video-retake_amd/csrc}
 OUT=$ROOT/video-retake_amd/retake/_lib/variants
 mkdir -p $OUT
-BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$SRC -ffp-contract=on -fno-fast-math"
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$SRC -ffp-contract=on -fno-fast-math -mllvm -amdgpu-mfma-vgpr-form=1"
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   tmp=$(mktemp -d)
-  for f in api dpselect rope pivotkv_score pivotkv_evict p2p; do
+  for f in api dpselect rope pivotkv_score pivotkv_evict pivotkv_update p2p; do
     /opt/rocm/bin/hipcc $BASE $flags -c $SRC/$f.hip -o $tmp/$f.o &
   done
   wait

@@ -1830,7 +1830,7 @@ static bool bf16_rcp_is_exact(float a2) {
 struct ScoreWs {
     size_t q_off, k_off, lse_off, part_off, total;
     int RS, KS;
-    bool ref;   // RTK_BF16_REFROUND: row statistics are (max, sum) pairs, column partials are per head
+    bool ref;   // RTK_BF16_REFROUND: the reference's rounding chain; column partials are per head
     bool fast;  // RTK_BF16_FAST: q~ (pre-scaled) and a second copy of k~ (at k_off) are fp16
     bool h16;   // RTK_F16: fp16 payloads (un-rotation rounds to fp16, the passes use the fp16 matrix instruction)
 };
@@ -1868,7 +1868,7 @@ static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
     w.q_off = 0;
     w.k_off = al((size_t)Hq * L * D * es);
     w.lse_off = w.k_off + al((size_t)Hkv * L * D * es);
-    w.part_off = w.lse_off + al((size_t)(w.ref ? 2 : 1) * w.KS * Hq * L * 4);
+    w.part_off = w.lse_off + al((size_t)w.KS * Hq * L * 4);
     w.total = w.part_off + al((size_t)(w.ref ? Hq : Hkv) * w.RS * L * 4);
     return w;
 }
@@ -1966,8 +1966,8 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                 return RTK_EUNSUPPORTED;
             }
             constexpr int TILE_BYTES = Tile<DT>::BYTES;
-            constexpr int LDS1 = 2 * TILE_BYTES, LDS2 = 2 * TILE_BYTES + 4 * TILE_ROWS * (int)sizeof(float);
-            const int jt = (L + REG_ROWS - 1) / REG_ROWS;
+            constexpr int LDS1 = 2 * TILE_BYTES, LDS2 = 2 * TILE_BYTES + 2 * TILE_ROWS * (int)sizeof(float);
+            const int jt = (L + REG_ROWS * REF_NB - 1) / (REG_ROWS * REF_NB), jt2 = (L + REG_ROWS * REF_NB2 - 1) / (REG_ROWS * REF_NB2);
             auto per_split = [](int n, int parts) { return (((n + parts - 1) / parts + TILE_ROWS - 1) / TILE_ROWS) * TILE_ROWS; };
             const int kps = per_split(L, w.KS), rps = per_split(L, w.RS);
             const int ks_n = (L + kps - 1) / kps;
@@ -1975,19 +1975,24 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
             const float sqrt_d = (float)sqrt((double)HD);   // python: math.sqrt(self.head_dim), then an fp32 opmath scalar
             const bool rcp_ok = bf16_rcp_is_exact(sqrt_d);
             const float rcp_sd = 1.0f / sqrt_d;
-            float* stat = lse;
             if (stages & RTK_SCORE_PASSES) {
-                const dim3 g1(Hkv * ks_n * jt * G, n_units), g2(Hkv * rs_n * jt, n_units);
+                const int n_tiles = Hkv * ks_n * jt * G;
+                const dim3 g1(n_tiles, n_units), gf((n_tiles + FIX_TILES - 1) / FIX_TILES, n_units), g2(Hkv * rs_n * jt2, n_units);
                 const int x1 = (int)((Hkv * ks_n) % NXCD == 0), x2 = (int)((Hkv * rs_n) % NXCD == 0);
                 const size_t su = ws_stride / sizeof(float);
+                // raw row sums + the fix-up launch for rows whose sum left fp32's range, lse combine over key splits,
+                // then the column sums of the bf16 probabilities per head
 #define RTK_REF_PASSES(DIV)                                                                                              \
     RTK_LAUNCH(KID_PASS1, (score_pass1_ref_kernel<DIV>), g1, dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt,   \
-               Hq, Hkv, L, kps, jt, x1, w.KS, stat, ws_stride, k_stride, su, sqrt_d, rcp_sd);                              \
-    RTK_LAUNCH(KID_FINALIZE, stat_combine_ref_kernel, dim3((unsigned)(((size_t)Hq * L + 255) / 256), n_units), dim3(256), \
-               0, st, stat, (size_t)Hq * L, ks_n, w.KS, su);                                                               \
+               Hq, Hkv, L, kps, jt, x1, lse, ws_stride, k_stride, su, sqrt_d, rcp_sd);                                     \
+    RTK_LAUNCH(KID_FINALIZE, (score_pass1_ref_fixup_kernel<DIV>), gf, dim3(SC_BLOCK), LDS1, st, (const char*)qt,           \
+               (const char*)kt, Hq, Hkv, L, kps, jt, n_tiles, lse, ws_stride, k_stride, su, sqrt_d, rcp_sd);               \
+    if (ks_n > 1)                                                                                                        \
+        RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<RTK_BF16>, dim3((unsigned)(((size_t)Hq * L + 255) / 256), n_units),    \
+                   dim3(256), 0, st, lse, (size_t)Hq * L, ks_n, su, 0);                                                    \
     RTK_LAUNCH(KID_PASS2, (score_pass2_ref_kernel<DIV>), g2, dim3(SC_BLOCK), LDS2, st, (const char*)qt, (const char*)kt,   \
-               (const float*)stat, Hq, Hkv, L, rps, jt, rs_n, x2, w.KS, part, ws_stride, k_stride, su, part_stride,        \
-               sqrt_d, rcp_sd, key_index)
+               (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n, x2, part, ws_stride, k_stride, su, part_stride, sqrt_d,      \
+               rcp_sd, key_index)
                 if (rcp_ok) { RTK_REF_PASSES(1); } else { RTK_REF_PASSES(2); }
 #undef RTK_REF_PASSES
                 RTK_LAUNCH_CHECK("score_ref_passes");

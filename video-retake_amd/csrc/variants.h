@@ -34,3 +34,9 @@
 #ifndef RTK_PREP_YSPLIT   // fused prepare kernel: the query heads are split over this many workgroups per token range (>= 2: k and v go to the first and the last)
 #define RTK_PREP_YSPLIT 2
 #endif
+#ifndef RTK_REF_P1_NB     // reference-rounding pass 1: 32-row register blocks per wave (1: 4 waves per SIMD, 2: 3)
+#define RTK_REF_P1_NB 2
+#endif
+#ifndef RTK_REF_P2_NB     // reference-rounding pass 2: 32-key register blocks per wave
+#define RTK_REF_P2_NB 1
+#endif
