@@ -131,6 +131,16 @@ int rtk_mallm_argmax(const float* cos, int T1, int N, int sync, int round_bf16, 
 int rtk_mallm_merge(const void* x, const void* sizes, const int64_t* idx, int T, int N, int C, int dtype,
                     int hard, void* out, void* sizes_out, rtk_stream_t stream);
 
+/* MA-LLM-hard run to its target length in one call (the reference loops the single step, qwen2_vl.py:406-408: one
+ * full pass over the bank per dropped frame).  A hard merge only drops the first frame of the most similar pair, so
+ * every other adjacent cosine of the next step is the one already computed: per step ONE new pair is scored (at every
+ * patch position when sync) with rtk_adjacent_cosine's arithmetic, bit for bit.  x [T,N,C] -> the surviving frame
+ * indices, ascending: async idx [tgt,N] int64 (column n = patch n), sync idx [tgt]; gather the rows with
+ * rtk_gather_frames (sync flag alike).  cos_ws: [T-1,N] fp32 scratch.  RTK_EUNSUPPORTED for rows that are not 16-byte
+ * vectors or T beyond the LDS-resident frame list (~12 000): loop the single step. */
+int rtk_mallm_hard_chain(const void* x, int T, int N, int C, int dtype, int tgt, int sync, float* cos_ws,
+                         int64_t* idx_out, rtk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * RoPE tables — replaces longvideo_cache.py:68-74 (M-RoPE section merge) and, optionally, the
  * rotary_emb_fn(...) calls at :249 and :298 when the rotary module is the standard

@@ -344,3 +344,66 @@ def test_layer_state_block_tracks_the_store():
         assert st.pending == 0 and st.length == (c + 1) * (L // 4) == st.pos_len and st.c.mask is None
     cache.key_cache[0] = cache.key_cache[0][:, :, ::2]      # an external writer hands over a strided view
     assert cache._layers[0].c.cap == 0                       # ... which the library must not touch
+
+
+# ---------------------------------------------------------------------------------------------------
+# MA-LLM-hard in one pass (rtk_mallm_hard_chain) against the reference's loop of single steps
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sync", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("T,N,C,tgt", [(24, 5, 64, 11), (96, 7, 1280, 40), (64, 3, 1152, 1), (33, 4, 256, 32),
+                                       (160, 12, 3584, 80)])
+def test_mallm_hard_chain_equals_the_loop_of_steps(T, N, C, tgt, dtype, sync):
+    """memory_bank_compress_MALLM_hard_to == `while T > tgt: bank = memory_bank_compress_MALLM_hard(bank)` bit for bit:
+    the same frames dropped in the same order (visual_compression.py:50-83 looped as qwen2_vl.py:406-408)."""
+    import retake.visual_compression as vc
+
+    x = torch.from_numpy(synth.frames_video(T + N + C, T, N, C)).to(dev()).to(dtype)
+    bank = x
+    while bank.shape[1] > tgt:
+        bank = vc.memory_bank_compress_MALLM_hard(bank, sync=sync)
+    got = vc.memory_bank_compress_MALLM_hard_to(x, tgt, sync=sync)
+    assert got.shape == bank.shape == (1, tgt, N, C) and got.dtype == dtype
+    assert torch.equal(got, bank)
+    assert vc.memory_bank_compress_MALLM_hard_to(x, T, sync=sync) is x      # nothing to drop
+
+
+def test_mallm_hard_chain_reference_fixtures():
+    """The reference's own MA-LLM-hard loops (fixtures recorded from the imported reference): the one-pass form drops
+    the same frames - the outputs are pure frame copies, so fp32 banks are bit-equal to the reference's."""
+    import golden_util as gu
+    import retake.visual_compression as vc
+
+    seen = 0
+    for name in gu.names("mallm_hard_") + gu.names("fp16mallm_hard_"):
+        g = gu.load(name)
+        dt = str(g["dtype"]) if "dtype" in g.files else "fp16"
+        x = g["x"]
+        if dt == "bf16":
+            xt = torch.from_numpy(x.view(np.int16)).to(dev()).view(torch.bfloat16)
+        elif name.startswith("fp16"):
+            xt = torch.from_numpy(x).to(dev()).view(torch.float16)
+        else:
+            xt = torch.from_numpy(x).to(dev())
+        out = vc.memory_bank_compress_MALLM_hard_to(xt, int(g["tgt"]), sync=bool(g["sync"]))
+        loop = xt
+        while loop.shape[1] > int(g["tgt"]):
+            loop = vc.memory_bank_compress_MALLM_hard(loop, sync=bool(g["sync"]))
+        assert torch.equal(out, loop), name
+        if xt.dtype == torch.float32:
+            np.testing.assert_array_equal(out.cpu().numpy(), g["out"])
+        seen += 1
+    assert seen >= 3
+
+
+def test_compress_memory_bank_dispatches_the_chain():
+    """qwen2_vl._compress_memory_bank('MA-LLM-hard') on the GPU = the reference's while loop (:402-410)."""
+    import retake.qwen2_vl as rq
+    import retake.visual_compression as vc
+
+    x = torch.from_numpy(synth.frames_video(5, 48, 6, 128)).to(dev()).bfloat16()
+    got, mask = rq._compress_memory_bank(x, 20, "MA-LLM-hard", False, True)
+    loop = x
+    while loop.shape[1] > 20:
+        loop = vc.memory_bank_compress_MALLM_hard(loop, sync=False)
+    assert mask is None and torch.equal(got, loop)

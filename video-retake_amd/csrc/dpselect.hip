@@ -6,6 +6,7 @@
 // coalesced loads, keeps the previous frame's normalised row in registers, and reduces with wave
 // shuffles.  The gather moves 2*t*N*C*sizeof(elem).  MFMA is not used: ~1 flop per byte.
 #include "common.cuh"
+#include "dprow.cuh"
 #include "select.cuh"
 
 namespace rtk {
@@ -13,62 +14,6 @@ namespace rtk {
 // ------------------------------------------------------------------------------------------------
 // K1-K2: distance.  One wave walks `strip` consecutive frames of one patch position.
 // ------------------------------------------------------------------------------------------------
-template <int DT> struct Elem;
-template <> struct Elem<RTK_F32> {
-    static constexpr int PER_VEC = 4;
-    using vec_t = float4;
-    __device__ static void unpack(const vec_t& v, float* f) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
-};
-template <> struct Elem<RTK_BF16> {
-    static constexpr int PER_VEC = 8;
-    using vec_t = u32x4;
-    __device__ static void unpack(const vec_t& v, float* f) {
-        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
-    }
-};
-
-template <> struct Elem<RTK_F16> {
-    static constexpr int PER_VEC = 8;
-    using vec_t = u32x4;
-    __device__ static void unpack(const vec_t& v, float* f) {
-        f[0] = H16<RTK_F16>::lo(v.x); f[1] = H16<RTK_F16>::hi(v.x); f[2] = H16<RTK_F16>::lo(v.y); f[3] = H16<RTK_F16>::hi(v.y);
-        f[4] = H16<RTK_F16>::lo(v.z); f[5] = H16<RTK_F16>::hi(v.z); f[6] = H16<RTK_F16>::lo(v.w); f[7] = H16<RTK_F16>::hi(v.w);
-    }
-};
-
-using bf16x2_dp = __attribute__((ext_vector_type(2))) __bf16;
-using f32x2_dp = __attribute__((ext_vector_type(2))) float;
-__device__ __forceinline__ uint32_t pack2_bf16_dp(float lo, float hi) {   // v_cvt_pk_bf16_f32
-    const f32x2_dp v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_dp));
-}
-
-// acc + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs (v_dot2c_f32_bf16): products of bf16 are exact in fp32
-__device__ __forceinline__ float dot2_bf16_dp(uint32_t a, uint32_t b, float acc) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_dp, a), __builtin_bit_cast(bf16x2_dp, b), acc, false);
-}
-
-// Sum over the 64 lanes, returned wave-uniform (read from lane 63).  Six DPP adds on the VALU instead of six
-// ds_bpermute round trips through the LDS crossbar: xor-1 and xor-2 inside quads, the two mirrors for 8 and 16
-// lanes, then row_bcast:15 / row_bcast:31 carry the row sums up to the last row.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    // lanes of rows outside ROW_MASK, and lanes whose DPP source is invalid, add 0 (old = 0, bound_ctrl off)
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-__device__ __forceinline__ float wave_sum_uniform(float v) {
-    v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
-    v = dpp_add<0x140, 0xf>(v);   // row_mirror        -> every lane holds its 16-lane row sum
-    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
 // VPL = 16-byte vectors per lane; a row has nvec = C / PER_VEC vectors, lane owns vec k*64+lane.  One wave walks
 // `strip` (<= 64) consecutive frames of one patch position; the strip's results stay in a register (lane i holds
 // row i) and are stored once at the end, and every load in the loop is unconditional (clamped addresses) so that

@@ -97,6 +97,7 @@ _SIGNATURES = {
     "rtk_adjacent_cosine": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rtk_mallm_argmax": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rtk_mallm_merge": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rtk_mallm_hard_chain": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "rtk_rope_merge": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "rtk_rope_table": (C.c_int, [_vp, _i64, _i, _i, _vp, _i, _f, _vp, _i, _i, _vp, _vp, _vp]),
     "rtk_rope_shift": (C.c_int, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),

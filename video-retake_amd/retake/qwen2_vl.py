@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import _prefill
 from .longvideo_cache import apply_multimodal_rotary_pos_emb, build_kvcache, repeat_kv
 from .visual_compression import (memory_bank_compress_keyframe, memory_bank_compress_MALLM,
-                                 memory_bank_compress_MALLM_hard)
+                                 memory_bank_compress_MALLM_hard, memory_bank_compress_MALLM_hard_to)
 
 DEBUG_MODE = False
 
@@ -195,6 +195,8 @@ def _compress_memory_bank(bank, tgt_len, method, patch_sync, return_mask):
             bank, size = memory_bank_compress_MALLM(bank, size, sync=patch_sync)
         return bank, None
     if method == "MA-LLM-hard":
+        if bank.is_cuda:   # the reference's loop of single steps (:406-408) in one pass over the bank, same values
+            return memory_bank_compress_MALLM_hard_to(bank, tgt_len, sync=patch_sync), None
         while bank.shape[1] > tgt_len:
             bank = memory_bank_compress_MALLM_hard(bank, sync=patch_sync)
         return bank, None

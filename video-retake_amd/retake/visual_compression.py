@@ -15,7 +15,7 @@ import torch
 from . import _native as nv
 
 __all__ = ["memory_bank_compress_keyframe", "memory_bank_compress_MALLM", "memory_bank_compress_MALLM_hard",
-           "dpselect_stages"]
+           "memory_bank_compress_MALLM_hard_to", "dpselect_stages"]
 
 
 def dpselect_stages(memory_bank: torch.Tensor, tgt_mem_len: int, window_size: int = 3, sync: bool = True):
@@ -120,3 +120,40 @@ def memory_bank_compress_MALLM_hard(memory_bank: torch.Tensor, sync: bool = Fals
     """MA-LLM-hard merge step (reference: visual_compression.py:50-83): the first frame of the most similar
     adjacent pair is replaced by the second.  Returns compressed_memory_bank [B,T-1,N,C]."""
     return _mallm_step(memory_bank, None, sync, hard=True)[0]
+
+
+def memory_bank_compress_MALLM_hard_to(memory_bank: torch.Tensor, tgt_mem_len: int, sync: bool = False) -> torch.Tensor:
+    """`while bank.shape[1] > tgt: bank = memory_bank_compress_MALLM_hard(bank, sync)` (the reference's loop,
+    qwen2_vl.py:406-408) in one pass over the bank: rtk_mallm_hard_chain finds the surviving frames - per step the only
+    new adjacent cosine is the pair that closes over the dropped frame - and rtk_gather_frames copies them.  Same
+    values as the loop, bit for bit; shapes the chain does not serve (odd row sizes, T beyond ~12 000) take the loop."""
+    if memory_bank.ndim != 4:
+        raise ValueError(f"memory_bank must be [B,T,N,C], got {tuple(memory_bank.shape)}")
+    B, T, N, Cc = memory_bank.shape
+    tgt = int(tgt_mem_len)
+    if T <= tgt:
+        return memory_bank
+    nv.require_device(memory_bank)
+    dev, dt = memory_bank.device, nv.dtype_code(memory_bank)
+    if tgt >= 1:
+        out = torch.empty((B, tgt, N, Cc), dtype=memory_bank.dtype, device=dev)
+        with torch.cuda.device(dev):
+            st = nv.stream()
+            cosv = torch.empty((T - 1, N), dtype=torch.float32, device=dev)
+            idx = torch.empty((tgt,) if sync else (tgt, N), dtype=torch.int64, device=dev)
+            ok = True
+            for b in range(B):  # batched in the reference; the callers pass B = 1
+                x = memory_bank[b] if memory_bank[b].is_contiguous() else memory_bank[b].contiguous()
+                rc = nv.lib.rtk_mallm_hard_chain(nv.ptr(x), T, N, Cc, dt, tgt, int(bool(sync)), nv.ptr(cosv), nv.ptr(idx), st)
+                if rc == nv.RTK_EUNSUPPORTED:
+                    ok = False
+                    break
+                nv.check(rc, "rtk_mallm_hard_chain")
+                nv.check(nv.lib.rtk_gather_frames(nv.ptr(x), T, N, Cc, dt, nv.ptr(idx), tgt, int(bool(sync)), nv.ptr(out[b]),
+                                                  st), "rtk_gather_frames")
+            if ok:
+                return out
+    bank = memory_bank
+    while bank.shape[1] > tgt:
+        bank = memory_bank_compress_MALLM_hard(bank, sync=sync)
+    return bank
