@@ -161,6 +161,14 @@ int rtk_rope_table(const int64_t* pos, int64_t pos_stride, int P, int L, const f
                    const int* sections_host, int nsec, int round_bf16, float* cos_out, float* sin_out,
                    rtk_stream_t stream);
 
+/* Forward rotation in place of UN-rotated key rows at given ids (longvideo_cache.py:297-306 for rows whose re-rotation
+ * was deferred, see rtk_pivotkv_batch.defer_rot): k [layers, H, rows, D] (element strides stride_layer, stride_h; rows
+ * contiguous), ids of layer l at pos + l*pos_stride_layer, row p of them at + p*pos_stride_p (P = 1 or 3).
+ * k' = (k*cos) + (rotate_half(k)*sin), the tables and roundings of rtk_pivotkv_evict_batched_rope, bit for bit. */
+int rtk_rope_rotate_rows(void* k, int64_t stride_layer, int64_t stride_h, int layers, int H, int rows, int D, int dtype,
+                         const int64_t* pos, int64_t pos_stride_layer, int64_t pos_stride_p, int P, const float* inv_freq,
+                         float attention_scaling, const int* sections_host, int nsec, int round_mode, rtk_stream_t stream);
+
 /* In-place k <- R(delta) k on the temporal channels (position row 0; every channel when P = 1) of keys
  * that are already rotated: k [H, n, D] with head stride `stride_h`, delta = one int64 in device
  * memory.  Used by the multi-GPU sharding (retake/sharded.py): ranks compress their chunks at
@@ -380,7 +388,9 @@ typedef struct rtk_evict_unit {
  * position ids: copy.  `units` is a HOST array. */
 int rtk_pivotkv_evict_batched(const rtk_evict_unit* units, int n_units, int Hkv, int D, int keep, int P,
                               int dtype, int stage_low_only, rtk_stream_t stream);
-/* stage_low_only != 0 (what PivotKVCache uses, together with rtk_pivotkv_place_batched): rows that are copied verbatim
+/* stage_low_only bit 1 (value 3 together with bit 0): K is copied verbatim from a buffer of its own (k_src is not the
+ * tail k_dst lies in - the un-rotated rows of a deferred re-rotation): EVERY kept K row is written to k_dst.
+ * stage_low_only != 0 (what PivotKVCache uses, together with rtk_pivotkv_place_batched): rows that are copied verbatim
  * (V; K when there are no tables) are written to k_dst / v_dst ONLY when keep_idx[r] < keep, i.e. when their source
  * lies inside the destination range of the compaction and has to be parked; the other rows are moved in place by
  * rtk_pivotkv_place_batched.  Re-rotated K rows are always written. */
@@ -465,7 +475,10 @@ typedef struct rtk_pivotkv_batch {
     int32_t rs_n;             /* row splits of the column partials (rtk_pivotkv_score_partials) */
     int32_t skip_masked;      /* pass 2 on the unmasked keys only */
     float attention_scaling;
-    int32_t pad0;
+    int32_t defer_rot;        /* pos_embed_reforge with the re-rotation of the kept keys deferred: the flush copies the
+                                 UN-rotated kept rows into the cache and their ids into the position cache; the owner
+                                 rotates them once, at their final ids, with rtk_rope_rotate_rows (chunk-sharded prefill:
+                                 a block's temporal offset is known only when the blocks before it are done) */
     const float* inv_freq;    /* [D/2] fp32 */
     void* score_ws;           /* slot s at score_ws + s*score_ws_stride (256-byte aligned): q~, lse, ... */
     uint64_t score_ws_stride, score_ws_bytes;

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Multi-rank GPU check of the chunk-sharded path, launched by tests/test_hip_parity.py::test_sharded_multi_rank_rccl as
     python -m torch.distributed.run --nproc-per-node W --master-addr 127.0.0.1 --master-port P tests/mp_sharded_gpu.py
-Every rank compresses its block of one small synthetic video (bench.py's deterministic tensors taken as pre-RoPE
-contents, rotated at the ids each run really uses - a block's provisional ids differ from the sequential run's) through
-retake.sharded.sharded_video_step - RCCL all-gathers of the distance rows, the temporal offsets and the compressed cache -
-and compares the assembled cache with the cache the same rank builds sequentially on its own: ids and V exact, K within
-3e-6 of the largest key (fp32).  Two shapes: chunks divisible by the world size (per-chunk overlapped gathers) and one chunk more (ragged
-blocks, padded assembly at the end).  Prints MP_SHARDED_OK on rank 0.
+Every rank compresses its block of one small synthetic video (bench.py's deterministic tensors as the pre-RoPE
+projections, through the attention prologue at the block's provisional ids) with retake.sharded.sharded_video_step - RCCL
+all-gathers of the distance rows, the temporal offsets and the compressed cache - and compares the assembled cache with
+the cache the same rank builds sequentially on its own: ids, V and K bit patterns equal, in fp32 and in bf16.  Two shapes
+per dtype: chunks divisible by the world size (per-chunk overlapped gathers) and one chunk more (ragged blocks, padded
+assembly at the end).  Prints MP_SHARDED_OK on rank 0.
 
 RETAKE_TEST_TRANSPORT=p2p runs the same check over the direct peer-to-peer pushes of retake/p2p.py with a gloo control
 plane and rank r on GPU r % device_count - two ranks can then share the one GPU of a test box (RCCL refuses that) - and
@@ -41,7 +41,7 @@ def main():
     counts = (2 * world, 2 * world + 1) + ((2 * world, 2 * world, 2 * world) if p2p else ())
     res = sharded.verify_sharded_equals_sequential(rank, world, dev, B.Rotary(dev), layers=2, chunk_counts=counts,
                                                    state={}, log=lambda m: print(m, flush=True))
-    assert res["equal"] and len(res["cases"]) == len(counts)
+    assert res["equal"] and len(res["cases"]) == 2 * len(counts) and {c["dtype"] for c in res["cases"]} == {"fp32", "bf16"}
     if p2p:
         sharded.disable_p2p()
     dist.destroy_process_group()

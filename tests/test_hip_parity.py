@@ -2288,7 +2288,7 @@ def test_bench_two_ranks_share_one_gpu_p2p():
     assert b["roofline"]["frac"] > 0 and b["cpu_baseline"] is None
     # the line carries its own proof: sharded == sequential was checked in process, over the same transport, before timing
     assert b["sharded_equals_sequential"] is True and b["p2p_world_size"] == 2
-    assert [c["chunks"] for c in b["sharded_check"]["cases"]] == [4, 5]
+    assert [(c["dtype"], c["chunks"]) for c in b["sharded_check"]["cases"]] == [("fp32", 4), ("fp32", 5), ("bf16", 4), ("bf16", 5)]
 
 
 def test_bench_forced_sharded_world1_rccl_self_verifies():
@@ -2311,7 +2311,7 @@ def test_bench_forced_sharded_world1_rccl_self_verifies():
     assert sh.returncode == 0, (sh.stdout[-2000:], sh.stderr[-3000:])
     b = json.loads([ln for ln in sh.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert b["sharded_equals_sequential"] is True and b["rccl_world_size"] == 1
-    assert [c["chunks"] for c in b["sharded_check"]["cases"]] == [2, 3]
+    assert [(c["dtype"], c["chunks"]) for c in b["sharded_check"]["cases"]] == [("fp32", 2), ("fp32", 3), ("bf16", 2), ("bf16", 3)]
     for key in ("tokens_per_layer", "layers", "ids_sum", "v_bits_sum"):
         assert b["cache_checksum"][key] == a["cache_checksum"][key], (key, a["cache_checksum"], b["cache_checksum"])
     assert abs(b["cache_checksum"]["k_abs_sum"] - a["cache_checksum"]["k_abs_sum"]) <= 1e-6 * a["cache_checksum"]["k_abs_sum"]

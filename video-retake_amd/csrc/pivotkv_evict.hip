@@ -715,8 +715,10 @@ __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, in
     const bool reforge = (NATIVE || un.cos_new != nullptr) && kd != nullptr;
     // low_only: rows copied verbatim (V; K without reforge) are staged only when their source lies inside the
     // destination range [0, keep) of the tail they will overwrite; the others are moved in place by place_batched_kernel
-    const bool stage_row = !low_only || l < keep;
-    const bool copy_k = kd != nullptr && !reforge && stage_row, copy_rows = vd != nullptr && stage_row;
+    const bool stage_row = !(low_only & 1) || l < keep;
+    // low_only bit 1: K comes from a buffer of its own (the un-rotated copy of a deferred re-rotation), not from the
+    // tail it is written to: every kept K row is copied
+    const bool copy_k = kd != nullptr && !reforge && (stage_row || (low_only & 2)), copy_rows = vd != nullptr && stage_row;
     u32x4 k_lo[HU], k_hi[HU], v_lo[HU], v_hi[HU];
     auto load_batch = [&](int hb) {
 #pragma unroll

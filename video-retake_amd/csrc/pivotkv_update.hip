@@ -436,7 +436,8 @@ extern "C" int rtk_pivotkv_flush(rtk_pivotkv_batch* b, rtk_layer_state* const* l
             u.k_src = (char*)b->k_unrot + (size_t)l * Hkv * L * D * es;
             u.k_src_stride_h = (int64_t)L * D;
             // keep-all chunks of pre-RoPE units: new ids == old ids and k~ == k0, so the tail already holds the result
-            u.k_dst = (b->keep_all && b->pre_rope) ? nullptr : (char*)ls->k + tail;
+            // (not with a deferred re-rotation: the cache has to hold the UN-rotated rows)
+            u.k_dst = (b->keep_all && b->pre_rope && !b->defer_rot) ? nullptr : (char*)ls->k + tail;
             u.k_dst_stride_h = ls->cap * D;
         } else {
             u.k_src = (char*)ls->k + tail;
@@ -481,7 +482,9 @@ extern "C" int rtk_pivotkv_flush(rtk_pivotkv_batch* b, rtk_layer_state* const* l
             u.pos_src_stride = u.pos_dst_stride = 0;
         }
     }
-    if (reforge)
+    if (reforge && b->defer_rot)   // un-rotated kept rows + their (provisional) ids; the owner rotates once, later
+        rc = rtk_pivotkv_evict_batched(eu.data(), n, Hkv, D, keep, P, b->dtype, 3, stream);
+    else if (reforge)
         rc = rtk_pivotkv_evict_batched_rope(eu.data(), n, Hkv, D, keep, P, b->dtype, b->inv_freq, b->attention_scaling,
                                             b->nsec ? b->sections : nullptr, b->nsec, b->round_mode, 1, stream);
     else if (!b->keep_all)

@@ -126,6 +126,55 @@ __global__ __launch_bounds__(256) void rope_shift_segments_kernel(void* __restri
     }
 }
 
+// Forward rotation IN PLACE of un-rotated key rows at given ids: k[l][h][r] <- (k*cos) + (rotate_half(k)*sin) with the
+// cos / sin of ids[l][:, r] (longvideo_cache.py:297-306 for rows whose re-rotation was deferred: the chunk-sharded
+// prefill keeps the kept keys un-rotated until the blocks' temporal offsets are known and rotates ONCE at the final
+// ids).  Same arithmetic as the eviction kernel's re-rotation: rope_chunk tables, one rounding per torch op.
+// One thread = one row x one 16-byte chunk pair, walking the heads.
+template <int DT>
+__global__ __launch_bounds__(256) void rope_rotate_rows_kernel(char* __restrict__ k, int64_t stride_layer, int64_t stride_h,
+                                                               int H, int rows, int D, const int64_t* __restrict__ pos,
+                                                               int64_t pos_stride_layer, int64_t pos_stride_p, int P,
+                                                               const float* __restrict__ inv_freq, float scaling, RowSel rs,
+                                                               int round_mode) {
+    using V = Vec16<DT>;
+    constexpr int VE = V::VE;
+    constexpr int ES = 16 / VE;
+    const int h2 = D / 2, lpr = h2 / VE;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = id / lpr;
+    if (r >= rows) return;
+    const int d = (id - r * lpr) * VE;
+    const int layer = blockIdx.y;
+    const int64_t* pl = pos + (size_t)layer * pos_stride_layer;
+    float pid[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pid[p] = (float)pl[(size_t)min(p, P - 1) * pos_stride_p + r];
+    float c1[VE], s1[VE], c2[VE], s2[VE];
+    rope_chunk<VE>(inv_freq, rs, d, h2, pid, scaling, round_mode, c1, s1, c2, s2);
+    char* base = k + ((size_t)layer * stride_layer + (size_t)r * D) * ES;
+    for (int h = 0; h < H; ++h) {
+        char* row = base + (size_t)h * stride_h * ES;
+        const u32x4 lo = *(const u32x4*)(row + (size_t)d * ES), hi = *(const u32x4*)(row + (size_t)(d + h2) * ES);
+        float x1[VE], x2[VE], o1[VE], o2[VE];
+        V::unpack(lo, x1);
+        V::unpack(hi, x2);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            if constexpr (DT != RTK_F32) {
+                using Hh = H16<DT>;
+                o1[e] = Hh::rnd(__fadd_rn(Hh::rnd(__fmul_rn(x1[e], c1[e])), Hh::rnd(__fmul_rn(-x2[e], s1[e]))));
+                o2[e] = Hh::rnd(__fadd_rn(Hh::rnd(__fmul_rn(x2[e], c2[e])), Hh::rnd(__fmul_rn(x1[e], s2[e]))));
+            } else {
+                o1[e] = __fadd_rn(__fmul_rn(x1[e], c1[e]), __fmul_rn(-x2[e], s1[e]));
+                o2[e] = __fadd_rn(__fmul_rn(x2[e], c2[e]), __fmul_rn(x1[e], s2[e]));
+            }
+        }
+        *(u32x4*)(row + (size_t)d * ES) = V::pack(o1);
+        *(u32x4*)(row + (size_t)(d + h2) * ES) = V::pack(o2);
+    }
+}
+
 // Temporal-id continuity fix of the attention patch (qwen2_vl.py:68-73), on the device: the whole row is
 // shifted so that its first id follows the last id stored for the layer.  One workgroup: the first id is
 // read by everyone before anyone writes.
@@ -160,6 +209,37 @@ extern "C" int rtk_position_shift(int64_t* temporal_ids, int n, const int64_t* p
     RTK_CHECK_ARG(temporal_ids && n >= 1, "rtk_position_shift: NULL pointer or empty row");
     RTK_LAUNCH(KID_SHIFT, position_shift_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, temporal_ids, n, prev_dev);
     RTK_LAUNCH_CHECK("position_shift_kernel");
+    return RTK_OK;
+}
+
+extern "C" int rtk_rope_rotate_rows(void* k, int64_t stride_layer, int64_t stride_h, int layers, int H, int rows, int D,
+                                    int dtype, const int64_t* pos, int64_t pos_stride_layer, int64_t pos_stride_p, int P,
+                                    const float* inv_freq, float attention_scaling, const int* sections_host, int nsec,
+                                    int round_mode, rtk_stream_t stream) {
+    RTK_CHECK_ARG(k && pos && inv_freq, "rtk_rope_rotate_rows: NULL pointer");
+    RTK_CHECK_ARG(layers >= 1 && H >= 1 && rows >= 0 && D >= 2, "rtk_rope_rotate_rows: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_rope_rotate_rows: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(P == 1 || P == 3, "rtk_rope_rotate_rows: P must be 1 or 3, got %d", P);
+    RTK_CHECK_ARG(pos_stride_p >= rows, "rtk_rope_rotate_rows: pos_stride_p < rows");
+    if (rows == 0) return RTK_OK;
+    const int ve = dtype != RTK_F32 ? 8 : 4, es = dtype != RTK_F32 ? 2 : 4;
+    if (D % (2 * ve) != 0 || D > 256 || (stride_h * es) % 16 || (stride_layer * es) % 16 || ((uintptr_t)k & 15)) {
+        set_error("rtk_rope_rotate_rows: needs 16-byte aligned rows and head_dim a multiple of %d (<= 256)", 2 * ve);
+        return RTK_EUNSUPPORTED;
+    }
+    RowSel rs;
+    int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_rope_rotate_rows");
+    if (rc) return rc;
+    const int threads = rows * (D / 2 / ve);
+    const dim3 grid((threads + 255) / 256, layers);
+#define RTK_RRR(DTV)                                                                                                  \
+    RTK_LAUNCH(KID_ROPE, rope_rotate_rows_kernel<DTV>, grid, dim3(256), 0, (hipStream_t)stream, (char*)k, stride_layer, \
+               stride_h, H, rows, D, pos, pos_stride_layer, pos_stride_p, P, inv_freq, attention_scaling, rs, round_mode)
+    if (dtype == RTK_BF16) RTK_RRR(RTK_BF16);
+    else if (dtype == RTK_F16) RTK_RRR(RTK_F16);
+    else RTK_RRR(RTK_F32);
+#undef RTK_RRR
+    RTK_LAUNCH_CHECK("rope_rotate_rows_kernel");
     return RTK_OK;
 }
 

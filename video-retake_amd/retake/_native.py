@@ -72,7 +72,7 @@ class PivotKVBatch(C.Structure):
     _fields_ = [("Hq", _i32), ("Hkv", _i32), ("L", _i32), ("D", _i32), ("keep", _i32), ("P", _i32), ("slots", _i32),
                 ("dtype", _i32), ("score_dtype", _i32), ("prep_dtype", _i32), ("reforge", _i32), ("keep_all", _i32),
                 ("round_mode", _i32), ("nsec", _i32), ("sections", _i32 * 8), ("rs_n", _i32), ("skip_masked", _i32),
-                ("attention_scaling", _f), ("pad0", _i32), ("inv_freq", _vp),
+                ("attention_scaling", _f), ("defer_rot", _i32), ("inv_freq", _vp),
                 ("score_ws", _vp), ("score_ws_stride", _u64), ("score_ws_bytes", _u64),
                 ("k_unrot", _vp), ("partials", _vp), ("partial_floats", _u64), ("score", _vp), ("pos_old", _vp),
                 ("keep_idx", _vp), ("pos_new", _vp), ("sel_ws", _vp), ("sel_ws_stride", _u64), ("key_index", _vp),
@@ -100,6 +100,7 @@ _SIGNATURES = {
     "rtk_mallm_hard_chain": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "rtk_rope_merge": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "rtk_rope_table": (C.c_int, [_vp, _i64, _i, _i, _vp, _i, _f, _vp, _i, _i, _vp, _vp, _vp]),
+    "rtk_rope_rotate_rows": (C.c_int, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i, _vp, _f, _vp, _i, _i, _vp]),
     "rtk_rope_shift": (C.c_int, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "rtk_rope_shift_segments": (C.c_int, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "rtk_pivotkv_score_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),

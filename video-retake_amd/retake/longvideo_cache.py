@@ -312,6 +312,7 @@ class _Batch:
         self.mask_obj = None       # the last key-patch mask tensor that passed validation, and its address
         self.mask_ptr = None
         self.shift_ids = None      # pre-RoPE units: the caller's ids tensor, shifted in place by the flush
+        self.defer = False         # deferred re-rotation (PivotKVCache.defer_rerotation)
         self.qshape, self.kshape = torch.Size((1, Hq, L, D)), torch.Size((1, Hkv, L, D))
         self.dev_index = device.index if device.index is not None else torch.cuda.current_device()
         # the one-call path (rtk_pivotkv_update / rtk_pivotkv_flush): argument blocks bound once per batch
@@ -469,6 +470,10 @@ class PivotKVCache(DynamicCache):
         # selection are not run then - the K round trip through the un-rotated frame and the bookkeeping still are.
         # True restores them (tests, `last_scores`)
         self.score_when_keeping_all = bool(kv_compression_kwargs.get("score_when_keeping_all", False))
+        # MI355X build option (retake/sharded.py sets it): the kept keys stay UN-rotated in the cache and their ids
+        # provisional; the owner rotates them once, at their final ids (rtk_rope_rotate_rows), when the temporal offset
+        # of its block is known.  key_cache then holds un-rotated rows until that call.
+        self.defer_rerotation = bool(kv_compression_kwargs.get("defer_rerotation", False))
         # MI355X build option (tests / A-B): False sends every update and flush through the stage-by-stage route
         # instead of the one-call entry points rtk_pivotkv_update / rtk_pivotkv_flush - same kernels, same results
         self.one_call_update = bool(kv_compression_kwargs.get("one_call_update", True))
@@ -766,7 +771,8 @@ class PivotKVCache(DynamicCache):
         # "fast" (opt in): bf16 chunks of head_dim 128 on the fp16 matrix instruction; every other shape scores as usual
         fast = self.score_rounding == "fast" and dtype == torch.bfloat16 and D == 128
         keep_all = keep == L and not self.score_when_keeping_all
-        key = (Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast, keep_all)
+        defer = bool(self.defer_rerotation and self.pos_embed_reforge)
+        key = (Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast, keep_all, defer)
         b = self._batch
         if b is not None and b.key == key and layer_idx < b.slots:
             return b
@@ -775,6 +781,8 @@ class PivotKVCache(DynamicCache):
         self._batch = None  # release the old buffers before allocating the new ones
         self._batch = _Batch(key, slots, Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast,
                              keep_all, self.skip_masked_columns)
+        self._batch.defer = defer
+        self._batch.c.defer_rot = int(defer)
         return self._batch
 
     def _flush(self):
@@ -892,9 +900,10 @@ class PivotKVCache(DynamicCache):
             # reforge: K is re-rotated at the NEW ids (reference :297-306).  With the native RoPE the eviction kernel
             # computes their cos/sin itself; a third-party rotary module is called once for every pending slot and its
             # section-merged fp32 tables are handed over.
-            rot = self._rotary(b.rotary_emb_fn, b.device) if (b.reforge and P) else None
+            defer = bool(getattr(b, "defer", False))
+            rot = self._rotary(b.rotary_emb_fn, b.device) if (b.reforge and P and not defer) else None
             rope_in_kernel = rot is not None
-            if b.reforge and not rope_in_kernel:
+            if b.reforge and not rope_in_kernel and not defer:
                 b.ensure_tables()
                 n = (hi - lo + 1) * keep
                 pos2d, ld = b.pos_new[:, lo:hi + 1].reshape(P, n), n  # a copy when the slot range is partial
@@ -910,7 +919,7 @@ class PivotKVCache(DynamicCache):
                 u = units[i]
                 if b.reforge:
                     u.k_src, u.k_src_stride_h = b.k_unrot[l].data_ptr(), b.L * D
-                    if rope_in_kernel:
+                    if rope_in_kernel or defer:
                         u.cos_new = u.sin_new = None
                     else:
                         u.cos_new = b.cos_new.data_ptr() + l * keep * D * 4
@@ -951,9 +960,9 @@ class PivotKVCache(DynamicCache):
                                                                len(b.mrope_section) if b.mrope_section else 0,
                                                                nv.round_mode(b.x_like.dtype), 1, s),
                          "rtk_pivotkv_evict_batched_rope")
-            elif b.reforge or not b.keep_all:
-                nv.check(nv.lib.rtk_pivotkv_evict_batched(units, len(layers), Hkv, D, keep, P if b.reforge else 0, dt, 1, s),
-                         "rtk_pivotkv_evict_batched")
+            elif b.reforge or not b.keep_all:   # (deferred re-rotation: every kept un-rotated K row is copied, bit 1)
+                nv.check(nv.lib.rtk_pivotkv_evict_batched(units, len(layers), Hkv, D, keep, P if b.reforge else 0, dt,
+                                                          3 if defer else 1, s), "rtk_pivotkv_evict_batched")
             # kept rows -> head of the tail: in place, except the ~ratio of them whose source lies inside the destination
             # range (parked in the staging rows by the launch above) - reference :313-318 without a full second copy
             if nc:
