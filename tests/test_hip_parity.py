@@ -85,7 +85,9 @@ def test_dpselect_bf16_golden(name):
     print(f"\n[{name}] rows {st['rows']}: exact {st['exact']}, tied-boundary {st['tied']}, relaxed {st['relaxed']} "
           f"({st['flipped_entries']} of {d.size} distances flipped, {st['peak_flags_differing']} peak flags and "
           f"{st['indices_differing']} picks differ from the reference's)")
-    assert st["exact"] + st["tied"] >= 0.5 * st["rows"] or sync
+    # measured on MI355X (profiles/r12_parity_stats.txt): 144/144, 196/196, 195/196 and >= 185/196 rows exact or tied; the one
+    # row of a sync fixture is whichever class its patch-mean distances put it in (all three are checked above)
+    assert (st["exact"] + st["tied"] >= 0.9 * st["rows"]) or (sync and st["rows"] == 1)
     # the gathered frames are copies of the frames the product's own indices name
     xi = xt[0]
     ii = idx if not sync else idx[:, None].expand(-1, xi.shape[1])
@@ -115,7 +117,7 @@ def test_dpselect_fp16_golden(name):
     print(f"\n[{name}] rows {st['rows']}: exact {st['exact']}, tied-boundary {st['tied']}, relaxed {st['relaxed']} "
           f"({st['flipped_entries']} of {d.size} distances flipped, {st['peak_flags_differing']} peak flags and "
           f"{st['indices_differing']} picks differ from the reference's)")
-    assert st["exact"] + st["tied"] >= 0.5 * st["rows"] or sync
+    assert (st["exact"] + st["tied"] >= 0.9 * st["rows"]) or (sync and st["rows"] == 1)
     xi = xt[0]
     ii = idx if not sync else idx[:, None].expand(-1, xi.shape[1])
     assert torch.equal(out[0], torch.gather(xi, 0, ii[:, :, None].expand(-1, -1, xi.shape[2])))
@@ -1990,7 +1992,10 @@ def test_pivotkv_bf16_against_reference_bf16(name, rounding):
         kk = cache.key_cache[l].cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
         pos_new = cache.position_cache[l].cpu().numpy()
         if rounding == "reference":
-            nbad, nxor, a, b = tog.check_bf16_against_reference(g, 0, score, idx, kk, pos_new, "HIP reference rounding")
+            # measured on MI355X (profiles/r12_parity_stats.txt): 0 / 0 / 1 / 2 scores off by one bf16 ulp at L 256 / 576 /
+            # 1568 / 6272; the bar is twice that (at least 1)
+            nbad, nxor, a, b = tog.check_bf16_against_reference(g, 0, score, idx, kk, pos_new, "HIP reference rounding",
+                                                                max_bad={256: 1, 576: 1, 1568: 2, 6272: 4}.get(L))
             np.testing.assert_array_equal(a, b)
             if l == 0:
                 print(f"{name}: {nbad} of {L} scores differ from the reference's by one bf16 ulp, kept xor {nxor} (ties)")
@@ -2003,7 +2008,9 @@ def test_pivotkv_bf16_against_reference_bf16(name, rounding):
             thr = np.sort(ref)[::-1][keep - 1]
             xor = np.setxor1d(idx, ref_idx)
             assert (np.abs(ref[xor] - thr) <= gu.bf16_ulp(np.full(xor.size, thr))).all()
-            assert xor.size <= max(4, L // 100)
+            # measured on MI355X (profiles/r12_parity_stats.txt): 0 / 0 / 2 / 5 kept tokens differ (xor 0 / 0 / 4 / 10) at
+            # L 256 / 576 / 1568 / 6272, every one within one bf16 ulp of the reference's threshold; the bar is twice that
+            assert xor.size <= {256: 2, 576: 0, 1568: 8, 6272: 20}.get(L, max(4, L // 100))
             if l == 0:
                 print(f"{name}: {rounding} mode vs the reference's bf16 kept set: {xor.size // 2} of {keep} tokens differ, all "
                       f"within one bf16 ulp of its threshold score {thr}; max |score - exact| {err:.2e}")

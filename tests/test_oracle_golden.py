@@ -46,7 +46,7 @@ def test_dpselect_bf16_matches_reference(name):
     print(f"\n[{name}] rows {st['rows']}: exact {st['exact']}, tied-boundary {st['tied']}, relaxed {st['relaxed']} "
           f"({st['flipped_entries']} of {d.size} distances flipped, {st['peak_flags_differing']} peak flags and "
           f"{st['indices_differing']} picks differ from the reference's)")
-    assert st["exact"] + st["tied"] >= 0.5 * st["rows"] or bool(g["sync"])
+    assert (st["exact"] + st["tied"] >= 0.9 * st["rows"]) or (bool(g["sync"]) and st["rows"] == 1)
 
 
 @pytest.mark.parametrize("sync", [True, False])
@@ -137,7 +137,7 @@ def test_pivotkv_matches_reference(name):
 # ---------------------------------------------------------------------------------------------------
 # PivotKV in the production dtype: the reference run on a bf16 model (fixtures pivotkv_bf16_*)
 # ---------------------------------------------------------------------------------------------------
-def check_bf16_against_reference(g, c, score, keep_idx, kept_k_bits, pos_new, what):
+def check_bf16_against_reference(g, c, score, keep_idx, kept_k_bits, pos_new, what, max_bad=None):
     """Shared by the oracle test (CPU) and the HIP reference-rounding test (GPU).  The reference's bf16 score chain
     (longvideo_cache.py:264-270) is reproduced up to the summation order inside ATen's bf16 gemm / sums, which may move
     an isolated entry by ONE bf16 ulp; torch.topk's pick among exact ties is backend-defined, so the
@@ -147,7 +147,8 @@ def check_bf16_against_reference(g, c, score, keep_idx, kept_k_bits, pos_new, wh
     ref = orc.bf16_bits_to_f32(g[pre + "score_bf16"])
     assert np.array_equal(orc.bf16_round(score), score), f"{what}: scores must be bf16 values"
     bad = np.nonzero(score != ref)[0]
-    assert bad.size <= max(2, L // 500), f"{what}: {bad.size} of {L} scores differ from the reference's"
+    limit = max(2, L // 500) if max_bad is None else max_bad
+    assert bad.size <= limit, f"{what}: {bad.size} of {L} scores differ from the reference's (bar {limit})"
     if bad.size:
         assert (np.abs(score[bad] - ref[bad]) <= gu.bf16_ulp(np.minimum(np.abs(score[bad]), np.abs(ref[bad])))).all()
     ref_idx = g[pre + "keep_idx"]
@@ -249,7 +250,7 @@ def test_dpselect_fp16_matches_reference(name):
     print(f"\n[{name}] rows {st['rows']}: exact {st['exact']}, tied-boundary {st['tied']}, relaxed {st['relaxed']} "
           f"({st['flipped_entries']} of {d.size} distances flipped, {st['peak_flags_differing']} peak flags and "
           f"{st['indices_differing']} picks differ from the reference's)")
-    assert st["exact"] + st["tied"] >= 0.5 * st["rows"] or bool(g["sync"])
+    assert (st["exact"] + st["tied"] >= 0.9 * st["rows"]) or (bool(g["sync"]) and st["rows"] == 1)
 
 
 def check_fp16_against_reference(g, score, keep_idx, kept_k16, pos_new, k_unrot16, what):

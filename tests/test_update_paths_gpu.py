@@ -407,3 +407,42 @@ def test_compress_memory_bank_dispatches_the_chain():
     while loop.shape[1] > 20:
         loop = vc.memory_bank_compress_MALLM_hard(loop, sync=False)
     assert mask is None and torch.equal(got, loop)
+
+
+def test_masked_columns_never_leak_uninitialised_partials():
+    """Pass 2 skips the columns of key-patch tokens (the reference overwrites their score with 1.0, :272-274) and leaves
+    their slots of the column partials unwritten.  With the scratch poisoned with NaN beforehand the scores must still be
+    finite everywhere, 1.0 at the masked tokens, and the kept set that of a cache that computes every column."""
+    import retake.longvideo_cache as lc
+
+    L, layers = 640, 2
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    caches = [lc.build_kvcache(cfg(layers)), lc.build_kvcache(cfg(layers, skip_masked_columns=False))]
+    results = []
+    for cache in caches:
+        got = []
+        for c in range(2):
+            mask = torch.from_numpy(np.random.default_rng(7 + c).uniform(size=L) < 0.4).to(dev())
+            cache.keypatches_mask_chunk = mask
+            cache.kvcache_compression = True
+            pos = chunk_ids(c, L)
+            for l in range(layers):
+                q0, k0, v = synth.qkv_chunk(300 + 10 * c + l, Hq, Hkv, L, D)
+                cache.shift_temporal_ids_(pos, l)
+                q = synth.rope_forward(torch.from_numpy(q0).to(dev()), pos, rot, SEC).bfloat16()
+                k = synth.rope_forward(torch.from_numpy(k0).to(dev()), pos, rot, SEC).bfloat16()
+                cache.update(k, torch.from_numpy(v).to(dev()).bfloat16(), l,
+                             {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": SEC})
+                if c == 0 and l == 0:
+                    b = cache._batch
+                    b.partials.fill_(float("nan"))      # whatever torch.empty handed out, now certainly not a number
+                    b.score.fill_(float("nan"))
+            cache.after_forward()
+            b = cache._batch
+            for l in range(layers):
+                s = b.score[l]
+                assert torch.isfinite(s).all() and (s[mask] == 1.0).all()
+                got.append((s.clone(), b.keep_idx[l].clone()))
+        results.append(got)
+    for (sa, ia), (sb, ib) in zip(*results):
+        assert torch.equal(ia, ib) and torch.equal(sa, sb)
