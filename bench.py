@@ -627,7 +627,13 @@ def main():
                                                "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                                "algorithmic_bytes_per_unit": ev_bytes, "us_per_unit": t_scan * 1e6,
                                                "stages_us_per_unit": stages,
-                                               "moved_bytes_per_unit": evu_bytes + cmu_bytes}
+                                               # beside SURVEY's byte count (every K / V row of the chunk read): what the
+                                               # two data-moving launches actually move, and that rate against the peak
+                                               "moved_bytes_per_unit": evu_bytes + cmu_bytes,
+                                               "moved_GBps": (evu_bytes + cmu_bytes) / t_scan / 1e9,
+                                               "moved_frac": (evu_bytes + cmu_bytes) / t_scan / 1e9 / HBM_PEAK_GBS,
+                                               "moved_GBps_data_launches_only": (evu_bytes + cmu_bytes) / (
+                                                   (stages.get("evict_batched", 0) + stages.get("commit_batched", 0)) * 1e-6) / 1e9}
             # the same plus the tail append update() owes the layer's attention (reference :238, P1): its own kernel,
             # or its byte share of the fused prepare kernel.  SURVEY's byte count has no term for it.
             t_app = kern["append"]["avg_us"] if not fused else kern["unrotate_pack"]["avg_us"] * ap_bytes / prep_bytes

@@ -153,3 +153,31 @@ def test_rope_helpers_match_formula():
     cm = torch.stack([c3[sel[d], 0, :, d] for d in range(8)], -1)[None]
     sm = torch.stack([s3[sel[d], 0, :, d] for d in range(8)], -1)[None]
     assert torch.allclose(qm, q * cm + lc.rotate_half(q) * sm)
+
+
+def test_host_argument_blocks_match_the_header(tmp_path):
+    """rtk_pivotkv_batch / rtk_layer_state / rtk_update_io and the unit structs are HOST memory the Python side fills:
+    the ctypes mirrors in retake/_native.py must have the layout gcc gives the header's structs (sizes and the offsets of
+    every field)."""
+    import subprocess
+
+    import retake._native as nv
+
+    mirrors = {"rtk_layer_state": nv.LayerState, "rtk_pivotkv_batch": nv.PivotKVBatch, "rtk_update_io": nv.UpdateIO,
+               "rtk_evict_unit": nv.EvictUnit, "rtk_select_unit": nv.SelectUnit, "rtk_place_unit": nv.PlaceUnit,
+               "rtk_copy_unit": nv.CopyUnit, "rtk_p2p_peers": nv.P2PPeers}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "retake_hip.h"', "int main(void) {"]
+    for cname, st in mirrors.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, st in mirrors.items():
+        assert int(got[cname]) == ctypes.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(st, fname).offset, f"{cname}.{fname}"

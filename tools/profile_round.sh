@@ -6,10 +6,15 @@ out=gpurun_out/${1:-round}
 mkdir -p $out
 export TMPDIR=/tmp
 if [ -z "$PROFILE_ONLY" ]; then
-timeout 1200 python -m pytest tests -m gpu -x -q -s > $out/pytest.log 2>&1 < /dev/null
+timeout 1500 python -m pytest tests -m gpu -x -q -s > $out/pytest.log 2>&1 < /dev/null
 grep -E "passed|failed" $out/pytest.log
-timeout 900 python bench.py > $out/bench_bf16.json 2> $out/bench_bf16.err < /dev/null
+# the parity statistics the tests print (per row / per fixture), kept with the round's numbers
+grep -E "^\[|^[a-z0-9_]+: |scores differ|kept tokens differ|mode vs" $out/pytest.log | grep -v "^tests/" > $out/parity_stats.txt
+timeout 1500 python bench.py > $out/bench_bf16.json 2> $out/bench_bf16.err < /dev/null
 python tools/show_bench.py < $out/bench_bf16.json | head -40
+timeout 600 python tools/bench_ratio1.py > $out/bench_ratio1.json 2>/dev/null < /dev/null
+timeout 900 python tools/bench_mallm.py > $out/bench_mallm.json 2>/dev/null < /dev/null
+timeout 900 python tools/bench_llava.py > $out/bench_llava.json 2>/dev/null < /dev/null
 fi
 # the rocprofv3 runs below use --no-self-check: the untimed self-check launches the score kernels once more per checked
 # unit with gridDim.y = 1, which would mix 28x shorter launches into the per-kernel averages
@@ -23,7 +28,9 @@ kt() {  # kt <name> <bench flags...>: rocprofv3 kernel trace + stats of one time
 }
 kt baseline
 kt qwen448 --geometry qwen448
-kt baseline_fast --score-rounding fast
+kt qwen448_prerope --geometry qwen448 --pre-rope
+kt baseline_prerope --pre-rope
+kt baseline_reference --score-rounding reference
 # PMC passes (counters only, own runs): HBM traffic and SQ activity on a 4-chunk video of each geometry
 pmc() {  # pmc <name> <bench flags...>
   name=$1; shift
@@ -38,5 +45,5 @@ pmc() {  # pmc <name> <bench flags...>
 }
 pmc baseline --frames 128
 pmc qwen448 --geometry qwen448 --frames 256
-pmc baseline_fast --frames 128 --score-rounding fast
+pmc qwen448_prerope --geometry qwen448 --frames 256 --pre-rope
 cat $out/baseline_pmc_hbm_traffic.csv

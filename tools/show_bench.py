@@ -15,11 +15,17 @@ for k, v in d.get("kernels_timed_region", {}).items():
 for k in ("roofline", "roofline_hbm_kernels", "cpu_baseline", "speedup_vs_cpu_baseline"):
     if k in d:
         print(k, d[k])
-for k in ("real_geometry", "reference_rounding", "fast_rounding", "fp16_dtype", "fp32_parity_dtype"):
-    if k in d:
-        c = d[k]
+comp = {k: d[k] for k in ("real_geometry", "rotary_module_called", "reference_rounding", "fast_rounding", "fp16_dtype",
+                         "fp32_parity_dtype") if k in d}
+for g, c in (d.get("pre_rope_prologue") or {}).items():
+    if isinstance(c, dict):
+        comp["pre_rope_prologue/" + g] = c
+for k, c in comp.items():
+    if True:
+        share = c.get("per_update_kernels_share_of_gpu_time")
         print(f"{k}: {c['value']:.1f} frames/s  ms_per_step={c['ms_per_step']:.1f}  roofline {c['roofline']['kernel']} "
-              f"frac={c['roofline']['frac']:.3f}  " + " ".join(f"{n}={v['avg_us']:.0f}us" for n, v in c["kernels_timed_region"].items()))
+              f"frac={c['roofline']['frac']:.3f}  " + " ".join(f"{n}={v['avg_us']:.0f}us" for n, v in c["kernels_timed_region"].items())
+              + (f"  per-update kernels {100 * share:.1f} % of GPU time" if share is not None else ""))
 for k in ("sharded_equals_sequential", "rccl_world_size", "p2p_world_size"):
     if k in d:
         print(k, d[k])
