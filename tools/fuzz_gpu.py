@@ -6,6 +6,9 @@ For random shapes / dtypes / masks / ratios / RoPE flavours it compresses the sa
   B  the cache with `skip_masked_columns=False` (the full pass 2)          -> caches, scores, kept sets BITWISE equal to A
   C  the CPU oracle (fp32 runs only)                                        -> scores <= 5e-6, kept sets margin-aware,
                                                                                kept V exact, kept K <= 1e-5, ids exact
+B also draws `one_call_update` at random: the stage-by-stage route against rtk_pivotkv_update / rtk_pivotkv_flush.
+  P  the attention prologue (update_pre_rope on the pre-RoPE projections, where it applies) against its own oracle run
+     on the tensors rotated at the continuity-shifted ids (fp32: same bars as C; 16-bit: ids and kept-row count)
     python tools/fuzz_gpu.py [--seconds 240] [--seed 0]
 """
 import argparse
@@ -33,7 +36,7 @@ def main():
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(a.seed)
     t_end = time.time() + a.seconds
-    n_cases = n_oracle = 0
+    n_cases = n_oracle = n_pre = 0
     worst_score = worst_k = 0.0
     while time.time() < t_end:
         Hkv = int(rng.choice([1, 2, 4, 8]))
@@ -61,17 +64,25 @@ def main():
         desc = (f"Hq={Hq} Hkv={Hkv} D={D} L={L} {str(dtype)[6:]} ratio={ratio} mask={mrate} reforge={reforge} mrope={mrope} "
                 f"layers={layers} chunks={chunks} native_rope={native} a={S:.3f} score_rounding={rounding}")
 
-        def make(skip):
+        staged_b = bool(rng.uniform() < 0.5)
+        desc += f" staged_twin={staged_b}"
+
+        def make(skip, **extra):
+            kw = {"compression_ratio": ratio, "compression_method": "pivotkv", "pos_embed_reforge": reforge,
+                  "native_rope": native, "skip_masked_columns": skip,
+                  # ratio 1: `ca` keeps the chunk without scoring it, `cb` scores like the reference
+                  "score_when_keeping_all": not skip, "score_rounding": rounding}
+            kw.update(extra)
             cfg = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=layers, num_attention_heads=Hq,
                                         num_key_value_heads=Hkv,
-                                        longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
-                                            "compression_ratio": ratio, "compression_method": "pivotkv",
-                                            "pos_embed_reforge": reforge, "native_rope": native, "skip_masked_columns": skip,
-                                            # ratio 1: `ca` keeps the chunk without scoring it, `cb` scores like the reference
-                                            "score_when_keeping_all": not skip, "score_rounding": rounding}})
+                                        longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": kw})
             return lc.build_kvcache(cfg)
 
-        ca, cb = make(True), make(False)
+        ca, cb = make(True), make(False, one_call_update=not staged_b)
+        # the prologue route, where it applies (reforging cache, inv_freq rotary, chunks of >= 512 tokens)
+        pre = reforge and native and L >= 512 and rounding != "reference"
+        cp = make(True, score_when_keeping_all=True) if pre else None
+        ocp = [orc.OraclePivotKV(Hq, Hkv, D, ratio, reforge) for _ in range(layers)] if pre and dtype == torch.float32 and L <= 1000 else None
         oc = [orc.OraclePivotKV(Hq, Hkv, D, ratio, reforge) for _ in range(layers)] if dtype == torch.float32 and L <= 1000 else None
         keep = max(1, int(ratio * L))
         try:
@@ -101,8 +112,54 @@ def main():
                     if oc is not None:
                         oc[l].keypatches_mask_chunk = mask_np if mask is not None else None
                         oc[l].update(k.numpy(), v, 0, q=q.numpy(), position_ids=pos_np, rotary=rot_cpu, mrope_section=sec)
+                    if cp is not None:
+                        cp.keypatches_mask_chunk = mask
+                        cp.kvcache_compression = True
+                        # projections in the [1, L, H*D] layout; the ids tensor is shared by the layers of the chunk
+                        qd = torch.from_numpy(q0).to(dtype).to(dev).transpose(1, 2).contiguous().transpose(1, 2)
+                        kd = torch.from_numpy(k0).to(dtype).to(dev).transpose(1, 2).contiguous().transpose(1, 2)
+                        if l == 0:
+                            pos_dev = torch.from_numpy(pos_np).to(dev)
+                        got = cp.update_pre_rope(qd, kd, vt.to(dev), l, pos_dev, rot, list(sec) if sec else None,
+                                                 query_out=torch.empty_like(qd) if rng.uniform() < 0.5 else None)
+                        assert got is not None, "the prologue declined a chunk it should serve"
+                        if ocp is not None:
+                            prev = ocp[l].get_prev_temporal_idx(0)
+                            psh = pos_np.copy()
+                            if mrope:
+                                psh[0, 0] += prev + 1 - psh[0, 0, 0]
+                            else:
+                                psh[0] += prev + 1 - psh[0, 0]
+                            pst = torch.from_numpy(psh)
+                            qs = synth.rope_forward(torch.from_numpy(q0), pst, rot_cpu, sec)
+                            ks = synth.rope_forward(torch.from_numpy(k0), pst, rot_cpu, sec)
+                            ocp[l].keypatches_mask_chunk = mask_np if mask is not None else None
+                            ocp[l].update(ks.numpy(), v, 0, q=qs.numpy(), position_ids=psh, rotary=rot_cpu, mrope_section=sec)
                 ca.after_forward()
                 cb.after_forward()
+                if cp is not None:
+                    cp.after_forward()
+                    for l in range(layers):
+                        assert cp.key_cache[l].shape[2] == (c + 1) * keep
+                        if ocp is not None:
+                            last = ocp[l].last
+                            so = last["score"]
+                            sp = cp._batch.score[l].cpu().numpy()
+                            bar = 2e-5 * max(1.0, float(np.abs(so).max()))
+                            assert float(np.abs(sp - so).max()) < bar, "prologue route: score vs oracle"
+                            idx = cp._batch.keep_idx[l].cpu().numpy()
+                            xor = np.setxor1d(idx, last["keep_idx"])
+                            if xor.size:
+                                thr = np.sort(so)[::-1][keep - 1]
+                                assert np.abs(so[xor] - thr).max() < 4 * bar, "prologue route: kept sets differ beyond noise"
+                            else:
+                                n0 = cp.key_cache[l].shape[2] - keep
+                                assert np.array_equal(cp.value_cache[l][0, :, n0:].cpu().numpy(), last["kept_v"][0])
+                                kerr = float(np.abs(cp.key_cache[l][0, :, n0:].cpu().numpy() - last["kept_k"][0]).max())
+                                assert kerr <= 1e-5 * max(1.0, float(np.abs(last["kept_k"]).max())), f"prologue kept K {kerr}"
+                                assert np.array_equal(cp.position_cache[l].cpu().numpy()[..., n0:].reshape(-1, keep),
+                                                      last["pos"].reshape(-1, keep))
+                            n_pre += 1
                 for l in range(layers):
                     sa, sb = ca._batch.score[l], cb._batch.score[l]
                     if ca._batch.keep_all:
@@ -141,8 +198,9 @@ def main():
             print("FUZZ FAILURE:", desc, "->", type(e).__name__, e, flush=True)
             raise
         n_cases += 1
-    print(f"fuzz ok: {n_cases} random configurations (live-key == full pass 2 bitwise), {n_oracle} layer-chunks against the CPU "
-          f"oracle (max score diff {worst_score:.2e}, max kept-K diff {worst_k:.2e})")
+    print(f"fuzz ok: {n_cases} random configurations (live-key == full pass 2 and one-call == staged route, bitwise), {n_oracle} "
+          f"layer-chunks against the CPU oracle (max score diff {worst_score:.2e}, max kept-K diff {worst_k:.2e}), {n_pre} "
+          f"prologue layer-chunks against the oracle")
     fuzz_dpselect(dev, rng, a.seconds / 4)
 
 

@@ -1053,6 +1053,7 @@ class PivotKVCache(DynamicCache):
         pre = q0 is not None
         if b.pending and bool(b.c.pre_rope) != pre:
             self._flush()
+        b.c.pre_rope = int(pre)   # what the units of this batch's next flush were appended from
         qs, ks, vs = q.stride(), key_states.stride(), value_states.stride()
         if qs[3] != 1 or ks[3] != 1 or vs[3] != 1:
             return None
@@ -1085,7 +1086,6 @@ class PivotKVCache(DynamicCache):
             ck.pop("rotary_emb", None)
             ck.pop("mrope_section", None)
         else:
-            b.c.pre_rope = 1
             if shift_ids_in_place:     # the flush shifts the caller's ids in place (qwen2_vl.py:73)
                 b.shift_ids = pos
                 b.c.shift_row = io.pos
@@ -1243,6 +1243,7 @@ class PivotKVCache(DynamicCache):
         self._bind_rotary(batch, rotary_emb_fn, mrope_section, rot)
         if batch.pending and batch.c.pre_rope:   # units of the prologue route are flushed among themselves
             self._flush()
+        batch.c.pre_rope = 0
         batch.x_like = value_states[:, :, :1]
         st = self.reserve(layer_idx, n_new, key_states)
         P0 = st.length
