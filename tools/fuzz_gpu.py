@@ -161,7 +161,8 @@ def main():
                                                       last["pos"].reshape(-1, keep))
                             n_pre += 1
                 for l in range(layers):
-                    sa, sb = ca._batch.score[l], cb._batch.score[l]
+                    sb = cb._batch.score[l]
+                    sa = ca._batch.score[l] if ca._batch.score is not None else sb   # (keep-all batches allocate no scores)
                     if ca._batch.keep_all:
                         assert keep == L and ca.last_scores is None
                         sa = sb   # nothing was scored on the default route; the oracle checks the scored twin
