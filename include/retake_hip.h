@@ -266,6 +266,18 @@ int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspace_stride, 
                                      int Hq, int Hkv, int L, int D, int dtype,
                                      const void* const* key_masks_host, int32_t* key_index_ws, rtk_stream_t stream);
 
+/* The same with the units' queries read in place: q_units_host is a HOST array of n_units device pointers to tensors the
+ * caller keeps alive until the launches have run, element (h, i, d) of unit u at q_units_host[u] + h*q_stride_h +
+ * i*q_stride_l + d (elements; 16-byte aligned rows).  For units whose score operands ARE the caller's tensors - the
+ * pre-RoPE projections of the attention prologue - no packed copy of the queries is made at all.  NULL: identical to
+ * rtk_pivotkv_score_passes_batched.  16-bit payloads, head_dim 128. */
+int rtk_pivotkv_score_passes_batched_q(void* workspace0, size_t workspace_stride, void* k_unrot0, size_t k_unrot_stride,
+                                       float* partial0, size_t partial_stride_floats, int n_units,
+                                       int Hq, int Hkv, int L, int D, int dtype,
+                                       const void* const* key_masks_host, int32_t* key_index_ws,
+                                       const void* const* q_units_host, int64_t q_stride_h, int64_t q_stride_l,
+                                       rtk_stream_t stream);
+
 /* P6-P7, P9-P10  longvideo_cache.py:272-277, :283-295.
  *   score [L] fp32: entries with mask != 0 are overwritten with 1.0 IN PLACE (masked_fill_, :274);
  *   mask may be NULL.
@@ -496,6 +508,9 @@ typedef struct rtk_pivotkv_batch {
     void* k_stage;            /* [slots, Hkv, keep, D] (no reforge only, else NULL) */
     int64_t* shift_row;       /* RTK_UPDATE_PRE_ROPE: the caller's temporal-id row; rtk_pivotkv_flush applies the last
                                  pending layer's continuity shift to it in place (qwen2_vl.py:73), then clears this field */
+    const void** q_units;     /* HOST array [slots] or NULL.  Non-NULL entries of the pending slots: the unit's queries are
+                                 scored where they are (RTK_UPDATE_Q_IN_PLACE; element strides below), all pending units alike */
+    int64_t q_stride_h, q_stride_l;
     int32_t pre_rope;         /* the pending units were appended from pre-RoPE projections: k~ == k0 */
     int32_t batched_passes;   /* 1: the score passes of all pending layers run from rtk_pivotkv_flush, one launch per kernel
                                  (16-bit payloads, head_dim 128); 0: rtk_pivotkv_update runs them per unit */
@@ -523,11 +538,15 @@ enum rtk_update_flags {
      *   q~, k~            the un-rotated operands of the score passes are the inputs themselves (un-rotating
      *                     a rotation returns the pre-RoPE value up to rounding), copied to the score workspace / k_unrot.
      * Needs pos_embed_reforge and an inv_freq rotary (batch.inv_freq). */
-    RTK_UPDATE_PRE_ROPE = 1
+    RTK_UPDATE_PRE_ROPE = 1,
+    /* with RTK_UPDATE_PRE_ROPE and q_rot != q: no copy of the queries is made - the score passes of the flush read
+     * io->q itself (the caller keeps it alive and unmodified until rtk_pivotkv_flush has run; the library records the
+     * pointer and strides in batch->q_units).  16-bit payloads scored by the batched passes only. */
+    RTK_UPDATE_Q_IN_PLACE = 2
 };
 /* longvideo_cache.py:217-310 up to the deferred selection, for layer slot `slot`.  Rows go to the layer's tail
  * (ls->k/v + length rows; the caller has made sure length + L <= cap), ls->pending / pending_keep are set. */
-int rtk_pivotkv_update(const rtk_pivotkv_batch* batch, rtk_layer_state* layer, int slot, const rtk_update_io* io,
+int rtk_pivotkv_update(rtk_pivotkv_batch* batch, rtk_layer_state* layer, int slot, const rtk_update_io* io,
                        rtk_stream_t stream);
 
 /* longvideo_cache.py:260-318 for the n pending layers slots[0..n) (ascending) of one chunk: score passes (unless

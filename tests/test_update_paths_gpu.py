@@ -139,12 +139,15 @@ def test_prologue_outputs_bitwise(dtype, mrope):
             prev = cache.get_prev_temporal_idx(l)
             prev = int(prev) if not isinstance(prev, int) else prev
             P0 = cache.get_seq_length(l)
-            qo = torch.empty_like(q0) if l == 1 else None     # layer 1: rotated queries to a tensor of their own
-            out = cache.update_pre_rope(q0, k0, v0, l, pos, rot, sec, shift_ids_in_place=mrope, query_out=qo)
+            # layer 0: rotation in place (q~ is then a packed copy in the score workspace); layer 1: the library's pick - for
+            # 16-bit tensors a fresh tensor for the rotated queries, q0 itself scored where it lies (no copy)
+            out = cache.update_pre_rope(q0, k0, v0, l, pos, rot, sec, shift_ids_in_place=mrope,
+                                        query_out=q0 if l == 0 else None)
             assert out is not None, "the prologue declined a plain video chunk"
             q_rot, K, V = out
-            assert q_rot.data_ptr() == (q0 if qo is None else qo).data_ptr() and K.shape[2] == P0 + L
-            assert qo is None or torch.equal(q0, q_keep)
+            in_place_scoring = l == 1 and dtype != torch.float32
+            assert (q_rot.data_ptr() != q0.data_ptr()) == in_place_scoring and K.shape[2] == P0 + L
+            assert not in_place_scoring or (torch.equal(q0, q_keep) and cache._batch.q_keep[l] is q0)
             want_ids = pos_in.clone()
             if mrope:
                 want_ids[0, 0] += prev + 1 - want_ids[0, 0, 0]
@@ -158,8 +161,9 @@ def test_prologue_outputs_bitwise(dtype, mrope):
             b = cache._batch
             assert torch.equal(b.pos_old[l].reshape(want_ids.shape), want_ids)
             assert torch.equal(b.k_unrot[l], k_keep[0])
-            ws = b.score_ws[(b.score_ws_base - b.score_ws.data_ptr()) + l * b.ws_stride:][: Hq * L * D * es]
-            assert torch.equal(ws.view(dtype).view(Hq, L, D), q_keep[0])
+            if not in_place_scoring:
+                ws = b.score_ws[(b.score_ws_base - b.score_ws.data_ptr()) + l * b.ws_stride:][: Hq * L * D * es]
+                assert torch.equal(ws.view(dtype).view(Hq, L, D), q_keep[0])
             assert torch.equal(pos, pos_in), "the caller's ids move at the flush, not before"
         last_prev = cache.get_prev_temporal_idx(layers - 1)   # (flushes: read it the way the reference would, then undo)
         cache.after_forward()
@@ -446,3 +450,38 @@ def test_masked_columns_never_leak_uninitialised_partials():
         results.append(got)
     for (sa, ia), (sb, ib) in zip(*results):
         assert torch.equal(ia, ib) and torch.equal(sa, sb)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("L", [640, 2304])
+def test_queries_scored_in_place_equal_the_packed_copy(dtype, L):
+    """Prologue route, 16-bit tensors: the chunk-batched passes reading q0 from the projection layout (row pitch Hq * D,
+    one pointer per layer) give bit for bit the scores, kept sets and caches of the route that packs a copy first."""
+    import retake.longvideo_cache as lc
+
+    layers = 3
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    zc, packed = lc.build_kvcache(cfg(layers)), lc.build_kvcache(cfg(layers))
+    for c in range(2):
+        mask = torch.from_numpy(np.random.default_rng(c).uniform(size=L) < 0.3).to(dev())
+        pz, pp = chunk_ids(c, L), chunk_ids(c, L)
+        for cache in (zc, packed):
+            cache.keypatches_mask_chunk = mask
+            cache.kvcache_compression = True
+        for l in range(layers):
+            q0, k0, v0 = projections(500 + 10 * c + l, L, dtype)
+            qz = q0.clone()
+            assert zc.update_pre_rope(qz, k0, v0, l, pz, rot, SEC) is not None              # fresh q_rot, q0 scored in place
+            assert zc._batch.q_keep[l] is qz
+            qq = q0.clone()
+            assert packed.update_pre_rope(qq, k0, v0, l, pp, rot, SEC, query_out=qq) is not None   # rotated in place: packed q~
+            assert packed._batch.q_keep[l] is None
+        for cache in (zc, packed):
+            cache.after_forward()
+        assert all(t is None for t in zc._batch.q_keep)
+        for l in range(layers):
+            assert torch.equal(zc._batch.score[l], packed._batch.score[l])
+            assert torch.equal(zc._batch.keep_idx[l], packed._batch.keep_idx[l])
+    for l in range(layers):
+        assert torch.equal(zc.key_cache[l], packed.key_cache[l]) and torch.equal(zc.value_cache[l], packed.value_cache[l])
+        assert torch.equal(zc.position_cache[l], packed.position_cache[l])

@@ -121,7 +121,7 @@ def main():
                         if l == 0:
                             pos_dev = torch.from_numpy(pos_np).to(dev)
                         got = cp.update_pre_rope(qd, kd, vt.to(dev), l, pos_dev, rot, list(sec) if sec else None,
-                                                 query_out=torch.empty_like(qd) if rng.uniform() < 0.5 else None)
+                                                 query_out=[None, qd, torch.empty_like(qd)][int(rng.integers(0, 3))])
                         assert got is not None, "the prologue declined a chunk it should serve"
                         if ocp is not None:
                             prev = ocp[l].get_prev_temporal_idx(0)

@@ -473,11 +473,11 @@ __device__ __forceinline__ int acc_row(int r, int hf) { return (r & 3) + 8 * (r 
 // Register fragment: row (lane & 31) of a 32-row block starting at `row0` of a contiguous [rows,128] matrix.
 template <int DT>
 __device__ __forceinline__ void load_reg_frag(const char* __restrict__ base, int row0, int nrows, int lane,
-                                              u32x4* rf) {
+                                              u32x4* rf, int pitch = HD * MM<DT>::ESIZE) {
     using M = MM<DT>;
     const int row = row0 + (lane & 31), hf = lane >> 5;
     const bool ok = row < nrows;
-    const u32x4* p = (const u32x4*)(base + (size_t)row * HD * M::ESIZE);
+    const u32x4* p = (const u32x4*)(base + (size_t)row * pitch);   // pitch: bytes between rows (a strided projection)
 #pragma unroll
     for (int r = 0; r < M::NREG; ++r) rf[r] = ok ? p[M::chunk_of(r, hf)] : u32x4{0, 0, 0, 0};
 }
@@ -1141,6 +1141,15 @@ _Pragma("unroll") \
 //   key_index[unit][0 .. n)  ascending indices of the unit's unmasked tokens, key_index[unit][L] = n  (-1: no mask, identity)
 // One 1024-thread workgroup per unit: ordered compaction by a block scan of per-thread counts.
 // ------------------------------------------------------------------------------------------------
+// Where the queries of the units of a batched launch live.  row_pitch == 0: the packed un-rotated copies inside the
+// units' score workspaces ([Hq, L, 128] at q + unit * q_unit_bytes).  Else: per-unit base pointers of tensors the caller
+// keeps alive - the pre-RoPE projections themselves (the prologue route scores q0 as it is, so no copy is made),
+// element (h, i, :) at unit[u] + h * head_stride + i * row_pitch bytes.
+constexpr int MAX_Q_UNITS = 32;
+struct QView {
+    const char* unit[MAX_Q_UNITS];
+    int head_stride, row_pitch;
+};
 constexpr int MAX_MASK_UNITS = 64;
 struct KeyMasks {
     const uint8_t* m[MAX_MASK_UNITS];
@@ -1192,7 +1201,9 @@ template <int NB, bool FAST = false, bool F16 = false>   // F16: exact softmax o
 __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q, const char* __restrict__ k,
                                                      const float* __restrict__ lse, int Hq, int Hkv, int L,
                                                      int rows_per_split, int RS, float* __restrict__ partial, int j_base,
-                                                     int g, int rs, const int* __restrict__ kidx, int Lk) {
+                                                     int g, int rs, const int* __restrict__ kidx, int Lk, int q_hs,
+                                                     int q_pitch) {
+    // q_hs / q_pitch: bytes between the heads / rows of q (packed copy: L * 256 and 256)
     // kidx / Lk: the unit's live keys (ascending token indices, Lk of them; kidx == NULL: all L tokens, Lk == L).  j_base
     // and the wave's key offsets count positions of THAT list; a position's token index names the k~ row it loads and
     // the column of `partial` it writes.
@@ -1236,28 +1247,33 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
     // DMA addressing: piece P = 4u + wid (u = 0..3) covers tile rows 4P .. 4P+3; this lane fills position
     // (lane & 15) of row 4P + (lane >> 4) with source chunk (lane & 15) ^ (row & 15)
     const int drow = 4 * wid + (lane >> 4);                                        // row inside a 16-row group
-    const int dvoff = drow * T::ROWB + (((lane & 15) ^ (drow & 15)) * 16);          // + u * 16 rows via soffset
-    const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, Hq * L * HD * M::ESIZE, 0x00020000);
+    const int dvoff = drow * q_pitch + (((lane & 15) ^ (drow & 15)) * 16);           // + u * 16 rows via soffset
+    // (a row past L lies past the buffer for a strided projection and inside the next head for the packed copy: zeros
+    // or finite values, either way met by lse = +inf)
+    const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)q, 0, (Hq - 1) * q_hs + (L - 1) * q_pitch + HD * M::ESIZE, 0x00020000);
     const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)lse, 0, Hq * L * 4, 0x00020000);
     const bool lse_dma = (nrows % TILE_ROWS == 0);   // uniform: no row of a tile lies past the split
     float lstA = 0.f;
     int nt = 0;
     const int last_row = Hq * L - 1;
-    int nrow0 = (g * G) * L + ib;
+    int nrow0 = (g * G) * L + ib;           // row of lse [Hq, L] the cursor's head starts its split at
+    int qoff0 = (g * G) * q_hs + ib * q_pitch;   // byte offset of that row in q
     // issues the DMA of the cursor tile into LDS buffer `b`, fetches this thread's lse element, advances the cursor
 #define RTK_DMA_ISSUE(b)                                                                                  \
     {                                                                                                     \
-        const int row_base = nrow0 + nt * TILE_ROWS;                                                      \
+        const int qb__ = qoff0 + nt * TILE_ROWS * q_pitch;                                                \
         _Pragma("unroll")                                                                                 \
         for (int u = 0; u < 4; ++u)                                                                       \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                     \
                 qrsrc, (void __attribute__((address_space(3)))*)(smem + (b) * T::BYTES + (4 * u + wid) * 1024), 16, \
-                dvoff, (row_base + 16 * u) * T::ROWB, 0, 0);                                              \
+                dvoff, qb__ + 16 * u * q_pitch, 0, 0);                                                    \
         const int r__ = nt * TILE_ROWS + (tid & (TILE_ROWS - 1));                                         \
         lstA = (r__ < nrows) ? lse[min(nrow0 + r__, last_row)] : (FAST ? -INFINITY : INFINITY);           \
         const bool wrap__ = (nt + 1 == tiles_per_head);                                                   \
         nt = wrap__ ? 0 : nt + 1;                                                                         \
         nrow0 += wrap__ ? L : 0;                                                                          \
+        qoff0 += wrap__ ? q_hs : 0;                                                                       \
     }
 #define RTK_DMA_PIECES(b, rb, U0, U1)                                                                     \
     {                                                                                                     \
@@ -1265,7 +1281,7 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
         for (int u = U0; u < U1; ++u)                                                                     \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                     \
                 qrsrc, (void __attribute__((address_space(3)))*)(smem + (b) * T::BYTES + (4 * u + wid) * 1024), 16, \
-                dvoff, ((rb) + 16 * u) * T::ROWB, 0, 0);                                                  \
+                dvoff, (rb) + 16 * u * q_pitch, 0, 0);                                                    \
     }
 #define RTK_DMA_TAIL(b)                                                                                   \
     {                                                                                                     \
@@ -1279,13 +1295,14 @@ __device__ __forceinline__ void score_pass2_dma_body(const char* __restrict__ q,
         const bool wrap__ = (nt + 1 == tiles_per_head);                                                   \
         nt = wrap__ ? 0 : nt + 1;                                                                         \
         nrow0 += wrap__ ? L : 0;                                                                          \
+        qoff0 += wrap__ ? q_hs : 0;                                                                       \
     }
 #define RTK_DMA_STEP(BUF, ISSUE)                                                                          \
     {                                                                                                     \
         constexpr int buf = BUF;                                                                          \
         const char* cur = smem + buf * T::BYTES;                                                          \
         const float* lcur = lse_s + buf * TILE_ROWS;                                                      \
-        const int rb__ = nrow0 + nt * TILE_ROWS;                                                          \
+        const int rb__ = qoff0 + nt * TILE_ROWS * q_pitch;   /* byte offset of the next tile's rows */    \
         if constexpr (ISSUE) RTK_DMA_TAIL(buf ^ 1)                                  \
         _Pragma("unroll")                                                                                 \
         for (int blk = 0; blk < 2; ++blk) {                                                               \
@@ -1373,8 +1390,9 @@ template <int NB, bool FAST = false, bool F16 = false>
 __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 2 : 2)))) void score_pass2_dma_kernel(
     const char* __restrict__ q, const char* __restrict__ k, const float* __restrict__ lse, int Hq, int Hkv, int L,
     int rows_per_split, int col_tiles, int RS, int xcd_remap, float* __restrict__ partial, size_t q_unit_bytes,
-    size_t k_unit_bytes, size_t lse_unit_floats, size_t part_unit_floats, const int* __restrict__ key_index = nullptr) {
-    q += blockIdx.y * q_unit_bytes;
+    size_t k_unit_bytes, size_t lse_unit_floats, size_t part_unit_floats, const int* __restrict__ key_index, QView qv) {
+    const int q_hs = qv.row_pitch ? qv.head_stride : L * HD * 2, q_pitch = qv.row_pitch ? qv.row_pitch : HD * 2;
+    q = qv.row_pitch ? qv.unit[blockIdx.y] : q + blockIdx.y * q_unit_bytes;
     k += blockIdx.y * k_unit_bytes;
     lse += blockIdx.y * lse_unit_floats;
     partial += blockIdx.y * part_unit_floats;
@@ -1407,11 +1425,12 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : (NB == 2 ? 3 : (NB == 3 ? 
     if (j_base >= Lk) return;
     if constexpr (NB == 2) {
         if (Lk - j_base <= REG_ROWS) {   // uniform per workgroup
-            score_pass2_dma_body<1, FAST, F16>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk);
+            score_pass2_dma_body<1, FAST, F16>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk, q_hs,
+                                               q_pitch);
             return;
         }
     }
-    score_pass2_dma_body<NB, FAST, F16>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk);
+    score_pass2_dma_body<NB, FAST, F16>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk, q_hs, q_pitch);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1428,7 +1447,7 @@ constexpr int P1_F16 = 1, P1_SCALED = 2, P1_RAW = 4;
 template <int NB, bool LAZY, int MODE = 0>
 __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv,
                                                      int L, int keys_per_split, float* __restrict__ lse_part, int i_base, int h,
-                                                     int ks, int neg_out = 0) {
+                                                     int ks, int neg_out, int q_hs, int q_pitch) {
     constexpr int DT = RTK_BF16;
     using M = MM<DT>;
     using T = Tile<DT>;
@@ -1448,7 +1467,7 @@ __device__ __forceinline__ void score_pass1_dma_body(const char* __restrict__ q,
     const int ntiles = (nkeys + TILE_ROWS - 1) / TILE_ROWS;
     u32x4 qf[NB][M::NREG];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) load_reg_frag<DT>(q + (size_t)h * L * HD * M::ESIZE, i0 + 32 * nb, L, lane, qf[nb]);
+    for (int nb = 0; nb < NB; ++nb) load_reg_frag<DT>(q + (size_t)h * q_hs, i0 + 32 * nb, L, lane, qf[nb], q_pitch);
     int frag_off[M::NREG];
     {
         const int row = lane & 31;
@@ -1585,8 +1604,9 @@ template <int NB, bool LAZY, int MODE = 0>
 __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_kernel(
     const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv, int L, int keys_per_split, int row_tiles,
     int xcd_remap, float* __restrict__ lse_part, size_t q_unit_bytes, size_t k_unit_bytes, size_t lse_unit_floats,
-    int neg_out = 0) {
-    q += blockIdx.y * q_unit_bytes;
+    int neg_out, QView qv) {
+    const int q_hs = qv.row_pitch ? qv.head_stride : L * HD * 2, q_pitch = qv.row_pitch ? qv.row_pitch : HD * 2;
+    q = qv.row_pitch ? qv.unit[blockIdx.y] : q + blockIdx.y * q_unit_bytes;
     k += blockIdx.y * k_unit_bytes;
     lse_part += blockIdx.y * lse_unit_floats;
     const int G = Hq / Hkv;
@@ -1609,11 +1629,11 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
     const int i_base = bx * (REG_ROWS * NB);
     if constexpr (NB == 2) {
         if (L - i_base <= REG_ROWS) {   // uniform per workgroup
-            score_pass1_dma_body<1, LAZY, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
+            score_pass1_dma_body<1, LAZY, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out, q_hs, q_pitch);
             return;
         }
     }
-    score_pass1_dma_body<NB, LAZY, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
+    score_pass1_dma_body<NB, LAZY, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out, q_hs, q_pitch);
 }
 
 // RTK_BF16_FAST fix-up launch: the row tiles whose plain sums left fp32's range (published as NaN by RowStatR) are
@@ -1627,8 +1647,9 @@ template <int NB, int MODE>   // MODE: the robust flags (no P1_RAW) of the launc
 __global__ __launch_bounds__(SC_BLOCK, 2) void score_pass1_fixup_kernel(   // (2: registers, not occupancy - no spills)
     const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv, int L, int keys_per_split, int row_tiles,
     int n_tiles, float* __restrict__ lse_part, size_t q_unit_bytes, size_t k_unit_bytes, size_t lse_unit_floats,
-    int neg_out) {
-    q += blockIdx.y * q_unit_bytes;
+    int neg_out, QView qv) {
+    const int q_hs = qv.row_pitch ? qv.head_stride : L * HD * 2, q_pitch = qv.row_pitch ? qv.row_pitch : HD * 2;
+    q = qv.row_pitch ? qv.unit[blockIdx.y] : q + blockIdx.y * q_unit_bytes;
     k += blockIdx.y * k_unit_bytes;
     lse_part += blockIdx.y * lse_unit_floats;
     const int t0 = blockIdx.x * FIX_TILES;
@@ -1657,9 +1678,9 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void score_pass1_fixup_kernel(   // (2
         const int h = kh % Hq, ks = kh / Hq;
         const int i_base = bx * (REG_ROWS * NB);
         if (NB == 2 && L - i_base <= REG_ROWS)
-            score_pass1_dma_body<1, true, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
+            score_pass1_dma_body<1, true, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out, q_hs, q_pitch);
         else
-            score_pass1_dma_body<NB, true, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out);
+            score_pass1_dma_body<NB, true, MODE>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, neg_out, q_hs, q_pitch);
         __syncthreads();   // the next tile's prologue writes the LDS buffers this one was still reading
     }
 }
@@ -1887,7 +1908,12 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                       int Hkv, int L, int D, const float* cosv, const float* sinv, float a, float* score,
                       void* k_unrot, char* ws, const ScoreWs& w, int stages, float* partial_out, hipStream_t st,
                       int n_units = 1, size_t ws_stride = 0, size_t k_stride = 0, size_t part_stride = 0,
-                      const int* key_index = nullptr) {
+                      const int* key_index = nullptr, const QView* q_view = nullptr) {
+    // q_view (bf16 LDS-DMA passes only, n_units <= MAX_Q_UNITS): the units' queries are read where the caller keeps
+    // them (per-unit pointers, head stride, row pitch) instead of from the packed copies inside the workspaces
+    QView qv;
+    memset(&qv, 0, sizeof(qv));
+    if (q_view) qv = *q_view;
     // n_units > 1 (RTK_SCORE_PASSES only): the same passes for n_units units whose workspaces / k~ / partials lie
     // ws_stride / k_stride bytes and part_stride floats apart — one launch per kernel, blockIdx.y = unit
     char* qt = ws + w.q_off;
@@ -2048,11 +2074,11 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
 #define RTK_P1(MODEV)                                                                                                  \
     RTK_LAUNCH(KID_PASS1, (score_pass1_dma_kernel<RTK_P1_NB, RTK_P1_LAZY, MODEV>), g1, dim3(SC_BLOCK), LDS1, st,           \
                (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1, x1, lse, ws_stride, k_stride,                     \
-               ws_stride / sizeof(float), neg);                                                                         \
+               ws_stride / sizeof(float), neg, qv);                                                                     \
     if ((MODEV) & P1_RAW)                                                                                               \
         RTK_LAUNCH(KID_FINALIZE, (score_pass1_fixup_kernel<RTK_P1_NB, (MODEV) & ~P1_RAW>), gf, dim3(SC_BLOCK), LDS1, st,   \
                    (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1, n_tiles, lse, ws_stride, k_stride,            \
-                   ws_stride / sizeof(float), neg)
+                   ws_stride / sizeof(float), neg, qv)
                 constexpr int RAWF = RTK_P1_RAW ? P1_RAW : 0;
                 if (w.fast) { RTK_P1(P1_F16 | P1_SCALED | P1_RAW); }
                 else if (w.h16) { RTK_P1(P1_F16 | RAWF); }
@@ -2074,17 +2100,17 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                     RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<RTK_P2_NB, true>), dim3(Hkv * rs_n * jt2, n_units), dim3(SC_BLOCK), LDS2, st,
                                (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n,
                                (int)((Hkv * rs_n) % NXCD == 0), part, ws_stride, k_stride, ws_stride / sizeof(float),
-                               part_stride, key_index);
+                               part_stride, key_index, qv);
                 else if (w.h16)
                     RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<RTK_P2_NB, false, true>), dim3(Hkv * rs_n * jt2, n_units), dim3(SC_BLOCK), LDS2, st,
                                (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n,
                                (int)((Hkv * rs_n) % NXCD == 0), part, ws_stride, k_stride, ws_stride / sizeof(float),
-                               part_stride, key_index);
+                               part_stride, key_index, qv);
                 else
                 RTK_LAUNCH(KID_PASS2, (score_pass2_dma_kernel<RTK_P2_NB>), dim3(Hkv * rs_n * jt2, n_units), dim3(SC_BLOCK), LDS2, st,
                            (const char*)qt, (const char*)kt, (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n,
                            (int)((Hkv * rs_n) % NXCD == 0), part, ws_stride, k_stride, ws_stride / sizeof(float),
-                           part_stride, key_index);
+                           part_stride, key_index, qv);
             }
             else
                 RTK_LAUNCH(KID_PASS2, (score_pass2_kernel<DT, NBR>), dim3(Hkv * rs_n * jt), dim3(SC_BLOCK), LDS2, st,
@@ -2153,6 +2179,67 @@ extern "C" int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspa
                                 k_unrot0, (char*)workspace0, w, RTK_SCORE_PASSES, partial0, (hipStream_t)stream, n_units,
                                 workspace_stride, k_unrot0 ? k_unrot_stride : workspace_stride, partial_stride_floats,
                                 key_index);
+}
+
+extern "C" int rtk_pivotkv_score_passes_batched_q(void* workspace0, size_t workspace_stride, void* k_unrot0,
+                                                  size_t k_unrot_stride, float* partial0, size_t partial_stride_floats,
+                                                  int n_units, int Hq, int Hkv, int L, int D, int dtype,
+                                                  const void* const* key_masks_host, int32_t* key_index_ws,
+                                                  const void* const* q_units_host, int64_t q_stride_h, int64_t q_stride_l,
+                                                  rtk_stream_t stream) {
+    if (!q_units_host)
+        return rtk_pivotkv_score_passes_batched(workspace0, workspace_stride, k_unrot0, k_unrot_stride, partial0,
+                                                partial_stride_floats, n_units, Hq, Hkv, L, D, dtype, key_masks_host,
+                                                key_index_ws, stream);
+    const int base = dtype & ~RTK_SCORE_MANY_UNITS;
+    RTK_CHECK_ARG(workspace0 && partial0 && k_unrot0 && n_units >= 1, "rtk_pivotkv_score_passes_batched_q: NULL pointer or no units");
+    if ((base != RTK_BF16 && base != RTK_F16) || D != HD) {
+        set_error("rtk_pivotkv_score_passes_batched_q: bf16 / fp16 payloads with head_dim %d only", HD);
+        return RTK_EUNSUPPORTED;
+    }
+    RTK_CHECK_ARG(q_stride_h > 0 && q_stride_l > 0 && (q_stride_h * 2) % 16 == 0 && (q_stride_l * 2) % 16 == 0 &&
+                      (Hq - 1) * q_stride_h * 2 + (int64_t)(L - 1) * q_stride_l * 2 < (1ll << 31),
+                  "rtk_pivotkv_score_passes_batched_q: bad query strides");
+    for (int u = 0; u < n_units; ++u)
+        RTK_CHECK_ARG(q_units_host[u] && ((uintptr_t)q_units_host[u] & 15) == 0,
+                      "rtk_pivotkv_score_passes_batched_q: unit %d: queries must be 16-byte aligned", u);
+    RTK_CHECK_ARG(((uintptr_t)workspace0 & 255) == 0 && workspace_stride % 256 == 0,
+                  "rtk_pivotkv_score_passes_batched_q: workspaces must be 256-byte aligned");
+    const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype);
+    RTK_CHECK_ARG(n_units == 1 || workspace_stride >= w.total, "rtk_pivotkv_score_passes_batched_q: workspace stride too small");
+    const int* key_index = nullptr;
+    if (key_masks_host && key_index_ws) {
+        bool any = false;
+        for (int u = 0; u < n_units; ++u) any = any || key_masks_host[u];
+        if (any) {
+            for (int u0 = 0; u0 < n_units; u0 += MAX_MASK_UNITS) {
+                KeyMasks km;
+                const int m = std::min(MAX_MASK_UNITS, n_units - u0);
+                for (int u = 0; u < MAX_MASK_UNITS; ++u) km.m[u] = u < m ? (const uint8_t*)key_masks_host[u0 + u] : nullptr;
+                RTK_LAUNCH(KID_FINALIZE, key_compact_kernel, dim3(m), dim3(1024), 0, (hipStream_t)stream, km, L,
+                           key_index_ws + (size_t)u0 * (L + 1));
+            }
+            RTK_LAUNCH_CHECK("key_compact_kernel");
+            key_index = key_index_ws;
+        }
+    }
+    float dummy_score = 0.f;
+    for (int u0 = 0; u0 < n_units; u0 += MAX_Q_UNITS) {   // the pointer table travels as a kernel argument
+        const int m = std::min(MAX_Q_UNITS, n_units - u0);
+        QView qv;
+        memset(&qv, 0, sizeof(qv));
+        for (int u = 0; u < m; ++u) qv.unit[u] = (const char*)q_units_host[u0 + u];
+        qv.head_stride = (int)(q_stride_h * 2);
+        qv.row_pitch = (int)(q_stride_l * 2);
+        char* ws_u = (char*)workspace0 + (size_t)u0 * workspace_stride;
+        const int rc = score_impl<RTK_BF16>(ws_u, 0, 0, ws_u, 0, 0, Hq, Hkv, L, D, nullptr, nullptr, 1.0f, &dummy_score,
+                                            (char*)k_unrot0 + (size_t)u0 * k_unrot_stride, ws_u, w, RTK_SCORE_PASSES,
+                                            partial0 + (size_t)u0 * partial_stride_floats, (hipStream_t)stream, m,
+                                            workspace_stride, k_unrot_stride, partial_stride_floats,
+                                            key_index ? key_index + (size_t)u0 * (L + 1) : nullptr, &qv);
+        if (rc) return rc;
+    }
+    return RTK_OK;
 }
 
 extern "C" size_t rtk_pivotkv_score_partials(int Hq, int Hkv, int L, int D, int dtype, int* rs_out) {

@@ -259,7 +259,7 @@ static int check_batch(const rtk_pivotkv_batch* b, const char* who) {
     return RTK_OK;
 }
 
-extern "C" int rtk_pivotkv_update(const rtk_pivotkv_batch* b, rtk_layer_state* ls, int slot, const rtk_update_io* io,
+extern "C" int rtk_pivotkv_update(rtk_pivotkv_batch* b, rtk_layer_state* ls, int slot, const rtk_update_io* io,
                                   rtk_stream_t stream) {
     int rc = check_batch(b, "rtk_pivotkv_update");
     if (rc) return rc;
@@ -313,6 +313,25 @@ extern "C" int rtk_pivotkv_update(const rtk_pivotkv_batch* b, rtk_layer_state* l
         if (rc) return rc;
         const int64_t* prev = (ls->pos && ls->pos_len > 0) ? ls->pos + (ls->pos_len - 1) : nullptr;
         char* q_out = b->keep_all ? nullptr : ws;   // q~ at offset 0 of the slot's score workspace
+        if ((io->flags & RTK_UPDATE_Q_IN_PLACE) && !b->keep_all) {
+            // q~ IS io->q: the batched passes of the flush stream it from where it lies
+            if (!b->q_units || !b->batched_passes || score_base == RTK_BF16_FAST || io->q_rot == io->q) {
+                set_error("rtk_pivotkv_update: RTK_UPDATE_Q_IN_PLACE needs batch.q_units, the batched passes, exact score "
+                          "arithmetic and rotated queries that go elsewhere");
+                return RTK_EINVAL;
+            }
+            for (int u = 0; u < b->slots; ++u)   // one pointer table, one pair of strides per flush
+                if (u != slot && b->q_units[u] && (b->q_stride_h != io->q_stride_h || b->q_stride_l != io->q_stride_l)) {
+                    set_error("rtk_pivotkv_update: the pending units' queries have other strides (flush first)");
+                    return RTK_EUNSUPPORTED;
+                }
+            b->q_units[slot] = io->q;
+            b->q_stride_h = io->q_stride_h;
+            b->q_stride_l = io->q_stride_l;
+            q_out = nullptr;
+        } else if (b->q_units) {
+            b->q_units[slot] = nullptr;
+        }
         // RTK_BF16_FAST: a second, fp16 copy of k~ inside the workspace, right behind q~ (score_ws: k_off)
         char* k_fast = nullptr;
         if (score_base == RTK_BF16_FAST && !b->keep_all)
@@ -325,6 +344,7 @@ extern "C" int rtk_pivotkv_update(const rtk_pivotkv_batch* b, rtk_layer_state* l
             rc = prologue_launch<RTK_F32>(b, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, nullptr, st);
         if (rc) return rc;
     } else {
+        if (b->q_units) b->q_units[slot] = nullptr;
         const int dt = b->prep_dtype | (b->keep_all ? RTK_PREPARE_K_ONLY : 0);
         rc = rtk_pivotkv_prepare(io->q, io->q_stride_h, io->q_stride_l, io->k, io->k_stride_h, io->k_stride_l, io->v,
                                  io->v_stride_h, io->v_stride_l, b->Hq, Hkv, L, D, dt, io->pos, io->pos_stride, b->P,
@@ -395,13 +415,24 @@ extern "C" int rtk_pivotkv_flush(rtk_pivotkv_batch* b, rtk_layer_state* const* l
                     masks[u] = b->skip_masked ? layers[i + u]->mask : nullptr;
                     any = any || masks[u];
                 }
-                rc = rtk_pivotkv_score_passes_batched(
+                // queries scored in place (prologue route): every unit of the run, or none
+                const void* const* qu = nullptr;
+                if (b->q_units && b->q_units[l0]) {
+                    for (int u = 0; u < cnt; ++u)
+                        RTK_CHECK_ARG(b->q_units[l0 + u], "rtk_pivotkv_flush: slot %d has no in-place queries but slot %d has",
+                                      l0 + u, l0);
+                    qu = b->q_units + l0;
+                }
+                rc = rtk_pivotkv_score_passes_batched_q(
                     (char*)b->score_ws + (size_t)l0 * b->score_ws_stride, b->score_ws_stride,
                     reforge ? (char*)b->k_unrot + (size_t)l0 * Hkv * L * D * es : nullptr, (size_t)Hkv * L * D * es,
                     b->partials + (size_t)l0 * b->partial_floats, b->partial_floats, cnt, b->Hq, Hkv, L, D, b->score_dtype,
                     (any && b->key_index) ? masks.data() : nullptr,
-                    (any && b->key_index) ? b->key_index + (size_t)l0 * (L + 1) : nullptr, stream);
+                    (any && b->key_index) ? b->key_index + (size_t)l0 * (L + 1) : nullptr, qu, b->q_stride_h, b->q_stride_l,
+                    stream);
                 if (rc) return rc;
+                if (qu)
+                    for (int u = 0; u < cnt; ++u) b->q_units[l0 + u] = nullptr;
                 i = j + 1;
             }
         }

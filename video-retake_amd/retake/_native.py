@@ -19,6 +19,7 @@ RTK_F32, RTK_BF16, RTK_BF16_REFROUND, RTK_BF16_FAST, RTK_F16 = 0, 1, 2, 3, 4
 RTK_SCORE_MANY_UNITS = 0x100   # flag for the dtype argument of the scoring entry points (split policy of batched launches)
 RTK_PREPARE_K_ONLY = 0x200     # flag for the dtype argument of rtk_pivotkv_prepare: keep-all chunk, no q~
 RTK_UPDATE_PRE_ROPE = 1        # rtk_update_io.flags: q / k are the pre-RoPE projections (attention prologue)
+RTK_UPDATE_Q_IN_PLACE = 2      # ... and the score passes read q where it is (no packed copy)
 SCORE_PREPARE, SCORE_PASSES, SCORE_FINALIZE = 1, 2, 4
 RTK_EINVAL, RTK_EUNSUPPORTED, RTK_EWORKSPACE, RTK_EHIP, RTK_EREFCRASH = -1, -2, -3, -4, -5
 
@@ -76,7 +77,8 @@ class PivotKVBatch(C.Structure):
                 ("score_ws", _vp), ("score_ws_stride", _u64), ("score_ws_bytes", _u64),
                 ("k_unrot", _vp), ("partials", _vp), ("partial_floats", _u64), ("score", _vp), ("pos_old", _vp),
                 ("keep_idx", _vp), ("pos_new", _vp), ("sel_ws", _vp), ("sel_ws_stride", _u64), ("key_index", _vp),
-                ("v_stage", _vp), ("k_stage", _vp), ("shift_row", _vp), ("pre_rope", _i32), ("batched_passes", _i32)]
+                ("v_stage", _vp), ("k_stage", _vp), ("shift_row", _vp), ("q_units", _vp), ("q_stride_h", _i64),
+                ("q_stride_l", _i64), ("pre_rope", _i32), ("batched_passes", _i32)]
 
 
 class UpdateIO(C.Structure):
@@ -111,6 +113,8 @@ _SIGNATURES = {
     "rtk_pivotkv_score_stages_masked": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp,
                                                   _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp]),
     "rtk_pivotkv_score_passes_batched": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rtk_pivotkv_score_passes_batched_q": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i64,
+                                                     _i64, _vp]),
     "rtk_pivotkv_score_partials": (C.c_size_t, [_i, _i, _i, _i, _i, C.POINTER(C.c_int)]),
     "rtk_pivotkv_select_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i, _vp]),
     "rtk_pivotkv_prepare": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i,

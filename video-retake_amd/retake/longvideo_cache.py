@@ -320,6 +320,10 @@ class _Batch:
         self.cref = C.addressof(self.c)
         self.io = nv.UpdateIO()
         self.ioref = C.addressof(self.io)
+        # prologue route: queries that are scored where they lie (no packed copy) - the pointers the library reads at
+        # the flush, and the tensors themselves, kept alive until then
+        self.q_units = (C.c_void_p * slots)()
+        self.q_keep: List[Optional[torch.Tensor]] = [None] * slots
         c = self.c
         c.Hq, c.Hkv, c.L, c.D, c.keep, c.P, c.slots = Hq, Hkv, L, D, keep, P, slots
         c.dtype = nv.RTK_BF16 if dtype == torch.bfloat16 else (nv.RTK_F16 if dtype == torch.float16 else nv.RTK_F32)
@@ -332,6 +336,7 @@ class _Batch:
         c.pos_old = self.pos_old.data_ptr() if P else None
         c.k_unrot = self.k_unrot.data_ptr() if reforge else None
         c.k_stage = self.k_stage.data_ptr() if self.k_stage is not None else None
+        c.q_units = C.addressof(self.q_units)
         # the one-call path serves the deferred chip-wide selection (L >= 512) of reforging caches with position ids
         self.c_capable = bool(reforge and P and L >= 512)
         if not keep_all:
@@ -826,6 +831,8 @@ class PivotKVCache(DynamicCache):
         b.scored.clear()
         b.selected.clear()
         b.shift_ids = None
+        for l in layers:
+            b.q_keep[l] = None
         if b.reforge and b.P:
             self._pos_layers = max(self._pos_layers, layers[-1] + 1)
         return True
@@ -869,11 +876,18 @@ class PivotKVCache(DynamicCache):
                 mptr = [b.masks.get(l) for l in range(l0, l0 + n)]
                 km = (C.c_void_p * n)(*[m.data_ptr() if m is not None else None for m in mptr]) \
                     if self.skip_masked_columns and any(m is not None for m in mptr) else None
-                nv.check(nv.lib.rtk_pivotkv_score_passes_batched(
+                qk = [b.q_keep[l] for l in range(l0, l0 + n)]
+                qu, qsh, qsl = None, 0, 0
+                if any(t is not None for t in qk):   # units of the prologue route whose queries are scored in place
+                    if any(t is None or t.stride() != qk[0].stride() for t in qk):
+                        raise RuntimeError("PivotKVCache: in-place and packed queries mixed in one run of pending layers")
+                    qu = (C.c_void_p * n)(*[t.data_ptr() for t in qk])
+                    qsh, qsl = qk[0].stride(1), qk[0].stride(2)
+                nv.check(nv.lib.rtk_pivotkv_score_passes_batched_q(
                     C.c_void_p(b.score_ws_base + l0 * b.ws_stride), b.ws_stride,
                     nv.ptr(b.k_unrot[l0]) if b.reforge else None, b.L * D * Hkv * es,
                     nv.ptr(b.partials[l0]), b.part_floats, n, b.Hq, Hkv, b.L, D, b.score_dt,
-                    km, nv.ptr(b.key_index[l0]) if km is not None else None, nv.stream()),
+                    km, nv.ptr(b.key_index[l0]) if km is not None else None, qu, qsh, qsl, nv.stream()),
                     "rtk_pivotkv_score_passes_batched")
                 i = j + 1
             b.scored.clear()
@@ -969,6 +983,8 @@ class PivotKVCache(DynamicCache):
                 nv.check(nv.lib.rtk_pivotkv_place_batched(places, nc, Hkv, keep, D, dt, s), "rtk_pivotkv_place_batched")
         for l in layers:
             st = self._layers[l]
+            b.q_keep[l] = None
+            b.q_units[l] = None
             st.length += keep
             st.pending = 0
             st.pending_keep = 0
@@ -1062,12 +1078,15 @@ class PivotKVCache(DynamicCache):
         io.k, io.k_stride_h, io.k_stride_l = key_states.data_ptr(), ks[1], ks[2]
         io.v, io.v_stride_h, io.v_stride_l = value_states.data_ptr(), vs[1], vs[2]
         io.pos, io.pos_stride = pos.data_ptr(), pos.stride(0)
+        q_in_place = False
         if pre:
-            if q_out is None:
+            if q_out is None or q_out is q:
                 io.q_rot, io.qr_stride_h, io.qr_stride_l, io.flags = io.q, qs[1], qs[2], nv.RTK_UPDATE_PRE_ROPE
             else:
                 io.q_rot, io.qr_stride_h, io.qr_stride_l = q_out.data_ptr(), q_out.stride(1), q_out.stride(2)
-                io.flags = nv.RTK_UPDATE_PRE_ROPE
+                # the rotated queries go elsewhere, so q0 survives: the batched passes score it where it lies
+                q_in_place = b.batched_passes and not b.fast and not b.keep_all
+                io.flags = nv.RTK_UPDATE_PRE_ROPE | (nv.RTK_UPDATE_Q_IN_PLACE if q_in_place else 0)
         else:
             io.q_rot, io.flags = None, 0
         c.mask = mptr
@@ -1096,6 +1115,7 @@ class PivotKVCache(DynamicCache):
             self.update_num_evicted_tokens(L - b.keep, layer_idx)
         if mask is not None:
             b.masks[layer_idx] = mask
+        b.q_keep[layer_idx] = q if q_in_place else None
         if b.keep_all:
             b.scored.add(layer_idx)
         elif not b.batched_passes:
@@ -1117,8 +1137,11 @@ class PivotKVCache(DynamicCache):
         shift_ids_in_place: the Qwen2-VL patch shifts the ids tensor it was handed (qwen2_vl.py:73; done here by the
         chunk's flush, with the last layer's rule - what the reference's layer loop leaves behind); the LLaVA patch
         shifts a private clone (llava_onevision.py:76-88), i.e. leaves the caller's tensor alone.
-        query_out: where the rotated queries go instead of over `query_states` (same shape and dtype, head_dim
-        contiguous); it is then the first element of the returned tuple."""
+        query_out: where the rotated queries go (same shape and dtype, head_dim contiguous); it is the first element of
+        the returned tuple.  None: the library's pick - a fresh tensor when the chunk-batched score passes can then read
+        `query_states` where it lies (no copy of the queries is made; `query_states` must stay unmodified until the
+        chunk's flush, and is kept alive by the cache), else over `query_states`; pass `query_states` itself to force
+        the in-place rotation."""
         if not (self.kvcache_compression and self.pos_embed_reforge and self.one_call_update) or self.overlap_streams > 0 \
                 or position_ids is None or not key_states.is_cuda or key_states.shape[0] != 1 \
                 or (torch.is_grad_enabled() and query_states.requires_grad):
@@ -1146,8 +1169,14 @@ class PivotKVCache(DynamicCache):
             b.x_like = value_states[:, :, :1]
             self.reserve(layer_idx, L, key_states)
         ck = {"position_ids": position_ids, "rotary_emb": rotary_emb, "mrope_section": mrope_section}
-        if query_out is not None and (query_out.shape != query_states.shape or query_out.dtype is not query_states.dtype
-                                      or query_out.device != query_states.device or query_out.stride(-1) != 1):
+        if query_out is None:
+            # the library's pick: a fresh tensor whenever the queries can then be scored where they lie (the chunk-batched
+            # passes read q0 itself - no packed copy, a quarter of the kernel's traffic), else over `query_states`
+            if b.batched_passes and not b.fast and not b.keep_all:
+                query_out = torch.empty_like(query_states)
+        elif query_out is not query_states and (query_out.shape != query_states.shape
+                                                or query_out.dtype is not query_states.dtype
+                                                or query_out.device != query_states.device or query_out.stride(-1) != 1):
             raise ValueError("query_out must match query_states in shape, dtype and device, with a contiguous head_dim")
         out = self._update_c(b, key_states, value_states, layer_idx, ck, query_states, shift_ids_in_place, query_out)
         if out is None:
