@@ -91,6 +91,8 @@ def parse():
     ap.add_argument("--pre-rope", action="store_true",
                     help="measure the attention patch's fused prologue instead (PivotKVCache.update_pre_rope on pre-RoPE "
                          "projections in the projection layout); not the contract line")
+    ap.add_argument("--cache-option", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra kvcache_compression_kwargs entry of the measured cache (A/B runs), e.g. score_queries_in_place=0")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-check", action="store_true")
@@ -454,6 +456,9 @@ def main():
     args = parse()
     OVERLAP_STREAMS = args.streams
     SCORE_ROUNDING = args.score_rounding
+    for kv in args.cache_option:
+        k_, v_ = kv.split("=", 1)
+        CACHE_EXTRA[k_] = {"0": False, "1": True, "false": False, "true": True}.get(v_.lower(), v_)
     set_geometry(args.geometry)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -600,7 +605,11 @@ def main():
         ga_bytes = 2 * T * N_PATCH * C_EMB * es
         extra = {}
         fused = "append" not in kern   # native-RoPE path: tables + un-rotate + append are ONE kernel (unrotate_pack)
+        # the attention prologue (--pre-rope): q read + rotated q written (the queries are scored where they lie: no packed
+        # copy), k read + k~ + rotated tail, v read + tail
+        pro_bytes = (2 * Hq + 5 * Hkv) * L * D * es
         for name, key, b in (("append", "append", ap_bytes),
+                             ("prologue", "prologue", pro_bytes),
                              ("prepare_fused" if fused else "unrotate", "unrotate_pack",
                               prep_bytes if fused else 2 * (Hq + Hkv) * L * D * es),
                              ("evict_batched", "evict_batched", evu_bytes * args.layers),
@@ -636,7 +645,10 @@ def main():
                                                    (stages.get("evict_batched", 0) + stages.get("commit_batched", 0)) * 1e-6) / 1e9}
             # the same plus the tail append update() owes the layer's attention (reference :238, P1): its own kernel,
             # or its byte share of the fused prepare kernel.  SURVEY's byte count has no term for it.
-            t_app = kern["append"]["avg_us"] if not fused else kern["unrotate_pack"]["avg_us"] * ap_bytes / prep_bytes
+            if "prologue" in kern:
+                t_app = kern["prologue"]["avg_us"] * ap_bytes / pro_bytes
+            else:
+                t_app = kern["append"]["avg_us"] if not fused else kern["unrotate_pack"]["avg_us"] * ap_bytes / prep_bytes
             t_unit = t_scan + t_app * 1e-6
             gbs = ev_bytes / t_unit / 1e9
             extra["cache_update_per_unit"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

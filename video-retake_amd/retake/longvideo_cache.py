@@ -479,6 +479,9 @@ class PivotKVCache(DynamicCache):
         # provisional; the owner rotates them once, at their final ids (rtk_rope_rotate_rows), when the temporal offset
         # of its block is known.  key_cache then holds un-rotated rows until that call.
         self.defer_rerotation = bool(kv_compression_kwargs.get("defer_rerotation", False))
+        # MI355X build option (tests / A-B): False makes the prologue route pack a copy of the queries for the score passes
+        # even when they could be read where they lie
+        self.score_queries_in_place = bool(kv_compression_kwargs.get("score_queries_in_place", True))
         # MI355X build option (tests / A-B): False sends every update and flush through the stage-by-stage route
         # instead of the one-call entry points rtk_pivotkv_update / rtk_pivotkv_flush - same kernels, same results
         self.one_call_update = bool(kv_compression_kwargs.get("one_call_update", True))
@@ -1085,7 +1088,7 @@ class PivotKVCache(DynamicCache):
             else:
                 io.q_rot, io.qr_stride_h, io.qr_stride_l = q_out.data_ptr(), q_out.stride(1), q_out.stride(2)
                 # the rotated queries go elsewhere, so q0 survives: the batched passes score it where it lies
-                q_in_place = b.batched_passes and not b.fast and not b.keep_all
+                q_in_place = b.batched_passes and not b.fast and not b.keep_all and self.score_queries_in_place
                 io.flags = nv.RTK_UPDATE_PRE_ROPE | (nv.RTK_UPDATE_Q_IN_PLACE if q_in_place else 0)
         else:
             io.q_rot, io.flags = None, 0
@@ -1172,7 +1175,7 @@ class PivotKVCache(DynamicCache):
         if query_out is None:
             # the library's pick: a fresh tensor whenever the queries can then be scored where they lie (the chunk-batched
             # passes read q0 itself - no packed copy, a quarter of the kernel's traffic), else over `query_states`
-            if b.batched_passes and not b.fast and not b.keep_all:
+            if b.batched_passes and not b.fast and not b.keep_all and self.score_queries_in_place:
                 query_out = torch.empty_like(query_states)
         elif query_out is not query_states and (query_out.shape != query_states.shape
                                                 or query_out.dtype is not query_states.dtype
