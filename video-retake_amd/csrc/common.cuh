@@ -134,7 +134,15 @@ __device__ __forceinline__ float finalize_ref_column(const float* __restrict__ p
         for (int hh = 0; hh < G; ++hh) {
             const float* p = partial + (size_t)(g * G + hh) * RS * L + j;
             float hs = 0.f;
-            for (int r = 0; r < RS; ++r) hs += p[(size_t)r * L];
+            int r = 0;
+            for (; r + 7 <= RS; r += 7) {          // seven independent loads in flight, summed in split order
+                float v[7];
+#pragma unroll
+                for (int u = 0; u < 7; ++u) v[u] = p[(size_t)(r + u) * L];
+#pragma unroll
+                for (int u = 0; u < 7; ++u) hs += v[u];
+            }
+            for (; r < RS; ++r) hs += p[(size_t)r * L];
             gs += rbf(hs);                         // .sum(1) -> bf16 (sums of <= 7 bf16 values are exact in fp32)
         }
         tot += rbf(__fdiv_rn(gs, (float)G));       // .mean(1) -> bf16
