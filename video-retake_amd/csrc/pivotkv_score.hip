@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
 // read + write traffic (45 MB per call at L = 2304) at ~3 TB/s plus the launch ramp.
 
 template <int DT, int DIV, bool FAST = false, int NW = 4>
-__global__ __launch_bounds__(64) void prepare_native_kernel(const char* __restrict__ q, int64_t q_sh, int64_t q_sl,
+__global__ __launch_bounds__(RTK_PREP_BLOCK) void prepare_native_kernel(const char* __restrict__ q, int64_t q_sh, int64_t q_sl,
                                                             const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
                                                             const char* __restrict__ v, int64_t v_sh, int64_t v_sl,
                                                             int Hq, int Hkv, int L, int D,
@@ -2345,11 +2345,11 @@ static int prepare_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, 
     const int VE = nw * 4 / (DT == RTK_F32 ? 4 : 2);
     const int threads = L * (D / 2 / VE);
     static_assert(RTK_PREP_YSPLIT >= 2, "the first y-slice takes k and the LAST one v: one slice would never append v");
-    const dim3 grid((threads + 63) / 64, RTK_PREP_YSPLIT);
+    const dim3 grid((threads + RTK_PREP_BLOCK - 1) / RTK_PREP_BLOCK, RTK_PREP_YSPLIT);
     char* kf = nullptr;
     float qscale = 1.f;
     auto launch = [&](auto kern) {
-        RTK_LAUNCH(KID_UNROT, kern, grid, dim3(64), 0, st, (const char*)q, qsh, qsl, (const char*)k, ksh, ksl, (const char*)v,
+        RTK_LAUNCH(KID_UNROT, kern, grid, dim3(RTK_PREP_BLOCK), 0, st, (const char*)q, qsh, qsl, (const char*)k, ksh, ksl, (const char*)v,
                    vsh, vsl, Hq, Hkv, L, D, pos, pos_stride, inv_freq, a, rs, round_bf16, a2, rcp, qt, kt, (char*)k_tail,
                    (char*)v_tail, tail_sh, P, pos_copy, kf, qscale);
     };

@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t upd_pack2_f16(float lo, float hi) {   // sat
 // before batch b is rotated and stored, and the first batch before the table arithmetic.
 // ------------------------------------------------------------------------------------------------
 template <int DT, bool FAST, int NW>
-__global__ __launch_bounds__(64) void prologue_kernel(const char* q, int64_t q_sh, int64_t q_sl,
+__global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q, int64_t q_sh, int64_t q_sl,
                                                       const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
                                                       const char* __restrict__ v, int64_t v_sh, int64_t v_sl,
                                                       int Hq, int Hkv, int L, int D,
@@ -210,10 +210,10 @@ static int prologue_launch(const rtk_pivotkv_batch* b, const rtk_update_io* io, 
     if constexpr (DT != RTK_F32) nw = RTK_PREP_NW;
     const int VE = nw * 4 / (DT == RTK_F32 ? 4 : 2);
     const int threads = b->L * (b->D / 2 / VE);
-    const dim3 grid((threads + 63) / 64, RTK_PREP_YSPLIT);
+    const dim3 grid((threads + RTK_PREP_BLOCK - 1) / RTK_PREP_BLOCK, RTK_PREP_YSPLIT);
     const float qscale = k_fast ? 1.4426950408889634f / sqrtf((float)b->D) : 1.f;
     auto launch = [&](auto kern) {
-        RTK_LAUNCH(KID_PROLOGUE, kern, grid, dim3(64), 0, st, (const char*)io->q, io->q_stride_h, io->q_stride_l,
+        RTK_LAUNCH(KID_PROLOGUE, kern, grid, dim3(RTK_PREP_BLOCK), 0, st, (const char*)io->q, io->q_stride_h, io->q_stride_l,
                    (const char*)io->k, io->k_stride_h, io->k_stride_l, (const char*)io->v, io->v_stride_h, io->v_stride_l,
                    b->Hq, b->Hkv, b->L, b->D, io->pos, io->pos_stride, prev, b->inv_freq, b->attention_scaling, rs,
                    b->round_mode, (char*)io->q_rot, io->qr_stride_h, io->qr_stride_l, q_out, k_out, k_tail, v_tail, tail_sh,

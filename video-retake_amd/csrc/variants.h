@@ -40,3 +40,6 @@
 #ifndef RTK_REF_P2_NB     // reference-rounding pass 2: 32-key register blocks per wave
 #define RTK_REF_P2_NB 1
 #endif
+#ifndef RTK_PREP_BLOCK    // threads per workgroup of the per-update kernels (fused prepare, attention prologue)
+#define RTK_PREP_BLOCK 64
+#endif
