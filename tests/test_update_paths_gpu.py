@@ -485,3 +485,46 @@ def test_queries_scored_in_place_equal_the_packed_copy(dtype, L):
     for l in range(layers):
         assert torch.equal(zc.key_cache[l], packed.key_cache[l]) and torch.equal(zc.value_cache[l], packed.value_cache[l])
         assert torch.equal(zc.position_cache[l], packed.position_cache[l])
+
+
+def test_llava_attention_patch_takes_the_prologue():
+    """The patched Qwen2 attention of LLaVA-Video (llava_onevision.py:59-141) on the stand-in module of tests/glue_stubs.py
+    (head_dim 16: the C update route that runs the score passes per unit), two 640-token chunks, 2-D ids, fp32: the fused
+    prologue and the op-by-op route agree on the attention output, the cache ids / values (exact) and keys (1e-5); the
+    ids tensor the caller handed over is left alone (the reference shifts a clone)."""
+    import glue_stubs as gs
+    import retake.llava_onevision as lo
+    import retake.longvideo_cache as lc
+
+    L = 640
+    att = gs.StubAttention(0, 64, 4, 2, None, A, seed=3).to_device(dev()).eval()
+    llm = types.SimpleNamespace(hidden_size=64, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2)
+
+    def make(**extra):
+        kw = {"compression_ratio": 0.25, "compression_method": "pivotkv", "pos_embed_reforge": True}
+        kw.update(extra)
+        return lc.build_kvcache(types.SimpleNamespace(text_config=llm, longvideo_kwargs={
+            "kvcache_compression": True, "kvcache_compression_kwargs": kw}))
+
+    caches = [make(), make(one_call_update=False)]
+    outs = [[], []]
+    g = torch.Generator(device=dev()).manual_seed(11)
+    with torch.no_grad():
+        for c in range(2):
+            x = torch.randn((1, L, 64), generator=g, device=dev()) * 0.5
+            ids = chunk_ids(c, L, mrope=False)
+            keepsake = ids.clone()
+            mask4 = gs.causal_mask(L, (c * (L // 4)) + L).to(dev())
+            for i, cache in enumerate(caches):
+                cache.kvcache_compression = True
+                cache.keypatches_mask_chunk = None
+                o = lo.retake_Qwen2Attention_forward(att, x, None, mask4, cache, None, position_ids=ids)
+                cache.after_forward()
+                outs[i].append(o[0].float())
+                assert torch.equal(ids, keepsake)
+    assert caches[0]._layers[0].length == 2 * (L // 4)
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
+    assert torch.equal(caches[0].position_cache[0], caches[1].position_cache[0])
+    assert torch.equal(caches[0].value_cache[0], caches[1].value_cache[0])
+    assert (caches[0].key_cache[0] - caches[1].key_cache[0]).abs().max().item() <= 1e-5
