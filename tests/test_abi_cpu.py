@@ -181,3 +181,68 @@ def test_host_argument_blocks_match_the_header(tmp_path):
         assert int(got[cname]) == ctypes.sizeof(st), cname
         for fname, _ in st._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(st, fname).offset, f"{cname}.{fname}"
+
+
+def test_round4_entry_points_validate_on_the_host():
+    """rtk_pivotkv_update / _flush / rtk_mallm_hard_chain / rtk_rope_rotate_rows reject bad argument blocks before any
+    launch (no GPU here), with a message."""
+    import retake._native as nv
+
+    lib = nv.lib
+    assert lib.rtk_pivotkv_update(None, None, 0, None, None) == nv.RTK_EINVAL and b"batch" in lib.rtk_last_error()
+    b = nv.PivotKVBatch()
+    assert lib.rtk_pivotkv_update(ctypes.addressof(b), None, 0, None, None) == nv.RTK_EINVAL   # zero geometry
+    b.Hq, b.Hkv, b.L, b.D, b.keep, b.P, b.slots, b.dtype = 28, 4, 640, 128, 160, 3, 2, nv.RTK_BF16
+    dummy = (ctypes.c_char * 64)()
+    p = ctypes.addressof(dummy)
+    b.keep_idx = b.v_stage = b.score_ws = b.partials = b.score = b.sel_ws = p
+    ls, io = nv.LayerState(), nv.UpdateIO()
+    rc = lib.rtk_pivotkv_update(ctypes.addressof(b), ctypes.addressof(ls), 5, ctypes.addressof(io), None)
+    assert rc == nv.RTK_EINVAL and b"slot" in lib.rtk_last_error()
+    io.q = io.k = io.v = p
+    rc = lib.rtk_pivotkv_update(ctypes.addressof(b), ctypes.addressof(ls), 0, ctypes.addressof(io), None)
+    assert rc == nv.RTK_EINVAL and b"no room" in lib.rtk_last_error()          # an unallocated layer
+    ls.k = ls.v = p
+    ls.cap = 4096
+    rc = lib.rtk_pivotkv_update(ctypes.addressof(b), ctypes.addressof(ls), 0, ctypes.addressof(io), None)
+    assert rc == nv.RTK_EUNSUPPORTED and b"reforge" in lib.rtk_last_error()    # no reforge / rotary bound: the per-stage calls
+    states = (ctypes.c_void_p * 1)(ctypes.addressof(ls))
+    slots = (ctypes.c_int32 * 1)(0)
+    assert lib.rtk_pivotkv_flush(ctypes.addressof(b), states, slots, 1, None) == nv.RTK_EINVAL   # nothing pending
+    assert b"pending" in lib.rtk_last_error() or b"staging" in lib.rtk_last_error()
+    assert lib.rtk_pivotkv_flush(ctypes.addressof(b), states, slots, 3, None) == nv.RTK_EINVAL   # more layers than slots
+    assert lib.rtk_mallm_hard_chain(None, 8, 4, 64, nv.RTK_BF16, 4, 0, None, None, None) == nv.RTK_EINVAL
+    assert lib.rtk_mallm_hard_chain(p, 8, 4, 64, nv.RTK_BF16, 9, 0, p, p, None) == nv.RTK_EINVAL and b"target" in lib.rtk_last_error()
+    assert lib.rtk_rope_rotate_rows(None, 0, 0, 1, 1, 1, 128, nv.RTK_BF16, None, 0, 1, 3, None, 1.0, None, 0, 1, None) == nv.RTK_EINVAL
+    assert lib.rtk_rope_rotate_rows(p, 0, 128, 1, 1, 4, 128, nv.RTK_BF16, p, 0, 2, 3, p, 1.0, None, 0, 1, None) == nv.RTK_EINVAL
+    assert b"pos_stride_p" in lib.rtk_last_error()
+    assert lib.rtk_profile_copy(p, p, 24, None) == nv.RTK_EINVAL
+
+
+def test_product_defaults_are_the_benched_configuration():
+    """bench.py builds its cache from the reference's YAML keys only (configs/retake_demo.yaml:18-24 + the ratio its
+    dynamic rule writes): no build-specific option is needed to get the path the headline times."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    kw = bench.cache_kwargs()
+    assert set(kw) == {"dynamic_compression_ratio", "compression_method", "pos_embed_reforge", "max_input_length",
+                       "compression_ratio"}
+    import retake.longvideo_cache as lc
+
+    c = lc.build_kvcache(bench.make_cache_config(2))
+    assert c.native_rope is True and c.one_call_update is True and c.score_rounding == "fp32" and c.overlap_streams == 0
+    assert c.defer_rerotation is False and c.score_queries_in_place is True
+
+    class Dyn:   # a rotary module whose frequencies depend on the sequence length has to be CALLED
+        inv_freq, attention_scaling, rope_type = torch.ones(4), 1.0, "dynamic"
+
+    class Static:
+        inv_freq, attention_scaling, rope_type = torch.ones(4), 1.0, "yarn"
+
+    a, b2 = Static(), Static()
+    ra, rb = c._rotary(a, torch.device("cpu")), c._rotary(b2, torch.device("cpu"))
+    assert ra is not None and ra is rb                       # equal contents: one entry, one batch for all layers
+    assert c._rotary(Dyn(), torch.device("cpu")) is None
