@@ -549,6 +549,16 @@ enum rtk_update_flags {
 int rtk_pivotkv_update(rtk_pivotkv_batch* batch, rtk_layer_state* layer, int slot, const rtk_update_io* io,
                        rtk_stream_t stream);
 
+/* The attention patch's prologue for a segment that is NOT compressed - text prefill, decode (qwen2_vl.py:68-86 with the
+ * cache's else-branch, longvideo_cache.py:319-321): continuity shift against the layer's last cached temporal id, rotary
+ * tables, RoPE of q (to io->q_rot, which may alias io->q) and of k, the append of the rotated k and of v at the layer's
+ * tail, and the shifted ids appended to the layer's position cache - one launch, plus rtk_position_shift on the caller's
+ * ids when shift_ids_in_place (Qwen2-VL's in-place semantics; LLaVA shifts a clone: 0).  io: q [Hq,n,D], k / v [Hkv,n,D],
+ * pos [P,n].  The caller has made room (rows and ids); length / pos_len are advanced.  pos_embed_reforge caches only. */
+int rtk_pivotkv_append_rope(rtk_layer_state* layer, const rtk_update_io* io, int Hq, int Hkv, int n, int D, int dtype, int P,
+                            const float* inv_freq, float attention_scaling, const int* sections_host, int nsec,
+                            int round_mode, int shift_ids_in_place, rtk_stream_t stream);
+
 /* longvideo_cache.py:260-318 for the n pending layers slots[0..n) (ascending) of one chunk: score passes (unless
  * keep_all), selection, eviction (re-rotated K straight into the cache, V compacted in place) and the bookkeeping of
  * rtk_layer_state (length, pos_len, pending).  layers[i] is the state of slot slots[i].  Native RoPE (batch.inv_freq)

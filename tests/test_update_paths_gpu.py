@@ -528,3 +528,73 @@ def test_llava_attention_patch_takes_the_prologue():
     assert torch.equal(caches[0].position_cache[0], caches[1].position_cache[0])
     assert torch.equal(caches[0].value_cache[0], caches[1].value_cache[0])
     assert (caches[0].key_cache[0] - caches[1].key_cache[0]).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("llava", [False, True])
+def test_whole_sequence_through_the_fused_prologues(llava):
+    """text(5) -> video chunk(640) x 2 -> text(3) -> decode(1) x 2 through the patched attention of both models on the
+    stand-in module, two layers, fp32: with the fused prologues (update_pre_rope for the chunks, append_pre_rope for text
+    and decode) and with the op-by-op route the attention outputs agree, the ids tensor the caller handed over is in the
+    same state after every layer call (shifted in place for Qwen2-VL, untouched for LLaVA), and the final caches hold the
+    same ids / values (exact) and keys (1e-5)."""
+    import glue_stubs as gs
+    import retake.llava_onevision as lo
+    import retake.longvideo_cache as lc
+    import retake.qwen2_vl as rq
+
+    layers = [gs.StubAttention(l, 64, 4, 2, None if llava else (2, 3, 3), A, seed=9).to_device(dev()).eval() for l in range(2)]
+    llm = types.SimpleNamespace(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2)
+
+    def make(**extra):
+        kw = {"compression_ratio": 0.25, "compression_method": "pivotkv", "pos_embed_reforge": True}
+        kw.update(extra)
+        lk = {"kvcache_compression": True, "kvcache_compression_kwargs": kw}
+        if llava:
+            return lc.build_kvcache(types.SimpleNamespace(text_config=llm, longvideo_kwargs=lk))
+        cfg_ = types.SimpleNamespace(**vars(llm))
+        cfg_.longvideo_kwargs = lk
+        return lc.build_kvcache(cfg_)
+
+    caches = [make(), make(one_call_update=False)]
+    steps = [("text", 5), ("video", 640), ("video", 640), ("text", 3), ("text", 1), ("text", 1)]
+    g = torch.Generator(device=dev()).manual_seed(21)
+    total = [0, 0]
+    t_next = 0
+    with torch.no_grad():
+        for si, (kind, n) in enumerate(steps):
+            x = torch.randn((1, n, 64), generator=g, device=dev()) * 0.5
+            if llava:
+                ids0 = (torch.arange(n, device=dev()) + 1000 * si).view(1, n)        # discontinuous on purpose
+            elif kind == "video":
+                ids0 = torch.from_numpy(synth.mrope_position_ids(50 * si, n // 64, 8, 8, hw0=2)).to(dev())
+            else:
+                ids0 = (torch.arange(n, device=dev()) + 1000 * si).view(1, 1, n).repeat(3, 1, 1)
+            outs, ids_after = [], []
+            for i, cache in enumerate(caches):
+                cache.kvcache_compression = kind == "video"
+                cache.keypatches_mask_chunk = None
+                ids = ids0.clone()
+                klen = cache.get_seq_length(0) + n
+                mask4 = gs.causal_mask(n, klen).to(dev())
+                per_layer = []
+                for l, att in enumerate(layers):
+                    if llava:
+                        o = lo.retake_Qwen2Attention_forward(att, x, None, mask4, cache, None, position_ids=ids)
+                    else:
+                        o = rq.retake_Qwen2VLAttention_forward(att, x, mask4, ids, cache, False, True, None)
+                    per_layer.append((o[0].float(), ids.clone()))
+                if kind == "video":
+                    cache.after_forward()
+                outs.append(per_layer)
+            for (oa, ia), (ob, ib) in zip(*outs):
+                assert (oa - ob).abs().max().item() <= 1e-4 * max(1.0, ob.abs().max().item()), (si, kind)
+                assert torch.equal(ia, ib), (si, kind, "ids after the layer call")
+                if llava:
+                    assert torch.equal(ia, ids0)
+    for l in range(2):
+        a, b = caches
+        assert a.key_cache[l].shape == b.key_cache[l].shape == (1, 2, 5 + 160 + 160 + 3 + 2, 16)
+        assert torch.equal(a.position_cache[l], b.position_cache[l])
+        assert torch.equal(a.value_cache[l], b.value_cache[l])
+        assert (a.key_cache[l] - b.key_cache[l]).abs().max().item() <= 1e-5
+    assert caches[0].num_evicted_tokens == caches[1].num_evicted_tokens

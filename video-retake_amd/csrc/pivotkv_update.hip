@@ -53,7 +53,7 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
                                                       char* __restrict__ q_out, char* __restrict__ k_out,
                                                       char* __restrict__ k_tail, char* __restrict__ v_tail,
                                                       int64_t tail_sh, int P, int64_t* __restrict__ pos_copy,
-                                                      char* __restrict__ k_fast, float qscale) {
+                                                      int64_t pos_copy_ld, char* __restrict__ k_fast, float qscale) {
     using V = Vec16<DT>;
     static_assert(NW == 4 || ((NW == 2 || NW == 1) && DT != RTK_F32), "8- / 4-byte chunks: 16-bit dtypes only");
     constexpr int ES = 16 / V::VE;          // bytes per element
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
         ids[p] = (long long)pos[(size_t)pr * pos_ld + l] + (pr == 0 ? delta : 0ll);
     }
     if (pos_copy && blockIdx.y == 0 && d == 0)
-        for (int p = 0; p < P; ++p) pos_copy[(size_t)p * L + l] = ids[p];
+        for (int p = 0; p < P; ++p) pos_copy[(size_t)p * pos_copy_ld + l] = ids[p];
     constexpr int HU = RTK_PREP_HU;
     const int ny = gridDim.y, qper = (Hq + ny - 1) / ny;
     const int qb = min((int)blockIdx.y * qper, Hq), qe = min(qb + qper, Hq);
@@ -177,9 +177,11 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
             if (h >= nkv) break;
             char* trow = tail + ((size_t)h * tail_sh + (size_t)l * D) * ES;
             if (is_k) {
-                char* orow = k_out + ((size_t)h * L + l) * D * ES;   // k~ := k0
-                *(W*)(orow + (size_t)d * ES) = lo[u];
-                *(W*)(orow + (size_t)(d + h2) * ES) = hi[u];
+                if (k_out) {   // k~ := k0 (a plain append - text segments, decode - scores nothing: no k~)
+                    char* orow = k_out + ((size_t)h * L + l) * D * ES;
+                    *(W*)(orow + (size_t)d * ES) = lo[u];
+                    *(W*)(orow + (size_t)(d + h2) * ES) = hi[u];
+                }
                 if constexpr (FAST) {
                     char* frow = k_fast + ((size_t)h * L + l) * D * ES;
                     *(W*)(frow + (size_t)d * ES) = to_f16(lo[u], 1.f);
@@ -202,22 +204,28 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
     }
 }
 
+struct PrologueGeom {
+    int Hq, Hkv, L, D, P, round_mode;
+    const float* inv_freq;
+    float scaling;
+};
+
 template <int DT>
-static int prologue_launch(const rtk_pivotkv_batch* b, const rtk_update_io* io, const RowSel& rs, const int64_t* prev,
+static int prologue_launch(const PrologueGeom& g, const rtk_update_io* io, const RowSel& rs, const int64_t* prev,
                            char* q_out, char* k_out, char* k_tail, char* v_tail, int64_t tail_sh, int64_t* pos_copy,
-                           char* k_fast, hipStream_t st) {
+                           int64_t pos_copy_ld, char* k_fast, hipStream_t st) {
     int nw = 4;
     if constexpr (DT != RTK_F32) nw = RTK_PREP_NW;
     const int VE = nw * 4 / (DT == RTK_F32 ? 4 : 2);
-    const int threads = b->L * (b->D / 2 / VE);
+    const int threads = g.L * (g.D / 2 / VE);
     const dim3 grid((threads + RTK_PREP_BLOCK - 1) / RTK_PREP_BLOCK, RTK_PREP_YSPLIT);
-    const float qscale = k_fast ? 1.4426950408889634f / sqrtf((float)b->D) : 1.f;
+    const float qscale = k_fast ? 1.4426950408889634f / sqrtf((float)g.D) : 1.f;
     auto launch = [&](auto kern) {
         RTK_LAUNCH(KID_PROLOGUE, kern, grid, dim3(RTK_PREP_BLOCK), 0, st, (const char*)io->q, io->q_stride_h, io->q_stride_l,
                    (const char*)io->k, io->k_stride_h, io->k_stride_l, (const char*)io->v, io->v_stride_h, io->v_stride_l,
-                   b->Hq, b->Hkv, b->L, b->D, io->pos, io->pos_stride, prev, b->inv_freq, b->attention_scaling, rs,
-                   b->round_mode, (char*)io->q_rot, io->qr_stride_h, io->qr_stride_l, q_out, k_out, k_tail, v_tail, tail_sh,
-                   b->P, pos_copy, k_fast, qscale);
+                   g.Hq, g.Hkv, g.L, g.D, io->pos, io->pos_stride, prev, g.inv_freq, g.scaling, rs, g.round_mode,
+                   (char*)io->q_rot, io->qr_stride_h, io->qr_stride_l, q_out, k_out, k_tail, v_tail, tail_sh, g.P, pos_copy,
+                   pos_copy_ld, k_fast, qscale);
     };
 #define RTK_PRO_NWSEL(FASTV)                                                              \
     do {                                                                                  \
@@ -336,12 +344,13 @@ extern "C" int rtk_pivotkv_update(rtk_pivotkv_batch* b, rtk_layer_state* ls, int
         char* k_fast = nullptr;
         if (score_base == RTK_BF16_FAST && !b->keep_all)
             k_fast = ws + (((size_t)b->Hq * L * D * es + 255) & ~(size_t)255);
+        const PrologueGeom pg{b->Hq, Hkv, L, D, b->P, b->round_mode, b->inv_freq, b->attention_scaling};
         if (b->dtype == RTK_F16)
-            rc = prologue_launch<RTK_F16>(b, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, nullptr, st);
+            rc = prologue_launch<RTK_F16>(pg, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, L, nullptr, st);
         else if (b->dtype == RTK_BF16)
-            rc = prologue_launch<RTK_BF16>(b, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, k_fast, st);
+            rc = prologue_launch<RTK_BF16>(pg, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, L, k_fast, st);
         else
-            rc = prologue_launch<RTK_F32>(b, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, nullptr, st);
+            rc = prologue_launch<RTK_F32>(pg, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, L, nullptr, st);
         if (rc) return rc;
     } else {
         if (b->q_units) b->q_units[slot] = nullptr;
@@ -364,6 +373,56 @@ extern "C" int rtk_pivotkv_update(rtk_pivotkv_batch* b, rtk_layer_state* ls, int
     }
     ls->pending = L;
     ls->pending_keep = b->keep;
+    return RTK_OK;
+}
+
+extern "C" int rtk_pivotkv_append_rope(rtk_layer_state* ls, const rtk_update_io* io, int Hq, int Hkv, int n, int D,
+                                       int dtype, int P, const float* inv_freq, float attention_scaling,
+                                       const int* sections_host, int nsec, int round_mode, int shift_ids_in_place,
+                                       rtk_stream_t stream) {
+    RTK_CHECK_ARG(ls && io && io->q && io->k && io->v && io->q_rot && io->pos && inv_freq, "rtk_pivotkv_append_rope: NULL pointer");
+    RTK_CHECK_ARG(Hq >= 1 && Hkv >= 1 && n >= 1 && D >= 2, "rtk_pivotkv_append_rope: bad shape");
+    RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_pivotkv_append_rope: unsupported dtype %d", dtype);
+    RTK_CHECK_ARG(P == 1 || P == 3, "rtk_pivotkv_append_rope: P must be 1 or 3, got %d", P);
+    RTK_CHECK_ARG(ls->k && ls->v && ls->pending == 0 && ls->length >= 0 && ls->length + n <= ls->cap,
+                  "rtk_pivotkv_append_rope: the layer's cache has no room for %d rows (or a chunk is pending)", n);
+    RTK_CHECK_ARG(ls->pos && ls->pos_len + n <= ls->pos_cap, "rtk_pivotkv_append_rope: the position cache has no room for %d ids", n);
+    RTK_CHECK_ARG(io->pos_stride >= n, "rtk_pivotkv_append_rope: pos_stride %lld < n %d", (long long)io->pos_stride, n);
+    const size_t es = esize(dtype);
+    char* k_tail = (char*)ls->k + (size_t)ls->length * D * es;
+    char* v_tail = (char*)ls->v + (size_t)ls->length * D * es;
+    const int64_t tail_sh = ls->cap * D;
+    const int ve = dtype != RTK_F32 ? 8 : 4;
+    const bool ok = (D % (2 * ve) == 0) && D <= 256 && (io->q_stride_h * es) % 16 == 0 && (io->q_stride_l * es) % 16 == 0 &&
+                    (io->k_stride_h * es) % 16 == 0 && (io->k_stride_l * es) % 16 == 0 && (io->v_stride_h * es) % 16 == 0 &&
+                    (io->v_stride_l * es) % 16 == 0 && (io->qr_stride_h * es) % 16 == 0 && (io->qr_stride_l * es) % 16 == 0 &&
+                    (tail_sh * es) % 16 == 0 &&
+                    (((uintptr_t)io->q | (uintptr_t)io->k | (uintptr_t)io->v | (uintptr_t)io->q_rot | (uintptr_t)k_tail |
+                      (uintptr_t)v_tail) & 15) == 0;
+    if (!ok) {
+        set_error("rtk_pivotkv_append_rope: needs 16-byte aligned pointers / strides and head_dim a multiple of %d", 2 * ve);
+        return RTK_EUNSUPPORTED;
+    }
+    RowSel rs;
+    int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_pivotkv_append_rope");
+    if (rc) return rc;
+    const int64_t* prev = ls->pos_len > 0 ? ls->pos + (ls->pos_len - 1) : nullptr;
+    int64_t* pos_out = ls->pos + ls->pos_len;   // the shifted ids join the layer's position cache (reference :319-321)
+    const PrologueGeom pg{Hq, Hkv, n, D, P, round_mode, inv_freq, attention_scaling};
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RTK_F16)
+        rc = prologue_launch<RTK_F16>(pg, io, rs, prev, nullptr, nullptr, k_tail, v_tail, tail_sh, pos_out, ls->pos_cap, nullptr, st);
+    else if (dtype == RTK_BF16)
+        rc = prologue_launch<RTK_BF16>(pg, io, rs, prev, nullptr, nullptr, k_tail, v_tail, tail_sh, pos_out, ls->pos_cap, nullptr, st);
+    else
+        rc = prologue_launch<RTK_F32>(pg, io, rs, prev, nullptr, nullptr, k_tail, v_tail, tail_sh, pos_out, ls->pos_cap, nullptr, st);
+    if (rc) return rc;
+    if (shift_ids_in_place) {   // qwen2_vl.py:73: later layers (and the caller) see the shifted ids; after the kernel read them
+        rc = rtk_position_shift((int64_t*)io->pos, n, prev, stream);
+        if (rc) return rc;
+    }
+    ls->length += n;
+    ls->pos_len += n;
     return RTK_OK;
 }
 

@@ -133,6 +133,7 @@ _SIGNATURES = {
     "rtk_position_shift": (C.c_int, [_vp, _i, _vp, _vp]),
     "rtk_pivotkv_update": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
     "rtk_pivotkv_flush": (C.c_int, [_vp, _vp, _vp, _i, _vp]),
+    "rtk_pivotkv_append_rope": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _i, _i, _i, _vp]),
     "rtk_p2p_alloc": (C.c_int, [_sz, _i, C.POINTER(_vp)]),
     "rtk_p2p_free": (C.c_int, [_vp]),
     "rtk_p2p_export": (C.c_int, [_vp, _vp, C.POINTER(_sz)]),

@@ -66,11 +66,14 @@ def retake_Qwen2Attention_forward(self, hidden_states, position_embeddings, atte
     fused = None
     reforge = past_key_value is not None and getattr(past_key_value, "pos_embed_reforge", False)
     if reforge and query_states.is_cuda and query_states.shape[0] == 1 and kwargs.get("position_ids") is not None \
-            and getattr(past_key_value, "kvcache_compression", False) and hasattr(past_key_value, "update_pre_rope"):
-        # video chunks on the GPU: the whole prologue in one kernel (see qwen2_vl._qkv_and_cache_update); the ids the
-        # caller handed over stay as they are, like the reference's clone
-        fused = past_key_value.update_pre_rope(query_states, key_states, value_states, self.layer_idx,
-                                               kwargs["position_ids"], self.rotary_emb, None, shift_ids_in_place=False)
+            and hasattr(past_key_value, "update_pre_rope"):
+        # on the GPU the whole prologue is one kernel (see qwen2_vl._qkv_and_cache_update): video chunks feed the
+        # deferred scoring, text segments and decode steps just append; the ids the caller handed over stay as they
+        # are, like the reference's clone
+        fuse = past_key_value.update_pre_rope if getattr(past_key_value, "kvcache_compression", False) \
+            else past_key_value.append_pre_rope
+        fused = fuse(query_states, key_states, value_states, self.layer_idx, kwargs["position_ids"], self.rotary_emb, None,
+                     shift_ids_in_place=False)
     if fused is not None:
         query_states, key_states, value_states = fused
     elif reforge:

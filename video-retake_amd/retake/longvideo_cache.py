@@ -456,6 +456,7 @@ class PivotKVCache(DynamicCache):
         # native_rope: False forces the call for every module (the bit-faithful opt-out).
         self.native_rope = bool(kv_compression_kwargs.get("native_rope", True))
         self._rotaries: Dict[int, Tuple[Any, Optional[_Rotary]]] = {}
+        self._aio = nv.UpdateIO()   # argument block of append_pre_rope
         # MI355X build option for bf16 models: "fp32" (default) scores with exact bf16 products, fp32 accumulation, softmax
         # and sums; "reference" reproduces the reference's own bf16 roundings of the logits, probabilities, per-head
         # sums and means (longvideo_cache.py:264-270 on bf16 tensors) - coarser, but what the reference computes
@@ -1185,6 +1186,62 @@ class PivotKVCache(DynamicCache):
         if out is None:
             return None
         return (query_states if query_out is None else query_out), out[0], out[1]
+
+    def append_pre_rope(self, query_states, key_states, value_states, layer_idx, position_ids, rotary_emb,
+                        mrope_section=None, shift_ids_in_place=True):
+        """The attention patch's prologue for a segment that is NOT compressed - text prefill, decode (qwen2_vl.py:68-86
+        + the cache's else-branch :319-321) - as one kernel (rtk_pivotkv_append_rope): continuity shift, rotary tables,
+        RoPE of q (in place) and k, append of the rotated k and of v, the shifted ids appended to the layer's position
+        cache; the caller's ids are shifted in place afterwards when `shift_ids_in_place` (Qwen2-VL; LLaVA shifts a
+        clone).  Replaces ~25 eager launches per layer and token.  Returns (rotated q, keys, values) like `update`, or
+        None - nothing touched - when the op-by-op route has to run (compression on: `update_pre_rope`; no reforging;
+        rotary modules that must be called; CPU tensors)."""
+        if self.kvcache_compression or not (self.pos_embed_reforge and self.one_call_update) or position_ids is None \
+                or not key_states.is_cuda or key_states.shape[0] != 1 \
+                or (torch.is_grad_enabled() and query_states.requires_grad):
+            return None
+        dev = key_states.device
+        rot = self._rotary(rotary_emb, dev)
+        if rot is None:
+            return None
+        q, k, v, pos = query_states, key_states, value_states, position_ids
+        n, D = k.shape[2], k.shape[3]
+        dt = k.dtype
+        P = 3 if pos.ndim == 3 else 1
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if q.ndim != 4 or q.shape[0] != 1 or q.shape[2] != n or q.shape[3] != D or v.shape != k.shape \
+                or q.dtype is not dt or v.dtype is not dt or dt not in (torch.float32, torch.bfloat16, torch.float16) \
+                or pos.dtype is not torch.int64 or not pos.is_cuda or pos.shape[-1] != n or pos.shape[0] != P \
+                or pos.stride(-1) != 1 or (pos.ndim == 3 and pos.shape[1] != 1) or pos.ndim not in (2, 3) \
+                or q.get_device() != idx or v.get_device() != idx or pos.get_device() != idx or nv.current_device() != idx:
+            return None
+        qs, ks, vs = q.stride(), k.stride(), v.stride()
+        if qs[3] != 1 or ks[3] != 1 or vs[3] != 1:
+            return None
+        st = self._store(layer_idx)
+        if st.pending:
+            self._flush()
+        st = self.reserve(layer_idx, n, k)
+        self._pos_reserve(st, P, pos.ndim, n, dev)
+        if st.c.pos_len != st.c.length:   # a cache whose earlier rows carry no ids (filled without reforging): not ours
+            return None
+        io = self._aio
+        io.q, io.q_stride_h, io.q_stride_l = q.data_ptr(), qs[1], qs[2]
+        io.k, io.k_stride_h, io.k_stride_l = k.data_ptr(), ks[1], ks[2]
+        io.v, io.v_stride_h, io.v_stride_l = v.data_ptr(), vs[1], vs[2]
+        io.pos, io.pos_stride = pos.data_ptr(), pos.stride(0)
+        io.q_rot, io.qr_stride_h, io.qr_stride_l, io.flags = io.q, qs[1], qs[2], 0
+        nsec = len(mrope_section) if mrope_section else 0
+        sec = (C.c_int * nsec)(*mrope_section) if nsec else None
+        rc = nv.lib.rtk_pivotkv_append_rope(st.cref, C.addressof(io), q.shape[1], k.shape[1], n, D, nv.dtype_code(k), P,
+                                            rot.inv.data_ptr(), rot.scaling, sec, nsec, nv.round_mode(dt),
+                                            int(bool(shift_ids_in_place)), nv.raw_stream(idx))
+        if rc == nv.RTK_EUNSUPPORTED:
+            return None
+        nv.check(rc, "rtk_pivotkv_append_rope")
+        self._pos_layers = max(self._pos_layers, layer_idx + 1)
+        m = st.c.length
+        return q, st._k.narrow(2, 0, m), st._v.narrow(2, 0, m)
 
     def _bind_rotary(self, b: _Batch, rotary_emb_fn, mrope_section, rot: Optional[_Rotary]):
         """The rotary module / M-RoPE sections the batch's pending units were (and its next units will be) rotated

@@ -42,13 +42,15 @@ def _qkv_and_cache_update(self, hidden_states, position_ids, past_key_value, cac
     value_states = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim).transpose(1, 2)
 
     reforge = past_key_value is not None and getattr(past_key_value, "pos_embed_reforge", False)
-    if reforge and bsz == 1 and query_states.is_cuda and getattr(past_key_value, "kvcache_compression", False) \
-            and hasattr(past_key_value, "update_pre_rope"):
-        # video chunks on the GPU: shift, rotary tables, RoPE of q / k, the cache append and the operands of the
-        # deferred PivotKV scoring in ONE kernel, straight from the projections (reference :68-86 + update :238-259).
+    if reforge and bsz == 1 and query_states.is_cuda and hasattr(past_key_value, "update_pre_rope"):
+        # on the GPU the whole prologue is ONE kernel, straight from the projections (reference :68-86 + the cache's
+        # update :238-259 / :319-321): shift, rotary tables, RoPE of q / k, the cache append, and - video chunks - the
+        # operands of the deferred PivotKV scoring; text segments and decode steps append the shifted ids instead.
         # None = this call takes the op-by-op route below (nothing has been touched).
-        fused = past_key_value.update_pre_rope(query_states, key_states, value_states, self.layer_idx, position_ids,
-                                               self.rotary_emb, self.rope_scaling["mrope_section"])
+        fuse = past_key_value.update_pre_rope if getattr(past_key_value, "kvcache_compression", False) \
+            else past_key_value.append_pre_rope
+        fused = fuse(query_states, key_states, value_states, self.layer_idx, position_ids, self.rotary_emb,
+                     self.rope_scaling["mrope_section"])
         if fused is not None:
             return fused
 
