@@ -585,10 +585,13 @@ def test_whole_sequence_through_the_fused_prologues(llava):
                     per_layer.append((o[0].float(), ids.clone()))
                 if kind == "video":
                     cache.after_forward()
+                    # a chunk's fused prologue leaves the caller's ids to the flush (the last layer's shift, what the
+                    # reference's layer loop leaves behind): compare the state after the chunk
+                    per_layer = [(o_, ids.clone()) for o_, _ in per_layer]
                 outs.append(per_layer)
             for (oa, ia), (ob, ib) in zip(*outs):
                 assert (oa - ob).abs().max().item() <= 1e-4 * max(1.0, ob.abs().max().item()), (si, kind)
-                assert torch.equal(ia, ib), (si, kind, "ids after the layer call")
+                assert torch.equal(ia, ib), (si, kind, "ids after the layer call / the chunk")
                 if llava:
                     assert torch.equal(ia, ids0)
     for l in range(2):
