@@ -587,6 +587,9 @@ def main():
         #   evict_batched   per chunk : kept K~,V rows + ids + new-position tables read, kept rows + ids written,
         #                               for all `layers` units of the chunk in one launch
         #   commit_batched  per chunk : staged V rows read + written, all units in one launch
+        # or, by default (in_place_compaction), ONE launch per chunk for the last two:
+        #   compact_units   per chunk : kept K~ rows read + written re-rotated, kept V rows read + written inside the
+        #                               tail, kept-index + ids read, ids written - nothing staged
         keep = int(RATIO * L)
         ap_bytes = 2 * 2 * Hkv * L * D * es
         prep_bytes = (2 * Hq + 5 * Hkv) * L * D * es        # q: read + q~; k: read + k~ + tail; v: read + tail
@@ -600,6 +603,7 @@ def main():
         f_low = (check or {}).get("staged_fraction", RATIO)
         evu_bytes = (2 + 2 * f_low) * Hkv * keep * D * es + (2 * keep * D * 4 if tables else 0) + 8 * keep + 2 * 8 * 3 * keep
         cmu_bytes = 2 * Hkv * keep * D * es + 8 * keep
+        cpu_bytes = 4 * Hkv * keep * D * es + 8 * keep + 2 * 8 * 3 * keep
         ev_bytes = 5 * L + 2 * Hkv * L * D * es + 2 * Hkv * keep * D * es + 8 * 3 * (L + keep)
         dp_bytes = T * N_PATCH * C_EMB * es + 4 * T * N_PATCH
         ga_bytes = 2 * T * N_PATCH * C_EMB * es
@@ -614,21 +618,26 @@ def main():
                               prep_bytes if fused else 2 * (Hq + Hkv) * L * D * es),
                              ("evict_batched", "evict_batched", evu_bytes * args.layers),
                              ("commit_batched", "commit_batched", cmu_bytes * args.layers),
+                             ("compact_units", "compact_units", cpu_bytes * args.layers),
                              ("dpselect_dis", "dpselect_dis", dp_bytes), ("gather_frames", "gather_frames", ga_bytes)):
             if key in kern:
                 gbs = b / (kern[key]["avg_us"] * 1e-6) / 1e9
                 tr = None
                 if args.dtype == "bf16" and T == 2048 and args.layers == LAYERS and args.geometry == "baseline":
                     tr = pmc_traffic({"append": "append_kernel", "evict_batched": "evict_batched_kernel",
-                                      "commit_batched": "place_batched_kernel",
+                                      "commit_batched": "place_batched_kernel", "compact_units": "compact_units_kernel",
                                       "prepare_fused": "prepare_native_kernel"}.get(name, "\0"))[0]
                 extra[name] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": gbs / HBM_PEAK_GBS, "traffic": tr, "algorithmic_bytes_per_launch": b}
-        if all(k in kern for k in ("evict_batched", "commit_batched")) and ("append" in kern or fused):
+        one_launch = "compact_units" in kern and kern["compact_units"]["launches"] >= kern.get("evict_batched", {"launches": 0})["launches"]
+        if (one_launch or all(k in kern for k in ("evict_batched", "commit_batched"))) and ("append" in kern or fused):
             # SURVEY §8(d) "PivotKV eviction scan (P6-P13)": mask override + select + kept-row gather / re-rotation +
             # id bookkeeping + compaction of one (layer, chunk) unit, against SURVEY's algorithmic byte count.  Every
             # stage is one launch per chunk covering all layers, so a unit's share is 1/layers of each launch.
-            per_chunk = {"pivotkv_select": 1, "pivotkv_emit": 1, "rope_table": 1, "evict_batched": 1, "commit_batched": 1}
+            per_chunk = {"pivotkv_select": 1, "pivotkv_emit": 1, "rope_table": 1}
+            per_chunk.update({"compact_units": 1} if one_launch else {"evict_batched": 1, "commit_batched": 1})
+            if one_launch:
+                evu_bytes, cmu_bytes = cpu_bytes, 0
             stages = {k: kern[k]["avg_us"] * n / args.layers for k, n in per_chunk.items() if k in kern}
             t_scan = sum(stages.values()) * 1e-6
             gbs = ev_bytes / t_scan / 1e9
@@ -642,7 +651,8 @@ def main():
                                                "moved_GBps": (evu_bytes + cmu_bytes) / t_scan / 1e9,
                                                "moved_frac": (evu_bytes + cmu_bytes) / t_scan / 1e9 / HBM_PEAK_GBS,
                                                "moved_GBps_data_launches_only": (evu_bytes + cmu_bytes) / (
-                                                   (stages.get("evict_batched", 0) + stages.get("commit_batched", 0)) * 1e-6) / 1e9}
+                                                   (stages.get("evict_batched", 0) + stages.get("commit_batched", 0) +
+                                                    stages.get("compact_units", 0)) * 1e-6) / 1e9}
             # the same plus the tail append update() owes the layer's attention (reference :238, P1): its own kernel,
             # or its byte share of the fused prepare kernel.  SURVEY's byte count has no term for it.
             if "prologue" in kern:

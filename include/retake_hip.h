@@ -446,6 +446,46 @@ typedef struct rtk_place_unit {
 int rtk_pivotkv_place_batched(const rtk_place_unit* units, int n_units, int H, int keep, int D, int dtype,
                               rtk_stream_t stream);
 
+/* P8-P13 in ONE launch, in place (ABI 14): longvideo_cache.py:278-288, :297-310, :313-318 for n_units (layer, chunk)
+ * units that share Hkv, D, keep, P and dtype - what rtk_pivotkv_evict_batched[_rope] + rtk_pivotkv_place_batched do in
+ * two launches with a staging hop.  Kept row r of a unit's V tail (and K tail, k_mode RTK_COMPACT_K_INPLACE) comes from
+ * chunk row keep_idx[r] >= r of the SAME tail: the workgroups of a unit run in ticket order and store a row block only
+ * after every lower block has its source rows in registers, so nothing is staged and the kernel moves
+ * 4 x keep x Hkv x D x es bytes per unit.  The rotary tables of the kept rows' new ids are built once per workgroup
+ * in LDS from the distinct ids of its rows (same arithmetic, same bits as rtk_pivotkv_evict_batched_rope). */
+typedef struct rtk_compact_unit {
+    const void* k_src;        /* RTK_COMPACT_K_ROTATE / _COPY: K rows of the chunk in a buffer of their own (the un-rotated
+                                 k~), element (h,l,d) at h*k_src_stride_h + l*D + d.  _INPLACE: ignored */
+    int64_t k_src_stride_h;
+    void* k_tail;             /* the chunk inside the layer's cache: chunk row l of head h at h*k_tail_stride_h + l*D;
+                                 kept row r is written to row r of the same block */
+    int64_t k_tail_stride_h;
+    void* v_tail;
+    int64_t v_tail_stride_h;
+    const int64_t* keep_idx;  /* [keep] ascending, from rtk_pivotkv_select[_batched] */
+    const int64_t* pos_src;   /* ids of the kept rows [P, keep] (row stride pos_src_stride): the NEW ids the rotation
+                                 uses (RTK_COMPACT_K_ROTATE: required) ... */
+    int64_t pos_src_stride;
+    int64_t* pos_dst;         /* ... copied to the layer's position cache tail (row stride pos_dst_stride), or NULL */
+    int64_t pos_dst_stride;
+} rtk_compact_unit;
+#define RTK_COMPACT_MAX_UNITS 28   /* units per launch (the array travels as a kernel argument) */
+enum rtk_compact_k_mode {
+    RTK_COMPACT_K_ROTATE = 0,   /* kept K = k_src row re-rotated at its new ids (pos_embed_reforge, :297-306) */
+    RTK_COMPACT_K_COPY = 1,     /* kept K = k_src row verbatim (deferred re-rotation: rtk_pivotkv_batch.defer_rot) */
+    RTK_COMPACT_K_INPLACE = 2   /* kept K = row keep_idx[r] of k_tail, compacted in place like V (no reforge, :279) */
+};
+/* ints of the sync workspace for this geometry: device memory, zero-initialised once by the caller and then used with
+ * this geometry only (tickets and flags live in it; every launch leaves the tickets at zero and tags its flags with
+ * `epoch`). */
+size_t rtk_pivotkv_compact_sync_ints(int n_units, int Hkv, int keep, int D, int dtype);
+/* `units` is a HOST array.  epoch: non-zero and different from the previous launch on the same workspace.
+ * inv_freq / attention_scaling / sections / round_mode as rtk_pivotkv_evict_batched_rope (RTK_COMPACT_K_ROTATE only). */
+int rtk_pivotkv_compact_batched(const rtk_compact_unit* units, int n_units, int Hkv, int D, int keep, int P, int dtype,
+                                int k_mode, const float* inv_freq, float attention_scaling, const int* sections_host,
+                                int nsec, int round_mode, int32_t* sync_ws, size_t sync_ws_ints, int32_t epoch,
+                                rtk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * One-call update and one-call flush (ABI 13).  PivotKVCache.update runs 1,792 times per 2048-frame video and
  * the reference calls cache.after_forward() once per chunk (qwen2_vl.py:715-716): on MI355X the per-call HOST work
@@ -455,7 +495,8 @@ int rtk_pivotkv_place_batched(const rtk_place_unit* units, int n_units, int H, i
  * entry points above would have been handed one by one.  Nothing new is computed here:
  *   rtk_pivotkv_update  = rtk_pivotkv_prepare (rotated q, k)  or the attention prologue (pre-RoPE q, k; below)
  *   rtk_pivotkv_flush   = rtk_pivotkv_score_passes_batched + rtk_pivotkv_select_batched +
- *                         rtk_pivotkv_evict_batched[_rope] + rtk_pivotkv_place_batched for the pending layers
+ *                         rtk_pivotkv_compact_batched (or, without batch.compact_sync, rtk_pivotkv_evict_batched[_rope] +
+ *                         rtk_pivotkv_place_batched) for the pending layers
  * ------------------------------------------------------------------------------------------- */
 
 /* One layer's pre-allocated cache (longvideo_cache.py: key_cache[l] / value_cache[l] / position_cache[l]). */
@@ -514,6 +555,11 @@ typedef struct rtk_pivotkv_batch {
     int32_t pre_rope;         /* the pending units were appended from pre-RoPE projections: k~ == k0 */
     int32_t batched_passes;   /* 1: the score passes of all pending layers run from rtk_pivotkv_flush, one launch per kernel
                                  (16-bit payloads, head_dim 128); 0: rtk_pivotkv_update runs them per unit */
+    int32_t* compact_sync;    /* zero-initialised sync workspace of rtk_pivotkv_compact_batched for (slots, Hkv, keep, D,
+                                 dtype), or NULL: the flush then stages through v_stage / k_stage (two launches) */
+    uint64_t compact_sync_ints;
+    int32_t compact_epoch;    /* advanced by rtk_pivotkv_flush */
+    int32_t pad1;
 } rtk_pivotkv_batch;
 
 /* The tensors of one update call.  Strides in elements; element (h, l, d) at h*stride_h + l*stride_l + d. */

@@ -10,7 +10,7 @@ BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$SRC -ffp-con
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   tmp=$(mktemp -d)
-  for f in api dpselect mallm_chain rope pivotkv_score pivotkv_evict pivotkv_update p2p; do
+  for f in api dpselect mallm_chain rope pivotkv_score pivotkv_evict pivotkv_compact pivotkv_update p2p; do
     /opt/rocm/bin/hipcc $BASE $flags -c $SRC/$f.hip -o $tmp/$f.o &
   done
   wait

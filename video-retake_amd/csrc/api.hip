@@ -30,7 +30,7 @@ static const char* const kKernelNames[KID_COUNT] = {"dpselect_dis", "dpselect_se
                                                     "unrotate_pack", "score_pass1", "score_pass2", "score_finalize",
                                                     "pivotkv_select", "evict_scan", "copy_rows", "append",
                                                     "evict_batched", "commit_batched", "position_shift", "pivotkv_emit",
-                                                    "prologue"};
+                                                    "prologue", "compact_units"};
 struct ProfRec { int kid; hipEvent_t a, b; };
 static std::mutex g_pm;
 static std::atomic<unsigned> g_prof{0};  // bit k set = time kernel id k
@@ -138,6 +138,6 @@ extern "C" int rtk_profile_copy(void* dst, const void* src, size_t bytes, rtk_st
     return RTK_OK;
 }
 
-extern "C" int rtk_version(void) { return 13; }
+extern "C" int rtk_version(void) { return 14; }
 extern "C" const char* rtk_last_error(void) { return rtk::g_err; }
 extern "C" const char* rtk_arch(void) { return "gfx950"; }

@@ -301,7 +301,7 @@ inline int make_rowsel(RowSel& rs, int P, int D, const int* sections, int nsec, 
 namespace rtk {
 enum KernelId {
     KID_DIS = 0, KID_DPSEL, KID_GATHER, KID_ROPE, KID_UNROT, KID_PASS1, KID_PASS2, KID_FINALIZE, KID_PSEL, KID_EVICT,
-    KID_COPY, KID_APPEND, KID_EVICTB, KID_COMMITB, KID_SHIFT, KID_PEMIT, KID_PROLOGUE, KID_COUNT
+    KID_COPY, KID_APPEND, KID_EVICTB, KID_COMMITB, KID_SHIFT, KID_PEMIT, KID_PROLOGUE, KID_COMPACT, KID_COUNT
 };
 bool profile_on(int kid);
 void profile_begin(int kid, hipStream_t st);

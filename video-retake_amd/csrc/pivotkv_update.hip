@@ -262,7 +262,7 @@ static int check_batch(const rtk_pivotkv_batch* b, const char* who) {
     RTK_CHECK_ARG(b->P == 0 || b->P == 1 || b->P == 3, "%s: P must be 0, 1 or 3, got %d", who, b->P);
     RTK_CHECK_ARG(b->dtype == RTK_F32 || b->dtype == RTK_BF16 || b->dtype == RTK_F16, "%s: unsupported dtype %d", who, b->dtype);
     RTK_CHECK_ARG(b->nsec >= 0 && b->nsec <= 8, "%s: nsec %d out of range", who, b->nsec);
-    RTK_CHECK_ARG(b->keep_idx && (b->keep_all || b->v_stage), "%s: NULL batch buffer", who);
+    RTK_CHECK_ARG(b->keep_idx && (b->keep_all || b->v_stage || b->compact_sync), "%s: NULL batch buffer", who);
     RTK_CHECK_ARG(b->keep_all || (b->score_ws && b->partials && b->score && b->sel_ws), "%s: NULL scoring buffer", who);
     return RTK_OK;
 }
@@ -438,7 +438,7 @@ extern "C" int rtk_pivotkv_flush(rtk_pivotkv_batch* b, rtk_layer_state* const* l
         set_error("rtk_pivotkv_flush: pos_embed_reforge needs position ids and an inv_freq rotary (use the per-stage calls)");
         return RTK_EUNSUPPORTED;
     }
-    if (!reforge && !b->keep_all && !b->k_stage) {
+    if (!reforge && !b->keep_all && !b->k_stage && !b->compact_sync) {
         set_error("rtk_pivotkv_flush: no K staging buffer");
         return RTK_EINVAL;
     }
@@ -511,6 +511,49 @@ extern "C" int rtk_pivotkv_flush(rtk_pivotkv_batch* b, rtk_layer_state* const* l
         rc = rtk_pivotkv_select_batched(su.data(), n, Hkv, b->rs_n, b->Hq / Hkv, L, keep, P, (int)reforge,
                                         (int64_t)b->slots * keep, b->score_dtype, stream);
         if (rc) return rc;
+    }
+    if (b->compact_sync && !b->keep_all) {
+        // the eviction scan as one in-place launch: kept K re-rotated (or copied) from k~ to the tail, V (and an
+        // un-reforged K) compacted inside the tail, ids to the position cache (:278-318)
+        std::vector<rtk_compact_unit> cu((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            const int l = slots[i];
+            rtk_layer_state* ls = layers[i];
+            const size_t tail = (size_t)ls->length * D * es;
+            rtk_compact_unit& u = cu[i];
+            u.k_src = reforge ? (char*)b->k_unrot + (size_t)l * Hkv * L * D * es : nullptr;
+            u.k_src_stride_h = (int64_t)L * D;
+            u.k_tail = (char*)ls->k + tail;
+            u.k_tail_stride_h = ls->cap * D;
+            u.v_tail = (char*)ls->v + tail;
+            u.v_tail_stride_h = ls->cap * D;
+            u.keep_idx = b->keep_idx + (size_t)l * keep;
+            if (reforge && P) {
+                u.pos_src = b->pos_new + (size_t)l * keep;
+                u.pos_src_stride = (int64_t)b->slots * keep;
+                u.pos_dst = ls->pos + ls->pos_len;
+                u.pos_dst_stride = ls->pos_cap;
+            } else {
+                u.pos_src = u.pos_dst = nullptr;
+                u.pos_src_stride = u.pos_dst_stride = 0;
+            }
+        }
+        b->compact_epoch = (b->compact_epoch <= 0 || b->compact_epoch >= 0x7ffffff0) ? 1 : b->compact_epoch + 1;
+        const int k_mode = !reforge ? RTK_COMPACT_K_INPLACE : (b->defer_rot ? RTK_COMPACT_K_COPY : RTK_COMPACT_K_ROTATE);
+        rc = rtk_pivotkv_compact_batched(cu.data(), n, Hkv, D, keep, reforge ? P : 0, b->dtype, k_mode, b->inv_freq,
+                                         b->attention_scaling, b->nsec ? b->sections : nullptr, b->nsec, b->round_mode,
+                                         b->compact_sync, (size_t)b->compact_sync_ints, b->compact_epoch, stream);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) {
+            rtk_layer_state* ls = layers[i];
+            ls->length += keep;
+            ls->pending = 0;
+            ls->pending_keep = 0;
+            ls->mask = nullptr;
+            if (reforge && P) ls->pos_len += keep;
+        }
+        b->pre_rope = 0;
+        return RTK_OK;
     }
     std::vector<rtk_evict_unit> eu((size_t)n);
     std::vector<rtk_place_unit> pl((size_t)2 * n);

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 RTK_F32, RTK_BF16, RTK_BF16_REFROUND, RTK_BF16_FAST, RTK_F16 = 0, 1, 2, 3, 4
 RTK_SCORE_MANY_UNITS = 0x100   # flag for the dtype argument of the scoring entry points (split policy of batched launches)
@@ -46,6 +46,14 @@ class PlaceUnit(C.Structure):
                 ("keep_idx", _vp)]
 
 
+class CompactUnit(C.Structure):
+    """rtk_compact_unit (include/retake_hip.h)."""
+    _fields_ = [("k_src", _vp), ("k_src_stride_h", _i64), ("k_tail", _vp), ("k_tail_stride_h", _i64), ("v_tail", _vp),
+                ("v_tail_stride_h", _i64), ("keep_idx", _vp), ("pos_src", _vp), ("pos_src_stride", _i64), ("pos_dst", _vp),
+                ("pos_dst_stride", _i64)]
+
+
+COMPACT_K_ROTATE, COMPACT_K_COPY, COMPACT_K_INPLACE = 0, 1, 2
 P2P_MAX_RANKS, IPC_HANDLE_BYTES = 16, 64
 
 
@@ -78,7 +86,8 @@ class PivotKVBatch(C.Structure):
                 ("k_unrot", _vp), ("partials", _vp), ("partial_floats", _u64), ("score", _vp), ("pos_old", _vp),
                 ("keep_idx", _vp), ("pos_new", _vp), ("sel_ws", _vp), ("sel_ws_stride", _u64), ("key_index", _vp),
                 ("v_stage", _vp), ("k_stage", _vp), ("shift_row", _vp), ("q_units", _vp), ("q_stride_h", _i64),
-                ("q_stride_l", _i64), ("pre_rope", _i32), ("batched_passes", _i32)]
+                ("q_stride_l", _i64), ("pre_rope", _i32), ("batched_passes", _i32), ("compact_sync", _vp),
+                ("compact_sync_ints", _u64), ("compact_epoch", _i32), ("pad1", _i32)]
 
 
 class UpdateIO(C.Structure):
@@ -130,6 +139,8 @@ _SIGNATURES = {
     "rtk_pivotkv_evict_batched_rope": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _i, _i, _i, _vp]),
     "rtk_pivotkv_place_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp]),
     "rtk_pivotkv_commit_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "rtk_pivotkv_compact_sync_ints": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "rtk_pivotkv_compact_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _i, _i, _vp, _sz, _i32, _vp]),
     "rtk_position_shift": (C.c_int, [_vp, _i, _vp, _vp]),
     "rtk_pivotkv_update": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
     "rtk_pivotkv_flush": (C.c_int, [_vp, _vp, _vp, _i, _vp]),

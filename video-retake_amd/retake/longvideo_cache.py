@@ -262,7 +262,7 @@ class _Batch:
     """Per-chunk batch of pending evictions: slot = layer index.  All units share the chunk geometry."""
 
     def __init__(self, key, slots, Hq, Hkv, L, D, keep, P, reforge, dtype, device, refround=False, fast=False,
-                 keep_all=False, skip_masked=True):
+                 keep_all=False, skip_masked=True, in_place_compaction=True):
         self.key, self.slots, self.keep, self.P, self.reforge = key, slots, keep, P, reforge
         self.keep_all = keep_all   # keep == L and no scoring asked for: the selection is the identity
         # dtype code of the scoring entry points: bf16 payloads with the reference's bf16 rounding chain, or through the
@@ -301,7 +301,7 @@ class _Batch:
             self.k_stage = None
         else:
             self.k_unrot = None
-            self.k_stage = None if keep_all else torch.empty((slots, Hkv, keep, D), dtype=dtype, device=device)
+            self.k_stage = None if (keep_all or in_place_compaction) else torch.empty((slots, Hkv, keep, D), dtype=dtype, device=device)
         self.cos_new = self.sin_new = None   # tables of a third-party rotary module, allocated when one is used
         self.pending: List[int] = []
         self.c_pending = 0         # how many of them were appended by rtk_pivotkv_update (the one-call path)
@@ -339,9 +339,18 @@ class _Batch:
         c.q_units = C.addressof(self.q_units)
         # the one-call path serves the deferred chip-wide selection (L >= 512) of reforging caches with position ids
         self.c_capable = bool(reforge and P and L >= 512)
+        # rtk_pivotkv_flush compacts the tails in place in one launch (rtk_pivotkv_compact_batched): tickets and flags
+        # of its workgroups live here, zeroed once; the staging rows are then only allocated by the stage-by-stage route
+        self.compact_sync = None
+        if in_place_compaction and not keep_all:
+            n_ints = nv.lib.rtk_pivotkv_compact_sync_ints(slots, Hkv, keep, D, c.dtype)
+            if n_ints:
+                self.compact_sync = torch.zeros(n_ints, dtype=torch.int32, device=device)
+                c.compact_sync, c.compact_sync_ints = self.compact_sync.data_ptr(), n_ints
         if not keep_all:
             self.ensure_scoring()
-            self.ensure_staging()
+            if self.compact_sync is None:
+                self.ensure_staging()
         else:  # nothing is scored or staged: the scratch is allocated only if a route that needs it comes along
             self._dummy = torch.empty(512, dtype=torch.uint8, device=device)
             c.score_ws = (self._dummy.data_ptr() + 255) & ~255
@@ -483,6 +492,9 @@ class PivotKVCache(DynamicCache):
         # MI355X build option (tests / A-B): False makes the prologue route pack a copy of the queries for the score passes
         # even when they could be read where they lie
         self.score_queries_in_place = bool(kv_compression_kwargs.get("score_queries_in_place", True))
+        # MI355X build option (tests / A-B): False makes rtk_pivotkv_flush stage the rows whose source lies inside the
+        # destination range and place them with a second launch, instead of the one in-place compaction launch
+        self.in_place_compaction = bool(kv_compression_kwargs.get("in_place_compaction", True))
         # MI355X build option (tests / A-B): False sends every update and flush through the stage-by-stage route
         # instead of the one-call entry points rtk_pivotkv_update / rtk_pivotkv_flush - same kernels, same results
         self.one_call_update = bool(kv_compression_kwargs.get("one_call_update", True))
@@ -789,7 +801,7 @@ class PivotKVCache(DynamicCache):
         slots = max(int(self.num_hidden_layers), layer_idx + 1, b.slots if b is not None and b.key == key else 0)
         self._batch = None  # release the old buffers before allocating the new ones
         self._batch = _Batch(key, slots, Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast,
-                             keep_all, self.skip_masked_columns)
+                             keep_all, self.skip_masked_columns, self.in_place_compaction)
         self._batch.defer = defer
         self._batch.c.defer_rot = int(defer)
         return self._batch
@@ -852,7 +864,6 @@ class PivotKVCache(DynamicCache):
             self._shift_row(ids, layers[-1])
         if not b.keep_all:
             b.ensure_scoring()
-            b.ensure_staging()
         keep, D, Hkv, P = b.keep, b.D, b.Hkv, b.P
         if b.keep_all:   # units of the one-call path carry their ids in pos_old only: ids x 1.0 = the ids (:288-292)
             for l in layers:
@@ -927,8 +938,15 @@ class PivotKVCache(DynamicCache):
                 pos2d, ld = b.pos_new[:, lo:hi + 1].reshape(P, n), n  # a copy when the slot range is partial
                 self._rope_tables(b.cos_new[lo * keep:], b.sin_new[lo * keep:], b.rotary_emb_fn, b.x_like, pos2d, ld,
                                   3 if P == 3 else 2, b.mrope_section, n, D)
-            units = (nv.EvictUnit * len(layers))()
-            places = (nv.PlaceUnit * (len(layers) * (1 if b.reforge else 2)))()
+            if b.compact_sync is not None and not b.keep_all and (rope_in_kernel or defer or not b.reforge):
+                self._compact(b, layers, rot, defer, dt, es)
+                layers_done, layers = layers, []
+            else:
+                layers_done = layers
+                if not b.keep_all:
+                    b.ensure_staging()
+            units = (nv.EvictUnit * max(1, len(layers)))()
+            places = (nv.PlaceUnit * max(1, len(layers) * (1 if b.reforge else 2)))()
             nc = 0
             for i, l in enumerate(layers):
                 st = self._layers[l]
@@ -971,7 +989,9 @@ class PivotKVCache(DynamicCache):
                 else:
                     u.pos_src = u.pos_dst = None
             s = nv.stream()
-            if rope_in_kernel:
+            if not layers:
+                pass
+            elif rope_in_kernel:
                 sec = (C.c_int * len(b.mrope_section))(*b.mrope_section) if b.mrope_section else None
                 nv.check(nv.lib.rtk_pivotkv_evict_batched_rope(units, len(layers), Hkv, D, keep, P, dt, nv.ptr(rot.inv),
                                                                rot.scaling, sec,
@@ -985,6 +1005,7 @@ class PivotKVCache(DynamicCache):
             # range (parked in the staging rows by the launch above) - reference :313-318 without a full second copy
             if nc:
                 nv.check(nv.lib.rtk_pivotkv_place_batched(places, nc, Hkv, keep, D, dt, s), "rtk_pivotkv_place_batched")
+            layers = layers_done
         for l in layers:
             st = self._layers[l]
             b.q_keep[l] = None
@@ -996,6 +1017,39 @@ class PivotKVCache(DynamicCache):
             if b.reforge and P:
                 st.pos_len += keep
                 self._pos_layers = max(self._pos_layers, l + 1)
+
+    def _compact(self, b: _Batch, layers, rot, defer, dt, es):
+        """The eviction scan of the pending layers as one in-place launch (rtk_pivotkv_compact_batched; reference
+        :278-318): kept K re-rotated at the new ids (or copied un-rotated when the rotation is deferred; compacted in
+        place without reforge), V compacted inside the tail, ids to the position cache."""
+        keep, D, Hkv, P = b.keep, b.D, b.Hkv, b.P
+        units = (nv.CompactUnit * len(layers))()
+        for i, l in enumerate(layers):
+            st = self._layers[l]
+            cap = st.k.shape[2]
+            tail = st.length * D * es
+            u = units[i]
+            if b.reforge:
+                u.k_src, u.k_src_stride_h = b.k_unrot[l].data_ptr(), b.L * D
+            else:
+                u.k_src, u.k_src_stride_h = None, 0
+            u.k_tail, u.k_tail_stride_h = st.k.data_ptr() + tail, cap * D
+            u.v_tail, u.v_tail_stride_h = st.v.data_ptr() + tail, cap * D
+            u.keep_idx = b.keep_idx[l].data_ptr()
+            if b.reforge and P:  # bookkeeping (reference :308-309)
+                self._pos_reserve(st, P, 3 if P == 3 else 2, keep, b.device)
+                u.pos_src, u.pos_src_stride = b.pos_new.data_ptr() + l * keep * 8, b.slots * keep
+                u.pos_dst, u.pos_dst_stride = st.pos.data_ptr() + st.pos_len * 8, st.pos.shape[1]
+            else:
+                u.pos_src = u.pos_dst = None
+        mode = nv.COMPACT_K_INPLACE if not b.reforge else (nv.COMPACT_K_COPY if defer else nv.COMPACT_K_ROTATE)
+        sec = (C.c_int * len(b.mrope_section))(*b.mrope_section) if (b.mrope_section and mode == nv.COMPACT_K_ROTATE) else None
+        b.c.compact_epoch = b.c.compact_epoch + 1 if 0 <= b.c.compact_epoch < 0x7ffffff0 else 1
+        nv.check(nv.lib.rtk_pivotkv_compact_batched(
+            units, len(layers), Hkv, D, keep, P if b.reforge else 0, dt, mode,
+            nv.ptr(rot.inv) if mode == nv.COMPACT_K_ROTATE else None, rot.scaling if mode == nv.COMPACT_K_ROTATE else 1.0,
+            sec, len(sec) if sec is not None else 0, nv.round_mode(b.x_like.dtype) if b.x_like is not None else nv.round_mode(b.dtype),
+            b.c.compact_sync, b.c.compact_sync_ints, b.c.compact_epoch, nv.stream()), "rtk_pivotkv_compact_batched")
 
     # ---- the hot path ---------------------------------------------------------------------------
     def update(
