@@ -451,8 +451,7 @@ int rtk_pivotkv_place_batched(const rtk_place_unit* units, int n_units, int H, i
  * two launches with a staging hop.  Kept row r of a unit's V tail (and K tail, k_mode RTK_COMPACT_K_INPLACE) comes from
  * chunk row keep_idx[r] >= r of the SAME tail: the workgroups of a unit run in ticket order and store a row block only
  * after every lower block has its source rows in registers, so nothing is staged and the kernel moves
- * 4 x keep x Hkv x D x es bytes per unit.  The rotary tables of the kept rows' new ids are built once per workgroup
- * in LDS from the distinct ids of its rows (same arithmetic, same bits as rtk_pivotkv_evict_batched_rope). */
+ * 4 x keep x Hkv x D x es bytes per unit.  Same arithmetic, same bits as rtk_pivotkv_evict_batched_rope. */
 typedef struct rtk_compact_unit {
     const void* k_src;        /* RTK_COMPACT_K_ROTATE / _COPY: K rows of the chunk in a buffer of their own (the un-rotated
                                  k~), element (h,l,d) at h*k_src_stride_h + l*D + d.  _INPLACE: ignored */

@@ -9,17 +9,17 @@ if [ "$1" = build ]; then
   python3 - $tmp/pivotkv_evict.hip <<'PY'
 import re, sys
 p = sys.argv[1]; s = open(p).read()
-a = s.index("template <int E>\n__device__ __forceinline__ void select_fast_body"); b = s.index("template <int E>\n__global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel")
+a = s.index("__device__ __forceinline__ void select_lds_body"); b = s.index("// ------------------------------------------------------------------------------------------------\n// Chip-wide selection")
 body = s[a:b]
 body = body.replace("int64_t* __restrict__ pos_out, int64_t pos_ld) {", "int64_t* __restrict__ pos_out, int64_t pos_ld, unsigned long long* stamp) {\n    int sn = 0;\n#define STAMP() do { if (threadIdx.x == 0 && stamp) stamp[sn++] = wall_clock64(); } while (0)\n    STAMP();", 1)
-body = body.replace("    auto valid = [&](int e)", "    STAMP();\n    auto valid = [&](int e)", 1)
+body = body.replace("    // ---- 1: exact k-th largest key", "    STAMP();\n    // ---- 1: exact k-th largest key", 1)
 body = body.replace("        pmask |= 255u << shift;\n    }", "        pmask |= 255u << shift;\n        STAMP();\n    }", 1)
-body = body.replace("    // selection flags of this thread's tokens", "    STAMP();\n    // selection flags of this thread's tokens", 1)
-body = body.replace("    const float ratio = (float)((double)keep / (double)L);  // comp_ratio", "    STAMP();\n    const float ratio = (float)((double)keep / (double)L);  // comp_ratio", 1)
-body = body[:body.rindex("}")] + "    __syncthreads();\n    STAMP();\n}\n"
+body = body.replace("    // ---- 3: kept indices, ascending", "    STAMP();\n    // ---- 3: kept indices, ascending", 1)
+body = body.replace("    // ---- 4: min_temp_id", "    STAMP();\n    // ---- 4: min_temp_id", 1)
+body = body.replace("    // ---- 5: outputs", "    STAMP();\n    // ---- 5: outputs", 1)
+body = body[:body.rindex("}")] + "    __syncthreads();\n    STAMP();\n}\n\n"
 s = s[:a] + body + s[b:]
-s = s.replace("select_fast_body<E>(score, mask, L, keep, pos, P, reforge, keep_idx, rank, pos_out, pos_ld);", "select_fast_body<E>(score, mask, L, keep, pos, P, reforge, keep_idx, rank, pos_out, pos_ld, nullptr);")
-s = s.replace("select_fast_body<E>(u.score, u.mask, L, keep, u.pos, P, reforge, u.keep_idx, u.rank, u.pos_out, pos_ld);", "select_fast_body<E>(u.score, u.mask, L, keep, u.pos, P, reforge, u.keep_idx, u.rank, u.pos_out, pos_ld, (unsigned long long*)u.workspace);")
+s = s.replace("select_lds_body(u.score, u.mask, L, keep, u.pos, P, reforge, u.keep_idx, u.rank, u.pos_out, pos_ld);", "select_lds_body(u.score, u.mask, L, keep, u.pos, P, reforge, u.keep_idx, u.rank, u.pos_out, pos_ld, (unsigned long long*)u.workspace);")
 open(p, "w").write(s)
 PY
   RTK_SRC=$tmp $ROOT/tools/variants.sh seltime ""
@@ -48,9 +48,9 @@ for L, keep in ((6272, 1568), (2304, 576)):
     for it in range(3):
         nv.check(nv.lib.rtk_pivotkv_select_batched(units, n, 4, 1, 7, L, keep, P, 1, n * keep, 0, nv.stream()), "sel")
     torch.cuda.synchronize()
-    names = ["loads+keys", "radix 24", "radix 16", "radix 8", "radix 0", "scans", "min", "emit"]
+    names = ["keys", "radix 24", "radix 16", "radix 8", "radix 0", "scan", "keepL", "min", "outputs"]
     for i in (0, 13, 27):
         st = hold[i][4][:80].view(torch.int64).tolist()
-        d = [(st[j + 1] - st[j]) * 0.01 for j in range(8)]
-        print("L=%d unit %2d: " % (L, i) + "  ".join("%s %.2f" % (nm, x) for nm, x in zip(names, d)) + "  | total %.2f us" % ((st[8] - st[0]) * 0.01))
+        d = [(st[j + 1] - st[j]) * 0.01 for j in range(9)]
+        print("L=%d unit %2d: " % (L, i) + "  ".join("%s %.2f" % (nm, x) for nm, x in zip(names, d)) + "  | total %.2f us" % ((st[9] - st[0]) * 0.01))
 PY

@@ -16,42 +16,33 @@
 // blocks of its (unit, head group) - the readers of its destination rows have indices <= its own, (5) stores.
 // No workgroup waits on a higher ticket or on anything a waiting workgroup holds: no deadlock at any occupancy.
 //
-// Rotary tables.  The new ids of a block's 32 rows take few distinct values per id row (M-RoPE: 1-2 temporal, a few
-// h, <= grid-width w): the block builds cos / sin for (id row, id value, channel of that row's section) once in LDS
-// - rope_table_kernel's arithmetic, so the same bits - instead of 8 correctly rounded sincos per thread; blocks whose
-// ids spread too far (plain 1-D ids) compute per thread as before.  The rotation rounds through v_cvt_pk_bf16_f32.
+// Rotation.  cos / sin of a kept row's new ids are computed per thread (8 correctly rounded sincos, shared by the KV
+// heads of the block) while the row loads are in flight; the rotation rounds through v_cvt_pk_bf16_f32 - one
+// instruction per pair instead of the integer sequence of rtk_pivotkv_evict_batched_rope, which was VALU-bound.
 #include "common.cuh"
+#include "variants.h"
 
 namespace rtk {
 
 struct CompactUnits {
     rtk_compact_unit u[RTK_COMPACT_MAX_UNITS];
 };
-// the channels d < D/2 grouped by the id row (t / h / w) that feeds them: chan[start[p] + j], j < cnt[p]
-struct SecMap {
-    uint8_t chan[128];
-    uint8_t start[4];
-    uint8_t cnt[4];
-};
 
 constexpr int CMP_BLOCK = 256;
-constexpr int CMP_HU = 4;            // KV heads per workgroup
-constexpr int CMP_TAB = 2048;        // (cos, sin) entries of the block's table: 16 KB
+constexpr int CMP_HU = RTK_CMP_HU;            // KV heads per workgroup
 constexpr int CMP_HDR = 32;          // ints before the flags of a (unit, head group): [0] ticket, [1] finished blocks
 
 template <int DT, int KMODE>
-__global__ __launch_bounds__(CMP_BLOCK, 4) void compact_units_kernel(CompactUnits units, int Hkv, int HG, int D, int keep,
+__global__ __launch_bounds__(CMP_BLOCK, RTK_CMP_WAVES) void compact_units_kernel(CompactUnits units, int Hkv, int HG, int D, int keep,
                                                                   int P, const float* __restrict__ inv_freq,
-                                                                  float scaling, RowSel rs, SecMap sm, int round_mode,
-                                                                  int use_tab, int32_t* __restrict__ sync,
+                                                                  float scaling, RowSel rs, int round_mode,
+                                                                  int32_t* __restrict__ sync,
                                                                   int sync_stride, int32_t epoch) {
     using V = Vec16<DT>;
     constexpr int VE = V::VE;
     constexpr int ES = 16 / VE;
     constexpr int HU = CMP_HU;
     __shared__ int s_b;
-    __shared__ int s_mm[CMP_BLOCK / WAVE][8];
-    __shared__ float2 tab[KMODE == 0 ? CMP_TAB : 1];
     const int tid = threadIdx.x;
     const int y = blockIdx.y, unit = y / HG, hg = y - unit * HG;
     const rtk_compact_unit& un = units.u[unit];
@@ -101,108 +92,15 @@ __global__ __launch_bounds__(CMP_BLOCK, 4) void compact_units_kernel(CompactUnit
         if (tid == 0) __hip_atomic_store(&sy[CMP_HDR + b], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if constexpr (KMODE == 0) {
-        // ---- cos / sin of the rows' new ids -------------------------------------------------------------------
+        // ---- cos / sin of the rows' new ids: rope_table_kernel's arithmetic per thread, while the row loads fly
+        // (a per-block LDS table of the rows' distinct ids was measured: no faster - with the packed-convert rotation
+        // below the kernel is bound by its memory traffic, not by the 8 correctly rounded sincos per thread)
         float c1[VE], s1[VE], c2[VE], s2[VE];
-        int idi[3], mn[3], mx[3];
-        bool bad = false;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            bad = bad || id[p] > (1ll << 29) || id[p] < -(1ll << 29);
-            idi[p] = (int)id[p];
-            mn[p] = mx[p] = idi[p];
-        }
-        int cum[3] = {0, 0, 0};
-        bool tabbed = false;
-        if (use_tab) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    mn[p] = min(mn[p], __shfl_xor(mn[p], o, WAVE));
-                    mx[p] = max(mx[p], __shfl_xor(mx[p], o, WAVE));
-                }
-            }
-            const bool wbad = __ballot(bad) != 0ull;
-            if ((tid & (WAVE - 1)) == 0) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    s_mm[tid / WAVE][p] = mn[p];
-                    s_mm[tid / WAVE][3 + p] = mx[p];
-                }
-                s_mm[tid / WAVE][6] = wbad;
-            }
-            __syncthreads();
-            int anybad = 0;
-#pragma unroll
-            for (int w = 0; w < CMP_BLOCK / WAVE; ++w) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    mn[p] = min(mn[p], s_mm[w][p]);
-                    mx[p] = max(mx[p], s_mm[w][3 + p]);
-                }
-                anybad |= s_mm[w][6];
-            }
-            int tot[3], slots = 0, total = 0;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const int rng = sm.cnt[p] ? mx[p] - mn[p] + 1 : 0;
-                cum[p] = slots;
-                slots += rng;
-                tot[p] = rng * (int)sm.cnt[p];
-                total += tot[p];
-            }
-            const int rows = min(R, keep - b * R);
-            // block-uniform: the table pays when it is at most half the per-thread work and fits
-            tabbed = !anybad && slots * h2 <= CMP_TAB && 2 * total <= rows * h2;
-            if (tabbed) {
-                for (int i = tid; i < total; i += CMP_BLOCK) {
-                    int q = i, p = 0;
-                    if (q >= tot[0]) {
-                        q -= tot[0];
-                        p = 1;
-                        if (q >= tot[1]) {
-                            q -= tot[1];
-                            p = 2;
-                        }
-                    }
-                    const int np = sm.cnt[p];
-                    const int ido = q / np, j = q - ido * np;
-                    const int dch = sm.chan[sm.start[p] + j];
-                    const int base = p == 0 ? cum[0] : (p == 1 ? cum[1] : cum[2]);
-                    const int m0 = p == 0 ? mn[0] : (p == 1 ? mn[1] : mn[2]);
-                    // rope_elem()'s arithmetic: fp32 id * inv_freq, correctly rounded sin / cos, * attention_scaling
-                    float sn, cs;
-                    sincos_cr((float)(long long)(m0 + ido) * inv_freq[dch], sn, cs);
-                    cs = round_to(cs * scaling, round_mode);
-                    sn = round_to(sn * scaling, round_mode);
-                    tab[(base + ido) * h2 + dch] = make_float2(cs, sn);
-                }
-            }
-        }
-        loads_landed();   // (also the barrier between the table's writers and its readers)
-        if (tabbed) {
-            uint8_t ra[VE];
-            if constexpr (VE == 8) {
-                const uint64_t wa = *(const uint64_t*)(rs.row + d);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ra[e] = (uint8_t)(wa >> (8 * e));
-            } else {
-                const uint32_t wa = *(const uint32_t*)(rs.row + d);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) ra[e] = (uint8_t)(wa >> (8 * e));
-            }
-#pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                const int p = ra[e];
-                const int slot = p == 0 ? cum[0] + idi[0] - mn[0] : (p == 1 ? cum[1] + idi[1] - mn[1] : cum[2] + idi[2] - mn[2]);
-                const float2 t = tab[slot * h2 + d + e];
-                c1[e] = c2[e] = t.x;
-                s1[e] = s2[e] = t.y;
-            }
-        } else {
+        {
             const float pid[3] = {(float)id[0], (float)id[1], (float)id[2]};
             rope_chunk<VE>(inv_freq, rs, d, h2, pid, scaling, round_mode, c1, s1, c2, s2);
         }
+        loads_landed();
         // ---- kept K = the un-rotated row rotated forward at its new position (:297-306): (k*cos) + (rotate_half(k)*sin),
         // one rounding per torch op, no fma contraction; straight into the tail (nobody reads K rows of the tail here)
 #pragma unroll
@@ -341,29 +239,11 @@ extern "C" int rtk_pivotkv_compact_batched(const rtk_compact_unit* units, int n_
         }
     }
     RowSel rs;
-    SecMap sm;
-    int use_tab = 0;
     if (k_mode == RTK_COMPACT_K_ROTATE) {
         const int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_pivotkv_compact_batched");
         if (rc != RTK_OK) return rc;
-        const int h2 = D / 2;
-        use_tab = h2 <= 128;
-        int at = 0;
-        for (int p = 0; p < 3; ++p) {
-            sm.start[p] = (uint8_t)at;
-            int cnt = 0;
-            for (int d = 0; d < h2 && use_tab; ++d) {
-                if (rs.row[d] != rs.row[d + h2]) use_tab = 0;   // a channel and its rotation partner on different id rows
-                if (rs.row[d] == p) sm.chan[at + cnt++] = (uint8_t)d;
-            }
-            sm.cnt[p] = (uint8_t)cnt;
-            at += cnt;
-        }
-        sm.start[3] = sm.cnt[3] = 0;
     } else {
         for (int d = 0; d < 256; ++d) rs.row[d] = 0;
-        for (int d = 0; d < 128; ++d) sm.chan[d] = 0;
-        for (int p = 0; p < 4; ++p) sm.start[p] = sm.cnt[p] = 0;
     }
     hipStream_t st = (hipStream_t)stream;
     for (int b = 0; b < n_units; b += RTK_COMPACT_MAX_UNITS) {
@@ -371,20 +251,20 @@ extern "C" int rtk_pivotkv_compact_batched(const rtk_compact_unit* units, int n_
         CompactUnits cu;
         for (int i = 0; i < RTK_COMPACT_MAX_UNITS; ++i) cu.u[i] = units[b + std::min(i, n - 1)];
         int32_t* sy = sync_ws + (size_t)b * HG * stride;
-#define RTK_CMP(DTV, KM)                                                                                              \
+#define RTK_LAUNCH_CMP(DTV, KM)                                                                                              \
     RTK_LAUNCH(KID_COMPACT, (compact_units_kernel<DTV, KM>), dim3(nb, n * HG), dim3(CMP_BLOCK), 0, st, cu, Hkv, HG, D, keep, \
-               P, inv_freq, attention_scaling, rs, sm, round_mode, use_tab, sy, (int)stride, epoch)
-#define RTK_CMP_DT(KM)                                  \
+               P, inv_freq, attention_scaling, rs, round_mode, sy, (int)stride, epoch)
+#define RTK_LAUNCH_CMP_DT(KM)                                  \
     do {                                                \
-        if (dtype == RTK_BF16) RTK_CMP(RTK_BF16, KM);   \
-        else if (dtype == RTK_F16) RTK_CMP(RTK_F16, KM); \
-        else RTK_CMP(RTK_F32, KM);                      \
+        if (dtype == RTK_BF16) RTK_LAUNCH_CMP(RTK_BF16, KM);   \
+        else if (dtype == RTK_F16) RTK_LAUNCH_CMP(RTK_F16, KM); \
+        else RTK_LAUNCH_CMP(RTK_F32, KM);                      \
     } while (0)
-        if (k_mode == RTK_COMPACT_K_ROTATE) RTK_CMP_DT(0);
-        else if (k_mode == RTK_COMPACT_K_COPY) RTK_CMP_DT(1);
-        else RTK_CMP_DT(2);
-#undef RTK_CMP_DT
-#undef RTK_CMP
+        if (k_mode == RTK_COMPACT_K_ROTATE) RTK_LAUNCH_CMP_DT(0);
+        else if (k_mode == RTK_COMPACT_K_COPY) RTK_LAUNCH_CMP_DT(1);
+        else RTK_LAUNCH_CMP_DT(2);
+#undef RTK_LAUNCH_CMP_DT
+#undef RTK_LAUNCH_CMP
         RTK_LAUNCH_CHECK("compact_units_kernel");
     }
     return RTK_OK;

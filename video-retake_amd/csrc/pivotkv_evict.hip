@@ -61,109 +61,101 @@ __global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_kernel(float* __res
     }
 }
 
-// Fast path for L <= 1024*E: every thread owns E CONSECUTIVE tokens and keeps their keys in registers,
-// so the four radix passes never touch memory again and the ordered compaction is two block-wide
-// exclusive scans (ownership ranges are ordered by index, so emitting in (thread, element) order is
-// ascending index order).
-__device__ __forceinline__ int block_excl_scan_1024(int v, uint32_t* wtot /*[16]*/, int tid) {
-    const int lane = tid & (WAVE - 1), wid = tid / WAVE;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const int t = __shfl_up(inc, o, WAVE);
-        if (lane >= o) inc += t;
-    }
-    if (lane == WAVE - 1) wtot[wid] = (uint32_t)inc;
-    __syncthreads();
-    int before = 0;
-#pragma unroll
-    for (int w = 0; w < PSEL_BLOCK / WAVE; ++w)
-        if (w < wid) before += (int)wtot[w];
-    __syncthreads();  // wtot may be reused by the next scan
-    return before + inc - v;
+constexpr uint32_t KEY_ONE = 0xBF800000u;   // f2key(1.0f)
+
+// ------------------------------------------------------------------------------------------------
+// One workgroup per unit, small code: the selection of a batched launch runs on ONE CU per unit, where what counts is
+// the number of instructions issued AND fetched - a kernel is entered with a cold instruction cache, and the
+// register-resident form of this kernel (keys of 8 consecutive tokens per thread, every loop unrolled: 14 KB of
+// straight-line code executed once) took 31 us per 28-unit launch at L = 6272 against 24 us for this one, 4.5 KB
+// (same-box A/B, profiles/r13_ab_select.txt).  The keys live in LDS
+// (thread t owns tokens [t*per, (t+1)*per), row stride per|1 words: conflict-free), every per-token loop is a real
+// loop, and all global traffic is coalesced:
+//   0  scores (+ mask override, :272-274) -> keys; the tokens at exactly 1.0 (every key-patch token) are counted once
+//   1  4 radix passes of 8 bits over the LDS keys: a wave whose digits all agree issues one atomic
+//   2  one packed block scan (greater | equal << 16): output position of every thread's first kept token
+//   3  kept indices -> LDS in ascending order
+//   4  cooperative over the kept rows: temporal ids gathered, min_temp_id (:293)
+//   5  cooperative, coalesced stores: keep_idx, gathered / rescaled ids (:283-295), rank
+// Exact radix select, ties lowest index first: the results of the chip-wide rank / emit pair and of the generic kernel above.
+// ------------------------------------------------------------------------------------------------
+constexpr int SEL_LDS_MAX_PER = 16;   // tokens per thread: L <= 16384
+__host__ __device__ inline size_t select_lds_bytes(int L, int keep) {
+    const int per = (L + PSEL_BLOCK - 1) / PSEL_BLOCK;
+    return ((size_t)(per | 1) * PSEL_BLOCK + (size_t)keep) * sizeof(uint32_t);
 }
 
-template <int E>
-__device__ __forceinline__ void select_fast_body(float* __restrict__ score, const uint8_t* __restrict__ mask, int L,
-                                                 int keep, const int64_t* __restrict__ pos, int P, int reforge,
-                                                 int64_t* __restrict__ keep_idx, int32_t* __restrict__ rank,
-                                                 int64_t* __restrict__ pos_out, int64_t pos_ld) {
+__device__ __forceinline__ void select_lds_body(float* __restrict__ score, const uint8_t* __restrict__ mask, int L, int keep,
+                                                const int64_t* __restrict__ pos, int P, int reforge,
+                                                int64_t* __restrict__ keep_idx, int32_t* __restrict__ rank,
+                                                int64_t* __restrict__ pos_out, int64_t pos_ld) {
+    extern __shared__ uint32_t sel_lds[];
     __shared__ SelectSmem sm;
     __shared__ uint32_t wtot[PSEL_BLOCK / WAVE];
     __shared__ long long red[PSEL_BLOCK / WAVE];
-    const int tid = threadIdx.x;
-    const int per = (L + PSEL_BLOCK - 1) / PSEL_BLOCK;  // <= E
-    const int base = tid * per;
-    uint32_t key[E];
-    long long t0[E];   // temporal ids of this thread's tokens: tmin and the rescale need no re-read
-    long long p1[E], p2[E];   // rows 1 and 2 of the ids (M-RoPE h / w), loaded up front so the emit loop only stores
-    const bool rf = pos && reforge;
-    {
-        // every load first (independent, in flight together), then the mask override stores
-        float sc[E];
-        uint8_t mk[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int i = min(base + e, L - 1);
-            sc[e] = score[i];
-            mk[e] = mask ? mask[i] : (uint8_t)0;
-            t0[e] = pos ? pos[i] : 0;
-            p1[e] = (pos && P > 1) ? pos[(size_t)L + i] : 0;
-            p2[e] = (pos && P > 2) ? pos[2 * (size_t)L + i] : 0;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+    const int per = (L + PSEL_BLOCK - 1) / PSEL_BLOCK, ps = per | 1;
+    uint32_t* keyL = sel_lds;                         // token i at (i / per) * ps + i % per
+    uint32_t* keepL = sel_lds + (size_t)ps * PSEL_BLOCK;
+    const int base = tid * per, kb = tid * ps;
+    const int mine = max(0, min(per, L - base));      // tokens this thread owns
+    // ---- 0: keys --------------------------------------------------------------------------------------------
+    uint32_t ones = 0;
+    // i / per as a multiply-high: exact for i < 2^14 and 2 <= per <= 16 (the error term i * (M - 2^20/per) / 2^20 < 1/per)
+    const uint32_t magic = (((1u << 20) + (uint32_t)per - 1u) / (uint32_t)per) << 12;
+    for (int i = tid; i < L; i += PSEL_BLOCK) {
+        float sc = score[i];
+        if (mask && mask[i]) {  // attn_weights.masked_fill_(mask, 1.)  (:274)
+            sc = 1.0f;
+            score[i] = 1.0f;
         }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int i = base + e;
-            key[e] = 0;
-            if (e < per && i < L) {
-                if (mk[e]) {  // attn_weights.masked_fill_(mask, 1.)  (:274)
-                    sc[e] = 1.0f;
-                    score[i] = 1.0f;
-                }
-                key[e] = f2key(sc[e]);
-            }
-        }
+        const uint32_t k = f2key(sc);
+        const int t = per == 1 ? i : (int)__umulhi((uint32_t)i, magic);
+        keyL[t * ps + (i - t * per)] = k;
+        ones += (uint32_t)__popcll(__ballot(k == KEY_ONE));
+        if (rank) rank[i] = -1;
     }
-    auto valid = [&](int e) { return e < per && base + e < L; };
-    // exact k-th largest key: 4 radix passes of 8 bits over the register-resident keys
+    if (lane == 0) wtot[wid] = ones;
+    // ---- 1: exact k-th largest key --------------------------------------------------------------------------
     uint32_t prefix = 0, pmask = 0;
     int kk = keep;
 #pragma unroll 1
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (tid < 256) sm.hist[tid] = 0;
         __syncthreads();
-        // Scores cluster (mean 1.0), so in the leading passes most lanes of a wave hit the SAME bin and plain
-        // LDS atomics would serialise 64-way.  Peel up to two popular digits per wave with a ballot (one
-        // atomic each, adding the population count); the remaining lanes use ordinary atomics.
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const bool m = valid(e) && (key[e] & pmask) == prefix;
-            const uint32_t d = (key[e] >> shift) & 255u;
-            unsigned long long todo = __ballot(m);
-#pragma unroll
-            for (int round = 0; round < 2; ++round) {
-                if (todo == 0) break;                                   // wave-uniform
-                const int leader = __ffsll((long long)todo) - 1;
-                const uint32_t dl = __shfl(d, leader, WAVE);
-                const unsigned long long grp = __ballot(m && d == dl) & todo;
-                if ((tid & (WAVE - 1)) == leader) atomicAdd(&sm.hist[dl], (uint32_t)__popcll(grp));
-                todo &= ~grp;
+        if (tid == PSEL_BLOCK - 1 && (KEY_ONE & pmask) == prefix) {   // the tokens at 1.0, as one count
+            uint32_t n1 = 0;
+            for (int w = 0; w < PSEL_BLOCK / WAVE; ++w) n1 += wtot[w];
+            if (n1) atomicAdd(&sm.hist[(KEY_ONE >> shift) & 255u], n1);
+        }
+#pragma unroll 1
+        for (int e = 0; e < per; ++e) {
+            const uint32_t k = keyL[kb + e];
+            const bool m = e < mine && k != KEY_ONE && (k & pmask) == prefix;
+            const uint32_t d = (k >> shift) & 255u;
+            const unsigned long long bal = __ballot(m);
+            if (bal != 0) {                                           // wave-uniform
+                const int leader = __ffsll((long long)bal) - 1;
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
+                if (__ballot(m && d == d0) == bal) {                  // every digit of the wave alike: one atomic
+                    if (lane == leader) atomicAdd(&sm.hist[d0], (uint32_t)__popcll(bal));
+                } else if (m) {
+                    atomicAdd(&sm.hist[d], 1u);
+                }
             }
-            if ((todo >> (tid & (WAVE - 1))) & 1ull) atomicAdd(&sm.hist[d], 1u);
         }
         __syncthreads();
         if (tid < WAVE) {
-            const int lane = tid;
             const uint32_t h0 = sm.hist[4 * lane], h1 = sm.hist[4 * lane + 1], h2 = sm.hist[4 * lane + 2],
                            h3 = sm.hist[4 * lane + 3];
-            const uint32_t mine = h0 + h1 + h2 + h3;
-            uint32_t incl = mine;
+            const uint32_t own = h0 + h1 + h2 + h3;
+            uint32_t incl = own;
 #pragma unroll
             for (int o = 1; o < WAVE; o <<= 1) {
                 const uint32_t t = __shfl_down(incl, o, WAVE);
                 if (lane + o < WAVE) incl += t;
             }
-            const uint32_t above = incl - mine;
+            const uint32_t above = incl - own;
             if (above < (uint32_t)kk && (uint32_t)kk <= incl) {
                 uint32_t c = above;
                 int b;
@@ -182,71 +174,66 @@ __device__ __forceinline__ void select_fast_body(float* __restrict__ score, cons
     }
     const uint32_t thr = prefix;
     const int need_eq = kk;
-    int cnt_eq = 0, cnt_gt = 0;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (!valid(e)) continue;
-        cnt_eq += key[e] == thr;
-        cnt_gt += key[e] > thr;
+    // ---- 2: where this thread's kept tokens go ----------------------------------------------------------------
+    uint32_t own = 0;
+#pragma unroll 1
+    for (int e = 0; e < mine; ++e) {
+        const uint32_t k = keyL[kb + e];
+        own += (k > thr ? 1u : 0u) + (k == thr ? 0x10000u : 0u);
     }
-    const int eq_before = block_excl_scan_1024(cnt_eq, wtot, tid);
-    const int eq_take = max(0, min(cnt_eq, need_eq - eq_before));  // ties: lowest index first
-    int r = block_excl_scan_1024(cnt_gt + eq_take, wtot, tid);
-    // selection flags of this thread's tokens (bit e), and min_temp_id over the kept tokens (:293)
-    unsigned selbits = 0;
-    long long mn = 0x7fffffffffffffffLL;
-    {
-        int eq_seen = 0;
+    uint32_t inc = own;
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (!valid(e)) continue;
-            bool sel = key[e] > thr;
-            if (key[e] == thr) sel = eq_seen++ < eq_take;
-            if (sel) {
-                selbits |= 1u << e;
-                mn = min(mn, t0[e]);
-            }
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, WAVE);
+        if (lane >= o) inc += t;
+    }
+    if (lane == WAVE - 1) wtot[wid] = inc;
+    __syncthreads();
+    uint32_t before = inc - own;
+    for (int w = 0; w < wid; ++w) before += wtot[w];
+    const int eq_before = (int)(before >> 16);
+    int eq_left = max(0, need_eq - eq_before);                   // ties: lowest index first
+    int r = (int)(before & 0xffffu) + min(eq_before, need_eq);
+    // ---- 3: kept indices, ascending ----------------------------------------------------------------------------
+#pragma unroll 1
+    for (int e = 0; e < mine; ++e) {
+        const uint32_t k = keyL[kb + e];
+        bool sel = k > thr;
+        if (k == thr && eq_left > 0) {
+            sel = true;
+            --eq_left;
         }
+        if (sel) keepL[r++] = (uint32_t)(base + e);
     }
+    __syncthreads();
+    // ---- 4: min_temp_id = compressed_position_ids[0].min()  (:293) ---------------------------------------------
+    const bool rf = pos && reforge;
+    long long mn = 0x7fffffffffffffffLL;
     if (rf) {
+        for (int q = tid; q < keep; q += PSEL_BLOCK) mn = min(mn, (long long)pos[keepL[q]]);
+#pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const long long t = __shfl_xor(mn, o, WAVE);
             mn = min(mn, t);
         }
-        if ((tid & (WAVE - 1)) == 0) red[tid / WAVE] = mn;
+        if (lane == 0) red[wid] = mn;
         __syncthreads();
         mn = red[0];
         for (int w = 1; w < PSEL_BLOCK / WAVE; ++w) mn = min(mn, red[w]);
     }
+    // ---- 5: outputs ----------------------------------------------------------------------------------------------
     const float ratio = (float)((double)keep / (double)L);  // comp_ratio = keep_len / k_len (:294)
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (!valid(e)) continue;
-        const int i = base + e;
-        if ((selbits >> e) & 1u) {
-            keep_idx[r] = i;  // topk(keep).sort()  (:276-277)
-            if (pos) {
-                // row 0: gathered id, rescaled when reforging: int64 -> float32 multiply -> truncation (:293-295)
-                pos_out[r] = rf ? mn + (long long)((float)(t0[e] - mn) * ratio) : t0[e];
-                if (P > 1) pos_out[(size_t)pos_ld + r] = p1[e];      // :283-288
-                if (P > 2) pos_out[2 * (size_t)pos_ld + r] = p2[e];
-            }
-            if (rank) rank[i] = r;
-            ++r;
-        } else if (rank) {
-            rank[i] = -1;
+    for (int q = tid; q < keep; q += PSEL_BLOCK) {
+        const int i = (int)keepL[q];
+        keep_idx[q] = i;  // topk(keep).sort()  (:276-277)
+        if (pos) {
+            const long long t0 = pos[i];
+            // row 0: gathered id, rescaled when reforging: int64 -> float32 multiply -> truncation (:293-295)
+            pos_out[q] = rf ? mn + (long long)((float)(t0 - mn) * ratio) : t0;
+            for (int p = 1; p < P; ++p) pos_out[(size_t)p * pos_ld + q] = pos[(size_t)p * L + i];   // :283-288
         }
+        if (rank) rank[i] = q;
     }
-}
-template <int E>
-__global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_fast_kernel(float* __restrict__ score,
-                                                                         const uint8_t* __restrict__ mask, int L,
-                                                                         int keep, const int64_t* __restrict__ pos,
-                                                                         int P, int reforge,
-                                                                         int64_t* __restrict__ keep_idx,
-                                                                         int32_t* __restrict__ rank,
-                                                                         int64_t* __restrict__ pos_out, int64_t pos_ld) {
-    select_fast_body<E>(score, mask, L, keep, pos, P, reforge, keep_idx, rank, pos_out, pos_ld);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -266,15 +253,15 @@ constexpr int RANK_BLOCK = RANK_TOK * RANK_SEG;
 struct SelUnits {
     rtk_select_unit u[RTK_SELECT_MAX_UNITS];
 };
-// Batched launches (one unit per layer of a chunk): one workgroup per unit runs the register-resident radix
-// select above, all units side by side.  With >= 8 units in flight that beats spreading every unit over the
-// chip: the 28 selections of a chunk take one workgroup's latency instead of 28 x 98 ranking workgroups.
-template <int E>
-__global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_units_kernel(SelUnits units, int L, int keep, int P,
-                                                                          int reforge, int64_t pos_ld) {
+// Batched launches (one unit per layer of a chunk): one workgroup per unit, all units side by side.  With >= 8 units in
+// flight that beats spreading every unit over the chip: the 28 selections of a chunk take one workgroup's latency
+// instead of 28 x 98 ranking workgroups.
+__global__ __launch_bounds__(PSEL_BLOCK) void pivotkv_select_lds_units_kernel(SelUnits units, int L, int keep, int P,
+                                                                              int reforge, int64_t pos_ld) {
     const rtk_select_unit& u = units.u[blockIdx.x];
-    select_fast_body<E>(u.score, u.mask, L, keep, u.pos, P, reforge, u.keep_idx, u.rank, u.pos_out, pos_ld);
+    select_lds_body(u.score, u.mask, L, keep, u.pos, P, reforge, u.keep_idx, u.rank, u.pos_out, pos_ld);
 }
+
 // scratch layout inside a unit's workspace: sel [L] bytes | per-rank-workgroup counts | per-rank-workgroup minima
 __host__ __device__ inline size_t sel_ws_cnt_off(int L) { return ((size_t)L + 255) & ~(size_t)255; }
 __host__ __device__ inline size_t sel_ws_tmin_off(int L) {
@@ -892,18 +879,22 @@ static bool chipwide_ok(int L) {
 
 // finalize (units that carry partials) -> rank -> emit, every unit in the same three launches
 constexpr int UNITS_ONE_WG = 8;   // batched launches with at least this many units select one workgroup per unit
+// > 64 KiB of dynamic LDS: opt-in per device, remembered in one atomic bit per device
+static void select_lds_opt_in() {
+    static std::atomic<uint64_t> opted{0};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    const uint64_t bit = 1ull << (dev_id & 63);
+    if (!(opted.load(std::memory_order_relaxed) & bit)) {
+        (void)hipFuncSetAttribute((const void*)pivotkv_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)pivotkv_select_lds_units_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        opted.fetch_or(bit, std::memory_order_relaxed);
+    }
+}
+
 static int select_units(const rtk_select_unit* units, int n, int Hkv, int RS, int G, int L, int keep, int P, int reforge,
                         int64_t pos_out_stride, hipStream_t st, bool refround = false) {
-    {   // > 64 KiB of dynamic LDS: opt-in per device, remembered in one atomic bit per device
-        static std::atomic<uint64_t> opted{0};
-        int dev_id = 0;
-        (void)hipGetDevice(&dev_id);
-        const uint64_t bit = 1ull << (dev_id & 63);
-        if (!(opted.load(std::memory_order_relaxed) & bit)) {
-            (void)hipFuncSetAttribute((const void*)pivotkv_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            opted.fetch_or(bit, std::memory_order_relaxed);
-        }
-    }
+    select_lds_opt_in();
     const size_t lds = ((size_t)((L + RANK_TOK - 1) / RANK_TOK) * RANK_TOK + RANK_BLOCK) * sizeof(uint32_t);
     for (int b = 0; b < n; b += RTK_SELECT_MAX_UNITS) {
         const int m = std::min(RTK_SELECT_MAX_UNITS, n - b);
@@ -922,15 +913,10 @@ static int select_units(const rtk_select_unit* units, int n, int Hkv, int RS, in
             RTK_LAUNCH_CHECK("finalize_units_kernel");
         }
         const int per = (L + PSEL_BLOCK - 1) / PSEL_BLOCK;
-        if (m >= UNITS_ONE_WG && per <= 8) {
-            if (per <= 2) {
-                RTK_LAUNCH(KID_PSEL, pivotkv_select_units_kernel<2>, dim3(m), dim3(PSEL_BLOCK), 0, st, su, L, keep, P, reforge,
-                           pos_out_stride);
-            } else {
-                RTK_LAUNCH(KID_PSEL, pivotkv_select_units_kernel<8>, dim3(m), dim3(PSEL_BLOCK), 0, st, su, L, keep, P, reforge,
-                           pos_out_stride);
-            }
-            RTK_LAUNCH_CHECK("pivotkv_select_units_kernel");
+        if (m >= UNITS_ONE_WG && per <= SEL_LDS_MAX_PER) {
+            RTK_LAUNCH(KID_PSEL, pivotkv_select_lds_units_kernel, dim3(m), dim3(PSEL_BLOCK), select_lds_bytes(L, keep), st, su, L,
+                       keep, P, reforge, pos_out_stride);
+            RTK_LAUNCH_CHECK("pivotkv_select_lds_units_kernel");
             continue;
         }
         RTK_LAUNCH(KID_PSEL, pivotkv_rank_kernel, dim3((L + RANK_TOK - 1) / RANK_TOK, m), dim3(RANK_BLOCK), lds, st, su, L, keep,
@@ -994,17 +980,25 @@ extern "C" int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int 
         return select_units(&u, 1, 0, 0, 0, L, keep, pos ? P : 0, reforge, pos_out_stride, st);
     }
     RTK_CHECK_ARG(rank, "rtk_pivotkv_select: the one-workgroup path needs the rank buffer");
-#define RTK_PSEL_FAST(E)                                                                                          \
-    RTK_LAUNCH(KID_PSEL, pivotkv_select_fast_kernel<E>, dim3(1), dim3(PSEL_BLOCK), 0, st, score, mask, L, keep, pos, \
-               P, reforge, keep_idx, rank, pos_out, pos_out_stride)
     const int per = (L + PSEL_BLOCK - 1) / PSEL_BLOCK;
-    if (per <= 2) RTK_PSEL_FAST(2);
-    else if (per <= 8) RTK_PSEL_FAST(8);
-    else if (per <= 32) RTK_PSEL_FAST(32);
-    else
+    if (per <= SEL_LDS_MAX_PER) {
+        rtk_select_unit u;
+        u.partial = nullptr;
+        u.score = score;
+        u.mask = mask;
+        u.pos = pos;
+        u.keep_idx = keep_idx;
+        u.rank = rank;
+        u.pos_out = pos_out;
+        u.workspace = nullptr;
+        SelUnits su;
+        for (int i = 0; i < RTK_SELECT_MAX_UNITS; ++i) su.u[i] = u;
+        select_lds_opt_in();
+        RTK_LAUNCH(KID_PSEL, pivotkv_select_lds_units_kernel, dim3(1), dim3(PSEL_BLOCK), select_lds_bytes(L, keep), st, su, L, keep,
+                   pos ? P : 0, reforge, pos_out_stride);
+    } else   // longer rows: keys re-read from memory on every pass
         RTK_LAUNCH(KID_PSEL, pivotkv_select_kernel, dim3(1), dim3(PSEL_BLOCK), 0, st, score, mask, L, keep, pos, P,
                    reforge, keep_idx, rank, pos_out, pos_out_stride);
-#undef RTK_PSEL_FAST
     RTK_LAUNCH_CHECK("pivotkv_select_kernel");
     return RTK_OK;
 }

@@ -43,3 +43,9 @@
 #ifndef RTK_PREP_BLOCK    // threads per workgroup of the per-update kernels (fused prepare, attention prologue)
 #define RTK_PREP_BLOCK 64
 #endif
+#ifndef RTK_CMP_HU        // in-place compaction: KV heads per workgroup (register batch of the row loads)
+#define RTK_CMP_HU 4
+#endif
+#ifndef RTK_CMP_WAVES     // in-place compaction: waves per SIMD the register allocation is bounded for
+#define RTK_CMP_WAVES 4
+#endif
