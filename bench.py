@@ -451,6 +451,65 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
         torch.cuda.empty_cache()
 
 
+def decode_prologue_measurement(dev, tokens=100, prefix=40000):
+    """Decode-time cost of the attention patch's prologue (qwen2_vl.py:68-86 + the cache's else-branch :319-321) for the
+    LAYERS layers of one generated token after a compressed prefill of `prefix` cached rows per layer: the op-by-op route
+    (continuity shift, rotary module, apply_multimodal_rotary_pos_emb, PivotKVCache.update - what the reference's patch
+    runs, ~25 launches per layer) against the fused one (PivotKVCache.append_pre_rope: one kernel + the in-place id
+    shift).  Wall time per step with the GPU drained at both ends; also for a 64-token text segment."""
+    import retake.longvideo_cache as lc
+
+    td = torch.bfloat16
+    layers = LAYERS
+    rot = Rotary(dev)
+    out = {"layers": layers, "dtype": "bf16", "prefix_tokens_per_layer": prefix, "steps": tokens,
+           "note": "wall time of the patch's prologue for all layers of one step, attention itself not included"}
+
+    def proj(n):
+        return tuple(torch.randn((1, n, h, D), device=dev, dtype=torch.float32).to(td).transpose(1, 2) for h in (Hq, Hkv, Hkv))
+
+    for n, label in ((1, "decode_token"), (64, "text_segment_64")):
+        res = {}
+        for fused in (True, False):
+            cache = lc.build_kvcache(make_cache_config(layers), reserve_tokens=prefix + (tokens + 8) * n + 64)
+            cache.kvcache_compression = False
+            for l in range(layers):   # the state a long compressed prompt leaves: `prefix` cached rows with their ids
+                st = cache.reserve(l, prefix, torch.empty((1, Hkv, 1, D), dtype=td, device=dev))
+                st.length = prefix
+                cache._pos_reserve(st, 3, 3, prefix, dev)
+                st.pos[:, :prefix] = torch.arange(prefix, device=dev)
+                st.pos_len = prefix
+            cache._pos_layers = layers
+            qkv = [proj(n) for _ in range(4)]
+
+            def step(t):
+                pos = (torch.arange(n, device=dev) + prefix + 10000 + t * n).view(1, 1, n).repeat(3, 1, 1)
+                for l in range(layers):
+                    q, k, v = qkv[(t + l) % 4]
+                    if fused:
+                        assert cache.append_pre_rope(q, k, v, l, pos, rot, MROPE) is not None
+                    else:
+                        cache.shift_temporal_ids_(pos, l)
+                        cos, sin = rot(v, pos)
+                        qr, kr = lc.apply_multimodal_rotary_pos_emb(q, k, cos, sin, MROPE)
+                        cache.update(kr, v, l, {"sin": sin, "cos": cos, "query_states": qr, "position_ids": pos,
+                                                "rotary_emb": rot, "mrope_section": MROPE})
+
+            for t in range(5):
+                step(t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in range(tokens):
+                step(5 + t)
+            torch.cuda.synchronize()
+            res["fused_us_per_step" if fused else "op_by_op_us_per_step"] = (time.perf_counter() - t0) / tokens * 1e6
+            del cache
+            torch.cuda.empty_cache()
+        res["speedup"] = res["op_by_op_us_per_step"] / res["fused_us_per_step"]
+        out[label] = res
+    return out
+
+
 def main():
     global OVERLAP_STREAMS, SCORE_ROUNDING
     args = parse()
@@ -722,6 +781,8 @@ def main():
         out["fp16_dtype"]["note"] = "float16 tensors (RTK_F16): fp16 rounding chains, exact fp16 products on the fp16 matrix instruction"
         out["fp32_parity_dtype"] = companion_measurement(dev, args.frames, args.layers, "fp32", 1, 1, args.pool,
                                                          warmup_chunks=2)
+        # decode / text prefill: the same patch's prologue for segments that are not compressed
+        out["decode_prologue"] = decode_prologue_measurement(dev)
         frames = torch.cat([chunk_frames(c, dev, tdtype) for c in range(min(n_chunks, 4))])[None]
     if not args.no_cpu_baseline:
         sample_T = 128

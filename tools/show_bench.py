@@ -26,6 +26,11 @@ for k, c in comp.items():
         print(f"{k}: {c['value']:.1f} frames/s  ms_per_step={c['ms_per_step']:.1f}  roofline {c['roofline']['kernel']} "
               f"frac={c['roofline']['frac']:.3f}  " + " ".join(f"{n}={v['avg_us']:.0f}us" for n, v in c["kernels_timed_region"].items())
               + (f"  per-update kernels {100 * share:.1f} % of GPU time" if share is not None else ""))
+if "decode_prologue" in d:
+    for k in ("decode_token", "text_segment_64"):
+        c = d["decode_prologue"][k]
+        print(f"decode_prologue/{k}: fused {c['fused_us_per_step']:.0f} us  op-by-op {c['op_by_op_us_per_step']:.0f} us  ({c['speedup']:.1f}x), "
+              f"{d['decode_prologue']['layers']} layers")
 for k in ("sharded_equals_sequential", "rccl_world_size", "p2p_world_size"):
     if k in d:
         print(k, d[k])
