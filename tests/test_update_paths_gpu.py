@@ -487,6 +487,37 @@ def test_queries_scored_in_place_equal_the_packed_copy(dtype, L):
         assert torch.equal(zc.position_cache[l], packed.position_cache[l])
 
 
+def test_in_place_and_packed_queries_mixed_within_a_chunk():
+    """Layers of one chunk may hand their queries over differently (fresh q_rot: scored where they lie; rotated in place:
+    a packed copy): the flush launches the passes per run of layers that agree - same bits as the all-packed route.
+    (tools/fuzz_gpu.py found the flush refusing such a chunk.)"""
+    import retake.longvideo_cache as lc
+
+    layers, L, dtype = 4, 640, torch.bfloat16
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    mixed, packed = lc.build_kvcache(cfg(layers)), lc.build_kvcache(cfg(layers))
+    pattern = [True, False, False, True]     # in place / packed per layer
+    for c in range(2):
+        pz, pp = chunk_ids(c, L), chunk_ids(c, L)
+        for cache in (mixed, packed):
+            cache.keypatches_mask_chunk = None
+            cache.kvcache_compression = True
+        for l in range(layers):
+            q0, k0, v0 = projections(800 + 10 * c + l, L, dtype)
+            qz = q0.clone()
+            assert mixed.update_pre_rope(qz, k0, v0, l, pz, rot, SEC, query_out=None if pattern[l] else qz) is not None
+            qq = q0.clone()
+            assert packed.update_pre_rope(qq, k0, v0, l, pp, rot, SEC, query_out=qq) is not None
+        assert [t is not None for t in mixed._batch.q_keep] == pattern
+        for cache in (mixed, packed):
+            cache.after_forward()
+        for l in range(layers):
+            assert torch.equal(mixed._batch.score[l], packed._batch.score[l])
+            assert torch.equal(mixed._batch.keep_idx[l], packed._batch.keep_idx[l])
+    for l in range(layers):
+        assert torch.equal(mixed.key_cache[l], packed.key_cache[l]) and torch.equal(mixed.value_cache[l], packed.value_cache[l])
+
+
 def test_llava_attention_patch_takes_the_prologue():
     """The patched Qwen2 attention of LLaVA-Video (llava_onevision.py:59-141) on the stand-in module of tests/glue_stubs.py
     (head_dim 16: the C update route that runs the score passes per unit), two 640-token chunks, 2-D ids, fp32: the fused

@@ -6,7 +6,8 @@ For random shapes / dtypes / masks / ratios / RoPE flavours it compresses the sa
   B  the cache with `skip_masked_columns=False` (the full pass 2)          -> caches, scores, kept sets BITWISE equal to A
   C  the CPU oracle (fp32 runs only)                                        -> scores <= 5e-6, kept sets margin-aware,
                                                                                kept V exact, kept K <= 1e-5, ids exact
-B also draws `one_call_update` at random: the stage-by-stage route against rtk_pivotkv_update / rtk_pivotkv_flush.
+B also draws `one_call_update` at random (the stage-by-stage route against rtk_pivotkv_update / rtk_pivotkv_flush) and
+`in_place_compaction` (the staged evict + place launches against rtk_pivotkv_compact_batched, which A always runs).
   P  the attention prologue (update_pre_rope on the pre-RoPE projections, where it applies) against its own oracle run
      on the tensors rotated at the continuity-shifted ids (fp32: same bars as C; 16-bit: ids and kept-row count)
     python tools/fuzz_gpu.py [--seconds 240] [--seed 0]
@@ -65,7 +66,8 @@ def main():
                 f"layers={layers} chunks={chunks} native_rope={native} a={S:.3f} score_rounding={rounding}")
 
         staged_b = bool(rng.uniform() < 0.5)
-        desc += f" staged_twin={staged_b}"
+        inplace_b = bool(rng.uniform() < 0.5)
+        desc += f" staged_twin={staged_b} twin_in_place_compaction={inplace_b}"
 
         def make(skip, **extra):
             kw = {"compression_ratio": ratio, "compression_method": "pivotkv", "pos_embed_reforge": reforge,
@@ -78,7 +80,7 @@ def main():
                                         longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": kw})
             return lc.build_kvcache(cfg)
 
-        ca, cb = make(True), make(False, one_call_update=not staged_b)
+        ca, cb = make(True), make(False, one_call_update=not staged_b, in_place_compaction=inplace_b)
         # the prologue route, where it applies (reforging cache, inv_freq rotary, chunks of >= 512 tokens)
         pre = reforge and native and L >= 512 and rounding != "reference"
         cp = make(True, score_when_keeping_all=True) if pre else None

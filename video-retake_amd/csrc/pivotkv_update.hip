@@ -465,9 +465,10 @@ extern "C" int rtk_pivotkv_flush(rtk_pivotkv_batch* b, rtk_layer_state* const* l
         if (b->batched_passes) {
             std::vector<const void*> masks((size_t)n);
             int i = 0;
-            while (i < n) {   // every run of consecutive slots in one launch per kernel (:260-268)
+            auto in_place = [&](int slot) { return b->q_units && b->q_units[slot] != nullptr; };
+            while (i < n) {   // every run of consecutive slots whose queries live alike in one launch per kernel (:260-268)
                 int j = i;
-                while (j + 1 < n && slots[j + 1] == slots[j] + 1) ++j;
+                while (j + 1 < n && slots[j + 1] == slots[j] + 1 && in_place(slots[j + 1]) == in_place(slots[i])) ++j;
                 const int l0 = slots[i], cnt = j - i + 1;
                 bool any = false;
                 for (int u = 0; u < cnt; ++u) {
@@ -475,13 +476,7 @@ extern "C" int rtk_pivotkv_flush(rtk_pivotkv_batch* b, rtk_layer_state* const* l
                     any = any || masks[u];
                 }
                 // queries scored in place (prologue route): every unit of the run, or none
-                const void* const* qu = nullptr;
-                if (b->q_units && b->q_units[l0]) {
-                    for (int u = 0; u < cnt; ++u)
-                        RTK_CHECK_ARG(b->q_units[l0 + u], "rtk_pivotkv_flush: slot %d has no in-place queries but slot %d has",
-                                      l0 + u, l0);
-                    qu = b->q_units + l0;
-                }
+                const void* const* qu = in_place(l0) ? b->q_units + l0 : nullptr;
                 rc = rtk_pivotkv_score_passes_batched_q(
                     (char*)b->score_ws + (size_t)l0 * b->score_ws_stride, b->score_ws_stride,
                     reforge ? (char*)b->k_unrot + (size_t)l0 * Hkv * L * D * es : nullptr, (size_t)Hkv * L * D * es,

@@ -883,9 +883,13 @@ class PivotKVCache(DynamicCache):
                     st.pending_event = None
             unscored = sorted(l for l in layers if l not in b.scored)
             i = 0
-            while i < len(unscored):  # the matrix passes of every run of consecutive slots in one launch each (:260-268)
-                j = i
-                while j + 1 < len(unscored) and unscored[j + 1] == unscored[j] + 1:
+            def qkey(l):   # queries scored where they lie (prologue route) carry their strides; packed ones None
+                t = b.q_keep[l]
+                return None if t is None else t.stride()
+
+            while i < len(unscored):  # the matrix passes of every run of consecutive slots whose queries live alike
+                j = i                   # in one launch per kernel (:260-268)
+                while j + 1 < len(unscored) and unscored[j + 1] == unscored[j] + 1 and qkey(unscored[j + 1]) == qkey(unscored[i]):
                     j += 1
                 l0, n = unscored[i], j - i + 1
                 mptr = [b.masks.get(l) for l in range(l0, l0 + n)]
@@ -893,9 +897,7 @@ class PivotKVCache(DynamicCache):
                     if self.skip_masked_columns and any(m is not None for m in mptr) else None
                 qk = [b.q_keep[l] for l in range(l0, l0 + n)]
                 qu, qsh, qsl = None, 0, 0
-                if any(t is not None for t in qk):   # units of the prologue route whose queries are scored in place
-                    if any(t is None or t.stride() != qk[0].stride() for t in qk):
-                        raise RuntimeError("PivotKVCache: in-place and packed queries mixed in one run of pending layers")
+                if qk[0] is not None:   # units of the prologue route whose queries are scored in place
                     qu = (C.c_void_p * n)(*[t.data_ptr() for t in qk])
                     qsh, qsl = qk[0].stride(1), qk[0].stride(2)
                 nv.check(nv.lib.rtk_pivotkv_score_passes_batched_q(
