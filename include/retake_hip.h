@@ -474,16 +474,14 @@ enum rtk_compact_k_mode {
     RTK_COMPACT_K_COPY = 1,     /* kept K = k_src row verbatim (deferred re-rotation: rtk_pivotkv_batch.defer_rot) */
     RTK_COMPACT_K_INPLACE = 2   /* kept K = row keep_idx[r] of k_tail, compacted in place like V (no reforge, :279) */
 };
-/* ints of the sync workspace for this geometry: device memory, zero-initialised once by the caller and then used with
- * this geometry only (tickets and flags live in it; every launch leaves the tickets at zero and tags its flags with
- * `epoch`). */
+/* ints of the sync workspace for this geometry: device memory, zero-initialised once by the caller (tickets and flags of
+ * the workgroups live in it; every launch that completes leaves it zeroed again - re-zero it after a failed launch). */
 size_t rtk_pivotkv_compact_sync_ints(int n_units, int Hkv, int keep, int D, int dtype);
-/* `units` is a HOST array.  epoch: non-zero and different from the previous launch on the same workspace.
- * inv_freq / attention_scaling / sections / round_mode as rtk_pivotkv_evict_batched_rope (RTK_COMPACT_K_ROTATE only). */
+/* `units` is a HOST array.  inv_freq / attention_scaling / sections / round_mode as rtk_pivotkv_evict_batched_rope
+ * (RTK_COMPACT_K_ROTATE only).  One launch at a time per workspace. */
 int rtk_pivotkv_compact_batched(const rtk_compact_unit* units, int n_units, int Hkv, int D, int keep, int P, int dtype,
                                 int k_mode, const float* inv_freq, float attention_scaling, const int* sections_host,
-                                int nsec, int round_mode, int32_t* sync_ws, size_t sync_ws_ints, int32_t epoch,
-                                rtk_stream_t stream);
+                                int nsec, int round_mode, int32_t* sync_ws, size_t sync_ws_ints, rtk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One-call update and one-call flush (ABI 13).  PivotKVCache.update runs 1,792 times per 2048-frame video and
@@ -557,8 +555,6 @@ typedef struct rtk_pivotkv_batch {
     int32_t* compact_sync;    /* zero-initialised sync workspace of rtk_pivotkv_compact_batched for (slots, Hkv, keep, D,
                                  dtype), or NULL: the flush then stages through v_stage / k_stage (two launches) */
     uint64_t compact_sync_ints;
-    int32_t compact_epoch;    /* advanced by rtk_pivotkv_flush */
-    int32_t pad1;
 } rtk_pivotkv_batch;
 
 /* The tensors of one update call.  Strides in elements; element (h, l, d) at h*stride_h + l*stride_l + d. */

@@ -13,7 +13,8 @@
 // so a destination row may still be somebody's source.  A workgroup owns R consecutive kept rows of one group of KV
 // heads; it (1) takes a ticket - its row block is the ticket, so a lower block has always started, (2) issues every
 // load of its rows, (3) raises its flag once the loads have landed in registers, (4) waits for the flags of ALL lower
-// blocks of its (unit, head group) - the readers of its destination rows have indices <= its own, (5) stores.
+// blocks of its (unit, head group) - the readers of its destination rows have indices <= its own, (5) stores;
+// the last block to finish puts tickets and flags back to zero.
 // No workgroup waits on a higher ticket or on anything a waiting workgroup holds: no deadlock at any occupancy.
 //
 // Rotation.  cos / sin of a kept row's new ids are computed per thread (8 correctly rounded sincos, shared by the KV
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(CMP_BLOCK, RTK_CMP_WAVES) void compact_units_kernel
                                                                   int P, const float* __restrict__ inv_freq,
                                                                   float scaling, RowSel rs, int round_mode,
                                                                   int32_t* __restrict__ sync,
-                                                                  int sync_stride, int32_t epoch) {
+                                                                  int sync_stride) {
     using V = Vec16<DT>;
     constexpr int VE = V::VE;
     constexpr int ES = 16 / VE;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(CMP_BLOCK, RTK_CMP_WAVES) void compact_units_kernel
     auto loads_landed = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(&sy[CMP_HDR + b], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(&sy[CMP_HDR + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if constexpr (KMODE == 0) {
         // ---- cos / sin of the rows' new ids: rope_table_kernel's arithmetic per thread, while the row loads fly
@@ -145,9 +146,15 @@ __global__ __launch_bounds__(CMP_BLOCK, RTK_CMP_WAVES) void compact_units_kernel
     if constexpr (KMODE == 2) loads_landed();
     // ---- the in-place rows: the lower blocks' loads landed -> stores ------------------------------------------------
     if (tid < WAVE) {
-        for (int bb = tid; bb < b; bb += WAVE)
-            while (__hip_atomic_load(&sy[CMP_HDR + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+        for (int bb = tid; bb < b; bb += WAVE) {
+            // a lower block raises its flag a few microseconds after it starts; ~2 s of polling means the workspace was
+            // not zeroed (a flag can then never be trusted): abort the launch loudly instead of hanging the queue
+            unsigned polls = 0;
+            while (__hip_atomic_load(&sy[CMP_HDR + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                 __builtin_amdgcn_s_sleep(2);
+                if (++polls > (1u << 21)) __builtin_trap();
+            }
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -169,10 +176,13 @@ __global__ __launch_bounds__(CMP_BLOCK, RTK_CMP_WAVES) void compact_units_kernel
             if (rr < keep) un.pos_dst[(size_t)p * un.pos_dst_stride + rr] = un.pos_src[(size_t)p * un.pos_src_stride + rr];
         }
     }
-    // the last block to get here has seen every ticket taken: counters back to zero for the next launch
-    if (tid == 0) {
-        const int done = atomicAdd(&sy[1], 1);
-        if (done == nb - 1) {
+    // the last block to get here has seen every ticket taken and every wait over: tickets and flags back to zero - the
+    // workspace is left as it was found, whatever launches next (a replayed graph included)
+    if (tid == 0) s_b = atomicAdd(&sy[1], 1) == nb - 1;
+    __syncthreads();
+    if (s_b) {
+        for (int i = tid; i < nb; i += CMP_BLOCK) __hip_atomic_store(&sy[CMP_HDR + i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
             __hip_atomic_store(&sy[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -202,7 +212,7 @@ extern "C" size_t rtk_pivotkv_compact_sync_ints(int n_units, int Hkv, int keep, 
 extern "C" int rtk_pivotkv_compact_batched(const rtk_compact_unit* units, int n_units, int Hkv, int D, int keep, int P,
                                            int dtype, int k_mode, const float* inv_freq, float attention_scaling,
                                            const int* sections_host, int nsec, int round_mode, int32_t* sync_ws,
-                                           size_t sync_ws_ints, int32_t epoch, rtk_stream_t stream) {
+                                           size_t sync_ws_ints, rtk_stream_t stream) {
     RTK_CHECK_ARG(units && n_units >= 1, "rtk_pivotkv_compact_batched: no units");
     RTK_CHECK_ARG(Hkv >= 1 && keep >= 1 && D >= 2, "rtk_pivotkv_compact_batched: bad shape");
     RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_F16, "rtk_pivotkv_compact_batched: unsupported dtype %d", dtype);
@@ -210,7 +220,7 @@ extern "C" int rtk_pivotkv_compact_batched(const rtk_compact_unit* units, int n_
                   "rtk_pivotkv_compact_batched: k_mode %d", k_mode);
     RTK_CHECK_ARG(P == 0 || P == 1 || P == 3, "rtk_pivotkv_compact_batched: P must be 0, 1 or 3, got %d", P);
     RTK_CHECK_ARG(k_mode != RTK_COMPACT_K_ROTATE || (inv_freq && P > 0), "rtk_pivotkv_compact_batched: the rotation needs inv_freq and the new ids");
-    RTK_CHECK_ARG(sync_ws && epoch != 0, "rtk_pivotkv_compact_batched: needs the zero-initialised sync workspace and a non-zero epoch");
+    RTK_CHECK_ARG(sync_ws, "rtk_pivotkv_compact_batched: needs the zero-initialised sync workspace");
     int R = 0;
     const int nb = compact_geometry(D, dtype, keep, &R);
     if (nb == 0 || D > 256) {
@@ -253,7 +263,7 @@ extern "C" int rtk_pivotkv_compact_batched(const rtk_compact_unit* units, int n_
         int32_t* sy = sync_ws + (size_t)b * HG * stride;
 #define RTK_LAUNCH_CMP(DTV, KM)                                                                                              \
     RTK_LAUNCH(KID_COMPACT, (compact_units_kernel<DTV, KM>), dim3(nb, n * HG), dim3(CMP_BLOCK), 0, st, cu, Hkv, HG, D, keep, \
-               P, inv_freq, attention_scaling, rs, round_mode, sy, (int)stride, epoch)
+               P, inv_freq, attention_scaling, rs, round_mode, sy, (int)stride)
 #define RTK_LAUNCH_CMP_DT(KM)                                  \
     do {                                                \
         if (dtype == RTK_BF16) RTK_LAUNCH_CMP(RTK_BF16, KM);   \

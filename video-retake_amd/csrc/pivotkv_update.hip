@@ -533,11 +533,10 @@ extern "C" int rtk_pivotkv_flush(rtk_pivotkv_batch* b, rtk_layer_state* const* l
                 u.pos_src_stride = u.pos_dst_stride = 0;
             }
         }
-        b->compact_epoch = (b->compact_epoch <= 0 || b->compact_epoch >= 0x7ffffff0) ? 1 : b->compact_epoch + 1;
         const int k_mode = !reforge ? RTK_COMPACT_K_INPLACE : (b->defer_rot ? RTK_COMPACT_K_COPY : RTK_COMPACT_K_ROTATE);
         rc = rtk_pivotkv_compact_batched(cu.data(), n, Hkv, D, keep, reforge ? P : 0, b->dtype, k_mode, b->inv_freq,
                                          b->attention_scaling, b->nsec ? b->sections : nullptr, b->nsec, b->round_mode,
-                                         b->compact_sync, (size_t)b->compact_sync_ints, b->compact_epoch, stream);
+                                         b->compact_sync, (size_t)b->compact_sync_ints, stream);
         if (rc) return rc;
         for (int i = 0; i < n; ++i) {
             rtk_layer_state* ls = layers[i];

@@ -87,7 +87,7 @@ class PivotKVBatch(C.Structure):
                 ("keep_idx", _vp), ("pos_new", _vp), ("sel_ws", _vp), ("sel_ws_stride", _u64), ("key_index", _vp),
                 ("v_stage", _vp), ("k_stage", _vp), ("shift_row", _vp), ("q_units", _vp), ("q_stride_h", _i64),
                 ("q_stride_l", _i64), ("pre_rope", _i32), ("batched_passes", _i32), ("compact_sync", _vp),
-                ("compact_sync_ints", _u64), ("compact_epoch", _i32), ("pad1", _i32)]
+                ("compact_sync_ints", _u64)]
 
 
 class UpdateIO(C.Structure):
@@ -140,7 +140,7 @@ _SIGNATURES = {
     "rtk_pivotkv_place_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp]),
     "rtk_pivotkv_commit_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp]),
     "rtk_pivotkv_compact_sync_ints": (C.c_size_t, [_i, _i, _i, _i, _i]),
-    "rtk_pivotkv_compact_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _i, _i, _vp, _sz, _i32, _vp]),
+    "rtk_pivotkv_compact_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _i, _i, _vp, _sz, _vp]),
     "rtk_position_shift": (C.c_int, [_vp, _i, _vp, _vp]),
     "rtk_pivotkv_update": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
     "rtk_pivotkv_flush": (C.c_int, [_vp, _vp, _vp, _i, _vp]),

@@ -1046,12 +1046,11 @@ class PivotKVCache(DynamicCache):
                 u.pos_src = u.pos_dst = None
         mode = nv.COMPACT_K_INPLACE if not b.reforge else (nv.COMPACT_K_COPY if defer else nv.COMPACT_K_ROTATE)
         sec = (C.c_int * len(b.mrope_section))(*b.mrope_section) if (b.mrope_section and mode == nv.COMPACT_K_ROTATE) else None
-        b.c.compact_epoch = b.c.compact_epoch + 1 if 0 <= b.c.compact_epoch < 0x7ffffff0 else 1
         nv.check(nv.lib.rtk_pivotkv_compact_batched(
             units, len(layers), Hkv, D, keep, P if b.reforge else 0, dt, mode,
             nv.ptr(rot.inv) if mode == nv.COMPACT_K_ROTATE else None, rot.scaling if mode == nv.COMPACT_K_ROTATE else 1.0,
             sec, len(sec) if sec is not None else 0, nv.round_mode(b.x_like.dtype) if b.x_like is not None else nv.round_mode(b.dtype),
-            b.c.compact_sync, b.c.compact_sync_ints, b.c.compact_epoch, nv.stream()), "rtk_pivotkv_compact_batched")
+            b.c.compact_sync, b.c.compact_sync_ints, nv.stream()), "rtk_pivotkv_compact_batched")
 
     # ---- the hot path ---------------------------------------------------------------------------
     def update(
