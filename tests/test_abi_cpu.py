@@ -234,7 +234,8 @@ def test_product_defaults_are_the_benched_configuration():
 
     c = lc.build_kvcache(bench.make_cache_config(2))
     assert c.native_rope is True and c.one_call_update is True and c.score_rounding == "fp32" and c.overlap_streams == 0
-    assert c.defer_rerotation is False and c.score_queries_in_place is True
+    assert c.defer_rerotation is False and c.score_queries_in_place is True and c.in_place_compaction is True
+    assert c.skip_masked_columns is True and c.score_when_keeping_all is False
 
     class Dyn:   # a rotary module whose frequencies depend on the sequence length has to be CALLED
         inv_freq, attention_scaling, rope_type = torch.ones(4), 1.0, "dynamic"

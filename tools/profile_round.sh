@@ -15,6 +15,7 @@ python tools/show_bench.py < $out/bench_bf16.json | head -40
 timeout 600 python tools/bench_ratio1.py > $out/bench_ratio1.json 2>/dev/null < /dev/null
 timeout 900 python tools/bench_mallm.py > $out/bench_mallm.json 2>/dev/null < /dev/null
 timeout 900 python tools/bench_llava.py > $out/bench_llava.json 2>/dev/null < /dev/null
+timeout 600 python tools/bench_decode_prologue.py > $out/bench_decode.json 2>/dev/null < /dev/null
 fi
 # the rocprofv3 runs below use --no-self-check: the untimed self-check launches the score kernels once more per checked
 # unit with gridDim.y = 1, which would mix 28x shorter launches into the per-kernel averages
