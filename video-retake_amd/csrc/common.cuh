@@ -192,6 +192,36 @@ template <> struct Vec16<RTK_F16> {
     }
 };
 
+// (x*cos) + (rotate_half(x)*sin) for one 16-byte chunk `lo` of the first half of a row and its partner `hi` in the second
+// half - apply_rotary_pos_emb's op chain with one rounding per torch op and no fma contraction.  16-bit payloads round
+// through the packed converts (H16<DT>::pack2: one instruction per pair); rotate_half(x)[d] = -x2,
+// rotate_half(x)[d + D/2] = x1.  c1 / s1: tables of the channels of `lo`, c2 / s2: of `hi`.
+template <int DT>
+__device__ __forceinline__ void rotate_chunk_pair(const u32x4& lo, const u32x4& hi, const float* c1, const float* s1,
+                                                  const float* c2, const float* s2, u32x4& olo, u32x4& ohi) {
+    if constexpr (DT != RTK_F32) {
+        using Hh = H16<DT>;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float x1a = Hh::lo(lo[w]), x1b = Hh::hi(lo[w]), x2a = Hh::lo(hi[w]), x2b = Hh::hi(hi[w]);
+            const int e = 2 * w;
+            const uint32_t p1 = Hh::pack2(x1a * c1[e], x1b * c1[e + 1]);
+            const uint32_t n1 = Hh::pack2(-x2a * s1[e], -x2b * s1[e + 1]);
+            const uint32_t p2 = Hh::pack2(x2a * c2[e], x2b * c2[e + 1]);
+            const uint32_t n2 = Hh::pack2(x1a * s2[e], x1b * s2[e + 1]);
+            olo[w] = Hh::pack2(Hh::lo(p1) + Hh::lo(n1), Hh::hi(p1) + Hh::hi(n1));
+            ohi[w] = Hh::pack2(Hh::lo(p2) + Hh::lo(n2), Hh::hi(p2) + Hh::hi(n2));
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x1 = __uint_as_float(lo[e]), x2 = __uint_as_float(hi[e]);
+            olo[e] = __float_as_uint(__fadd_rn(__fmul_rn(x1, c1[e]), __fmul_rn(-x2, s1[e])));
+            ohi[e] = __float_as_uint(__fadd_rn(__fmul_rn(x2, c2[e]), __fmul_rn(x1, s2[e])));
+        }
+    }
+}
+
 // NW 32-bit words of a row as one aligned load / store (the narrow-chunk forms of the per-update kernels)
 template <int NW> struct alignas(4 * NW) WV { uint32_t w[NW]; };
 

@@ -108,27 +108,7 @@ __global__ __launch_bounds__(CMP_BLOCK, RTK_CMP_WAVES) void compact_units_kernel
         for (int u = 0; u < HU; ++u) {
             if (u >= nh || !active) break;
             u32x4 olo, ohi;
-            if constexpr (DT != RTK_F32) {
-                using Hh = H16<DT>;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const float x1a = Hh::lo(k_lo[u][w]), x1b = Hh::hi(k_lo[u][w]), x2a = Hh::lo(k_hi[u][w]), x2b = Hh::hi(k_hi[u][w]);
-                    const int e = 2 * w;
-                    const uint32_t p1 = Hh::pack2(x1a * c1[e], x1b * c1[e + 1]);
-                    const uint32_t n1 = Hh::pack2(-x2a * s1[e], -x2b * s1[e + 1]);
-                    const uint32_t p2 = Hh::pack2(x2a * c2[e], x2b * c2[e + 1]);
-                    const uint32_t n2 = Hh::pack2(x1a * s2[e], x1b * s2[e + 1]);
-                    olo[w] = Hh::pack2(Hh::lo(p1) + Hh::lo(n1), Hh::hi(p1) + Hh::hi(n1));
-                    ohi[w] = Hh::pack2(Hh::lo(p2) + Hh::lo(n2), Hh::hi(p2) + Hh::hi(n2));
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < VE; ++e) {
-                    const float x1 = __uint_as_float(k_lo[u][e]), x2 = __uint_as_float(k_hi[u][e]);
-                    olo[e] = __float_as_uint(__fadd_rn(__fmul_rn(x1, c1[e]), __fmul_rn(-x2, s1[e])));
-                    ohi[e] = __float_as_uint(__fadd_rn(__fmul_rn(x2, c2[e]), __fmul_rn(x1, s2[e])));
-                }
-            }
+            rotate_chunk_pair<DT>(k_lo[u], k_hi[u], c1, s1, c2, s2, olo, ohi);
             char* ko = kt + ((size_t)(h0 + u) * un.k_tail_stride_h + (size_t)r * D) * ES;
             *(u32x4*)(ko + (size_t)d * ES) = olo;
             *(u32x4*)(ko + (size_t)(d + h2) * ES) = ohi;

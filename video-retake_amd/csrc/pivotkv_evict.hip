@@ -751,17 +751,11 @@ __global__ __launch_bounds__(256) void evict_batched_kernel(EvictUnits units, in
             char* ko = kd + ((size_t)h * un.k_dst_stride_h + (size_t)r * D) * ES;
             char* vo = vd + ((size_t)h * un.v_dst_stride_h + (size_t)r * D) * ES;
             if (reforge) {  // kept K = un-rotated row rotated forward at its new position (:297-306)
-                float x1[VE], x2[VE], o1[VE], o2[VE];
-                R::unpack(k_lo[u], x1);
-                R::unpack(k_hi[u], x2);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) {
-                    // (k*cos) + (rotate_half(k)*sin), one rounding per torch op, no fma contraction
-                    o1[e] = R::rnd(__fadd_rn(R::rnd(__fmul_rn(x1[e], c1[e])), R::rnd(__fmul_rn(-x2[e], s1[e]))));
-                    o2[e] = R::rnd(__fadd_rn(R::rnd(__fmul_rn(x2[e], c2[e])), R::rnd(__fmul_rn(x1[e], s2[e]))));
-                }
-                *(u32x4*)(ko + (size_t)d * ES) = R::pack(o1);
-                *(u32x4*)(ko + (size_t)(d + h2) * ES) = R::pack(o2);
+                // (the 16-bit roundings through the packed converts: the integer sequence made this kernel VALU-bound)
+                u32x4 olo, ohi;
+                rotate_chunk_pair<DT>(k_lo[u], k_hi[u], c1, s1, c2, s2, olo, ohi);
+                *(u32x4*)(ko + (size_t)d * ES) = olo;
+                *(u32x4*)(ko + (size_t)(d + h2) * ES) = ohi;
             } else if (copy_k) {   // torch.gather(key_states, 2, keep)  (:279)
                 *(u32x4*)(ko + (size_t)d * ES) = k_lo[u];
                 *(u32x4*)(ko + (size_t)(d + h2) * ES) = k_hi[u];

@@ -156,22 +156,10 @@ __global__ __launch_bounds__(256) void rope_rotate_rows_kernel(char* __restrict_
     for (int h = 0; h < H; ++h) {
         char* row = base + (size_t)h * stride_h * ES;
         const u32x4 lo = *(const u32x4*)(row + (size_t)d * ES), hi = *(const u32x4*)(row + (size_t)(d + h2) * ES);
-        float x1[VE], x2[VE], o1[VE], o2[VE];
-        V::unpack(lo, x1);
-        V::unpack(hi, x2);
-#pragma unroll
-        for (int e = 0; e < VE; ++e) {
-            if constexpr (DT != RTK_F32) {
-                using Hh = H16<DT>;
-                o1[e] = Hh::rnd(__fadd_rn(Hh::rnd(__fmul_rn(x1[e], c1[e])), Hh::rnd(__fmul_rn(-x2[e], s1[e]))));
-                o2[e] = Hh::rnd(__fadd_rn(Hh::rnd(__fmul_rn(x2[e], c2[e])), Hh::rnd(__fmul_rn(x1[e], s2[e]))));
-            } else {
-                o1[e] = __fadd_rn(__fmul_rn(x1[e], c1[e]), __fmul_rn(-x2[e], s1[e]));
-                o2[e] = __fadd_rn(__fmul_rn(x2[e], c2[e]), __fmul_rn(x1[e], s2[e]));
-            }
-        }
-        *(u32x4*)(row + (size_t)d * ES) = V::pack(o1);
-        *(u32x4*)(row + (size_t)(d + h2) * ES) = V::pack(o2);
+        u32x4 olo, ohi;
+        rotate_chunk_pair<DT>(lo, hi, c1, s1, c2, s2, olo, ohi);
+        *(u32x4*)(row + (size_t)d * ES) = olo;
+        *(u32x4*)(row + (size_t)(d + h2) * ES) = ohi;
     }
 }
 
