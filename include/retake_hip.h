@@ -301,7 +301,7 @@ int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep,
  * rank -> emit): what PivotKVCache runs from after_forward for all layers of a chunk.  Units share L, keep, P
  * and the partial layout (Hkv, RS, G as reported by rtk_pivotkv_score_partials).  RTK_EUNSUPPORTED for L < 512
  * (call rtk_pivotkv_select per unit).  Fewer than 8 units are ranked chip-wide one after the other; 8 or more
- * (L <= 8192) get one radix-select workgroup each, all side by side - same result, bit for bit.
+ * (L <= 16384) get one radix-select workgroup each (keys in LDS), all side by side - same result, bit for bit.
  * `units` is a HOST array. */
 typedef struct rtk_select_unit {
     const float* partial;   /* column partials [Hkv, RS, L] written by RTK_SCORE_PASSES (partial_out), or NULL: score is final */
