@@ -203,7 +203,7 @@ def main():
         n_cases += 1
     print(f"fuzz ok: {n_cases} random configurations (live-key == full pass 2 and one-call == staged route, bitwise), {n_oracle} "
           f"layer-chunks against the CPU oracle (max score diff {worst_score:.2e}, max kept-K diff {worst_k:.2e}), {n_pre} "
-          f"prologue layer-chunks against the oracle")
+          f"prologue layer-chunks against the oracle", flush=True)
     fuzz_dpselect(dev, rng, a.seconds / 4)
 
 
@@ -250,7 +250,7 @@ def fuzz_dpselect(dev, rng, seconds):
             print("FUZZ FAILURE:", desc, "->", type(e).__name__, e, flush=True)
             raise
         n += 1
-    print(f"fuzz ok: {n} random DPSelect calls against the CPU oracle ({relaxed} rows took the relaxed rule)")
+    print(f"fuzz ok: {n} random DPSelect calls against the CPU oracle ({relaxed} rows took the relaxed rule)", flush=True)
 
 
 if __name__ == "__main__":
