@@ -55,7 +55,11 @@ enum rtk_dtype {
     /* fp16 payloads (a float16 model).  Like RTK_BF16, every entry point restates the reference's chain of torch ops
      * with one rounding to the tensor dtype per op; the score uses exact fp16 products with fp32 accumulation.
      * Wherever an argument is called `round_bf16`, 2 selects fp16 tables (1 = bf16, 0 = fp32). */
-    RTK_F16 = 4
+    RTK_F16 = 4,
+    /* Scoring entry points only: fp16 payloads AND the reference's rounding chain on a float16 model - RTK_BF16_REFROUND's
+     * chain with every rounding to fp16 instead of bf16 (logits, probabilities, per-head sums, both means); head_dim 128.
+     * rtk_pivotkv_prepare takes RTK_F16 for such a batch. */
+    RTK_F16_REFROUND = 5
 };
 
 /* Flag for the `dtype` argument of the SCORING entry points (rtk_pivotkv_score_workspace_bytes, _score_partials,
@@ -316,8 +320,8 @@ typedef struct rtk_select_unit {
 #define RTK_SELECT_MAX_UNITS 28
 int rtk_pivotkv_select_batched(const rtk_select_unit* units, int n_units, int Hkv, int RS, int G, int L,
                                int keep, int P, int reforge, int64_t pos_out_stride,
-                               int score_dtype /* RTK_BF16_REFROUND: partials are per head [Hkv*G, RS, L] and the
-                                                  finalize applies the reference's bf16 roundings; else 0 */,
+                               int score_dtype /* RTK_BF16_REFROUND / RTK_F16_REFROUND: partials are per head
+                                                  [Hkv*G, RS, L] and the finalize applies the reference's roundings; else 0 */,
                                rtk_stream_t stream);
 
 /* Layout of the column partials rtk_pivotkv_score_stages(RTK_SCORE_PASSES) produces for these sizes: returns the

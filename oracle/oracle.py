@@ -35,7 +35,7 @@ def lib():
         for name in ("orc_dpselect_dis_f32", "orc_dpselect_dis_bf16", "orc_topk_sorted", "orc_dpselect_select",
                      "orc_gather_frames", "orc_mrope_merge", "orc_rope_apply", "orc_pivotkv_score",
                      "orc_pivotkv_select", "orc_gather_rows", "orc_pivotkv_positions", "orc_num_threads", "orc_mallm_step",
-                     "orc_rope_apply_bf16", "orc_pivotkv_score_bf16"):
+                     "orc_rope_apply_bf16", "orc_pivotkv_score_bf16", "orc_pivotkv_score_fp16", "orc_round_fp16"):
             getattr(_lib, name).restype = C.c_int
         _lib.orc_rope_apply.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_double, C.c_void_p]
@@ -224,6 +224,24 @@ def pivotkv_score_bf16(q: np.ndarray, k: np.ndarray) -> np.ndarray:
     return score
 
 
+def pivotkv_score_fp16(q: np.ndarray, k: np.ndarray) -> np.ndarray:
+    """The same chain on a float16 model (every rounding to fp16): fp32 arrays of fp16 values in, fp16 values out."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    k = np.ascontiguousarray(k, dtype=np.float32)
+    Hq, L, D = q.shape
+    score = np.empty(L, dtype=np.float32)
+    _chk(lib().orc_pivotkv_score_fp16(_p(q), _p(k), Hq, k.shape[0], L, D, _p(score)), "score_fp16")
+    return score
+
+
+def round_fp16(x: np.ndarray) -> np.ndarray:
+    """The C oracle's fp16 rounding (gcc 11 has no _Float16 on x86-64): checked against numpy.float16 by the tests."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    _chk(lib().orc_round_fp16(_p(x), C.c_long(x.size), _p(out)), "round_fp16")
+    return out
+
+
 def pivotkv_score(q: np.ndarray, k: np.ndarray) -> np.ndarray:
     """q [Hq,L,D], k [Hkv,L,D] fp32 -> score [L] (longvideo_cache.py:260-270)."""
     q = np.ascontiguousarray(q, dtype=np.float32)
@@ -278,7 +296,8 @@ class OraclePivotKV:
         bf16 model; score_rounding 'reference' = the reference's bf16 score chain, 'fp32' = exact products with fp32
         accumulation and fp32 softmax / sums (what the HIP default computes for bf16 inputs)."""
         self.bf16, self.score_rounding = bf16, score_rounding
-        self.fp16 = fp16   # inputs are fp32 arrays of fp16 values, RoPE steps round to fp16, the score is exact ("fp32")
+        self.fp16 = fp16   # inputs are fp32 arrays of fp16 values, RoPE steps round to fp16; the score is exact unless
+                           # score_rounding == "reference16" (the reference's fp16 chain; the default "reference" names the bf16 one)
         assert not (bf16 and fp16)
         self.Hq, self.Hkv, self.D = num_heads, num_kv_heads, head_dim
         self.compression_ratio = compression_ratio
@@ -355,6 +374,8 @@ class OraclePivotKV:
         keep = max(1, int(self.compression_ratio * L))  # :263
         if self.bf16 and self.score_rounding == "reference":
             score = pivotkv_score_bf16(qs, ks)
+        elif self.fp16 and self.score_rounding == "reference16":
+            score = pivotkv_score_fp16(qs, ks)
         else:
             score = pivotkv_score(qs, ks)  # :264-270
         idx = pivotkv_select(score, self.keypatches_mask_chunk, keep)  # :272-277

@@ -2148,6 +2148,54 @@ def test_pivotkv_fp16_against_reference_fp16(name, native_rope):
             assert torch.equal(cache._batch.score[l], cache._batch.score[0]) and torch.equal(cache.key_cache[l], cache.key_cache[0])
 
 
+@pytest.mark.parametrize("name", gu.names("pivotkv_fp16_"))
+def test_pivotkv_fp16_reference_rounding_matches_reference_fp16(name):
+    """score_rounding='reference' on float16 tensors (RTK_F16_REFROUND): the reference's own fp16 chain - logits,
+    probabilities, per-head sums and both means rounded to fp16 (longvideo_cache.py:264-270 on a float16 model) - against
+    the REFERENCE's fp16 run, three layers (L >= 512: the chunk-batched flush): scores equal its fp16 scores except
+    isolated entries by one fp16 ulp, kept set equal up to ties at the threshold, kept keys bit-exact, V rows copies."""
+    import retake.longvideo_cache as lc
+    import test_oracle_golden as tog
+
+    g = gu.load(name)
+    Hq, Hkv, D, L, keep = (int(g[k]) for k in ("Hq", "Hkv", "D", "L", "keep"))
+    sec = [int(x) for x in g["mrope_section"]]
+    n_layers = 3
+    llm = types.SimpleNamespace(hidden_size=Hq * D, num_hidden_layers=n_layers, num_attention_heads=Hq, num_key_value_heads=Hkv,
+                                longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": {
+                                    "compression_ratio": float(g["ratio"]), "compression_method": "pivotkv",
+                                    "pos_embed_reforge": True, "native_rope": False, "score_rounding": "reference"}})
+    cache = lc.build_kvcache(llm)
+    rot = _CpuTablesRotary(g["inv_freq"], float(g["attention_scaling"]), dev())
+    q, k, v, pos, mask = gu.pivotkv_fp16_chunk_inputs(g)
+
+    def dv(a):
+        return torch.from_numpy(a.view(np.int16)).view(torch.float16).to(dev())
+
+    cache.keypatches_mask_chunk = torch.from_numpy(mask).to(dev())
+    cache.kvcache_compression = True
+    qd, kd, vd = dv(q), dv(k), dv(v)
+    for l in range(n_layers):
+        cache.update(kd, vd, l, {"query_states": qd, "position_ids": torch.from_numpy(pos).to(dev()), "rotary_emb": rot,
+                                 "mrope_section": list(sec)})
+    if L >= 512:
+        assert cache._batch.batched_passes and len(cache._batch.pending) == n_layers
+    cache.after_forward()
+    for l in range(n_layers):
+        score = cache._batch.score[l].cpu().numpy()
+        idx = cache._batch.keep_idx[l].cpu().numpy()
+        kk = cache.key_cache[l].cpu().contiguous().view(torch.int16).numpy().view(np.float16)
+        pos_new = cache.position_cache[l].cpu().numpy()
+        nbad, nxor = tog.check_fp16_refchain_against_reference(g, score, idx, kk, pos_new, "HIP fp16 reference rounding",
+                                                               max_bad={256: 2, 1568: 14}.get(L, max(4, L // 100)))   # measured on MI355X: 1 / 7, each by one fp16 ulp (fp32 summation order; the CPU oracle, which sums in double, has 0)
+        if l == 0:
+            print(f"{name}: {nbad} of {L} scores differ from the reference's by one fp16 ulp, kept xor {nxor} (ties)")
+        assert np.array_equal(cache.value_cache[l].cpu().view(torch.int16).numpy().view(np.uint16)[0],
+                              v.view(np.uint16)[0][:, idx])
+        if l:
+            assert torch.equal(cache._batch.score[l], cache._batch.score[0]) and torch.equal(cache.key_cache[l], cache.key_cache[0])
+
+
 def test_pivotkv_reference_rounding_batched_equals_per_layer():
     """score_rounding='reference' through the chunk-batched launches (gridDim.y = layers, per-head partials, the bf16
     finalize inside rtk_pivotkv_select_batched) must leave the cache that flushing every layer on its own leaves."""

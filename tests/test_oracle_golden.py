@@ -285,6 +285,64 @@ def check_fp16_against_reference(g, score, keep_idx, kept_k16, pos_new, k_unrot1
     return xor.size, err
 
 
+def check_fp16_refchain_against_reference(g, score, keep_idx, kept_k16, pos_new, what, max_bad):
+    """Shared by the oracle test (CPU) and the HIP test (GPU) of the reference's fp16 score chain (longvideo_cache.py:264-270
+    on a float16 model: logits, probabilities, per-head sums and both means rounded to fp16).  Like the bf16 twin: the
+    scores equal the reference's fp16 scores except isolated entries by one fp16 ulp (summation order inside ATen's
+    gemm / sum kernels), the kept sets agree up to tokens within one ulp of the threshold, kept keys bit-exact."""
+    L, keep = int(g["L"]), int(g["keep"])
+    ref = g["c0_score_bits"].view(np.float16).astype(np.float32)
+    assert np.array_equal(score.astype(np.float16).astype(np.float32), score), f"{what}: scores must be fp16 values"
+    bad = np.nonzero(score != ref)[0]
+    assert bad.size <= max_bad, f"{what}: {bad.size} of {L} scores differ from the reference's (bar {max_bad})"
+    if bad.size:
+        assert (np.abs(score[bad] - ref[bad]) <= gu.fp16_ulp(np.minimum(np.abs(score[bad]), np.abs(ref[bad])))).all()
+    ref_idx = g["c0_keep_idx"]
+    thr = np.sort(ref)[::-1][keep - 1]
+    xor = np.setxor1d(keep_idx, ref_idx)
+    assert (np.abs(ref[xor] - thr) <= gu.fp16_ulp(np.full(xor.size, thr))).all(), f"{what}: kept sets differ beyond ties"
+    ties = np.nonzero(score == np.sort(score)[::-1][keep - 1])[0]   # canonical tie rule on this side: lowest index first
+    picked = np.intersect1d(ties, keep_idx)
+    np.testing.assert_array_equal(picked, ties[: picked.size])
+    ref_pos = g["c0_position_cache"][..., -keep:].reshape(-1, keep)
+    common, ia, ib = np.intersect1d(keep_idx, ref_idx, return_indices=True)
+    same_pos = (pos_new.reshape(-1, keep)[:, ia] == ref_pos[:, ib]).all(0)
+    assert same_pos.mean() > 0.9
+    a = np.asarray(kept_k16).view(np.uint16).reshape(-1, keep, int(g["D"]))[:, ia[same_pos]]
+    b = g["c0_kept_k_bits"].reshape(-1, keep, int(g["D"]))[:, ib[same_pos]]
+    np.testing.assert_array_equal(a, b, err_msg=f"{what}: re-rotated kept keys")
+    return bad.size, xor.size
+
+
+def test_oracle_fp16_rounding_is_numpy_float16():
+    """gcc 11 has no _Float16 on x86-64: the C oracle spells the fp16 rounding out; here against numpy.float16 over normal,
+    subnormal, overflowing and special values."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(50000).astype(np.float32) * s for s in (1e-8, 1e-6, 1e-4, 1e-2, 1, 100, 3e4, 7e4)]
+                       + [np.array([65504, 65519.99, 65520, 65536, 6e-8, 2.98e-8, 2.99e-8, 0, -0.0, np.inf, -np.inf], dtype=np.float32)])
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).astype(np.float32)
+    assert np.array_equal(ref.view(np.uint32), orc.round_fp16(x).view(np.uint32))
+
+
+@pytest.mark.parametrize("name", gu.names("pivotkv_fp16_"))
+def test_pivotkv_fp16_reference_chain_matches_reference(name):
+    """The oracle's fp16 score chain (score_rounding 'reference16') against the reference's own fp16 run."""
+    g = gu.load(name)
+    Hq, Hkv, D, L = (int(g[k]) for k in ("Hq", "Hkv", "D", "L"))
+    sec = [int(x) for x in g["mrope_section"]]
+    rot = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]))
+    oc = orc.OraclePivotKV(Hq, Hkv, D, float(g["ratio"]), True, fp16=True, score_rounding="reference16")
+    q, k, v, pos, mask = gu.pivotkv_fp16_chunk_inputs(g)
+    oc.keypatches_mask_chunk = mask
+    oc.update(k.astype(np.float32), v.astype(np.float32), 0, q=q.astype(np.float32), position_ids=pos, rotary=rot,
+              mrope_section=sec)
+    last = oc.last
+    nbad, nxor = check_fp16_refchain_against_reference(g, last["score"], last["keep_idx"], last["kept_k"].astype(np.float16),
+                                                       last["pos"], "oracle fp16 chain", max_bad=max(2, L // 500))
+    print(f"\n[{name}] oracle fp16 chain vs the reference's fp16 run: {nbad} of {L} scores differ by one fp16 ulp, kept xor {nxor}")
+
+
 @pytest.mark.parametrize("name", gu.names("pivotkv_fp16_"))
 def test_pivotkv_fp16_chain_matches_reference(name):
     g = gu.load(name)

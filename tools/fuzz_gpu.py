@@ -53,7 +53,11 @@ def main():
         layers = int(rng.integers(1, 4))
         chunks = int(rng.integers(1, 3))
         native = bool(rng.uniform() < 0.5)
-        rounding = str(rng.choice(["fp32", "fp32", "reference", "fast"])) if dtype == torch.bfloat16 and D == 128 else "fp32"
+        rounding = "fp32"
+        if D == 128 and dtype == torch.bfloat16:
+            rounding = str(rng.choice(["fp32", "fp32", "reference", "fast"]))
+        elif D == 128 and dtype == torch.float16:
+            rounding = str(rng.choice(["fp32", "fp32", "reference"]))
         sec = None
         if mrope:
             h = D // 2

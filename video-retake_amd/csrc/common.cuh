@@ -127,7 +127,9 @@ __device__ __forceinline__ void sincos_cr(float x, float& sn, float& cs) {
 
 // the reference's three bf16 roundings after the probabilities (longvideo_cache.py:268-270) for key j:
 //   partial [Hq][RS][L] fp32 sums of bf16 probabilities  ->  score (a bf16 value held in fp32)
+template <bool F16 = false>
 __device__ __forceinline__ float finalize_ref_column(const float* __restrict__ partial, int Hkv, int RS, int G, int L, int j) {
+    auto rnd16 = [](float x) { return F16 ? rhf(x) : rbf(x); };   // the tensor dtype of the reference's sums and means
     float tot = 0.f;
     for (int g = 0; g < Hkv; ++g) {
         float gs = 0.f;
@@ -143,11 +145,11 @@ __device__ __forceinline__ float finalize_ref_column(const float* __restrict__ p
                 for (int u = 0; u < 7; ++u) hs += v[u];
             }
             for (; r < RS; ++r) hs += p[(size_t)r * L];
-            gs += rbf(hs);                         // .sum(1) -> bf16 (sums of <= 7 bf16 values are exact in fp32)
+            gs += rnd16(hs);                        // .sum(1) -> bf16 (sums of <= 7 bf16 values are exact in fp32)
         }
-        tot += rbf(__fdiv_rn(gs, (float)G));       // .mean(1) -> bf16
+        tot += rnd16(__fdiv_rn(gs, (float)G));       // .mean(1) -> bf16
     }
-    return rbf(__fdiv_rn(tot, (float)Hkv));        // .mean(0) -> bf16
+    return rnd16(__fdiv_rn(tot, (float)Hkv));        // .mean(0) -> bf16
 }
 
 // 16-byte vector types

@@ -300,13 +300,14 @@ __global__ __launch_bounds__(256) void finalize_units_kernel(SelUnits units, int
     }
 }
 
-// the same for RTK_BF16_REFROUND partials ([Hkv*G][RS][L], per head): the reference's bf16 roundings of the per-head
+// the same for RTK_BF16_REFROUND / RTK_F16_REFROUND partials ([Hkv*G][RS][L], per head): the reference's 16-bit roundings of the per-head
 // sums and the two means (longvideo_cache.py:268-270), finalize_ref_column() in common.cuh
+template <bool F16>
 __global__ __launch_bounds__(256) void finalize_units_ref_kernel(SelUnits units, int Hkv, int RS, int G, int L) {
     const rtk_select_unit& un = units.u[blockIdx.y];
     if (!un.partial) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j < L) un.score[j] = finalize_ref_column(un.partial, Hkv, RS, G, L, j);
+    if (j < L) un.score[j] = finalize_ref_column<F16>(un.partial, Hkv, RS, G, L, j);
 }
 
 __global__ __launch_bounds__(RANK_BLOCK) void pivotkv_rank_kernel(SelUnits units, int L, int keep, int reforge) {
@@ -887,7 +888,7 @@ static void select_lds_opt_in() {
 }
 
 static int select_units(const rtk_select_unit* units, int n, int Hkv, int RS, int G, int L, int keep, int P, int reforge,
-                        int64_t pos_out_stride, hipStream_t st, bool refround = false) {
+                        int64_t pos_out_stride, hipStream_t st, int refround = 0 /* 1: bf16 chain, 2: fp16 chain */) {
     select_lds_opt_in();
     const size_t lds = ((size_t)((L + RANK_TOK - 1) / RANK_TOK) * RANK_TOK + RANK_BLOCK) * sizeof(uint32_t);
     for (int b = 0; b < n; b += RTK_SELECT_MAX_UNITS) {
@@ -899,8 +900,10 @@ static int select_units(const rtk_select_unit* units, int n, int Hkv, int RS, in
             any_partial = any_partial || (i < m && su.u[i].partial != nullptr);
         }
         if (any_partial) {
-            if (refround)
-                RTK_LAUNCH(KID_FINALIZE, finalize_units_ref_kernel, dim3((L + 255) / 256, m), dim3(256), 0, st, su, Hkv, RS, G, L);
+            if (refround == 2)
+                RTK_LAUNCH(KID_FINALIZE, finalize_units_ref_kernel<true>, dim3((L + 255) / 256, m), dim3(256), 0, st, su, Hkv, RS, G, L);
+            else if (refround)
+                RTK_LAUNCH(KID_FINALIZE, finalize_units_ref_kernel<false>, dim3((L + 255) / 256, m), dim3(256), 0, st, su, Hkv, RS, G, L);
             else
                 RTK_LAUNCH(KID_FINALIZE, finalize_units_kernel, dim3((L + 63) / 64, m), dim3(256),
                            (size_t)Hkv * 64 * sizeof(float), st, su, Hkv, RS, G, L);
@@ -945,7 +948,8 @@ extern "C" int rtk_pivotkv_select_batched(const rtk_select_unit* units, int n_un
         return RTK_EUNSUPPORTED;
     }
     return select_units(units, n_units, Hkv, RS, G, L, keep, P, reforge, pos_out_stride, (hipStream_t)stream,
-                        (score_dtype & ~RTK_SCORE_MANY_UNITS) == RTK_BF16_REFROUND);
+                        (score_dtype & ~RTK_SCORE_MANY_UNITS) == RTK_BF16_REFROUND ? 1
+                        : ((score_dtype & ~RTK_SCORE_MANY_UNITS) == RTK_F16_REFROUND ? 2 : 0));
 }
 
 extern "C" int rtk_pivotkv_select(float* score, const uint8_t* mask, int L, int keep, const int64_t* pos, int P,

@@ -1851,9 +1851,9 @@ static bool bf16_rcp_is_exact(float a2) {
 struct ScoreWs {
     size_t q_off, k_off, lse_off, part_off, total;
     int RS, KS;
-    bool ref;   // RTK_BF16_REFROUND: the reference's rounding chain; column partials are per head
+    bool ref;   // RTK_BF16_REFROUND / RTK_F16_REFROUND: the reference's rounding chain; column partials are per head
     bool fast;  // RTK_BF16_FAST: q~ (pre-scaled) and a second copy of k~ (at k_off) are fp16
-    bool h16;   // RTK_F16: fp16 payloads (un-rotation rounds to fp16, the passes use the fp16 matrix instruction)
+    bool h16;   // RTK_F16 / RTK_F16_REFROUND: fp16 payloads (un-rotation rounds to fp16, the passes use the fp16 matrix instruction)
 };
 static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
     const bool many = !RTK_IGNORE_MANY_UNITS && (dtype & RTK_SCORE_MANY_UNITS) != 0;   // the caller batches many units per launch
@@ -1861,9 +1861,9 @@ static ScoreWs score_ws(int Hq, int Hkv, int L, int D, int dtype) {
     const size_t es = dtype == RTK_F32 ? 4 : 2;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     ScoreWs w;
-    w.ref = dtype == RTK_BF16_REFROUND;
+    w.ref = dtype == RTK_BF16_REFROUND || dtype == RTK_F16_REFROUND;
     w.fast = dtype == RTK_BF16_FAST;
-    w.h16 = dtype == RTK_F16;
+    w.h16 = dtype == RTK_F16 || dtype == RTK_F16_REFROUND;
     const int nbr = REG_ROWS;
     const int reg_tiles = (L + nbr - 1) / nbr, stream_tiles = (L + TILE_ROWS - 1) / TILE_ROWS;
     w.RS = (D == HD) ? pick_splits(reg_tiles, Hkv, stream_tiles, 32, Hkv) : 1;
@@ -1988,7 +1988,7 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
     if (w.ref) {
         if constexpr (DT == RTK_BF16) {
             if (D != HD) {
-                set_error("rtk_pivotkv_score: RTK_BF16_REFROUND needs head_dim %d", HD);
+                set_error("rtk_pivotkv_score: the reference-rounding modes need head_dim %d", HD);
                 return RTK_EUNSUPPORTED;
             }
             constexpr int TILE_BYTES = Tile<DT>::BYTES;
@@ -1999,7 +1999,7 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
             const int ks_n = (L + kps - 1) / kps;
             rs_n = (L + rps - 1) / rps;
             const float sqrt_d = (float)sqrt((double)HD);   // python: math.sqrt(self.head_dim), then an fp32 opmath scalar
-            const bool rcp_ok = bf16_rcp_is_exact(sqrt_d);
+            const bool rcp_ok = !w.h16 && bf16_rcp_is_exact(sqrt_d);   // (fp16 payloads: IEEE division)
             const float rcp_sd = 1.0f / sqrt_d;
             if (stages & RTK_SCORE_PASSES) {
                 const int n_tiles = Hkv * ks_n * jt * G;
@@ -2008,24 +2008,28 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                 const size_t su = ws_stride / sizeof(float);
                 // raw row sums + the fix-up launch for rows whose sum left fp32's range, lse combine over key splits,
                 // then the column sums of the bf16 probabilities per head
-#define RTK_REF_PASSES(DIV)                                                                                              \
-    RTK_LAUNCH(KID_PASS1, (score_pass1_ref_kernel<DIV>), g1, dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt,   \
+#define RTK_REF_PASSES(DIV, F16)                                                                                             \
+    RTK_LAUNCH(KID_PASS1, (score_pass1_ref_kernel<DIV, F16>), g1, dim3(SC_BLOCK), LDS1, st, (const char*)qt, (const char*)kt,   \
                Hq, Hkv, L, kps, jt, x1, lse, ws_stride, k_stride, su, sqrt_d, rcp_sd);                                     \
-    RTK_LAUNCH(KID_FINALIZE, (score_pass1_ref_fixup_kernel<DIV>), gf, dim3(SC_BLOCK), LDS1, st, (const char*)qt,           \
+    RTK_LAUNCH(KID_FINALIZE, (score_pass1_ref_fixup_kernel<DIV, F16>), gf, dim3(SC_BLOCK), LDS1, st, (const char*)qt,           \
                (const char*)kt, Hq, Hkv, L, kps, jt, n_tiles, lse, ws_stride, k_stride, su, sqrt_d, rcp_sd);               \
     if (ks_n > 1)                                                                                                        \
         RTK_LAUNCH(KID_FINALIZE, lse_combine_kernel<RTK_BF16>, dim3((unsigned)(((size_t)Hq * L + 255) / 256), n_units),    \
                    dim3(256), 0, st, lse, (size_t)Hq * L, ks_n, su, 0);                                                    \
-    RTK_LAUNCH(KID_PASS2, (score_pass2_ref_kernel<DIV>), g2, dim3(SC_BLOCK), LDS2, st, (const char*)qt, (const char*)kt,   \
+    RTK_LAUNCH(KID_PASS2, (score_pass2_ref_kernel<DIV, F16>), g2, dim3(SC_BLOCK), LDS2, st, (const char*)qt, (const char*)kt,   \
                (const float*)lse, Hq, Hkv, L, rps, jt2, rs_n, x2, part, ws_stride, k_stride, su, part_stride, sqrt_d,      \
                rcp_sd, key_index)
-                if (rcp_ok) { RTK_REF_PASSES(1); } else { RTK_REF_PASSES(2); }
+                if (w.h16) { RTK_REF_PASSES(2, true); } else if (rcp_ok) { RTK_REF_PASSES(1, false); } else { RTK_REF_PASSES(2, false); }
 #undef RTK_REF_PASSES
                 RTK_LAUNCH_CHECK("score_ref_passes");
             }
             if (stages & RTK_SCORE_FINALIZE) {
-                RTK_LAUNCH(KID_FINALIZE, score_finalize_ref_kernel, dim3((L + 255) / 256), dim3(256), 0, st, part, Hkv, rs_n,
-                           G, L, score);
+                if (w.h16)
+                    RTK_LAUNCH(KID_FINALIZE, score_finalize_ref_kernel<true>, dim3((L + 255) / 256), dim3(256), 0, st, part, Hkv,
+                               rs_n, G, L, score);
+                else
+                    RTK_LAUNCH(KID_FINALIZE, score_finalize_ref_kernel<false>, dim3((L + 255) / 256), dim3(256), 0, st, part, Hkv,
+                               rs_n, G, L, score);
                 RTK_LAUNCH_CHECK("score_finalize_ref_kernel");
             }
         }
@@ -2153,7 +2157,7 @@ extern "C" int rtk_pivotkv_score_passes_batched(void* workspace0, size_t workspa
                   "rtk_pivotkv_score_passes_batched: workspaces must be 256-byte aligned");
     const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype_full);
     RTK_CHECK_ARG(n_units == 1 || workspace_stride >= w.total, "rtk_pivotkv_score_passes_batched: workspace stride too small");
-    if ((dtype != RTK_BF16 && dtype != RTK_BF16_REFROUND && dtype != RTK_BF16_FAST && dtype != RTK_F16) || D != HD) {
+    if ((dtype != RTK_BF16 && dtype != RTK_BF16_REFROUND && dtype != RTK_BF16_FAST && dtype != RTK_F16 && dtype != RTK_F16_REFROUND) || D != HD) {
         set_error("rtk_pivotkv_score_passes_batched: bf16 with head_dim %d only (call RTK_SCORE_PASSES per unit)", HD);
         return RTK_EUNSUPPORTED;
     }
@@ -2293,7 +2297,7 @@ static int score_stages_impl(const void* q, int64_t q_stride_h, int64_t q_stride
     RTK_CHECK_ARG(L >= 1 && D >= 2 && D % 2 == 0, "rtk_pivotkv_score: bad shape L=%d D=%d", L, D);
     RTK_CHECK_ARG((cosv == nullptr) == (sinv == nullptr), "rtk_pivotkv_score: cos and sin must both be given or both NULL");
     RTK_CHECK_ARG(dtype == RTK_F32 || dtype == RTK_BF16 || dtype == RTK_BF16_REFROUND || dtype == RTK_BF16_FAST ||
-                      dtype == RTK_F16, "rtk_pivotkv_score: unsupported dtype %d", dtype);
+                      dtype == RTK_F16 || dtype == RTK_F16_REFROUND, "rtk_pivotkv_score: unsupported dtype %d", dtype);
     RTK_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "rtk_pivotkv_score: workspace must be 256-byte aligned");
     RTK_CHECK_ARG(stages > 0 && stages <= 7, "rtk_pivotkv_score: stages mask %d out of range", stages);
     const ScoreWs w = score_ws(Hq, Hkv, L, D, dtype_full);

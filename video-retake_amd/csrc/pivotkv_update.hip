@@ -294,7 +294,7 @@ extern "C" int rtk_pivotkv_update(rtk_pivotkv_batch* b, rtk_layer_state* ls, int
     hipStream_t st = (hipStream_t)stream;
     if (io->flags & RTK_UPDATE_PRE_ROPE) {
         RTK_CHECK_ARG(io->q_rot, "rtk_pivotkv_update: RTK_UPDATE_PRE_ROPE needs q_rot");
-        if (score_base == RTK_BF16_REFROUND) {
+        if (score_base == RTK_BF16_REFROUND || score_base == RTK_F16_REFROUND) {
             set_error("rtk_pivotkv_update: score_rounding='reference' scores the reference's round-tripped q~ / k~ "
                       "(rotate first, then update without RTK_UPDATE_PRE_ROPE)");
             return RTK_EUNSUPPORTED;

@@ -1,4 +1,5 @@
-// score_refround.cuh — PivotKV scoring in the REFERENCE's bf16 semantics (dtype code RTK_BF16_REFROUND), included by
+// score_refround.cuh — PivotKV scoring in the REFERENCE's 16-bit semantics (dtype codes RTK_BF16_REFROUND and, template
+// flag F16, RTK_F16_REFROUND: the same chain with every "-> bf16" below read as "-> fp16"), included by
 // pivotkv_score.hip.  longvideo_cache.py:264-270 run on a bf16 model rounds
 //     matmul(q, k^T)                 -> bf16      (fp32 accumulation, one rounding)
 //     / math.sqrt(D)                 -> bf16
@@ -25,14 +26,15 @@ constexpr float LOG2E_F = 1.4426950408889634f;
 // two fp32 matmul results -> the reference's bf16 logits: bf16(bf16(acc) / sqrt(D)).  DIV 1: the division is a
 // multiplication by fl32(1/sqrt(D)), used only after the host has verified over all 65536 bf16 inputs that it rounds
 // identically (bf16_rcp_is_exact); DIV 2: IEEE division.
-template <int DIV>
+template <int DIV, bool F16>
 __device__ __forceinline__ void ref_logits2(float a0, float a1, float sqrt_d, float rcp_sd, float& l0, float& l1) {
-    const uint32_t p = pack2_bf16(a0, a1);
+    using Hh = H16<F16 ? RTK_F16 : RTK_BF16>;   // (fp16: an overflowing product becomes inf, as the reference's fp16 matmul does)
+    const uint32_t p = Hh::pack2(a0, a1);
     uint32_t o;
-    if constexpr (DIV == 1) o = pack2_bf16(bf_lo(p) * rcp_sd, bf_hi(p) * rcp_sd);
-    else o = pack2_bf16(__fdiv_rn(bf_lo(p), sqrt_d), __fdiv_rn(bf_hi(p), sqrt_d));
-    l0 = bf_lo(o);
-    l1 = bf_hi(o);
+    if constexpr (DIV == 1) o = Hh::pack2(Hh::lo(p) * rcp_sd, Hh::hi(p) * rcp_sd);
+    else o = Hh::pack2(__fdiv_rn(Hh::lo(p), sqrt_d), __fdiv_rn(Hh::hi(p), sqrt_d));
+    l0 = Hh::lo(o);
+    l1 = Hh::hi(o);
 }
 
 // Row statistic of pass 1 in the reference's semantics, as ONE number per row: lse2_i = log2 sum_j exp(l_ij) over the
@@ -46,12 +48,12 @@ __device__ __forceinline__ void ref_logits2(float a0, float a1, float sqrt_d, fl
 struct RowStatRefRaw {
     float sum;
     __device__ __forceinline__ void init() { sum = 0.f; }
-    template <int DIV, bool RAGGED>
+    template <int DIV, bool RAGGED, bool F16>
     __device__ __forceinline__ void update(const f32x16& a, int j0, int j_end, int hf, float sqrt_d, float rcp_sd) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             float l0, l1;
-            ref_logits2<DIV>(a[r], a[r + 1], sqrt_d, rcp_sd, l0, l1);
+            ref_logits2<DIV, F16>(a[r], a[r + 1], sqrt_d, rcp_sd, l0, l1);
             float e0 = __builtin_amdgcn_exp2f(l0 * LOG2E_F), e1 = __builtin_amdgcn_exp2f(l1 * LOG2E_F);
             if (RAGGED) {
                 if (j0 + acc_row(r, hf) >= j_end) e0 = 0.f;
@@ -71,11 +73,11 @@ struct RowStatRefRaw {
 struct RowStatRef {  // online max / sum of exp(l - max) of one query row over the keys this lane sees (natural exp)
     float m, sum;
     __device__ __forceinline__ void init() { m = -INFINITY; sum = 0.f; }
-    template <int DIV, bool RAGGED>
+    template <int DIV, bool RAGGED, bool F16>
     __device__ __forceinline__ void update(const f32x16& a, int j0, int j_end, int hf, float sqrt_d, float rcp_sd) {
         float l[16];
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) ref_logits2<DIV>(a[r], a[r + 1], sqrt_d, rcp_sd, l[r], l[r + 1]);
+        for (int r = 0; r < 16; r += 2) ref_logits2<DIV, F16>(a[r], a[r + 1], sqrt_d, rcp_sd, l[r], l[r + 1]);
         if (RAGGED) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -103,7 +105,7 @@ struct RowStatRef {  // online max / sum of exp(l - max) of one query row over t
 // pass 1 of one workgroup: NB x 32 query rows of head h per wave starting at i_base + wid * 32 * NB, key split ks ->
 // lse_part[ks][h][i] (base-2 log-sum-exp of the row's bf16 logits over the split).  ROBUST: RowStatRef, else RowStatRefRaw.
 // Same LDS-DMA staging as score_pass1_dma_body; every A fragment read from LDS feeds NB MFMAs.
-template <int DIV, bool ROBUST, int NB>
+template <int DIV, bool ROBUST, int NB, bool F16>
 __device__ __forceinline__ void score_pass1_ref_body(const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv,
                                                      int L, int keys_per_split, float* __restrict__ lse_part, int i_base,
                                                      int h, int ks, float sqrt_d, float rcp_sd) {
@@ -161,12 +163,12 @@ __device__ __forceinline__ void score_pass1_ref_body(const char* __restrict__ q,
                 for (int r = 0; r < M::NREG; ++r) {
                     const u32x4 a = *(const u32x4*)(cur + blk * 32 * T::ROWB + frag_off[r]);
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) M::mma(acc[nb], a, qf[nb][r]);
+                    for (int nb = 0; nb < NB; ++nb) mma16<F16>(acc[nb], a, qf[nb][r], acc[nb]);
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    if (jt < nfull) rs[nb].template update<DIV, false>(acc[nb], 0, 0, hf, sqrt_d, rcp_sd);
-                    else rs[nb].template update<DIV, true>(acc[nb], jt * TILE_ROWS + 32 * blk, nkeys, hf, sqrt_d, rcp_sd);
+                    if (jt < nfull) rs[nb].template update<DIV, false, F16>(acc[nb], 0, 0, hf, sqrt_d, rcp_sd);
+                    else rs[nb].template update<DIV, true, F16>(acc[nb], jt * TILE_ROWS + 32 * blk, nkeys, hf, sqrt_d, rcp_sd);
                 }
             }
         }
@@ -184,7 +186,7 @@ constexpr int REF_NB = RTK_REF_P1_NB;    // 32-row register blocks per wave, pas
 constexpr int REF_NB2 = RTK_REF_P2_NB;   // 32-key register blocks per wave, pass 2
 
 // blockIdx.x -> (row tile bx, head h, key split ks), blockIdx.y = unit of a batched launch
-template <int DIV>
+template <int DIV, bool F16>
 __global__ __launch_bounds__(SC_BLOCK, (REF_NB == 1 ? 4 : 3)) void score_pass1_ref_kernel(const char* __restrict__ q, const char* __restrict__ k,
                                                                       int Hq, int Hkv, int L, int keys_per_split,
                                                                       int row_tiles, int xcd_remap,
@@ -213,15 +215,15 @@ __global__ __launch_bounds__(SC_BLOCK, (REF_NB == 1 ? 4 : 3)) void score_pass1_r
     }
     const int i_base = bx * (REG_ROWS * REF_NB);
     if (REF_NB == 2 && L - i_base <= REG_ROWS)   // a last tile that is at most half full: 32 rows per wave
-        score_pass1_ref_body<DIV, false, 1>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, sqrt_d, rcp_sd);
+        score_pass1_ref_body<DIV, false, 1, F16>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, sqrt_d, rcp_sd);
     else
-        score_pass1_ref_body<DIV, false, REF_NB>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, sqrt_d, rcp_sd);
+        score_pass1_ref_body<DIV, false, REF_NB, F16>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, sqrt_d, rcp_sd);
 }
 
 // fix-up launch of the reference-rounding pass 1 (see score_pass1_fixup_kernel): the row tiles whose plain sums left
 // fp32's range (NaN) are recomputed with the online-max form; normally none.  Tiles are numbered
 // ((ks * Hq + h) * row_tiles + bx).
-template <int DIV>
+template <int DIV, bool F16>
 __global__ __launch_bounds__(SC_BLOCK, 2) void score_pass1_ref_fixup_kernel(
     const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv, int L, int keys_per_split, int row_tiles,
     int n_tiles, float* __restrict__ lse_part, size_t q_unit_bytes, size_t k_unit_bytes, size_t lse_unit_floats,
@@ -255,9 +257,9 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void score_pass1_ref_fixup_kernel(
         const int h = kh % Hq, ks = kh / Hq;
         const int i_base = bx * (REG_ROWS * REF_NB);
         if (REF_NB == 2 && L - i_base <= REG_ROWS)
-            score_pass1_ref_body<DIV, true, 1>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, sqrt_d, rcp_sd);
+            score_pass1_ref_body<DIV, true, 1, F16>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, sqrt_d, rcp_sd);
         else
-            score_pass1_ref_body<DIV, true, REF_NB>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, sqrt_d, rcp_sd);
+            score_pass1_ref_body<DIV, true, REF_NB, F16>(q, k, Hq, Hkv, L, keys_per_split, lse_part, i_base, h, ks, sqrt_d, rcp_sd);
         __syncthreads();
     }
 }
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void score_pass1_ref_fixup_kernel(
 //   partial[h][rs][j] = sum_{i in split} bf16(exp2(l_ij * log2(e) - lse2_i))           per HEAD
 // The probabilities are rounded to bf16 in pairs (v_cvt_pk_bf16_f32) and summed straight from the packed pair
 // (v_dot2_f32_bf16 against (1, 1): fp32 accumulation of exact bf16 values, no unpacking).
-template <int DIV, int NB>
+template <int DIV, int NB, bool F16>
 __device__ __forceinline__ void score_pass2_ref_body(const char* __restrict__ q, const char* __restrict__ k,
                                                      const float* __restrict__ lse, int Hq, int Hkv, int L,
                                                      int rows_per_split, int RS, float* __restrict__ partial, int j_base,
@@ -344,7 +346,7 @@ __device__ __forceinline__ void score_pass2_ref_body(const char* __restrict__ q,
             for (int r = 0; r < M::NREG; ++r) {   // one fragment at a time: each feeds NB MFMAs and is dead afterwards
                 const u32x4 a = *(const u32x4*)(cur + blk * 32 * T::ROWB + frag_off[r]);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) M::mma(acc[nb], a, kf[nb][r]);
+                for (int nb = 0; nb < NB; ++nb) mma16<F16>(acc[nb], a, kf[nb][r], acc[nb]);
             }
             float ls[16];
             load_ls(ls, lse_s + buf * TILE_ROWS, blk, hf);
@@ -353,10 +355,11 @@ __device__ __forceinline__ void score_pass2_ref_body(const char* __restrict__ q,
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     float l0, l1;
-                    ref_logits2<DIV>(acc[nb][r], acc[nb][r + 1], sqrt_d, rcp_sd, l0, l1);
+                    ref_logits2<DIV, F16>(acc[nb][r], acc[nb][r + 1], sqrt_d, rcp_sd, l0, l1);
                     const float p0 = __builtin_amdgcn_exp2f(fmaf(l0, LOG2E_F, -ls[r]));
                     const float p1 = __builtin_amdgcn_exp2f(fmaf(l1, LOG2E_F, -ls[r + 1]));
-                    col[nb] = H16<RTK_BF16>::dot2(pack2_bf16(p0, p1), H16<RTK_BF16>::ONE2, col[nb]);   // .to(bf16), .sum
+                    using Hh = H16<F16 ? RTK_F16 : RTK_BF16>;
+                    col[nb] = Hh::dot2(Hh::pack2(p0, p1), Hh::ONE2, col[nb]);   // .to(bf16 / fp16), .sum
                 }
             }
         }
@@ -375,7 +378,7 @@ __device__ __forceinline__ void score_pass2_ref_body(const char* __restrict__ q,
     }
 }
 
-template <int DIV>
+template <int DIV, bool F16>
 __global__ __launch_bounds__(SC_BLOCK, (REF_NB2 == 1 ? 4 : 3)) void score_pass2_ref_kernel(
     const char* __restrict__ q, const char* __restrict__ k, const float* __restrict__ lse, int Hq, int Hkv, int L,
     int rows_per_split, int col_tiles, int RS, int xcd_remap, float* __restrict__ partial, size_t q_unit_bytes,
@@ -413,16 +416,17 @@ __global__ __launch_bounds__(SC_BLOCK, (REF_NB2 == 1 ? 4 : 3)) void score_pass2_
     const int j_base = bx * (REG_ROWS * REF_NB2);
     if (j_base >= Lk) return;   // uniform per workgroup
     if (REF_NB2 == 2 && Lk - j_base <= REG_ROWS)
-        score_pass2_ref_body<DIV, 1>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk, sqrt_d, rcp_sd);
+        score_pass2_ref_body<DIV, 1, F16>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk, sqrt_d, rcp_sd);
     else
-        score_pass2_ref_body<DIV, REF_NB2>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk, sqrt_d,
+        score_pass2_ref_body<DIV, REF_NB2, F16>(q, k, lse, Hq, Hkv, L, rows_per_split, RS, partial, j_base, g, rs, kidx, Lk, sqrt_d,
                                            rcp_sd);
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void score_finalize_ref_kernel(const float* __restrict__ partial, int Hkv, int RS, int G,
                                                                  int L, float* __restrict__ score) {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j < L) score[j] = finalize_ref_column(partial, Hkv, RS, G, L, j);
+    if (j < L) score[j] = finalize_ref_column<F16>(partial, Hkv, RS, G, L, j);
 }
 
 }  // namespace rtk

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
 ABI_VERSION = 14
 
-RTK_F32, RTK_BF16, RTK_BF16_REFROUND, RTK_BF16_FAST, RTK_F16 = 0, 1, 2, 3, 4
+RTK_F32, RTK_BF16, RTK_BF16_REFROUND, RTK_BF16_FAST, RTK_F16, RTK_F16_REFROUND = 0, 1, 2, 3, 4, 5
 RTK_SCORE_MANY_UNITS = 0x100   # flag for the dtype argument of the scoring entry points (split policy of batched launches)
 RTK_PREPARE_K_ONLY = 0x200     # flag for the dtype argument of rtk_pivotkv_prepare: keep-all chunk, no q~
 RTK_UPDATE_PRE_ROPE = 1        # rtk_update_io.flags: q / k are the pre-RoPE projections (attention prologue)

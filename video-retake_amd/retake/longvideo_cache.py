@@ -268,13 +268,15 @@ class _Batch:
         # dtype code of the scoring entry points: bf16 payloads with the reference's bf16 rounding chain, or through the
         # fp16 matrix instruction with pre-scaled queries (score_rounding="fast"), on request
         self.score_dt = ((nv.RTK_BF16_REFROUND if refround else (nv.RTK_BF16_FAST if fast else nv.RTK_BF16))
-                         if dtype == torch.bfloat16 else (nv.RTK_F16 if dtype == torch.float16 else nv.RTK_F32))
+                         if dtype == torch.bfloat16 else
+                         ((nv.RTK_F16_REFROUND if refround else nv.RTK_F16) if dtype == torch.float16 else nv.RTK_F32))
         self.fast = self.score_dt == nv.RTK_BF16_FAST
         self.batched_passes = dtype in (torch.bfloat16, torch.float16) and D == 128 and L >= 512
         if self.batched_passes:   # all layers of a chunk per launch: splits chosen for the stream length (same flag everywhere)
             self.score_dt |= nv.RTK_SCORE_MANY_UNITS
         # what rtk_pivotkv_prepare is told: the payload dtype (the reference-rounding mode prepares like plain bf16)
-        self.prep_dt = (nv.RTK_BF16 if refround and dtype == torch.bfloat16 else self.score_dt & 0xFF) | (self.score_dt & ~0xFF)
+        self.prep_dt = ((nv.RTK_BF16 if dtype == torch.bfloat16 else nv.RTK_F16) if refround else self.score_dt & 0xFF) \
+            | (self.score_dt & ~0xFF)
         self.Hkv, self.L, self.D, self.dtype, self.device = Hkv, L, D, dtype, device
         self.Hq = Hq
         self.keep_idx = torch.arange(keep, dtype=torch.int64, device=device).repeat(slots, 1) if keep_all \
@@ -466,9 +468,10 @@ class PivotKVCache(DynamicCache):
         self.native_rope = bool(kv_compression_kwargs.get("native_rope", True))
         self._rotaries: Dict[int, Tuple[Any, Optional[_Rotary]]] = {}
         self._aio = nv.UpdateIO()   # argument block of append_pre_rope
-        # MI355X build option for bf16 models: "fp32" (default) scores with exact bf16 products, fp32 accumulation, softmax
-        # and sums; "reference" reproduces the reference's own bf16 roundings of the logits, probabilities, per-head
-        # sums and means (longvideo_cache.py:264-270 on bf16 tensors) - coarser, but what the reference computes
+        # MI355X build option for 16-bit models: "fp32" (default) scores with exact bf16 / fp16 products, fp32 accumulation,
+        # softmax and sums; "reference" reproduces the reference's own bf16 (fp16 on a float16 model) roundings of the
+        # logits, probabilities, per-head sums and means (longvideo_cache.py:264-270) - coarser, but what the reference
+        # computes; "fast" (bf16 only) is the two-instruction softmax on the fp16 matrix path
         self.score_rounding = str(kv_compression_kwargs.get("score_rounding", "fp32"))
         if self.score_rounding not in ("fp32", "reference", "fast"):
             raise ValueError(f"score_rounding must be 'fp32', 'reference' or 'fast', got {self.score_rounding!r}")
@@ -786,7 +789,7 @@ class PivotKVCache(DynamicCache):
 
     # ---- deferred eviction -----------------------------------------------------------------------
     def _get_batch(self, layer_idx, Hq, Hkv, L, D, keep, P, dtype, device) -> _Batch:
-        refround = self.score_rounding == "reference" and dtype == torch.bfloat16
+        refround = self.score_rounding == "reference" and dtype in (torch.bfloat16, torch.float16)
         if refround and D != 128:
             raise NotImplementedError("score_rounding='reference' needs head_dim 128")
         # "fast" (opt in): bf16 chunks of head_dim 128 on the fp16 matrix instruction; every other shape scores as usual
@@ -1217,7 +1220,7 @@ class PivotKVCache(DynamicCache):
             rot = self._rotary(rotary_emb, dev)
             keep_len = max(1, int(self.compression_ratio * L))
             if rot is None or L < 512 or keep_len > L or (self.score_rounding == "reference"
-                                                         and key_states.dtype == torch.bfloat16):
+                                                         and key_states.dtype in (torch.bfloat16, torch.float16)):
                 return None
             Hq, D = query_states.shape[1], query_states.shape[3]
             b = self._get_batch(layer_idx, Hq, key_states.shape[1], L, D, keep_len, 3 if position_ids.ndim == 3 else 1,
