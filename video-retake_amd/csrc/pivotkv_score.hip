@@ -1643,11 +1643,53 @@ __global__ __launch_bounds__(SC_BLOCK, (NB == 1 ? 4 : 3)) void score_pass1_dma_k
 // main kernel's workgroups instead of a full-size grid whose 39 200 workgroups read 1 KB each and leave: ~60 us).
 // Tiles are numbered ((ks * Hq + h) * row_tiles + bx); no XCD-aware decode (nothing streams in the common case).
 constexpr int FIX_TILES = 32;   // tiles per workgroup = bits of its NaN mask; 28 units x 700 tiles -> 616 workgroups: one resident round
+// NaN scan of FIX_TILES consecutive row tiles (RT rows each) of the row statistics, by the whole workgroup: bit u of the
+// result (valid after the caller's barriers, OR-ed into an LDS word) says tile t0 + u holds a NaN.  Tile t =
+// kh * row_tiles + bx covers lse_part[kh * L + bx * RT + (0 .. RT)).  16-byte loads, every thread busy, 4 loads per
+// thread for 32 tiles of 128 rows (the first form - one scalar load per thread and tile from half the threads - cost
+// 12-15 us per launch: tools/debug/fixup_probe.sh).
+template <int RT>
+__device__ __forceinline__ unsigned scan_nan_tiles(const float* __restrict__ lse_part, int t0, int n_tiles, int row_tiles, int L) {
+    constexpr int V4 = RT / 4;                       // 16-byte groups per tile
+    constexpr int TPP = SC_BLOCK / V4;               // tiles the workgroup covers per load
+    static_assert(SC_BLOCK % V4 == 0 && FIX_TILES % TPP == 0, "scan shape");
+    const int tid = (int)threadIdx.x;
+    const int ul = tid / V4, r0 = (tid - ul * V4) * 4;
+    unsigned mine = 0;
+    if ((L & 3) == 0) {
+        float4 v[FIX_TILES / TPP];
+#pragma unroll
+        for (int j = 0; j < FIX_TILES / TPP; ++j) {
+            const int t = t0 + ul + j * TPP;
+            const int bx = t % row_tiles, kh = t / row_tiles;
+            const int i = bx * RT + r0;
+            v[j] = (t < n_tiles && i < L) ? *(const float4*)(lse_part + (size_t)kh * L + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < FIX_TILES / TPP; ++j)
+            mine |= (v[j].x != v[j].x || v[j].y != v[j].y || v[j].z != v[j].z || v[j].w != v[j].w) ? (1u << (ul + j * TPP)) : 0u;
+    } else {
+        for (int j = 0; j < FIX_TILES / TPP; ++j) {
+            const int t = t0 + ul + j * TPP;
+            const int bx = t % row_tiles, kh = t / row_tiles;
+            bool nan = false;
+            for (int e = 0; e < 4; ++e) {
+                const int i = bx * RT + r0 + e;
+                const float x = (t < n_tiles && i < L) ? lse_part[(size_t)kh * L + i] : 0.f;
+                nan = nan || x != x;
+            }
+            mine |= nan ? (1u << (ul + j * TPP)) : 0u;
+        }
+    }
+    return mine;
+}
+
 template <int NB, int MODE>   // MODE: the robust flags (no P1_RAW) of the launch being repaired
 __global__ __launch_bounds__(SC_BLOCK, 2) void score_pass1_fixup_kernel(   // (2: registers, not occupancy - no spills)
     const char* __restrict__ q, const char* __restrict__ k, int Hq, int Hkv, int L, int keys_per_split, int row_tiles,
     int n_tiles, float* __restrict__ lse_part, size_t q_unit_bytes, size_t k_unit_bytes, size_t lse_unit_floats,
     int neg_out, QView qv) {
+    if (RTK_FIXUP_PROBE == 1) return;
     const int q_hs = qv.row_pitch ? qv.head_stride : L * HD * 2, q_pitch = qv.row_pitch ? qv.row_pitch : HD * 2;
     q = qv.row_pitch ? qv.unit[blockIdx.y] : q + blockIdx.y * q_unit_bytes;
     k += blockIdx.y * k_unit_bytes;
@@ -1655,21 +1697,11 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void score_pass1_fixup_kernel(   // (2
     const int t0 = blockIdx.x * FIX_TILES;
     __shared__ unsigned nan_tiles;       // bit u: tile t0 + u holds a NaN
     if (threadIdx.x == 0) nan_tiles = 0;
-    float v[FIX_TILES];
-#pragma unroll
-    for (int u = 0; u < FIX_TILES; ++u) {
-        const int t = t0 + u;
-        const int bx = t % row_tiles, kh = t / row_tiles;          // kh = ks * Hq + h
-        const int i = bx * (REG_ROWS * NB) + (int)threadIdx.x;
-        v[u] = (t < n_tiles && (int)threadIdx.x < REG_ROWS * NB && i < L) ? lse_part[(size_t)kh * L + i] : 0.f;
-    }
-    unsigned mine = 0;                   // (a bit mask, not an indexed array: v[] must stay in registers)
-#pragma unroll
-    for (int u = 0; u < FIX_TILES; ++u) mine |= (v[u] != v[u]) ? (1u << u) : 0u;
+    const unsigned mine = scan_nan_tiles<REG_ROWS * NB>(lse_part, t0, n_tiles, row_tiles, L);
     __syncthreads();
     if (mine) atomicOr(&nan_tiles, mine);
     __syncthreads();
-    unsigned todo = nan_tiles;           // uniform: the whole workgroup takes the same path
+    unsigned todo = RTK_FIXUP_PROBE >= 2 ? 0u : nan_tiles;           // uniform: the whole workgroup takes the same path
     while (todo) {
         const int u = __builtin_ctz(todo);
         todo &= todo - 1;
@@ -2080,7 +2112,7 @@ static int score_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, in
                (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1, x1, lse, ws_stride, k_stride,                     \
                ws_stride / sizeof(float), neg, qv);                                                                     \
     if ((MODEV) & P1_RAW)                                                                                               \
-        RTK_LAUNCH(KID_FINALIZE, (score_pass1_fixup_kernel<RTK_P1_NB, (MODEV) & ~P1_RAW>), gf, dim3(SC_BLOCK), LDS1, st,   \
+        RTK_LAUNCH(KID_FINALIZE, (score_pass1_fixup_kernel<RTK_P1_NB, (MODEV) & ~P1_RAW>), gf, dim3(SC_BLOCK), (RTK_FIXUP_PROBE == 3 ? 0 : LDS1), st,   \
                    (const char*)qt, (const char*)kt, Hq, Hkv, L, kps, jt1, n_tiles, lse, ws_stride, k_stride,            \
                    ws_stride / sizeof(float), neg, qv)
                 constexpr int RAWF = RTK_P1_RAW ? P1_RAW : 0;

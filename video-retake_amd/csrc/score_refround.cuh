@@ -234,17 +234,7 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void score_pass1_ref_fixup_kernel(
     const int t0 = blockIdx.x * FIX_TILES;
     __shared__ unsigned nan_tiles;
     if (threadIdx.x == 0) nan_tiles = 0;
-    float v[FIX_TILES];
-#pragma unroll
-    for (int u = 0; u < FIX_TILES; ++u) {
-        const int t = t0 + u;
-        const int bx = t % row_tiles, kh = t / row_tiles;
-        const int i = bx * (REG_ROWS * REF_NB) + (int)threadIdx.x;
-        v[u] = (t < n_tiles && (int)threadIdx.x < REG_ROWS * REF_NB && i < L) ? lse_part[(size_t)kh * L + i] : 0.f;
-    }
-    unsigned mine = 0;
-#pragma unroll
-    for (int u = 0; u < FIX_TILES; ++u) mine |= (v[u] != v[u]) ? (1u << u) : 0u;
+    const unsigned mine = scan_nan_tiles<REG_ROWS * REF_NB>(lse_part, t0, n_tiles, row_tiles, L);
     __syncthreads();
     if (mine) atomicOr(&nan_tiles, mine);
     __syncthreads();

@@ -49,3 +49,6 @@
 #ifndef RTK_CMP_WAVES     // in-place compaction: waves per SIMD the register allocation is bounded for
 #define RTK_CMP_WAVES 4
 #endif
+#ifndef RTK_FIXUP_PROBE   // measurement only: 1 = the pass-1 fix-up launch returns at entry, 2 = it scans for NaNs but never repairs
+#define RTK_FIXUP_PROBE 0
+#endif
