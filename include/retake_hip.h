@@ -19,7 +19,8 @@
  *     a mutex-guarded memo of exhaustive bf16 reciprocal checks keyed by attention_scaling^2.  No results
  *     depend on any of it, and the library reads no environment variables;
  *   - return value 0 = success, negative = rtk_status; no C++ exception crosses the ABI;
- *   - dtype: RTK_F32 or RTK_BF16 for the frame / q / k / v payloads; scores, distances and RoPE
+ *   - dtype: RTK_F32, RTK_BF16 or RTK_F16 for the frame / q / k / v payloads (the scoring entry points take the
+ *     mode-carrying codes as well); scores, distances and RoPE
  *     tables are always fp32; indices are int64 and masks are 1 byte per element (torch.bool layout);
  *   - strides are in ELEMENTS; the innermost (channel / head_dim) axis is always contiguous.
  */
