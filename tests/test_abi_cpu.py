@@ -219,6 +219,34 @@ def test_round4_entry_points_validate_on_the_host():
     assert lib.rtk_profile_copy(p, p, 24, None) == nv.RTK_EINVAL
 
 
+def test_compaction_entry_point_validates_on_the_host():
+    """rtk_pivotkv_compact_batched / rtk_pivotkv_compact_sync_ints (ABI 14): sizes and argument errors without a launch."""
+    import retake._native as nv
+
+    lib = nv.lib
+    # 28 units x one head group x (32 header ints + 49 row blocks, rounded up to 32): keep 1568, head_dim 128, bf16
+    assert lib.rtk_pivotkv_compact_sync_ints(28, 4, 1568, 128, nv.RTK_BF16) == 28 * 96
+    assert lib.rtk_pivotkv_compact_sync_ints(28, 8, 1568, 128, nv.RTK_BF16) == 28 * 2 * 96      # two head groups
+    assert lib.rtk_pivotkv_compact_sync_ints(3, 4, 100, 128, nv.RTK_F32) == 3 * 64               # 16 rows per block in fp32
+    assert lib.rtk_pivotkv_compact_sync_ints(1, 4, 100, 100, nv.RTK_BF16) == 0                   # unsupported head_dim
+    dummy = (ctypes.c_char * 256)()
+    p = ctypes.addressof(dummy)
+    units = (nv.CompactUnit * 1)()
+    call = lambda mode, sync, n, P=1: lib.rtk_pivotkv_compact_batched(units, 1, 4, 128, 4, P, nv.RTK_BF16, mode, p, 1.0,  # noqa: E731
+                                                                     None, 0, 1, sync, n, None)
+    assert call(1, p, 256) == nv.RTK_EINVAL and b"NULL pointer" in lib.rtk_last_error()          # empty unit
+    units[0].k_tail = units[0].v_tail = units[0].keep_idx = p
+    units[0].k_src = p
+    assert call(1, p, 256) == nv.RTK_EINVAL and b"own" in lib.rtk_last_error()                   # k_src aliases the tail
+    units[0].k_src = p + 128
+    assert call(0, p, 256) == nv.RTK_EINVAL and b"pos_src" in lib.rtk_last_error()               # rotation without the new ids
+    assert call(1, None, 256) == nv.RTK_EINVAL and b"sync" in lib.rtk_last_error()
+    assert call(1, p, 8) == nv.RTK_EWORKSPACE
+    assert call(9, p, 256) == nv.RTK_EINVAL
+    assert call(1, p, 256, P=2) == nv.RTK_EINVAL
+    assert lib.rtk_pivotkv_compact_batched(None, 0, 4, 128, 4, 1, nv.RTK_BF16, 1, p, 1.0, None, 0, 1, p, 256, None) == nv.RTK_EINVAL
+
+
 def test_product_defaults_are_the_benched_configuration():
     """bench.py builds its cache from the reference's YAML keys only (configs/retake_demo.yaml:18-24 + the ratio its
     dynamic rule writes): no build-specific option is needed to get the path the headline times."""
