@@ -598,8 +598,9 @@ int rtk_pivotkv_update(rtk_pivotkv_batch* batch, rtk_layer_state* layer, int slo
 /* The attention patch's prologue for a segment that is NOT compressed - text prefill, decode (qwen2_vl.py:68-86 with the
  * cache's else-branch, longvideo_cache.py:319-321): continuity shift against the layer's last cached temporal id, rotary
  * tables, RoPE of q (to io->q_rot, which may alias io->q) and of k, the append of the rotated k and of v at the layer's
- * tail, and the shifted ids appended to the layer's position cache - one launch, plus rtk_position_shift on the caller's
- * ids when shift_ids_in_place (Qwen2-VL's in-place semantics; LLaVA shifts a clone: 0).  io: q [Hq,n,D], k / v [Hkv,n,D],
+ * tail, and the shifted ids appended to the layer's position cache - one launch.  shift_ids_in_place (Qwen2-VL's in-place
+ * semantics; LLaVA shifts a clone: 0): the caller's ids are shifted too - by the same launch for n == 1 (a decode step),
+ * by rtk_position_shift after it otherwise.  io: q [Hq,n,D], k / v [Hkv,n,D],
  * pos [P,n].  The caller has made room (rows and ids); length / pos_len are advanced.  pos_embed_reforge caches only. */
 int rtk_pivotkv_append_rope(rtk_layer_state* layer, const rtk_update_io* io, int Hq, int Hkv, int n, int D, int dtype, int P,
                             const float* inv_freq, float attention_scaling, const int* sections_host, int nsec,

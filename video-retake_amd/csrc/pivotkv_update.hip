@@ -46,14 +46,15 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
                                                       const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
                                                       const char* __restrict__ v, int64_t v_sh, int64_t v_sl,
                                                       int Hq, int Hkv, int L, int D,
-                                                      const int64_t* __restrict__ pos, int64_t pos_ld,
+                                                      const int64_t* pos, int64_t pos_ld,
                                                       const int64_t* __restrict__ prev,
                                                       const float* __restrict__ inv_freq, float scaling, RowSel rs,
                                                       int round_mode, char* q_rot, int64_t qr_sh, int64_t qr_sl,
                                                       char* __restrict__ q_out, char* __restrict__ k_out,
                                                       char* __restrict__ k_tail, char* __restrict__ v_tail,
                                                       int64_t tail_sh, int P, int64_t* __restrict__ pos_copy,
-                                                      int64_t pos_copy_ld, char* __restrict__ k_fast, float qscale) {
+                                                      int64_t pos_copy_ld, char* __restrict__ k_fast, float qscale,
+                                                      int64_t* shift_back) {
     using V = Vec16<DT>;
     static_assert(NW == 4 || ((NW == 2 || NW == 1) && DT != RTK_F32), "8- / 4-byte chunks: 16-bit dtypes only");
     constexpr int ES = 16 / V::VE;          // bytes per element
@@ -73,6 +74,10 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
     }
     if (pos_copy && blockIdx.y == 0 && d == 0)
         for (int p = 0; p < P; ++p) pos_copy[(size_t)p * pos_copy_ld + l] = ids[p];
+    // a one-token segment (decode): the caller's temporal id is shifted in place by this launch (qwen2_vl.py:73) - the
+    // shift is idempotent (afterwards t[0] == prev + 1, so a workgroup that reads the new value computes delta 0 and the
+    // same id) and a single aligned 8-byte store cannot be seen torn, so no workgroup order is needed
+    if (shift_back && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) shift_back[0] = ids[0];
     constexpr int HU = RTK_PREP_HU;
     const int ny = gridDim.y, qper = (Hq + ny - 1) / ny;
     const int qb = min((int)blockIdx.y * qper, Hq), qe = min(qb + qper, Hq);
@@ -213,7 +218,7 @@ struct PrologueGeom {
 template <int DT>
 static int prologue_launch(const PrologueGeom& g, const rtk_update_io* io, const RowSel& rs, const int64_t* prev,
                            char* q_out, char* k_out, char* k_tail, char* v_tail, int64_t tail_sh, int64_t* pos_copy,
-                           int64_t pos_copy_ld, char* k_fast, hipStream_t st) {
+                           int64_t pos_copy_ld, char* k_fast, hipStream_t st, int64_t* shift_back = nullptr) {
     int nw = 4;
     if constexpr (DT != RTK_F32) nw = RTK_PREP_NW;
     const int VE = nw * 4 / (DT == RTK_F32 ? 4 : 2);
@@ -225,7 +230,7 @@ static int prologue_launch(const PrologueGeom& g, const rtk_update_io* io, const
                    (const char*)io->k, io->k_stride_h, io->k_stride_l, (const char*)io->v, io->v_stride_h, io->v_stride_l,
                    g.Hq, g.Hkv, g.L, g.D, io->pos, io->pos_stride, prev, g.inv_freq, g.scaling, rs, g.round_mode,
                    (char*)io->q_rot, io->qr_stride_h, io->qr_stride_l, q_out, k_out, k_tail, v_tail, tail_sh, g.P, pos_copy,
-                   pos_copy_ld, k_fast, qscale);
+                   pos_copy_ld, k_fast, qscale, shift_back);
     };
 #define RTK_PRO_NWSEL(FASTV)                                                              \
     do {                                                                                  \
@@ -410,14 +415,19 @@ extern "C" int rtk_pivotkv_append_rope(rtk_layer_state* ls, const rtk_update_io*
     int64_t* pos_out = ls->pos + ls->pos_len;   // the shifted ids join the layer's position cache (reference :319-321)
     const PrologueGeom pg{Hq, Hkv, n, D, P, round_mode, inv_freq, attention_scaling};
     hipStream_t st = (hipStream_t)stream;
+    // one token (a decode step): the kernel shifts the caller's id itself; longer segments take the shift launch after it
+    int64_t* shift_back = (shift_ids_in_place && n == 1) ? (int64_t*)io->pos : nullptr;
     if (dtype == RTK_F16)
-        rc = prologue_launch<RTK_F16>(pg, io, rs, prev, nullptr, nullptr, k_tail, v_tail, tail_sh, pos_out, ls->pos_cap, nullptr, st);
+        rc = prologue_launch<RTK_F16>(pg, io, rs, prev, nullptr, nullptr, k_tail, v_tail, tail_sh, pos_out, ls->pos_cap, nullptr, st,
+                                      shift_back);
     else if (dtype == RTK_BF16)
-        rc = prologue_launch<RTK_BF16>(pg, io, rs, prev, nullptr, nullptr, k_tail, v_tail, tail_sh, pos_out, ls->pos_cap, nullptr, st);
+        rc = prologue_launch<RTK_BF16>(pg, io, rs, prev, nullptr, nullptr, k_tail, v_tail, tail_sh, pos_out, ls->pos_cap, nullptr, st,
+                                       shift_back);
     else
-        rc = prologue_launch<RTK_F32>(pg, io, rs, prev, nullptr, nullptr, k_tail, v_tail, tail_sh, pos_out, ls->pos_cap, nullptr, st);
+        rc = prologue_launch<RTK_F32>(pg, io, rs, prev, nullptr, nullptr, k_tail, v_tail, tail_sh, pos_out, ls->pos_cap, nullptr, st,
+                                      shift_back);
     if (rc) return rc;
-    if (shift_ids_in_place) {   // qwen2_vl.py:73: later layers (and the caller) see the shifted ids; after the kernel read them
+    if (shift_ids_in_place && !shift_back) {   // qwen2_vl.py:73: later layers (and the caller) see the shifted ids; after the kernel read them
         rc = rtk_position_shift((int64_t*)io->pos, n, prev, stream);
         if (rc) return rc;
     }
