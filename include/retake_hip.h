@@ -480,10 +480,13 @@ enum rtk_compact_k_mode {
     RTK_COMPACT_K_INPLACE = 2   /* kept K = row keep_idx[r] of k_tail, compacted in place like V (no reforge, :279) */
 };
 /* ints of the sync workspace for this geometry: device memory, zero-initialised once by the caller (tickets and flags of
- * the workgroups live in it; every launch that completes leaves it zeroed again - re-zero it after a failed launch). */
+ * the workgroups live in it; every launch that completes leaves it zeroed again, and a call that fails at a launch
+ * re-zeroes it on `stream` before returning).  A kernel that aborts on the device (its bounded flag wait traps instead
+ * of hanging) leaves the HIP context in error: the workspace - like every other buffer - is then to be re-created. */
 size_t rtk_pivotkv_compact_sync_ints(int n_units, int Hkv, int keep, int D, int dtype);
 /* `units` is a HOST array.  inv_freq / attention_scaling / sections / round_mode as rtk_pivotkv_evict_batched_rope
- * (RTK_COMPACT_K_ROTATE only).  One launch at a time per workspace. */
+ * (RTK_COMPACT_K_ROTATE only).  One launch at a time per workspace: calls that share a workspace must be ordered on
+ * ONE stream (PivotKVCache flushes a batch on the caller's current stream only). */
 int rtk_pivotkv_compact_batched(const rtk_compact_unit* units, int n_units, int Hkv, int D, int keep, int P, int dtype,
                                 int k_mode, const float* inv_freq, float attention_scaling, const int* sections_host,
                                 int nsec, int round_mode, int32_t* sync_ws, size_t sync_ws_ints, rtk_stream_t stream);

@@ -561,13 +561,16 @@ def test_llava_attention_patch_takes_the_prologue():
     assert (caches[0].key_cache[0] - caches[1].key_cache[0]).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("llava", [False, True])
-def test_whole_sequence_through_the_fused_prologues(llava):
+@pytest.mark.parametrize("llava,expanded", [(False, False), (True, False), (False, True)])
+def test_whole_sequence_through_the_fused_prologues(llava, expanded):
     """text(5) -> video chunk(640) x 2 -> text(3) -> decode(1) x 2 through the patched attention of both models on the
     stand-in module, two layers, fp32: with the fused prologues (update_pre_rope for the chunks, append_pre_rope for text
     and decode) and with the op-by-op route the attention outputs agree, the ids tensor the caller handed over is in the
     same state after every layer call (shifted in place for Qwen2-VL, untouched for LLaVA), and the final caches hold the
-    same ids / values (exact) and keys (1e-5)."""
+    same ids / values (exact) and keys (1e-5).
+    expanded: the text / decode ids of Qwen2-VL the way HF builds them - ONE row seen three times, `.unsqueeze(0).expand(3,
+    -1, -1)` (qwen2_vl.py:589, strides (0, n, 1)): the reference's in-place shift of row 0 then moves t, h and w together,
+    and so must the fused append (it once refused such ids with ValueError)."""
     import glue_stubs as gs
     import retake.llava_onevision as lo
     import retake.longvideo_cache as lc
@@ -587,6 +590,15 @@ def test_whole_sequence_through_the_fused_prologues(llava):
         return lc.build_kvcache(cfg_)
 
     caches = [make(), make(one_call_update=False)]
+    taken = []
+    fused_append = caches[0].append_pre_rope
+
+    def counting(*a, **k):
+        out = fused_append(*a, **k)
+        taken.append(out is not None)
+        return out
+
+    caches[0].append_pre_rope = counting
     steps = [("text", 5), ("video", 640), ("video", 640), ("text", 3), ("text", 1), ("text", 1)]
     g = torch.Generator(device=dev()).manual_seed(21)
     total = [0, 0]
@@ -605,6 +617,11 @@ def test_whole_sequence_through_the_fused_prologues(llava):
                 cache.kvcache_compression = kind == "video"
                 cache.keypatches_mask_chunk = None
                 ids = ids0.clone()
+                if expanded and kind == "text":
+                    ids = ids0[0].clone().unsqueeze(0).expand(3, -1, -1)
+                    assert ids.stride(0) == 0
+                    prev_t = cache.get_prev_temporal_idx(0)
+                    prev_t = int(prev_t)
                 klen = cache.get_seq_length(0) + n
                 mask4 = gs.causal_mask(n, klen).to(dev())
                 per_layer = []
@@ -614,6 +631,10 @@ def test_whole_sequence_through_the_fused_prologues(llava):
                     else:
                         o = rq.retake_Qwen2VLAttention_forward(att, x, mask4, ids, cache, False, True, None)
                     per_layer.append((o[0].float(), ids.clone()))
+                    if expanded and kind == "text":   # the reference's semantics, restated: all three rows follow the cache
+                        want = (torch.arange(n, device=dev()) + prev_t + 1).view(1, 1, n).expand(3, -1, -1)
+                        assert torch.equal(ids, want), (si, l, i)
+                        assert torch.equal(cache.position_cache[l][..., -n:], want)
                 if kind == "video":
                     cache.after_forward()
                     # a chunk's fused prologue leaves the caller's ids to the flush (the last layer's shift, what the
@@ -632,3 +653,31 @@ def test_whole_sequence_through_the_fused_prologues(llava):
         assert torch.equal(a.value_cache[l], b.value_cache[l])
         assert (a.key_cache[l] - b.key_cache[l]).abs().max().item() <= 1e-5
     assert caches[0].num_evicted_tokens == caches[1].num_evicted_tokens
+    assert len(taken) == 4 * 2 and all(taken), "a text / decode segment fell off the fused append"
+
+
+def test_native_rope_snapshot_follows_the_rotary_module():
+    """The cache snapshots a rotary module's inv_freq once (native RoPE); a module whose inv_freq is then written in place
+    or re-assigned must be snapshotted again - the prologue's rotated queries follow the module's CURRENT frequencies."""
+    import retake.longvideo_cache as lc
+
+    L, dtype = 640, torch.float32
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    cache = lc.build_kvcache(cfg(1))
+    for c, change in enumerate((None, "in place", "re-assigned")):
+        if change == "in place":
+            rot.inv_freq.mul_(0.5)
+        elif change == "re-assigned":
+            rot.inv_freq = (rot.inv_freq * 3.0).contiguous()
+        q0, k0, v0 = projections(70 + c, L, dtype)
+        qk = q0.clone()
+        pos = chunk_ids(c, L)
+        prev = cache.get_prev_temporal_idx(0)
+        cache.kvcache_compression = True
+        out = cache.update_pre_rope(q0, k0, v0, 0, pos, rot, SEC, query_out=q0)
+        assert out is not None
+        want_ids = pos.clone()
+        want_ids[0, 0] += int(prev) + 1 - want_ids[0, 0, 0]
+        cos, sin = native_tables(want_ids, rot, dtype)
+        assert torch.equal(out[0], (qk * cos) + (rot_half(qk) * sin)), change
+        cache.after_forward()

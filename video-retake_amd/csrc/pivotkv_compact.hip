@@ -255,7 +255,11 @@ extern "C" int rtk_pivotkv_compact_batched(const rtk_compact_unit* units, int n_
         else RTK_LAUNCH_CMP_DT(2);
 #undef RTK_LAUNCH_CMP_DT
 #undef RTK_LAUNCH_CMP
-        RTK_LAUNCH_CHECK("compact_units_kernel");
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+            // an earlier launch of this call may have taken tickets: leave the workspace as the next call expects it
+            (void)hipMemsetAsync(sync_ws, 0, (size_t)n_units * HG * stride * sizeof(int32_t), st);
+            return rtk::hip_fail(e, "compact_units_kernel");
+        }
     }
     return RTK_OK;
 }

@@ -64,20 +64,31 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= L * lpr) return;
     const int l = id / lpr, d = (id - l * lpr) * VE;
-    // continuity shift: the whole temporal row moves so that its first id follows the layer's last cached id
-    const long long delta = (prev ? (long long)prev[0] : -1ll) + 1 - (long long)pos[0];
+    // continuity shift: the whole temporal row moves so that its first id follows the layer's last cached id.  The row's
+    // first id is read ONCE per thread (a relaxed atomic load the compiler can neither split nor repeat): a one-token
+    // segment's launch stores the shifted id back into pos[0] while other workgroups may still be reading it, and both
+    // the delta and the token's own id must come from the same value (old: delta = prev + 1 - t0, id = prev + 1; new:
+    // delta = 0, id = prev + 1).
+    const long long t0 = (long long)__hip_atomic_load(pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long delta = (prev ? (long long)prev[0] : -1ll) + 1 - t0;
+    // pos_ld == 0: the three M-RoPE rows are ONE row seen three times (HF's decode ids, `.expand(3, -1, -1)`,
+    // qwen2_vl.py:589): the reference's in-place shift of row 0 moves the shared storage, i.e. t, h and w together
+    const bool rows_alias = pos_ld == 0;
     long long ids[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const int pr = min(p, P - 1);
-        ids[p] = (long long)pos[(size_t)pr * pos_ld + l] + (pr == 0 ? delta : 0ll);
+        const bool temporal = pr == 0 || rows_alias;
+        const long long raw = (temporal && l == 0) ? t0 : (long long)pos[(size_t)pr * pos_ld + l];
+        ids[p] = raw + (temporal ? delta : 0ll);
     }
     if (pos_copy && blockIdx.y == 0 && d == 0)
         for (int p = 0; p < P; ++p) pos_copy[(size_t)p * pos_copy_ld + l] = ids[p];
     // a one-token segment (decode): the caller's temporal id is shifted in place by this launch (qwen2_vl.py:73) - the
-    // shift is idempotent (afterwards t[0] == prev + 1, so a workgroup that reads the new value computes delta 0 and the
-    // same id) and a single aligned 8-byte store cannot be seen torn, so no workgroup order is needed
-    if (shift_back && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) shift_back[0] = ids[0];
+    // shift is idempotent (afterwards t[0] == prev + 1, so a thread that reads the new value computes delta 0 and the
+    // same id) and a single aligned 8-byte atomic store cannot be seen torn, so no workgroup order is needed
+    if (shift_back && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(shift_back, (int64_t)ids[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int HU = RTK_PREP_HU;
     const int ny = gridDim.y, qper = (Hq + ny - 1) / ny;
     const int qb = min((int)blockIdx.y * qper, Hq), qe = min(qb + qper, Hq);
@@ -315,7 +326,10 @@ extern "C" int rtk_pivotkv_update(rtk_pivotkv_batch* b, rtk_layer_state* ls, int
             set_error("rtk_pivotkv_update: the prologue needs 16-byte aligned pointers / strides and head_dim a multiple of %d", 2 * ve);
             return RTK_EUNSUPPORTED;
         }
-        RTK_CHECK_ARG(io->pos_stride >= L, "rtk_pivotkv_update: pos_stride %lld < L %d", (long long)io->pos_stride, L);
+        if (b->P == 3 && io->pos_stride < L && io->pos_stride != 0) {   // partially overlapping id rows: the eager route
+            set_error("rtk_pivotkv_update: position-id rows overlap (pos_stride %lld < L %d)", (long long)io->pos_stride, L);
+            return RTK_EUNSUPPORTED;
+        }
         const size_t need = rtk_pivotkv_score_workspace_bytes(b->Hq, Hkv, L, D, b->score_dtype);
         if (!b->keep_all && b->score_ws_bytes < need) {
             set_error("rtk_pivotkv_update: workspace %zu < required %zu bytes", (size_t)b->score_ws_bytes, need);
@@ -392,7 +406,10 @@ extern "C" int rtk_pivotkv_append_rope(rtk_layer_state* ls, const rtk_update_io*
     RTK_CHECK_ARG(ls->k && ls->v && ls->pending == 0 && ls->length >= 0 && ls->length + n <= ls->cap,
                   "rtk_pivotkv_append_rope: the layer's cache has no room for %d rows (or a chunk is pending)", n);
     RTK_CHECK_ARG(ls->pos && ls->pos_len + n <= ls->pos_cap, "rtk_pivotkv_append_rope: the position cache has no room for %d ids", n);
-    RTK_CHECK_ARG(io->pos_stride >= n, "rtk_pivotkv_append_rope: pos_stride %lld < n %d", (long long)io->pos_stride, n);
+    if (P == 3 && io->pos_stride < n && io->pos_stride != 0) {   // rows that overlap partially: not a layout torch hands out;
+        set_error("rtk_pivotkv_append_rope: position-id rows overlap (pos_stride %lld < n %d)", (long long)io->pos_stride, n);
+        return RTK_EUNSUPPORTED;                                     // fully aliased rows (stride 0, `.expand(3, ..)`) are served
+    }
     const size_t es = esize(dtype);
     char* k_tail = (char*)ls->k + (size_t)ls->length * D * es;
     char* v_tail = (char*)ls->v + (size_t)ls->length * D * es;

@@ -258,6 +258,13 @@ class _Rotary:
         self.inv, self.scaling, self.device = inv, scaling, device
 
 
+def _inv_stamp(rotary_emb_fn):
+    """Identity + write counter of a rotary module's inv_freq: the native-RoPE snapshot of the module (_Rotary) is only
+    valid while this is unchanged (a module whose inv_freq is re-assigned or modified in place is snapshotted again)."""
+    inv = getattr(rotary_emb_fn, "inv_freq", None)
+    return (inv.data_ptr(), inv._version) if isinstance(inv, torch.Tensor) else None
+
+
 class _Batch:
     """Per-chunk batch of pending evictions: slot = layer index.  All units share the chunk geometry."""
 
@@ -344,6 +351,7 @@ class _Batch:
         # rtk_pivotkv_flush compacts the tails in place in one launch (rtk_pivotkv_compact_batched): tickets and flags
         # of its workgroups live here, zeroed once; the staging rows are then only allocated by the stage-by-stage route
         self.compact_sync = None
+        self.sync_stream = None    # the stream the batch's last in-place compaction was launched on
         if in_place_compaction and not keep_all:
             n_ints = nv.lib.rtk_pivotkv_compact_sync_ints(slots, Hkv, keep, D, c.dtype)
             if n_ints:
@@ -466,7 +474,7 @@ class PivotKVCache(DynamicCache):
         # (dynamic / longrope types, no inv_freq) is CALLED, exactly as the reference does (:249, :298).
         # native_rope: False forces the call for every module (the bit-faithful opt-out).
         self.native_rope = bool(kv_compression_kwargs.get("native_rope", True))
-        self._rotaries: Dict[int, Tuple[Any, Optional[_Rotary]]] = {}
+        self._rotaries: Dict[int, Tuple[Any, Optional[_Rotary], Any]] = {}
         self._aio = nv.UpdateIO()   # argument block of append_pre_rope
         # MI355X build option for 16-bit models: "fp32" (default) scores with exact bf16 / fp16 products, fp32 accumulation,
         # softmax and sums; "reference" reproduces the reference's own bf16 (fp16 on a float16 model) roundings of the
@@ -744,7 +752,8 @@ class PivotKVCache(DynamicCache):
         Memoised per module object; modules with equal inv_freq / attention_scaling (HF: one per layer) share one
         entry, so a chunk's layers stay in one batch."""
         hit = self._rotaries.get(id(rotary_emb_fn))
-        if hit is not None and hit[0] is rotary_emb_fn and (hit[1] is None or hit[1].device == device):
+        if hit is not None and hit[0] is rotary_emb_fn and (hit[1] is None or hit[1].device == device) \
+                and hit[2] == _inv_stamp(rotary_emb_fn):
             return hit[1]
         entry = None
         inv = getattr(rotary_emb_fn, "inv_freq", None)
@@ -752,14 +761,15 @@ class PivotKVCache(DynamicCache):
                 and getattr(rotary_emb_fn, "rope_type", "default") in self._STATIC_ROPE_TYPES):
             inv = inv.detach().to(device=device, dtype=torch.float32).contiguous()
             scaling = float(rotary_emb_fn.attention_scaling)
-            for _, other in self._rotaries.values():
+            for _, other, _ in self._rotaries.values():
                 if (other is not None and other.device == device and other.scaling == scaling
                         and other.inv.shape == inv.shape and torch.equal(other.inv, inv)):
                     entry = other
                     break
             if entry is None:
                 entry = _Rotary(inv, scaling, device)
-        self._rotaries[id(rotary_emb_fn)] = (rotary_emb_fn, entry)   # the strong reference pins the id
+        # (the strong reference pins the id; the stamp notices a module whose inv_freq was replaced or written in place)
+        self._rotaries[id(rotary_emb_fn)] = (rotary_emb_fn, entry, _inv_stamp(rotary_emb_fn))
         return entry
 
     def _rope_tables(self, cos_t, sin_t, rotary_emb_fn, x_like, pos2d, pos_ld, ndim, mrope_section, n, D):
@@ -836,6 +846,7 @@ class PivotKVCache(DynamicCache):
         states = (C.c_void_p * n)(*[L_[l].cref for l in layers])
         slots = (C.c_int32 * n)(*layers)
         idx = b.dev_index
+        self._order_compaction(b)
         if nv.current_device() == idx:
             rc = nv.lib.rtk_pivotkv_flush(b.cref, states, slots, n, nv.raw_stream(idx))
         else:
@@ -843,6 +854,8 @@ class PivotKVCache(DynamicCache):
                 rc = nv.lib.rtk_pivotkv_flush(b.cref, states, slots, n, nv.raw_stream(idx))
         if rc == nv.RTK_EUNSUPPORTED:
             return False
+        if rc:
+            self._reset_compaction(b)
         nv.check(rc, "rtk_pivotkv_flush")
         b.pending = []
         b.c_pending = 0
@@ -1023,6 +1036,25 @@ class PivotKVCache(DynamicCache):
                 st.pos_len += keep
                 self._pos_layers = max(self._pos_layers, l + 1)
 
+    def _order_compaction(self, b: _Batch):
+        """The in-place compaction's tickets and flags (batch.compact_sync) serve ONE launch at a time: flushes of a batch
+        are ordered on one stream.  A flush that arrives on another stream than the batch's previous one first waits for
+        the device (rare: the caller changed its current stream between two chunks)."""
+        if b.compact_sync is None:
+            return
+        cur = nv.raw_stream(b.dev_index)
+        if b.sync_stream is not None and b.sync_stream != cur:
+            torch.cuda.synchronize(b.device)
+        b.sync_stream = cur
+
+    def _reset_compaction(self, b: _Batch):
+        """After a failed flush: tickets / flags back to zero (a launch that completes leaves them zeroed itself)."""
+        if b.compact_sync is not None:
+            try:
+                b.compact_sync.zero_()
+            except Exception:  # noqa: BLE001  (a device-side abort leaves the context unusable; the first error is what is raised)
+                pass
+
     def _compact(self, b: _Batch, layers, rot, defer, dt, es):
         """The eviction scan of the pending layers as one in-place launch (rtk_pivotkv_compact_batched; reference
         :278-318): kept K re-rotated at the new ids (or copied un-rotated when the rotation is deferred; compacted in
@@ -1049,6 +1081,7 @@ class PivotKVCache(DynamicCache):
                 u.pos_src = u.pos_dst = None
         mode = nv.COMPACT_K_INPLACE if not b.reforge else (nv.COMPACT_K_COPY if defer else nv.COMPACT_K_ROTATE)
         sec = (C.c_int * len(b.mrope_section))(*b.mrope_section) if (b.mrope_section and mode == nv.COMPACT_K_ROTATE) else None
+        self._order_compaction(b)
         nv.check(nv.lib.rtk_pivotkv_compact_batched(
             units, len(layers), Hkv, D, keep, P if b.reforge else 0, dt, mode,
             nv.ptr(rot.inv) if mode == nv.COMPACT_K_ROTATE else None, rot.scaling if mode == nv.COMPACT_K_ROTATE else 1.0,
@@ -1095,7 +1128,7 @@ class PivotKVCache(DynamicCache):
         rot_fn = ck.get("rotary_emb")
         hit = self._rotaries.get(id(rot_fn))
         if hit is None or hit[0] is not rot_fn or hit[1] is None or hit[1] is not b.rot \
-                or ck.get("mrope_section") != b.mrope_section:
+                or ck.get("mrope_section") != b.mrope_section or hit[2] != _inv_stamp(rot_fn):
             return None
         dt = b.dtype
         if q.shape != b.qshape or key_states.shape != b.kshape or value_states.shape != b.kshape \
@@ -1108,8 +1141,8 @@ class PivotKVCache(DynamicCache):
             return None
         L, P = b.L, b.P
         if pos.dtype is not torch.int64 or pos.shape[-1] != L or pos.shape[0] != P or pos.ndim != (3 if P == 3 else 2) \
-                or pos.stride(-1) != 1 or (pos.ndim == 3 and pos.shape[1] != 1):
-            return None
+                or pos.stride(-1) != 1 or (pos.ndim == 3 and (pos.shape[1] != 1 or pos.stride(0) < L)):
+            return None   # (ids whose rows alias - `.expand(3, ..)` - take the stage-by-stage route)
         mask = self.keypatches_mask_chunk
         if mask is None:
             mptr = None
@@ -1212,7 +1245,7 @@ class PivotKVCache(DynamicCache):
         b = self._batch
         hit = self._rotaries.get(id(rotary_emb))
         if b is None or b.L != L or not b.c_capable or hit is None or hit[0] is not rotary_emb or hit[1] is None \
-                or hit[1] is not b.rot \
+                or hit[1] is not b.rot or hit[2] != _inv_stamp(rotary_emb) \
                 or layer_idx >= b.slots or layer_idx >= len(self._layers) \
                 or self._layers[layer_idx].c.length + L > self._layers[layer_idx].c.cap:
             # not the steady state: find / build the batch of this geometry, bind the rotary, make room
@@ -1276,6 +1309,11 @@ class PivotKVCache(DynamicCache):
         qs, ks, vs = q.stride(), k.stride(), v.stride()
         if qs[3] != 1 or ks[3] != 1 or vs[3] != 1:
             return None
+        # M-RoPE ids of a decode step are one row seen three times (`.expand(3, -1, -1)`, qwen2_vl.py:589: stride 0); the
+        # kernel then moves t, h and w together, like the reference's in-place shift of the shared storage.  Rows that
+        # overlap only partly are not served.
+        if P == 3 and 0 < pos.stride(0) < n:
+            return None
         st = self._store(layer_idx)
         if st.pending:
             self._flush()
@@ -1304,7 +1342,7 @@ class PivotKVCache(DynamicCache):
     def _bind_rotary(self, b: _Batch, rotary_emb_fn, mrope_section, rot: Optional[_Rotary]):
         """The rotary module / M-RoPE sections the batch's pending units were (and its next units will be) rotated
         with; units of different rotaries never share a flush."""
-        same_fn = b.rotary_emb_fn is rotary_emb_fn or (rot is not None and b.rot is rot)
+        same_fn = (b.rotary_emb_fn is rotary_emb_fn and b.rot is rot) or (rot is not None and b.rot is rot)
         if b.pending and (not same_fn or b.mrope_section != mrope_section):
             self._flush()
         b.rotary_emb_fn, b.rot = rotary_emb_fn, rot

@@ -468,6 +468,10 @@ class ShardedPivotKV:
         self._seen: List[int] = []
 
     def update(self, key_states, value_states, layer_idx, cache_kwargs):
+        """PivotKVCache.update on this rank's block.  NOT attention-ready: while the re-rotation is deferred the
+        returned keys are [un-rotated kept prefix | rotated current chunk] (the prefix takes its rotation in `finalize`,
+        once its final ids are known), so only the current chunk's rows of the returned K may be attended to - which is
+        all the sharded prefill does (scores are chunk-local, longvideo_cache.py:264)."""
         return self.cache.update(key_states, value_states, layer_idx, cache_kwargs)
 
     def update_pre_rope(self, *args, **kwargs):
@@ -524,10 +528,11 @@ class ShardedPivotKV:
         delta = table[dist.get_rank(self.group)]                                                   # [layers]
         sec = (C.c_int * len(mrope_section))(*mrope_section) if mrope_section else None
         nsec = len(mrope_section) if mrope_section else 0
-        if attention_scaling is None:
-            rot = cache._batch.rot if cache._batch is not None else None
-            attention_scaling = rot.scaling if rot is not None else float(getattr(cache._batch.rotary_emb_fn,
-                                                                                  "attention_scaling", 1.0))
+        if attention_scaling is None:   # (a cache that never saw a compressed update has no batch: plain RoPE scaling)
+            b = cache._batch
+            rot = b.rot if b is not None else None
+            attention_scaling = rot.scaling if rot is not None else float(
+                getattr(b.rotary_emb_fn if b is not None else None, "attention_scaling", 1.0))
         keys, values, pos = [], [], []
         with torch.cuda.device(dev):
             st = nv.stream()
