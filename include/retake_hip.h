@@ -557,7 +557,8 @@ typedef struct rtk_pivotkv_batch {
     const void** q_units;     /* HOST array [slots] or NULL.  Non-NULL entries of the pending slots: the unit's queries are
                                  scored where they are (RTK_UPDATE_Q_IN_PLACE; element strides below), all pending units alike */
     int64_t q_stride_h, q_stride_l;
-    int32_t pre_rope;         /* the pending units were appended from pre-RoPE projections: k~ == k0 */
+    int32_t pre_rope;         /* the pending units were appended from pre-RoPE projections: 1 k~ == k0 (pre-RoPE operands),
+                                 2 k~ = the reference's un-rotation of the rotated row (RTK_UPDATE_ROUNDTRIP); 0 otherwise */
     int32_t batched_passes;   /* 1: the score passes of all pending layers run from rtk_pivotkv_flush, one launch per kernel
                                  (16-bit payloads, head_dim 128); 0: rtk_pivotkv_update runs them per unit */
     int32_t* compact_sync;    /* zero-initialised sync workspace of rtk_pivotkv_compact_batched for (slots, Hkv, keep, D,
@@ -591,7 +592,14 @@ enum rtk_update_flags {
     /* with RTK_UPDATE_PRE_ROPE and q_rot != q: no copy of the queries is made - the score passes of the flush read
      * io->q itself (the caller keeps it alive and unmodified until rtk_pivotkv_flush has run; the library records the
      * pointer and strides in batch->q_units).  16-bit payloads scored by the batched passes only. */
-    RTK_UPDATE_Q_IN_PLACE = 2
+    RTK_UPDATE_Q_IN_PLACE = 2,
+    /* with RTK_UPDATE_PRE_ROPE (ABI 15): q~ / k~ are what the REFERENCE scores and re-rotates - the un-rotation
+     * ((x*cos) - (rotate_half(x)*sin)) / a^2 of the rotated rows this launch produced, one rounding of the model dtype
+     * per torch op (longvideo_cache.py:76-78, :248-259) - instead of the inputs themselves.  On a bf16 / fp16 model the
+     * round trip moves an operand by up to a few ulps, which is what the reference's scores and kept keys carry; with this
+     * flag the score operands and the kept keys equal the reference's bit for bit (tables within one fp32 ulp of the rotary
+     * module's).  Excludes RTK_UPDATE_Q_IN_PLACE; allows the reference-rounding score modes. */
+    RTK_UPDATE_ROUNDTRIP = 4
 };
 /* longvideo_cache.py:217-310 up to the deferred selection, for layer slot `slot`.  Rows go to the layer's tail
  * (ls->k/v + length rows; the caller has made sure length + L <= cap), ls->pending / pending_keep are set. */

@@ -356,7 +356,7 @@ def score_fp64(q, k, Hkv):
     return w.numpy()
 
 
-def gen_pivotkv(lc, outdir):
+def gen_pivotkv(lc, outdir, only=None):
     # name, Hq, Hkv, D, gh, gw, grids/chunk, chunks, ratio, reforge, mrope, a, mask_rate, seed, layer, raw
     S = synth.YARN_FACTOR4_ATTENTION_SCALING
     cases = [
@@ -381,7 +381,14 @@ def gen_pivotkv(lc, outdir):
         ("small_ratio1_mrope_reforge", 4, 2, 32, 4, 4, 4, 3, 1, True, [4, 6, 6], S, 0.3, 114, 0, True),
         ("small_ratio1_rope1d_noreforge", 4, 2, 32, 4, 4, 4, 2, 1, False, None, 1.0, 0.2, 115, 0, True),
         ("qwen_L576_ratio1", 28, 4, 128, 12, 12, 4, 2, 1, True, [16, 24, 24], S, 0.3, 116, 0, False),
+        # round 5: chunks over the L >= 512 gate of the attention prologue (PivotKVCache.update_pre_rope takes them), two
+        # chunks each, both RoPE flavours, and the synthetic headline geometry L = 6272
+        ("qwen_L1568", 28, 4, 128, 14, 14, 8, 2, 0.25, True, [16, 24, 24], S, 0.3, 117, 0, False),
+        ("llava_L1568", 28, 4, 128, 14, 14, 8, 2, 0.25, True, None, S, 0.3, 118, 0, False),
+        ("qwen_L6272", 28, 4, 128, 14, 14, 32, 1, 0.25, True, [16, 24, 24], S, 0.3, 119, 0, False),
     ]
+    if only:
+        cases = [c for c in cases if c[0] in only]
     for (name, Hq, Hkv, D, gh, gw, gpc, nch, ratio, reforge, mrope, a, mrate, seed, layer, raw) in cases:
         for attempt in range(50):
             sd = seed + 1000 * attempt
@@ -724,6 +731,125 @@ def gen_pivotkv_bf16(lc, outdir):
 
 
 # --------------------------------------------------------------------------------------
+# round 5: the reference's whole attention-side chain on a bf16 MODEL, from the bf16 PRE-RoPE projections: the rotary
+# module's tables rounded to bf16 (`.to(x.dtype)`), the reference's own apply_multimodal_rotary_pos_emb /
+# apply_rotary_pos_emb on bf16 tensors (longvideo_cache.py:35-116; what qwen2_vl.py:75-79 / llava_onevision.py:90-100
+# call), then PivotKVCache.update (:217-323).  Pins PivotKVCache.update_pre_rope - the route the build's own attention
+# patch takes - which is handed the same q0 / k0 and never sees the rotated tensors.
+# --------------------------------------------------------------------------------------
+def gen_pivotkv_prerope_bf16(lc, outdir):
+    S = synth.YARN_FACTOR4_ATTENTION_SCALING
+    M = [16, 24, 24]
+    # name, gh, gw, grids per chunk, chunks, ratio, mask rate, seed, raw, mrope
+    cases = [("prerope_bf16_qwen_L256", 8, 8, 4, 2, 0.25, 0.3, 231, True, M),
+             ("prerope_bf16_qwen_L1568", 14, 14, 8, 2, 0.25, 0.3, 232, False, M),
+             ("prerope_bf16_qwen_L6272", 14, 14, 32, 1, 0.25, 0.3, 233, False, M),
+             ("prerope_bf16_llava_L1568", 14, 14, 8, 2, 0.25, 0.3, 234, False, None)]
+    Hq, Hkv, D = 28, 4, 128
+    for (name, gh, gw, gpc, nch, ratio, mrate, seed, raw, mrope) in cases:
+        L = gpc * gh * gw
+        inv_f = synth.inv_freq(D, 1e6)
+        rotary = synth.RotaryStub(inv_f, S)
+        cache = lc.PivotKVCache(make_config(Hq, Hkv, D, 1, ratio, True, llava=(mrope is None)))
+        rec = dict(Hq=Hq, Hkv=Hkv, D=D, L=L, gh=gh, gw=gw, grids_per_chunk=gpc, n_chunks=nch, ratio=ratio, reforge=True,
+                   mrope_section=np.array(mrope if mrope else [], dtype=np.int64), attention_scaling=S, inv_freq=inv_f,
+                   seed=seed, layer=0, raw=raw, theta=1e6, dtype="bf16")
+        rng = np.random.default_rng(seed + 7)
+        captured = {}
+        orig_topk = torch.Tensor.topk
+
+        def spy_topk(self, *args, **kw):
+            captured["score"] = self.detach().clone()
+            return orig_topk(self, *args, **kw)
+
+        for c in range(nch):
+            q0, k0, v = (torch.from_numpy(a).bfloat16() for a in synth.qkv_chunk(seed * 100 + c, Hq, Hkv, L, D))
+            if mrope:
+                pos_in = torch.from_numpy(synth.mrope_position_ids(5 + c * gpc, gpc, gh, gw, hw0=5))
+            else:
+                pos_in = (torch.arange(L, dtype=torch.int64) + 5 + c * L)[None]
+            # the attention patch's continuity shift (qwen2_vl.py:68-73 / llava_onevision.py:78-88)
+            pos = pos_in.clone()
+            prev = cache.get_prev_temporal_idx(0)
+            cur = pos[0, 0, 0] if mrope else pos[0, 0]
+            if prev + 1 != cur:
+                if mrope:
+                    pos[0, 0, :] += prev + 1 - cur
+                else:
+                    pos[0, :] += prev + 1 - cur
+            cos, sin = rotary(v, pos)                      # bf16 tables, like HF's rotary module on a bf16 model
+            assert cos.dtype == torch.bfloat16
+            if mrope:
+                q, k = lc.apply_multimodal_rotary_pos_emb(q0, k0, cos, sin, list(mrope))
+            else:
+                q, k = lc.apply_rotary_pos_emb(q0, k0, cos, sin)
+            assert q.dtype == torch.bfloat16
+            mask = torch.from_numpy(rng.uniform(size=L) < mrate)
+            cache.keypatches_mask_chunk = mask
+            cache.kvcache_compression = True
+            kw = {"sin": sin, "cos": cos, "cache_position": None, "query_states": q, "position_ids": pos.clone(),
+                  "rotary_emb": rotary}
+            if mrope:
+                kw["mrope_section"] = list(mrope)
+            prev_len = 0 if not len(cache.key_cache) or len(cache.key_cache[0]) == 0 else cache.key_cache[0].shape[2]
+            torch.Tensor.topk = spy_topk
+            try:
+                cache.update(k, v, 0, kw)
+            finally:
+                torch.Tensor.topk = orig_topk
+            keep = max(1, int(ratio * L))
+            kept_k = cache.key_cache[0][:, :, prev_len:]
+            kept_v = cache.value_cache[0][:, :, prev_len:]
+            vb, kvb = bf16_bits(v), bf16_bits(kept_v)
+            idx = np.empty(keep, dtype=np.int64)        # kept rows are exact copies of V rows
+            look = {}
+            for i in range(L):
+                look.setdefault(vb[0, 0, i, :8].tobytes(), []).append(i)
+            for r in range(keep):
+                m = [i for i in look[kvb[0, 0, r, :8].tobytes()] if np.array_equal(vb[0, :, i], kvb[0, :, r])]
+                assert len(m) == 1
+                idx[r] = m[0]
+            assert (np.diff(idx) > 0).all()
+            score_ref = captured["score"]                  # bf16 [L], after masked_fill_
+            assert score_ref.dtype == torch.bfloat16
+            s64_pre = score_fp64(q0, k0, Hkv)              # the exact score of the PRE-RoPE operands (what the prologue scores)
+            # ... and of the reference's own round-tripped operands (its helper, its dtype)
+            if mrope:
+                qt, kt = lc.apply_multimodal_rotary_pos_emb(q, k, cos, sin, list(mrope), reverse=True, attention_scaling=S)
+            else:
+                qt, kt = lc.apply_rotary_pos_emb(q, k, cos, sin, reverse=True, attention_scaling=S)
+            s64_rt = score_fp64(qt, kt, Hkv)
+            pre = f"c{c}_"
+            rec[pre + "pos_in"] = pos_in.numpy()            # what the caller hands over ...
+            rec[pre + "pos"] = pos.numpy()                  # ... and what the reference rotates with
+            rec[pre + "mask"] = mask.numpy()
+            rec[pre + "score_bf16"] = bf16_bits(score_ref)
+            rec[pre + "score64_pre"] = s64_pre              # both before the mask override
+            rec[pre + "score64"] = s64_rt
+            rec[pre + "keep_idx"] = idx
+            rec[pre + "kept_k_bits"] = bf16_bits(kept_k)
+            rec[pre + "position_cache"] = cache.position_cache[0].numpy().copy()
+            rec[pre + "q_rot_crc"], rec[pre + "k_rot_crc"] = synth.checksum(bf16_bits(q)), synth.checksum(bf16_bits(k))
+            if raw:
+                rec[pre + "q0_bits"], rec[pre + "k0_bits"], rec[pre + "v_bits"] = bf16_bits(q0), bf16_bits(k0), vb
+            else:
+                rec[pre + "q0_crc"], rec[pre + "k0_crc"] = synth.checksum(bf16_bits(q0)), synth.checksum(bf16_bits(k0))
+                rec[pre + "v_crc"] = synth.checksum(vb)
+            sr = score_ref.float().numpy()
+            m_ = mask.numpy()
+            s64m = s64_pre.copy()
+            s64m[m_] = 1.0
+            exact = np.sort(np.lexsort((np.arange(L), -s64m))[:keep])
+            thr = np.sort(sr)[::-1][keep - 1]
+            print(f"pivotkv_{name} c{c}: L={L} keep={keep} kept-set overlap with exact pre-RoPE scoring "
+                  f"{np.intersect1d(idx, exact).size}/{keep}, ties at the threshold {int((sr == thr).sum())}, "
+                  f"max |score_bf16 - exact pre| {np.abs(sr - s64m).max():.4f}, "
+                  f"max |exact round-trip - exact pre| {np.abs(s64_rt - s64_pre).max():.2e}")
+        rec["keep"] = keep
+        np.savez_compressed(os.path.join(outdir, f"pivotkv_{name}.npz"), **rec)
+
+
+# --------------------------------------------------------------------------------------
 # fp16 (round 3): the reference run on float16 tensors - DPSelect and PivotKV.  Same recording as the bf16 fixtures;
 # 16-bit payloads are stored as their bit patterns.
 # --------------------------------------------------------------------------------------
@@ -859,6 +985,10 @@ def main():
         gen_pivotkv(lc, HERE)
     if args.only in (None, "pivotkv_bf16"):
         gen_pivotkv_bf16(lc, HERE)
+    if args.only == "pivotkv_r5":     # only the fp32 cases round 5 added (the others are unchanged)
+        gen_pivotkv(lc, HERE, only=("qwen_L1568", "llava_L1568", "qwen_L6272"))
+    if args.only in (None, "pivotkv_prerope_bf16"):
+        gen_pivotkv_prerope_bf16(lc, HERE)
     if args.only in (None, "glue"):
         gen_glue(HERE)
     if args.only in (None, "mallm"):

@@ -235,3 +235,62 @@ def fp16_ulp(x: np.ndarray) -> np.ndarray:
     """Spacing of fp16 numbers at |x| (normal range)."""
     e = np.floor(np.log2(np.maximum(np.abs(np.asarray(x, dtype=np.float64)), 2.0 ** -14)))
     return 2.0 ** (e - 10)
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 5: fixtures of the reference's whole attention-side chain on a bf16 model, from the bf16 PRE-RoPE projections
+# (gen_golden.py --only pivotkv_prerope_bf16)
+# ---------------------------------------------------------------------------------------------------
+def pivotkv_prerope_chunk_inputs(g, c: int):
+    """(q0, k0, v) as uint16 bf16 bit patterns [1,H,L,D] - the PRE-RoPE projections of a bf16 model -, pos_in (the ids the
+    caller hands to the attention layer), pos (after the continuity shift: what the reference rotates with), mask [L]."""
+    import torch
+
+    pre = f"c{c}_"
+    pos_in, pos, mask = g[pre + "pos_in"], g[pre + "pos"], g[pre + "mask"]
+    if bool(g["raw"]):
+        return g[pre + "q0_bits"], g[pre + "k0_bits"], g[pre + "v_bits"], pos_in, pos, mask
+    Hq, Hkv, D, L = (int(g[k]) for k in ("Hq", "Hkv", "D", "L"))
+
+    def bits(a):
+        return torch.from_numpy(a).bfloat16().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+    q0, k0, v = (bits(a) for a in synth.qkv_chunk(int(g["seed"]) * 100 + c, Hq, Hkv, L, D))
+    assert synth.checksum(q0) == int(g[pre + "q0_crc"]) and synth.checksum(k0) == int(g[pre + "k0_crc"])
+    assert synth.checksum(v) == int(g[pre + "v_crc"])
+    return q0, k0, v, pos_in, pos, mask
+
+
+def rotate_like_a_bf16_model(g, c: int, q0_bits: np.ndarray, k0_bits: np.ndarray):
+    """The rotated q, k a bf16 HF model hands to PivotKVCache.update (uint16 bits): the rotary module's tables rounded to
+    bf16, then (x*cos) + (rotate_half(x)*sin) with one bf16 rounding per torch op (longvideo_cache.py:68-81 / :109-114).
+    Verified against the crc of the tensors the reference's own helper produced at generation time."""
+    import torch
+
+    pre = f"c{c}_"
+    pos = torch.from_numpy(g[pre + "pos"])
+    sec = [int(s) for s in g["mrope_section"]]
+    rotary = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]))
+
+    def bf(bits):
+        return torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16)
+
+    q0, k0 = bf(q0_bits), bf(k0_bits)
+    cos, sin = rotary(k0, pos)
+    if sec:
+        s2 = sec * 2
+        cos = torch.cat([m[i % 3] for i, m in enumerate(cos.split(s2, dim=-1))], dim=-1).unsqueeze(1)
+        sin = torch.cat([m[i % 3] for i, m in enumerate(sin.split(s2, dim=-1))], dim=-1).unsqueeze(1)
+    else:
+        cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
+
+    def rot_half(x):
+        h = x.shape[-1] // 2
+        return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+    out = []
+    for x, name in ((q0, "q_rot_crc"), (k0, "k_rot_crc")):
+        y = ((x * cos) + (rot_half(x) * sin)).contiguous().view(torch.int16).numpy().view(np.uint16)
+        assert synth.checksum(y) == int(g[pre + name]), "restated bf16 rotation differs from the reference helper's output"
+        out.append(y)
+    return out[0], out[1]

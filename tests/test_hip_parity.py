@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 DP_FP32 = [n for n in gu.names("dpselect_") if "edge" not in n and "bf16" not in n and "fp16" not in n]
 DP_BF16 = [n for n in gu.names("dpselect_") if "bf16" in n]
 DP_FP16 = [n for n in gu.names("dpselect_") if "fp16" in n]
-PK = [n for n in gu.names("pivotkv_") if not n.startswith(("pivotkv_bf16_", "pivotkv_fp16_"))]
+PK = [n for n in gu.names("pivotkv_") if not n.startswith(("pivotkv_bf16_", "pivotkv_fp16_", "pivotkv_prerope_"))]
 
 
 def dev():

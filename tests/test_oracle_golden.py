@@ -14,7 +14,7 @@ from oracle import oracle as orc
 DP_FP32 = [n for n in gu.names("dpselect_") if "edge" not in n and "bf16" not in n and "fp16" not in n]
 DP_BF16 = [n for n in gu.names("dpselect_") if "bf16" in n]
 DP_FP16 = [n for n in gu.names("dpselect_") if "fp16" in n]
-PK = [n for n in gu.names("pivotkv_") if not n.startswith(("pivotkv_bf16_", "pivotkv_fp16_"))]
+PK = [n for n in gu.names("pivotkv_") if not n.startswith(("pivotkv_bf16_", "pivotkv_fp16_", "pivotkv_prerope_"))]
 
 
 @pytest.mark.parametrize("name", DP_FP32)
@@ -188,6 +188,37 @@ def test_pivotkv_bf16_chain_matches_reference(name):
     kk = (np.ascontiguousarray(last["kept_k"]).view(np.uint32) >> 16).astype(np.uint16)
     nbad, nxor, a, b = check_bf16_against_reference(g, 0, last["score"], last["keep_idx"], kk, last["pos"], "oracle")
     np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", gu.names("pivotkv_prerope_bf16_"))
+def test_pivotkv_bf16_chain_from_pre_rope_projections_matches_reference(name):
+    """Round-5 fixtures: the reference run on a bf16 model FROM the bf16 pre-RoPE projections (its rotation helper in bf16,
+    then PivotKVCache.update).  The oracle is handed the rotated tensors - the rotation restated with torch's bf16 ops and
+    crc-pinned to the tensors the reference's own helper produced - every chunk, both RoPE flavours: scores equal the
+    reference's bf16 scores up to isolated 1-ulp entries, kept set equal up to exact ties, kept K bit-exact, ids exact."""
+    g = gu.load(name)
+    Hq, Hkv, D, L = (int(g[k]) for k in ("Hq", "Hkv", "D", "L"))
+    if L > 2000 and orc.num_threads() < 4:
+        pytest.skip("L = 6272 needs a few cores")
+    sec = [int(x) for x in g["mrope_section"]] or None
+    rot = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]))
+    oc = orc.OraclePivotKV(Hq, Hkv, D, float(g["ratio"]), True, bf16=True)
+    for c in range(int(g["n_chunks"])):
+        q0, k0, v, pos_in, pos, mask = gu.pivotkv_prerope_chunk_inputs(g, c)
+        q, k = gu.rotate_like_a_bf16_model(g, c, q0, k0)
+        prev = oc.get_prev_temporal_idx(0)
+        shifted = pos_in.copy()
+        shifted[0, ..., :] += prev + 1 - shifted.reshape(-1)[0]          # the attention patch's continuity shift
+        np.testing.assert_array_equal(shifted, pos)
+        oc.keypatches_mask_chunk = mask
+        oc.update(orc.bf16_bits_to_f32(k), orc.bf16_bits_to_f32(v), 0, q=orc.bf16_bits_to_f32(q), position_ids=pos,
+                  rotary=rot, mrope_section=sec)
+        last = oc.last
+        kk = (np.ascontiguousarray(last["kept_k"]).view(np.uint32) >> 16).astype(np.uint16)
+        nbad, nxor, a, b = check_bf16_against_reference(g, c, last["score"], last["keep_idx"], kk, last["pos"], "oracle")
+        np.testing.assert_array_equal(a, b)
+        if nxor:
+            break   # later chunks depend on which tied tokens were kept
 
 
 def test_topk_ties_lowest_index_first():

@@ -114,18 +114,23 @@ def test_one_call_update_and_flush_equal_the_staged_route(dtype, ratio):
     assert torch.equal(last_one[1], last_staged[1])
 
 
+@pytest.mark.parametrize("operands", ["reference", "pre_rope"])
 @pytest.mark.parametrize("mrope", [True, False])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
-def test_prologue_outputs_bitwise(dtype, mrope):
+def test_prologue_outputs_bitwise(dtype, mrope, operands):
     """update_pre_rope on two chunks x two layers: the rotated queries, the cache tail, the ids and the scoring operands
     are bit for bit what torch computes op by op (one rounding per op, like the reference's eager chain) from the
     kernels' own tables: q_rot = (q0*cos) + (rotate_half(q0)*sin) over the shifted ids; tail K the same of k0, tail V = v0;
-    q~ = q0 and k~ = k0; the caller's ids are shifted in place by the flush (Qwen2-VL) or left alone (LLaVA)."""
+    the caller's ids are shifted in place by the flush (Qwen2-VL) or left alone (LLaVA).  Scoring operands:
+      prologue_operands="reference" (default)  q~, k~ = ((x*cos) - (rotate_half(x)*sin)) / a**2 of the ROTATED rows, the
+                                               un-rotation the reference applies (longvideo_cache.py:76-78) in the model dtype;
+      prologue_operands="pre_rope"             q~ = q0 and k~ = k0 (queries scored where they lie when q_rot goes elsewhere)."""
     import retake.longvideo_cache as lc
 
     layers, L = 2, 640
     rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
-    cache = lc.build_kvcache(cfg(layers))
+    cache = lc.build_kvcache(cfg(layers, prologue_operands=operands))
+    assert lc.build_kvcache(cfg(layers)).prologue_operands == "reference"
     sec = SEC if mrope else None
     es = 4 if dtype == torch.float32 else 2
     for c in range(2):
@@ -145,7 +150,7 @@ def test_prologue_outputs_bitwise(dtype, mrope):
                                         query_out=q0 if l == 0 else None)
             assert out is not None, "the prologue declined a plain video chunk"
             q_rot, K, V = out
-            in_place_scoring = l == 1 and dtype != torch.float32
+            in_place_scoring = l == 1 and dtype != torch.float32 and operands == "pre_rope"
             assert (q_rot.data_ptr() != q0.data_ptr()) == in_place_scoring and K.shape[2] == P0 + L
             assert not in_place_scoring or (torch.equal(q0, q_keep) and cache._batch.q_keep[l] is q0)
             want_ids = pos_in.clone()
@@ -160,10 +165,17 @@ def test_prologue_outputs_bitwise(dtype, mrope):
             assert torch.equal(K[:, :, P0:], want_k) and torch.equal(V[:, :, P0:], v0)
             b = cache._batch
             assert torch.equal(b.pos_old[l].reshape(want_ids.shape), want_ids)
-            assert torch.equal(b.k_unrot[l], k_keep[0])
+            if operands == "reference":   # torch's own un-rotation of the rotated rows, op by op in the tensor dtype
+                # (the division on the CPU, the parity platform: ATen's device kernel multiplies by the reciprocal of a
+                # scalar divisor instead, which rounds differently in fp32 - the fixtures carry the CPU's true division)
+                want_qt = (((want_q * cos) - (rot_half(want_q) * sin)).cpu() / A ** 2).to(dev())
+                want_kt = (((want_k * cos) - (rot_half(want_k) * sin)).cpu() / A ** 2).to(dev())
+            else:
+                want_qt, want_kt = q_keep, k_keep
+            assert torch.equal(b.k_unrot[l], want_kt[0])
             if not in_place_scoring:
                 ws = b.score_ws[(b.score_ws_base - b.score_ws.data_ptr()) + l * b.ws_stride:][: Hq * L * D * es]
-                assert torch.equal(ws.view(dtype).view(Hq, L, D), q_keep[0])
+                assert torch.equal(ws.view(dtype).view(Hq, L, D), want_qt[0])
             assert torch.equal(pos, pos_in), "the caller's ids move at the flush, not before"
         last_prev = cache.get_prev_temporal_idx(layers - 1)   # (flushes: read it the way the reference would, then undo)
         cache.after_forward()
@@ -219,15 +231,18 @@ def test_prologue_cache_against_oracle_fp32(L):
     assert fragile < 2, "both chunks had a fragile k-th boundary: pick another seed"
 
 
-def test_prologue_keep_all_leaves_the_appended_rows():
-    """compression_ratio 1 through the prologue: nothing is scored, staged or copied - the cache holds the rotated keys
-    and the values the append wrote, and the (shifted) ids; the staged route builds the same ids / values and keys that
-    differ only by the rounding of the reference's un-rotate / re-rotate round trip."""
+@pytest.mark.parametrize("operands", ["reference", "pre_rope"])
+def test_prologue_keep_all_leaves_the_appended_rows(operands):
+    """compression_ratio 1 through the prologue: nothing is scored or staged - the cache holds the values the append
+    wrote and the (shifted) ids.  Keys: with pre-RoPE operands the rotated rows the append wrote stay (they differ from the
+    staged route's only by the rounding of the reference's un-rotate / re-rotate round trip); with the reference's
+    operands (default) the kept keys ARE that round trip - equal to the staged route's up to the rare table entry where the
+    rotary module's sin / cos and the kernel's correctly rounded ones land on different bf16 values."""
     import retake.longvideo_cache as lc
 
     layers, L, dtype = 2, 640, torch.bfloat16
     rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
-    cache = lc.build_kvcache(cfg(layers, 1))
+    cache = lc.build_kvcache(cfg(layers, 1, prologue_operands=operands))
     eager = lc.build_kvcache(cfg(layers, 1, one_call_update=False))
     for c in range(2):
         pos, pos_e = chunk_ids(c, L), chunk_ids(c, L)
@@ -253,12 +268,15 @@ def test_prologue_keep_all_leaves_the_appended_rows():
         # the round trip mixes a channel with its rotation partner: its bf16 roundings scale with the pair's norm
         pair = (b[..., : D // 2] ** 2 + b[..., D // 2:] ** 2).sqrt()
         assert ((a - b).abs() <= 2.0 ** -5 * torch.cat((pair, pair), -1).clamp_min(1e-3)).all()
+        if operands == "reference":
+            assert (a != b).float().mean().item() < 1e-3, (a != b).float().mean().item()
     assert cache.last_scores is None
 
 
 def test_prologue_declines_what_it_cannot_serve():
     """None - and nothing touched - for text segments (compression off), small chunks, rotary modules that have to be
-    called, CPU tensors and score_rounding='reference'."""
+    called, CPU tensors and score_rounding='reference' on pre-RoPE operands (the reference's rounding chain scores the
+    reference's operands: with prologue_operands='reference' it is served, see the bf16 fixture test)."""
     import retake.longvideo_cache as lc
 
     rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
@@ -271,7 +289,8 @@ def test_prologue_declines_what_it_cannot_serve():
 
     L = 640
     pos = chunk_ids(0, L)
-    for kw, rotary, n in (({}, rot, 128), ({}, Opaque(), L), ({"score_rounding": "reference"}, rot, L),
+    for kw, rotary, n in (({}, rot, 128), ({}, Opaque(), L),
+                          ({"score_rounding": "reference", "prologue_operands": "pre_rope"}, rot, L),
                           ({"native_rope": False}, rot, L)):
         cache = lc.build_kvcache(cfg(1, **kw))
         q0, k0, v0 = projections(1, n, torch.bfloat16)
@@ -461,7 +480,7 @@ def test_queries_scored_in_place_equal_the_packed_copy(dtype, L):
 
     layers = 3
     rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
-    zc, packed = lc.build_kvcache(cfg(layers)), lc.build_kvcache(cfg(layers))
+    zc, packed = (lc.build_kvcache(cfg(layers, prologue_operands="pre_rope")) for _ in range(2))
     for c in range(2):
         mask = torch.from_numpy(np.random.default_rng(c).uniform(size=L) < 0.3).to(dev())
         pz, pp = chunk_ids(c, L), chunk_ids(c, L)
@@ -495,7 +514,7 @@ def test_in_place_and_packed_queries_mixed_within_a_chunk():
 
     layers, L, dtype = 4, 640, torch.bfloat16
     rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
-    mixed, packed = lc.build_kvcache(cfg(layers)), lc.build_kvcache(cfg(layers))
+    mixed, packed = (lc.build_kvcache(cfg(layers, prologue_operands="pre_rope")) for _ in range(2))
     pattern = [True, False, False, True]     # in place / packed per layer
     for c in range(2):
         pz, pp = chunk_ids(c, L), chunk_ids(c, L)
@@ -681,3 +700,246 @@ def test_native_rope_snapshot_follows_the_rotary_module():
         cos, sin = native_tables(want_ids, rot, dtype)
         assert torch.equal(out[0], (qk * cos) + (rot_half(qk) * sin)), change
         cache.after_forward()
+
+
+# ---------------------------------------------------------------------------------------------------
+# The route the product's own attention patch takes (update_pre_rope on the PRE-RoPE projections) against the REFERENCE:
+#   * its fp32 goldens (the reference was handed the rotated tensors; here the library gets q0 / k0 of the same seed), and
+#   * its own run on a bf16 model from the same bf16 q0 / k0 (fixtures pivotkv_prerope_bf16_*: the reference's rotation
+#     helper on bf16 tensors, then PivotKVCache.update, longvideo_cache.py:35-116, :217-323).
+# ---------------------------------------------------------------------------------------------------
+import golden_util as gu  # noqa: E402
+
+PK_PROLOGUE = [n for n in gu.names("pivotkv_") if not n.startswith(("pivotkv_bf16_", "pivotkv_fp16_", "pivotkv_prerope_"))
+               and int(gu.load(n)["L"]) >= 512 and bool(gu.load(n)["reforge"]) and not bool(gu.load(n)["tie_case"])]
+
+
+def _fixture_cache(g, n_layers, **extra):
+    import retake.longvideo_cache as lc
+
+    Hq_, Hkv_, D_ = (int(g[k]) for k in ("Hq", "Hkv", "D"))
+    kw = {"compression_ratio": float(g["ratio"]), "compression_method": "pivotkv", "pos_embed_reforge": True}
+    kw.update(extra)
+    llm = types.SimpleNamespace(hidden_size=Hq_ * D_, num_hidden_layers=n_layers, num_attention_heads=Hq_,
+                                num_key_value_heads=Hkv_)
+    lk = {"kvcache_compression": True, "kvcache_compression_kwargs": kw}
+    if len(g["mrope_section"]) == 0:      # LLaVA: the LLM's config sits under text_config (longvideo_cache.py:124)
+        return lc.build_kvcache(types.SimpleNamespace(text_config=llm, longvideo_kwargs=lk))
+    llm.longvideo_kwargs = lk
+    return lc.build_kvcache(llm)
+
+
+def _as_projection(x: torch.Tensor) -> torch.Tensor:
+    """[1, H, L, D] values in the memory layout q_proj / k_proj / v_proj leave: [1, L, H*D], viewed [1, H, L, D]."""
+    return x.transpose(1, 2).contiguous().transpose(1, 2)
+
+
+@pytest.mark.parametrize("name", PK_PROLOGUE)
+def test_reference_fp32_goldens_through_the_prologue(name):
+    """Every fp32 golden whose chunks the prologue serves (L >= 512, reforging), all its chunks: update_pre_rope on the
+    q0 / k0 the fixture's rotated inputs were made from -> kept indices bit-exact, kept V and ids exact, kept K within
+    1e-5, scores within 5e-6 of the reference's - the same bars the reference-protocol route meets (test_hip_parity)."""
+    g = gu.load(name)
+    Hq_, Hkv_, D_, L, keep, layer = (int(g[k]) for k in ("Hq", "Hkv", "D", "L", "keep", "layer"))
+    sec = [int(s) for s in g["mrope_section"]] or None
+    cache = _fixture_cache(g, layer + 1)
+    rot = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]), device=dev())
+    for c in range(int(g["n_chunks"])):
+        pre = f"c{c}_"
+        q0, k0, v = synth.qkv_chunk(int(g["seed"]) * 100 + c, Hq_, Hkv_, L, D_)
+        mask = g[pre + "mask"]
+        cache.keypatches_mask_chunk = torch.from_numpy(mask).to(dev()) if mask.size else None
+        cache.kvcache_compression = True
+        # the fixture stores the ids after the attention patch's continuity shift; the prologue's own shift of them is 0
+        ids = torch.from_numpy(g[pre + "pos"]).to(dev())
+        out = cache.update_pre_rope(_as_projection(torch.from_numpy(q0).to(dev())), _as_projection(torch.from_numpy(k0).to(dev())),
+                                    _as_projection(torch.from_numpy(v).to(dev())), layer, ids, rot, sec,
+                                    shift_ids_in_place=sec is not None)
+        assert out is not None, "the prologue declined a golden chunk"
+        assert torch.equal(cache._batch.pos_old[layer].reshape(ids.shape), torch.from_numpy(g[pre + "pos"]).to(dev()))
+        score = None if cache._batch.keep_all else cache.last_scores.cpu().numpy()
+        idx = cache.last_keep_indices.cpu().numpy()
+        cache.after_forward()
+        if score is not None:
+            assert np.abs(score - g[pre + "score32"]).max() < 5e-6 and np.abs(score - g[pre + "score64"]).max() < 5e-6
+        np.testing.assert_array_equal(idx, g[pre + "keep_idx"])
+        kk = cache.key_cache[layer][:, :, -keep:].cpu().numpy()
+        err = np.abs(kk - g[pre + "kept_k"]).max()
+        assert err <= 1e-5, err
+        assert synth.checksum(cache.value_cache[layer][:, :, -keep:].cpu().numpy()) == int(g[pre + "kept_v_crc"])
+        np.testing.assert_array_equal(cache.position_cache[layer].cpu().numpy(), g[pre + "position_cache"])
+        assert cache.num_evicted_tokens[layer] == int(g[pre + "num_evicted"])
+        print(f"\n[{name} c{c}] prologue route: indices exact, max |K - reference| {err:.2e}")
+
+
+def _bf(bits):
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(torch.bfloat16)
+
+
+@pytest.mark.parametrize("mode", ["reference/fp32", "reference/reference", "pre_rope/fp32"])
+@pytest.mark.parametrize("name", gu.names("pivotkv_prerope_bf16_"))
+def test_prologue_bf16_against_the_reference_run_from_pre_rope_projections(name, mode):
+    """Production dtype, the route the product's attention patch takes.  The reference was run on a bf16 model's tensors:
+    bf16 q0 / k0 -> its rotation helper in bf16 -> PivotKVCache.update (un-rotation, bf16 logits / probabilities / sums,
+    topk, re-rotation).  update_pre_rope gets the same q0 / k0 / v and unshifted ids, three layers per chunk, every chunk:
+      ids      the shifted ids equal the reference's; the new ids of the kept tokens equal its position cache;
+      q_rot    equals the reference helper's bf16 rotation except where a table entry's fp32 value straddles a bf16
+               midpoint (correctly rounded vs libm sin / cos); counted;
+      kept V   exact copies of the rows the product's indices name.
+    mode = prologue_operands / score_rounding:
+      reference/fp32 (the DEFAULT)  operands = the reference's round-tripped q~ / k~; scores fp32-accurate on them (within
+               2e-5 of their exact score); every token the kept sets disagree on has a reference score within ONE bf16 ulp of
+               the reference's threshold (the quantisation its own scores carry); kept K bit-exact where ids agree;
+      reference/reference           + the reference's bf16 rounding chain: scores equal its bf16 scores up to isolated 1-ulp
+               entries, kept set equal up to exact ties (test_oracle_golden.check_bf16_against_reference);
+      pre_rope/fp32 (opt-in)        operands = q0 / k0: scores within 2e-5 of THEIR exact score, which differs from the
+               round-tripped operands' by up to E ~ 2e-2 (6 bf16 ulps): a token may change sides only if its reference
+               score lies within 2E of the reference's threshold (order statistics are 1-Lipschitz); counted; kept K is one
+               rotation of k0 - compared in bf16 ulps and against the exact rotation (closer than the reference's)."""
+    import test_oracle_golden as tog
+
+    operands, rounding = mode.split("/")
+    g = gu.load(name)
+    if int(g["L"]) < 512 and operands == "pre_rope":
+        pytest.skip("chunks under the prologue's gate take the op-by-op route: the reference's operands whatever the option")
+    Hq_, Hkv_, D_, L, keep = (int(g[k]) for k in ("Hq", "Hkv", "D", "L", "keep"))
+    sec = [int(s) for s in g["mrope_section"]] or None
+    a_scale = float(g["attention_scaling"])
+    n_layers = 3
+    cache = _fixture_cache(g, n_layers, prologue_operands=operands, score_rounding=rounding)
+    rot = synth.RotaryStub(g["inv_freq"], a_scale, device=dev())
+    # measured on MI355X (profiles/r14_parity_stats.txt); the bars are twice the measurement (at least 2)
+    XOR_BAR = {"reference": {256: 2, 1568: 12, 6272: 48}, "pre_rope": {256: 4, 1568: 24, 6272: 80}}[operands][L]
+    for c in range(int(g["n_chunks"])):
+        pre = f"c{c}_"
+        q0b, k0b, vb, pos_in, pos, mask = gu.pivotkv_prerope_chunk_inputs(g, c)
+        q0, k0, v = (_as_projection(_bf(x).to(dev())) for x in (q0b, k0b, vb))
+        cache.keypatches_mask_chunk = torch.from_numpy(mask).to(dev())
+        cache.kvcache_compression = True
+        ids = torch.from_numpy(pos_in).to(dev())
+        q_rots = []
+        for l in range(n_layers):
+            ql = q0.clone()     # (the rotated queries may be written over the projection, as in the model)
+            out = cache.update_pre_rope(ql, k0, v, l, ids, rot, sec, shift_ids_in_place=sec is not None)
+            if L < 512:
+                # chunks below the prologue's gate: the patch's op-by-op route (qwen2_vl.py:68-86 as the build restates it in
+                # retake/qwen2_vl.py:_qkv_and_cache_update) - id shift on the device, rotary module, the rotation helper, update
+                assert out is None
+                import retake.longvideo_cache as lc
+
+                cache.shift_temporal_ids_(ids, l)
+                cos, sin = rot(v, ids)
+                qr, kr = lc.apply_multimodal_rotary_pos_emb(ql, k0, cos, sin, sec) if sec else lc.apply_rotary_pos_emb(ql, k0, cos, sin)
+                cache.update(kr, v, l, {"query_states": qr, "position_ids": ids, "rotary_emb": rot, "mrope_section": sec})
+                q_rots.append(qr)
+                continue
+            assert out is not None, "the prologue declined a fixture chunk"
+            q_rots.append(out[0])
+        b = cache._batch
+        assert b.batched_passes == (L >= 512) and len(b.pending) == n_layers
+        want_ids = torch.from_numpy(pos).to(dev())
+        for l in range(n_layers):
+            shifted = b.pos_old[l].reshape(want_ids.shape) if L >= 512 else ids   # (small chunks: shifted in place, eagerly)
+            assert torch.equal(shifted, want_ids), "continuity shift differs from the reference's"
+        cache.after_forward()
+        # --- rotated queries against the reference helper's (restated on the CPU, crc-pinned to the generator's tensors)
+        qr_ref, _ = gu.rotate_like_a_bf16_model(g, c, q0b, k0b)
+        qr = q_rots[0].cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+        n_q = int((qr != qr_ref).sum())
+        dq = np.abs(orc.bf16_bits_to_f32(qr) - orc.bf16_bits_to_f32(qr_ref))
+        assert (dq <= gu.bf16_ulp(orc.bf16_bits_to_f32(qr_ref))).all() and n_q <= max(8, qr.size // 20000)
+        ref = orc.bf16_bits_to_f32(g[pre + "score_bf16"])
+        ref_idx = g[pre + "keep_idx"]
+        thr = np.sort(ref)[::-1][keep - 1]
+        ref_pos = g[pre + "position_cache"][..., -keep:].reshape(-1, keep)
+        s64 = g[pre + ("score64" if operands == "reference" else "score64_pre")].copy()
+        s64[mask] = 1.0
+        E = np.abs(ref - s64).max()      # how far the reference's bf16 scores are from the exact score of these operands
+        for l in range(n_layers):
+            score = b.score[l].cpu().numpy()
+            idx = b.keep_idx[l].cpu().numpy()
+            vv = cache.value_cache[l][:, :, -keep:].cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+            assert np.array_equal(vv[0], vb[0][:, idx])
+            pos_new = cache.position_cache[l][..., -keep:].cpu().numpy().reshape(-1, keep)
+            kk = cache.key_cache[l][:, :, -keep:].cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+            xor = np.setxor1d(idx, ref_idx)
+            # the new ids are the reference's formula on the product's own kept set (longvideo_cache.py:283-295): gather, then
+            # on the temporal row t' = tmin + trunc((t - tmin) * float32(keep / L)), fp32 multiply
+            pk = pos.reshape(-1, L)[:, idx].copy()
+            pk[0] = pk[0].min() + ((pk[0] - pk[0].min()).astype(np.float32) * np.float32(keep / L)).astype(np.int64)
+            np.testing.assert_array_equal(pos_new, pk)
+            # (plain-RoPE ids are one per token: tmin is the id of the FIRST kept token, so a kept set that differs there
+            # moves every new id - then only the sets are comparable with the reference's, not ids / keys)
+            same_tmin = pos.reshape(-1, L)[0, idx].min() == pos.reshape(-1, L)[0, ref_idx].min()
+            if l:   # identical inputs: identical layers, bit for bit
+                assert torch.equal(b.score[l], b.score[0]) and torch.equal(cache.key_cache[l], cache.key_cache[0])
+            if rounding == "reference" and not same_tmin:
+                assert (score != ref).sum() <= 4 and (np.abs(ref[xor] - thr) <= gu.bf16_ulp(np.full(xor.size, thr))).all()
+                print(f"\n[{name} c{c}] {mode}: kept xor {xor.size} (ties) includes the first kept token: new ids not comparable")
+                continue
+            if rounding == "reference":
+                nbad, nxor, a, bb = tog.check_bf16_against_reference(g, c, score, idx, kk, pos_new, "prologue, reference rounding",
+                                                                     max_bad={256: 1, 1568: 2, 6272: 4}.get(L))
+                np.testing.assert_array_equal(a, bb)
+                if l == 0:
+                    print(f"\n[{name} c{c}] {mode}: {nbad} of {L} scores differ from the reference's by one bf16 ulp, kept xor {nxor} "
+                          f"(ties), kept K bit-exact; q_rot: {n_q} of {qr.size} entries differ by one bf16 ulp")
+                continue
+            err = np.abs(score - s64).max()
+            assert err < 2e-5, err
+            if operands == "reference":
+                assert (np.abs(ref[xor] - thr) <= gu.bf16_ulp(np.full(xor.size, thr))).all(), \
+                    "kept sets differ beyond the reference's own score quantisation"
+            else:
+                assert (np.abs(ref[xor] - thr) <= 2 * E + 4e-5).all(), "a token changed sides farther from the threshold than 2E"
+            assert xor.size <= XOR_BAR, (xor.size, XOR_BAR)
+            common, ia, ib = np.intersect1d(idx, ref_idx, return_indices=True)
+            same_pos = (pos_new[:, ia] == ref_pos[:, ib]).all(0)
+            if not same_tmin:
+                print(f"\n[{name} c{c}] {mode}: {xor.size // 2} of {keep} kept tokens differ (xor {xor.size}), the first kept token among "
+                      f"them: new ids not comparable with the reference's")
+                continue
+            assert same_pos.mean() > 0.9
+            if xor.size == 0:
+                np.testing.assert_array_equal(pos_new, ref_pos)
+            mine_bits = kk[0][:, ia[same_pos]]
+            theirs_bits = g[pre + "kept_k_bits"][0][:, ib[same_pos]]
+            if operands == "reference":
+                np.testing.assert_array_equal(mine_bits, theirs_bits)
+                if l == 0:
+                    print(f"\n[{name} c{c}] {mode} (product default): {xor.size // 2} of {keep} kept tokens differ (xor {xor.size}), all "
+                          f"within one bf16 ulp of the reference's threshold {thr}; max |score - exact| {err:.2e}; kept K of "
+                          f"{int(same_pos.sum())} common tokens bit-exact; q_rot: {n_q} of {qr.size} entries differ by one bf16 ulp")
+                continue
+            mine = orc.bf16_bits_to_f32(mine_bits).astype(np.float64)
+            theirs = orc.bf16_bits_to_f32(theirs_bits).astype(np.float64)
+            # exact: a * (k0 * cos + rotate_half(k0) * sin) at the new ids, fp64 tables
+            k0f = orc.bf16_bits_to_f32(k0b)[0].astype(np.float64)                     # [Hkv, L, D]
+            inv = g["inv_freq"].astype(np.float64)
+            tok = common[same_pos]
+            pn = ref_pos[:, ib[same_pos]].astype(np.float64)                       # [P, n]
+            if sec:
+                rows = np.concatenate([np.full(sz, i % 3) for i, sz in enumerate(sec * 2)])[: D_ // 2]
+                ang = pn[rows].T * inv[None, :]                                    # [n, D/2]: the id row of the channel's section
+            else:
+                ang = pn[0][:, None] * inv[None, :]
+            cosx, sinx = np.cos(ang) * a_scale, np.sin(ang) * a_scale
+            x = k0f[:, tok]                                                       # [Hkv, n, D]
+            x1, x2 = x[..., : D_ // 2], x[..., D_ // 2:]
+            exact = np.concatenate([x1 * cosx - x2 * sinx, x2 * cosx + x1 * sinx], -1)
+            e_mine, e_theirs = np.abs(mine - exact).mean(), np.abs(theirs - exact).mean()
+            # a rotation mixes a channel with its partner: the roundings scale with the pair's norm, not the element's value
+            pair = np.sqrt(x1 ** 2 + x2 ** 2) * a_scale
+            ulp = gu.bf16_ulp(np.maximum(np.concatenate([pair, pair], -1), 2.0 ** -6).astype(np.float32))
+            worst = (np.abs(mine - theirs) / ulp).max()
+            frac_equal = (mine == theirs).mean()
+            assert e_mine <= e_theirs, (e_mine, e_theirs)
+            assert worst <= 8.0, worst
+            if l == 0:
+                far = int((np.abs(ref[xor] - thr) > gu.bf16_ulp(np.full(xor.size, thr))).sum())
+                print(f"\n[{name} c{c}] {mode} (opt-in): {xor.size // 2} of {keep} kept tokens differ (xor {xor.size}; {far} of them "
+                      f"farther than one bf16 ulp from the reference's threshold {thr}, all within 2E = {2 * E:.3f}); max |score - "
+                      f"exact pre-RoPE| {err:.2e}; kept K of {int(same_pos.sum())} common tokens: {100 * frac_equal:.1f} % bit-equal, "
+                      f"worst {worst:.1f} bf16 ulp (of the pair norm) apart, mean |K - exact| {e_mine:.3e} (prologue) vs {e_theirs:.3e} (reference)")
+        if not torch.equal(cache.position_cache[0][..., -1:].cpu(), torch.from_numpy(g[pre + "position_cache"][..., -1:])):
+            break   # the next chunk's continuity shift starts from another id than the reference's did

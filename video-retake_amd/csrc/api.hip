@@ -109,20 +109,19 @@ extern "C" int rtk_profile_read(int kid, long long* count, double* total_ms) {
 
 // ---- calibration copy for the HBM rooflines ------------------------------------------------------------
 namespace rtk {
-// dst[i] = src[i] over 16-byte vectors, non-temporal on both sides (no L2 / MALL residue between repetitions), four
-// independent vectors in flight per thread: the "float4 copy" MI355X_MICROARCH.md quotes 6.29 TB/s for.
+// dst[i] = src[i] over 16-byte vectors, non-temporal on both sides (no L2 / MALL residue between repetitions).  One
+// workgroup = ONE contiguous 16 KiB piece (4 vectors per thread, a wave's four loads 1 KiB apart), no loop: measured
+// 6.26 TB/s on a 2 GiB buffer (tools/ubench/copy_variants.hip, profiles/r14_copy_variants.txt) - the guide's 6.29 TB/s
+// "float4 copy".  The round-4 form (grid-strided, a thread's four vectors a whole grid = 32 MiB apart) reached 4.9-5.2.
 __global__ __launch_bounds__(256) void copy_nt_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
-                    c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i);
-        __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride);
-        __builtin_nontemporal_store(d, dst + i + 3 * stride);
-    }
-    for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    const size_t c = (size_t)blockIdx.x * (4 * 256) + threadIdx.x;
+    u32x4 buf[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (c + (size_t)u * 256 < n) buf[u] = __builtin_nontemporal_load(src + c + (size_t)u * 256);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (c + (size_t)u * 256 < n) __builtin_nontemporal_store(buf[u], dst + c + (size_t)u * 256);
 }
 }  // namespace rtk
 
@@ -131,13 +130,14 @@ extern "C" int rtk_profile_copy(void* dst, const void* src, size_t bytes, rtk_st
                   "rtk_profile_copy: 16-byte aligned buffers of a multiple of 16 bytes");
     if (bytes == 0) return RTK_OK;
     const size_t n = bytes / 16;
-    const unsigned grid = (unsigned)std::min<size_t>((n + 4 * 256 - 1) / (4 * 256), 256 * 32);
+    RTK_CHECK_ARG((n + 4 * 256 - 1) / (4 * 256) <= 0x7fffffffu, "rtk_profile_copy: buffer too large for one launch");
+    const unsigned grid = (unsigned)((n + 4 * 256 - 1) / (4 * 256));
     hipLaunchKernelGGL(rtk::copy_nt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const rtk::u32x4*)src,
                        (rtk::u32x4*)dst, n);
     RTK_LAUNCH_CHECK("copy_nt_kernel");
     return RTK_OK;
 }
 
-extern "C" int rtk_version(void) { return 14; }
+extern "C" int rtk_version(void) { return 15; }
 extern "C" const char* rtk_last_error(void) { return rtk::g_err; }
 extern "C" const char* rtk_arch(void) { return "gfx950"; }

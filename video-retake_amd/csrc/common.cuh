@@ -303,6 +303,9 @@ __device__ __forceinline__ void rope_chunk(const float* __restrict__ inv_freq, c
     for (int e = 0; e < VE; ++e) rope_elem(f[e], ra[e], rb[e], pid, scaling, round_bf16, c1[e], s1[e], c2[e], s2[e]);
 }
 
+// bf16(x * (1/a2)) == bf16(x / a2) for every finite bf16 x?  (pivotkv_score.hip; exhaustive, cached per a2)
+bool bf16_rcp_is_exact(float a2);
+
 inline int make_rowsel(RowSel& rs, int P, int D, const int* sections, int nsec, const char* who) {
     if (D > 256 || (D & 1)) {
         set_error("%s: head_dim %d unsupported (must be even and <= 256)", who, D);

@@ -1850,7 +1850,7 @@ static int pick_splits(int tiles_fixed, int heads, int stream_tiles, int cap, in
 
 // bf16(x * (1/a2)) == bf16(x / a2) for EVERY finite bf16 x?  (x is bf16-valued in the un-rotate chain, so the
 // check is exhaustive: 65536 cases, cached per a2.)  True for the YaRN factor-4 scaling 1.1386^2.
-static bool bf16_rcp_is_exact(float a2) {
+bool bf16_rcp_is_exact(float a2) {
     static std::mutex mu;
     static std::map<uint32_t, bool> cache;
     uint32_t key;

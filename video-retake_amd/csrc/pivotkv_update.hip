@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t upd_pack2_f16(float lo, float hi) {   // sat
 // k, the last y takes v.  Same software pipeline as prepare_native_kernel: the rows of head batch b+1 are requested
 // before batch b is rotated and stored, and the first batch before the table arithmetic.
 // ------------------------------------------------------------------------------------------------
-template <int DT, bool FAST, int NW>
+template <int DT, bool FAST, int NW, bool RT = false>
 __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q, int64_t q_sh, int64_t q_sl,
                                                       const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
                                                       const char* __restrict__ v, int64_t v_sh, int64_t v_sl,
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
                                                       char* __restrict__ k_tail, char* __restrict__ v_tail,
                                                       int64_t tail_sh, int P, int64_t* __restrict__ pos_copy,
                                                       int64_t pos_copy_ld, char* __restrict__ k_fast, float qscale,
-                                                      int64_t* shift_back) {
+                                                      int64_t* shift_back, float a2, float rcp_a2, int div) {
     using V = Vec16<DT>;
     static_assert(NW == 4 || ((NW == 2 || NW == 1) && DT != RTK_F32), "8- / 4-byte chunks: 16-bit dtypes only");
     constexpr int ES = 16 / V::VE;          // bytes per element
@@ -149,6 +149,48 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
             }
         }
     };
+    // RT (reference operands): x~ = ((x*cos) - (rotate_half(x)*sin)) / a^2 of the ROTATED pair, one rounding per torch op
+    // (longvideo_cache.py:76-78) - the un-rotation the reference applies to what its attention handed over; same
+    // arithmetic as prepare_native_kernel's.  div (uniform): 0 a^2 == 1, 1 multiply by the reciprocal (bf16, proven
+    // identical for every bf16 input: bf16_rcp_is_exact), 2 IEEE division.
+    auto unrot = [&](const W& lo, const W& hi, W& olo, W& ohi) {
+        if constexpr (DT != RTK_F32) {
+            using Hh = H16<DT>;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float x1a = Hh::lo(lo.w[w]), x1b = Hh::hi(lo.w[w]), x2a = Hh::lo(hi.w[w]), x2b = Hh::hi(hi.w[w]);
+                const int e = 2 * w;
+                const uint32_t p1 = Hh::pack2(x1a * c1[e], x1b * c1[e + 1]);
+                const uint32_t n1 = Hh::pack2(x2a * s1[e], x2b * s1[e + 1]);
+                const uint32_t p2 = Hh::pack2(x2a * c2[e], x2b * c2[e + 1]);
+                const uint32_t n2 = Hh::pack2(x1a * s2[e], x1b * s2[e + 1]);
+                uint32_t t1 = Hh::pack2(Hh::lo(p1) + Hh::lo(n1), Hh::hi(p1) + Hh::hi(n1));
+                uint32_t t2 = Hh::pack2(Hh::lo(p2) - Hh::lo(n2), Hh::hi(p2) - Hh::hi(n2));
+                if (div == 1) {
+                    t1 = Hh::pack2(Hh::lo(t1) * rcp_a2, Hh::hi(t1) * rcp_a2);
+                    t2 = Hh::pack2(Hh::lo(t2) * rcp_a2, Hh::hi(t2) * rcp_a2);
+                } else if (div == 2) {
+                    t1 = Hh::pack2(__fdiv_rn(Hh::lo(t1), a2), __fdiv_rn(Hh::hi(t1), a2));
+                    t2 = Hh::pack2(__fdiv_rn(Hh::lo(t2), a2), __fdiv_rn(Hh::hi(t2), a2));
+                }
+                olo.w[w] = t1;
+                ohi.w[w] = t2;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float x1 = __uint_as_float(lo.w[e]), x2 = __uint_as_float(hi.w[e]);
+                float o1 = __fsub_rn(__fmul_rn(x1, c1[e]), __fmul_rn(-x2, s1[e]));
+                float o2 = __fsub_rn(__fmul_rn(x2, c2[e]), __fmul_rn(x1, s2[e]));
+                if (div != 0) {
+                    o1 = __fdiv_rn(o1, a2);
+                    o2 = __fdiv_rn(o2, a2);
+                }
+                olo.w[e] = __float_as_uint(o1);
+                ohi.w[e] = __float_as_uint(o2);
+            }
+        }
+    };
     auto to_f16 = [&](const W& x, float scale) {   // bf16 pairs -> fp16 pairs of (value * scale): RTK_BF16_FAST operands
         W o;
 #pragma unroll
@@ -163,18 +205,20 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
         for (int u = 0; u < HU; ++u) {
             const int h = hb + u;
             if (h >= qe) break;
-            if (q_out) {   // q~ := q0 (keep-all chunks are not scored: no q~)
-                char* orow = q_out + ((size_t)h * L + l) * D * ES;
-                if constexpr (FAST) {
-                    *(W*)(orow + (size_t)d * ES) = to_f16(lo[u], qscale);
-                    *(W*)(orow + (size_t)(d + h2) * ES) = to_f16(hi[u], qscale);
-                } else {
-                    *(W*)(orow + (size_t)d * ES) = lo[u];
-                    *(W*)(orow + (size_t)(d + h2) * ES) = hi[u];
-                }
-            }
             W olo, ohi;
             rot(lo[u], hi[u], olo, ohi);
+            if (q_out) {   // q~ := q0, or (RT) the un-rotation of the rotated row (keep-all chunks are not scored: no q~)
+                W ql = lo[u], qh = hi[u];
+                if constexpr (RT) unrot(olo, ohi, ql, qh);
+                char* orow = q_out + ((size_t)h * L + l) * D * ES;
+                if constexpr (FAST) {
+                    *(W*)(orow + (size_t)d * ES) = to_f16(ql, qscale);
+                    *(W*)(orow + (size_t)(d + h2) * ES) = to_f16(qh, qscale);
+                } else {
+                    *(W*)(orow + (size_t)d * ES) = ql;
+                    *(W*)(orow + (size_t)(d + h2) * ES) = qh;
+                }
+            }
             char* rrow = q_rot + ((size_t)h * qr_sh + (size_t)l * qr_sl) * ES;
             *(W*)(rrow + (size_t)d * ES) = olo;
             *(W*)(rrow + (size_t)(d + h2) * ES) = ohi;
@@ -193,18 +237,20 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
             if (h >= nkv) break;
             char* trow = tail + ((size_t)h * tail_sh + (size_t)l * D) * ES;
             if (is_k) {
-                if (k_out) {   // k~ := k0 (a plain append - text segments, decode - scores nothing: no k~)
+                W olo, ohi;
+                rot(lo[u], hi[u], olo, ohi);
+                W kl = lo[u], kh = hi[u];
+                if constexpr (RT) unrot(olo, ohi, kl, kh);
+                if (k_out) {   // k~ := k0 / (RT) un-rotated tail row (a plain append - text segments, decode - scores nothing: no k~)
                     char* orow = k_out + ((size_t)h * L + l) * D * ES;
-                    *(W*)(orow + (size_t)d * ES) = lo[u];
-                    *(W*)(orow + (size_t)(d + h2) * ES) = hi[u];
+                    *(W*)(orow + (size_t)d * ES) = kl;
+                    *(W*)(orow + (size_t)(d + h2) * ES) = kh;
                 }
                 if constexpr (FAST) {
                     char* frow = k_fast + ((size_t)h * L + l) * D * ES;
-                    *(W*)(frow + (size_t)d * ES) = to_f16(lo[u], 1.f);
-                    *(W*)(frow + (size_t)(d + h2) * ES) = to_f16(hi[u], 1.f);
+                    *(W*)(frow + (size_t)d * ES) = to_f16(kl, 1.f);
+                    *(W*)(frow + (size_t)(d + h2) * ES) = to_f16(kh, 1.f);
                 }
-                W olo, ohi;
-                rot(lo[u], hi[u], olo, ohi);
                 *(W*)(trow + (size_t)d * ES) = olo;
                 *(W*)(trow + (size_t)(d + h2) * ES) = ohi;
             } else {
@@ -229,7 +275,13 @@ struct PrologueGeom {
 template <int DT>
 static int prologue_launch(const PrologueGeom& g, const rtk_update_io* io, const RowSel& rs, const int64_t* prev,
                            char* q_out, char* k_out, char* k_tail, char* v_tail, int64_t tail_sh, int64_t* pos_copy,
-                           int64_t pos_copy_ld, char* k_fast, hipStream_t st, int64_t* shift_back = nullptr) {
+                           int64_t pos_copy_ld, char* k_fast, hipStream_t st, int64_t* shift_back = nullptr,
+                           bool roundtrip = false) {
+    // reference operands (roundtrip): the divisor of the un-rotation, as torch evaluates `/ attention_scaling ** 2` on
+    // a tensor of the model dtype - fp32 opmath with the Python double rounded to fp32 (prepare_impl's rule)
+    const float a2 = (float)((double)g.scaling * (double)g.scaling);
+    const int div = !roundtrip || a2 == 1.0f ? 0 : ((DT == RTK_BF16 && bf16_rcp_is_exact(a2)) ? 1 : 2);
+    const float rcp_a2 = 1.0f / a2;
     int nw = 4;
     if constexpr (DT != RTK_F32) nw = RTK_PREP_NW;
     const int VE = nw * 4 / (DT == RTK_F32 ? 4 : 2);
@@ -241,24 +293,28 @@ static int prologue_launch(const PrologueGeom& g, const rtk_update_io* io, const
                    (const char*)io->k, io->k_stride_h, io->k_stride_l, (const char*)io->v, io->v_stride_h, io->v_stride_l,
                    g.Hq, g.Hkv, g.L, g.D, io->pos, io->pos_stride, prev, g.inv_freq, g.scaling, rs, g.round_mode,
                    (char*)io->q_rot, io->qr_stride_h, io->qr_stride_l, q_out, k_out, k_tail, v_tail, tail_sh, g.P, pos_copy,
-                   pos_copy_ld, k_fast, qscale, shift_back);
+                   pos_copy_ld, k_fast, qscale, shift_back, a2, rcp_a2, div);
     };
-#define RTK_PRO_NWSEL(FASTV)                                                              \
+#define RTK_PRO_NWSEL(FASTV, RTV)                                                         \
     do {                                                                                  \
         if constexpr (DT != RTK_F32) {                                                    \
-            if (nw == 2) { launch(prologue_kernel<DT, FASTV, 2>); break; }                \
-            if (nw == 1) { launch(prologue_kernel<DT, FASTV, 1>); break; }                \
+            if (nw == 2) { launch(prologue_kernel<DT, FASTV, 2, RTV>); break; }           \
+            if (nw == 1) { launch(prologue_kernel<DT, FASTV, 1, RTV>); break; }           \
         }                                                                                 \
-        launch(prologue_kernel<DT, FASTV, 4>);                                            \
+        launch(prologue_kernel<DT, FASTV, 4, RTV>);                                       \
     } while (0)
     bool done = false;
     if constexpr (DT == RTK_BF16) {
         if (k_fast) {
-            RTK_PRO_NWSEL(true);
+            if (roundtrip) RTK_PRO_NWSEL(true, true);
+            else RTK_PRO_NWSEL(true, false);
             done = true;
         }
     }
-    if (!done) RTK_PRO_NWSEL(false);
+    if (!done) {
+        if (roundtrip) RTK_PRO_NWSEL(false, true);
+        else RTK_PRO_NWSEL(false, false);
+    }
 #undef RTK_PRO_NWSEL
     RTK_LAUNCH_CHECK("prologue_kernel");
     return RTK_OK;
@@ -310,11 +366,14 @@ extern "C" int rtk_pivotkv_update(rtk_pivotkv_batch* b, rtk_layer_state* ls, int
     hipStream_t st = (hipStream_t)stream;
     if (io->flags & RTK_UPDATE_PRE_ROPE) {
         RTK_CHECK_ARG(io->q_rot, "rtk_pivotkv_update: RTK_UPDATE_PRE_ROPE needs q_rot");
-        if (score_base == RTK_BF16_REFROUND || score_base == RTK_F16_REFROUND) {
+        const bool roundtrip = (io->flags & RTK_UPDATE_ROUNDTRIP) != 0;
+        if ((score_base == RTK_BF16_REFROUND || score_base == RTK_F16_REFROUND) && !roundtrip) {
             set_error("rtk_pivotkv_update: score_rounding='reference' scores the reference's round-tripped q~ / k~ "
-                      "(rotate first, then update without RTK_UPDATE_PRE_ROPE)");
+                      "(set RTK_UPDATE_ROUNDTRIP, or rotate first and update without RTK_UPDATE_PRE_ROPE)");
             return RTK_EUNSUPPORTED;
         }
+        RTK_CHECK_ARG(!(roundtrip && (io->flags & RTK_UPDATE_Q_IN_PLACE)),
+                      "rtk_pivotkv_update: RTK_UPDATE_ROUNDTRIP makes q~ differ from q0: it cannot be scored in place");
         const int ve = b->dtype != RTK_F32 ? 8 : 4;
         const bool ok = (D % (2 * ve) == 0) && D <= 256 && (io->q_stride_h * es) % 16 == 0 && (io->q_stride_l * es) % 16 == 0 &&
                         (io->k_stride_h * es) % 16 == 0 && (io->k_stride_l * es) % 16 == 0 && (io->v_stride_h * es) % 16 == 0 &&
@@ -365,11 +424,11 @@ extern "C" int rtk_pivotkv_update(rtk_pivotkv_batch* b, rtk_layer_state* ls, int
             k_fast = ws + (((size_t)b->Hq * L * D * es + 255) & ~(size_t)255);
         const PrologueGeom pg{b->Hq, Hkv, L, D, b->P, b->round_mode, b->inv_freq, b->attention_scaling};
         if (b->dtype == RTK_F16)
-            rc = prologue_launch<RTK_F16>(pg, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, L, nullptr, st);
+            rc = prologue_launch<RTK_F16>(pg, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, L, nullptr, st, nullptr, roundtrip);
         else if (b->dtype == RTK_BF16)
-            rc = prologue_launch<RTK_BF16>(pg, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, L, k_fast, st);
+            rc = prologue_launch<RTK_BF16>(pg, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, L, k_fast, st, nullptr, roundtrip);
         else
-            rc = prologue_launch<RTK_F32>(pg, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, L, nullptr, st);
+            rc = prologue_launch<RTK_F32>(pg, io, rs, prev, q_out, k_unrot, k_tail, v_tail, tail_sh, pos_copy, L, nullptr, st, nullptr, roundtrip);
         if (rc) return rc;
     } else {
         if (b->q_units) b->q_units[slot] = nullptr;
@@ -591,7 +650,8 @@ extern "C" int rtk_pivotkv_flush(rtk_pivotkv_batch* b, rtk_layer_state* const* l
             u.k_src_stride_h = (int64_t)L * D;
             // keep-all chunks of pre-RoPE units: new ids == old ids and k~ == k0, so the tail already holds the result
             // (not with a deferred re-rotation: the cache has to hold the UN-rotated rows)
-            u.k_dst = (b->keep_all && b->pre_rope && !b->defer_rot) ? nullptr : (char*)ls->k + tail;
+            // (pre_rope == 2: reference operands - k~ carries the round trip's roundings, the kept row is ITS re-rotation)
+            u.k_dst = (b->keep_all && b->pre_rope == 1 && !b->defer_rot) ? nullptr : (char*)ls->k + tail;
             u.k_dst_stride_h = ls->cap * D;
         } else {
             u.k_src = (char*)ls->k + tail;

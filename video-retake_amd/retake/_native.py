@@ -13,13 +13,14 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 RTK_F32, RTK_BF16, RTK_BF16_REFROUND, RTK_BF16_FAST, RTK_F16, RTK_F16_REFROUND = 0, 1, 2, 3, 4, 5
 RTK_SCORE_MANY_UNITS = 0x100   # flag for the dtype argument of the scoring entry points (split policy of batched launches)
 RTK_PREPARE_K_ONLY = 0x200     # flag for the dtype argument of rtk_pivotkv_prepare: keep-all chunk, no q~
 RTK_UPDATE_PRE_ROPE = 1        # rtk_update_io.flags: q / k are the pre-RoPE projections (attention prologue)
 RTK_UPDATE_Q_IN_PLACE = 2      # ... and the score passes read q where it is (no packed copy)
+RTK_UPDATE_ROUNDTRIP = 4       # ... or: q~ / k~ = the reference's un-rotation of the rotated rows (its bf16 round trip)
 SCORE_PREPARE, SCORE_PASSES, SCORE_FINALIZE = 1, 2, 4
 RTK_EINVAL, RTK_EUNSUPPORTED, RTK_EWORKSPACE, RTK_EHIP, RTK_EREFCRASH = -1, -2, -3, -4, -5
 

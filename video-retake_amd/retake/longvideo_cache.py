@@ -500,8 +500,19 @@ class PivotKVCache(DynamicCache):
         # provisional; the owner rotates them once, at their final ids (rtk_rope_rotate_rows), when the temporal offset
         # of its block is known.  key_cache then holds un-rotated rows until that call.
         self.defer_rerotation = bool(kv_compression_kwargs.get("defer_rerotation", False))
+        # MI355X build option: what the attention prologue (update_pre_rope) hands to the score passes and the re-rotation.
+        #   "reference" (default)  q~ / k~ = the reference's own operands: the un-rotation of the rotated rows, with the
+        #                          model dtype's rounding per torch op (longvideo_cache.py:76-78, :248-259).  On a bf16 model
+        #                          that round trip moves the exact score of a token by up to ~2e-2 (6 bf16 ulps; measured,
+        #                          tests/golden/gen_golden.py --only pivotkv_prerope_bf16) - it is part of what the reference
+        #                          computes, so scores, kept sets and kept keys follow it bit for bit;
+        #   "pre_rope"             q~ := q0, k~ := k0 (equal up to that rounding; more accurate, not the
+        #                          reference's bits) - no copy of the queries (they are scored where they lie).
+        self.prologue_operands = str(kv_compression_kwargs.get("prologue_operands", "reference"))
+        if self.prologue_operands not in ("reference", "pre_rope"):
+            raise ValueError(f"prologue_operands must be 'reference' or 'pre_rope', got {self.prologue_operands!r}")
         # MI355X build option (tests / A-B): False makes the prologue route pack a copy of the queries for the score passes
-        # even when they could be read where they lie
+        # even when they could be read where they lie (prologue_operands="pre_rope" only)
         self.score_queries_in_place = bool(kv_compression_kwargs.get("score_queries_in_place", True))
         # MI355X build option (tests / A-B): False makes rtk_pivotkv_flush stage the rows whose source lies inside the
         # destination range and place them with a second launch, instead of the one in-place compaction launch
@@ -1162,9 +1173,11 @@ class PivotKVCache(DynamicCache):
         if P0 + L > c.cap:   # (cap is 0 for buffers the library may not use)
             return None
         pre = q0 is not None
-        if b.pending and bool(b.c.pre_rope) != pre:
+        roundtrip = pre and self.prologue_operands == "reference"
+        mode = (2 if roundtrip else 1) if pre else 0
+        if b.pending and b.c.pre_rope != mode:
             self._flush()
-        b.c.pre_rope = int(pre)   # what the units of this batch's next flush were appended from
+        b.c.pre_rope = mode   # what the units of this batch's next flush were appended from
         qs, ks, vs = q.stride(), key_states.stride(), value_states.stride()
         if qs[3] != 1 or ks[3] != 1 or vs[3] != 1:
             return None
@@ -1175,13 +1188,14 @@ class PivotKVCache(DynamicCache):
         io.pos, io.pos_stride = pos.data_ptr(), pos.stride(0)
         q_in_place = False
         if pre:
+            rt = nv.RTK_UPDATE_ROUNDTRIP if roundtrip else 0
             if q_out is None or q_out is q:
-                io.q_rot, io.qr_stride_h, io.qr_stride_l, io.flags = io.q, qs[1], qs[2], nv.RTK_UPDATE_PRE_ROPE
+                io.q_rot, io.qr_stride_h, io.qr_stride_l, io.flags = io.q, qs[1], qs[2], nv.RTK_UPDATE_PRE_ROPE | rt
             else:
                 io.q_rot, io.qr_stride_h, io.qr_stride_l = q_out.data_ptr(), q_out.stride(1), q_out.stride(2)
                 # the rotated queries go elsewhere, so q0 survives: the batched passes score it where it lies
-                q_in_place = b.batched_passes and not b.fast and not b.keep_all and self.score_queries_in_place
-                io.flags = nv.RTK_UPDATE_PRE_ROPE | (nv.RTK_UPDATE_Q_IN_PLACE if q_in_place else 0)
+                q_in_place = self._scores_q0_in_place(b)
+                io.flags = nv.RTK_UPDATE_PRE_ROPE | rt | (nv.RTK_UPDATE_Q_IN_PLACE if q_in_place else 0)
         else:
             io.q_rot, io.flags = None, 0
         c.mask = mptr
@@ -1221,6 +1235,11 @@ class PivotKVCache(DynamicCache):
         n = P0 + L
         return st._k.narrow(2, 0, n), st._v.narrow(2, 0, n)
 
+    def _scores_q0_in_place(self, b: _Batch) -> bool:
+        """Can the chunk-batched passes read the pre-RoPE queries where they lie?  Only when q~ IS q0."""
+        return bool(b.batched_passes and not b.fast and not b.keep_all and self.score_queries_in_place
+                    and self.prologue_operands == "pre_rope")
+
     def update_pre_rope(self, query_states, key_states, value_states, layer_idx, position_ids, rotary_emb,
                         mrope_section=None, shift_ids_in_place=True, query_out=None):
         """The attention patch's whole prologue as ONE kernel (not in the reference: there it is the continuity shift,
@@ -1253,8 +1272,9 @@ class PivotKVCache(DynamicCache):
             rot = self._rotary(rotary_emb, dev)
             keep_len = max(1, int(self.compression_ratio * L))
             if rot is None or L < 512 or keep_len > L or (self.score_rounding == "reference"
+                                                         and self.prologue_operands != "reference"
                                                          and key_states.dtype in (torch.bfloat16, torch.float16)):
-                return None
+                return None   # (the reference's rounding chain scores the reference's operands)
             Hq, D = query_states.shape[1], query_states.shape[3]
             b = self._get_batch(layer_idx, Hq, key_states.shape[1], L, D, keep_len, 3 if position_ids.ndim == 3 else 1,
                                 key_states.dtype, dev)
@@ -1267,7 +1287,7 @@ class PivotKVCache(DynamicCache):
         if query_out is None:
             # the library's pick: a fresh tensor whenever the queries can then be scored where they lie (the chunk-batched
             # passes read q0 itself - no packed copy, a quarter of the kernel's traffic), else over `query_states`
-            if b.batched_passes and not b.fast and not b.keep_all and self.score_queries_in_place:
+            if self._scores_q0_in_place(b):
                 query_out = torch.empty_like(query_states)
         elif query_out is not query_states and (query_out.shape != query_states.shape
                                                 or query_out.dtype is not query_states.dtype
