@@ -271,6 +271,7 @@ class _Batch:
     def __init__(self, key, slots, Hq, Hkv, L, D, keep, P, reforge, dtype, device, refround=False, fast=False,
                  keep_all=False, skip_masked=True, in_place_compaction=True):
         self.key, self.slots, self.keep, self.P, self.reforge = key, slots, keep, P, reforge
+        self.wrap = False          # flush_every_layers: slot = layer % slots (else slot == layer)
         self.keep_all = keep_all   # keep == L and no scoring asked for: the selection is the identity
         # dtype code of the scoring entry points: bf16 payloads with the reference's bf16 rounding chain, or through the
         # fp16 matrix instruction with pre-scaled queries (score_rounding="fast"), on request
@@ -365,6 +366,9 @@ class _Batch:
             self._dummy = torch.empty(512, dtype=torch.uint8, device=device)
             c.score_ws = (self._dummy.data_ptr() + 255) & ~255
             c.score_ws_stride, c.score_ws_bytes = 0, 0
+
+    def slot(self, layer_idx: int) -> int:
+        return layer_idx % self.slots if self.wrap else layer_idx
 
     def ensure_scoring(self):
         """Scoring scratch of every slot (q~ / lse workspace, column partials, scores, selection scratch, live-key
@@ -520,6 +524,13 @@ class PivotKVCache(DynamicCache):
         # MI355X build option (tests / A-B): False sends every update and flush through the stage-by-stage route
         # instead of the one-call entry points rtk_pivotkv_update / rtk_pivotkv_flush - same kernels, same results
         self.one_call_update = bool(kv_compression_kwargs.get("one_call_update", True))
+        # MI355X build option: bound the scratch of the deferred eviction.  0 (default): one flush per chunk for ALL layers -
+        # every layer's q~ / k~ / partials wait in their own slot until `after_forward` (scratch = layers x ~(Hq + Hkv) L D
+        # elements: 1.4 GB at L = 6272, 28 layers, bf16).  N > 0: the batch has N slots (slot = layer mod N) and is flushed
+        # whenever the next layer's slot is taken, i.e. every N layers - scratch / launches-per-chunk trade N/layers : layers/N
+        self.flush_every_layers = int(kv_compression_kwargs.get("flush_every_layers", 0))
+        if self.flush_every_layers < 0:
+            raise ValueError("flush_every_layers must be >= 0")
         self._sides: List[_Side] = []
         self._side_rr = 0
         self._pos_layers = 0          # len(position_cache) of the reference (skipped layers are padded with [])
@@ -542,6 +553,51 @@ class PivotKVCache(DynamicCache):
         b, l = self._last_slot
         self._flush()
         return b.keep_idx[l]
+
+    def memory_footprint(self) -> Dict[str, int]:
+        """Device bytes this cache holds right now, by what they are for (not in the reference; bench.py's `memory` block and
+        tests/test_memory_gpu.py read it).  The reference's cache is the compressed rows only (longvideo_cache.py:313-318) -
+        its transients (the [Hq, L, L] fp32 softmax and its casts, two torch.cat copies of the layer) come and go inside
+        every update; here the transients are pre-allocated once per chunk geometry and reused:
+          cache_rows        K / V / id rows of the committed tokens (what the reference's lists hold)
+          cache_headroom    the rest of the pre-allocated K / V / id buffers: room for the in-flight chunk (the uncompressed
+                            tail update() returns to the layer's attention) and for generation, or unused growth
+          k_unrotated       per-slot copy of the chunk's un-rotated keys (re-rotated into the cache by the flush)
+          score_operands    per-slot q~ (and the fast mode's fp16 k~) + row statistics of the deferred score passes
+          score_partials    per-slot column partials, final scores, live-key lists
+          selection         kept indices, ids of the pending chunk (old / new), selection scratch, compaction tickets
+          staging           kept-row staging of the two-launch eviction (in_place_compaction=False / no reforge)
+          deferred_queries  pre-RoPE queries kept alive for a flush that scores them where they lie (prologue_operands="pre_rope")
+          worker_scratch    per-update scratch of the stage-by-stage route / worker streams."""
+        def nbytes(t):
+            return 0 if t is None else t.numel() * t.element_size()
+
+        out = dict.fromkeys(("cache_rows", "cache_headroom", "k_unrotated", "score_operands", "score_partials", "selection",
+                             "staging", "deferred_queries", "worker_scratch"), 0)
+        for st in self._layers:
+            if st.k is not None:
+                row = 2 * st.k.shape[1] * st.k.shape[3] * st.k.element_size()
+                out["cache_rows"] += row * st.length
+                out["cache_headroom"] += nbytes(st.k) + nbytes(st.v) - row * st.length
+            if st.pos is not None:
+                out["cache_rows"] += 8 * st.pos.shape[0] * st.pos_len
+                out["cache_headroom"] += nbytes(st.pos) - 8 * st.pos.shape[0] * st.pos_len
+        b = self._batch
+        if b is not None:
+            out["k_unrotated"] = nbytes(b.k_unrot)
+            out["score_operands"] = nbytes(b.score_ws)
+            out["score_partials"] = nbytes(b.partials) + nbytes(b.score) + nbytes(b.key_index)
+            out["selection"] = (nbytes(b.keep_idx) + nbytes(b.pos_new) + nbytes(b.pos_old) + nbytes(b.sel_ws)
+                                + nbytes(b.compact_sync) + nbytes(b.cos_new) + nbytes(b.sin_new))
+            out["staging"] = nbytes(b.v_stage) + nbytes(b.k_stage)
+            seen = set()
+            for t in b.q_keep:
+                if t is not None and t.data_ptr() not in seen:
+                    seen.add(t.data_ptr())
+                    out["deferred_queries"] += nbytes(t)
+        out["worker_scratch"] = sum(nbytes(t) for t in self._ws.values()) + sum(nbytes(t) for sd in self._sides for t in sd.ws.values())
+        out["total"] = sum(out.values())
+        return out
 
     # ---- list views --------------------------------------------------------------------------
     @property
@@ -819,16 +875,29 @@ class PivotKVCache(DynamicCache):
         defer = bool(self.defer_rerotation and self.pos_embed_reforge)
         key = (Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast, keep_all, defer)
         b = self._batch
-        if b is not None and b.key == key and layer_idx < b.slots:
+        wrap = self.flush_every_layers > 0
+        if b is not None and b.key == key and (layer_idx < b.slots or b.wrap) and b.wrap == wrap:
             return b
         self._flush()
-        slots = max(int(self.num_hidden_layers), layer_idx + 1, b.slots if b is not None and b.key == key else 0)
+        if wrap:
+            slots = min(self.flush_every_layers, max(int(self.num_hidden_layers), 1))
+        else:
+            slots = max(int(self.num_hidden_layers), layer_idx + 1, b.slots if b is not None and b.key == key else 0)
         self._batch = None  # release the old buffers before allocating the new ones
         self._batch = _Batch(key, slots, Hq, Hkv, L, D, keep, P, bool(self.pos_embed_reforge), dtype, device, refround, fast,
                              keep_all, self.skip_masked_columns, self.in_place_compaction)
+        self._batch.wrap = wrap
         self._batch.defer = defer
         self._batch.c.defer_rot = int(defer)
         return self._batch
+
+    def _claim_slot(self, b: _Batch, layer_idx: int) -> int:
+        """The layer's slot in the batch; with flush_every_layers the pending units are flushed first when that slot (or
+        a later one: the slots of a flush ascend with its layers) is still taken."""
+        sl = b.slot(layer_idx)
+        if b.wrap and b.pending and (sl <= b.slot(b.pending[-1]) or layer_idx <= b.pending[-1]):
+            self._flush()
+        return sl
 
     def _flush(self):
         """Evict every pending (layer, chunk) unit (reference :260-318 for all layers of the chunk): the score passes,
@@ -855,7 +924,7 @@ class PivotKVCache(DynamicCache):
                 elif st.pos_ndim == 0:
                     st.pos_ndim = 3 if b.P == 3 else 2
         states = (C.c_void_p * n)(*[L_[l].cref for l in layers])
-        slots = (C.c_int32 * n)(*layers)
+        slots = (C.c_int32 * n)(*[b.slot(l) for l in layers])
         idx = b.dev_index
         self._order_compaction(b)
         if nv.current_device() == idx:
@@ -875,7 +944,7 @@ class PivotKVCache(DynamicCache):
         b.selected.clear()
         b.shift_ids = None
         for l in layers:
-            b.q_keep[l] = None
+            b.q_keep[b.slot(l)] = None
         if b.reforge and b.P:
             self._pos_layers = max(self._pos_layers, layers[-1] + 1)
         return True
@@ -885,6 +954,10 @@ class PivotKVCache(DynamicCache):
         modules that have to be called for the tables of the new ids."""
         layers, b.pending = b.pending, []
         b.c_pending = 0
+        # slot of a layer: the layer itself, or (flush_every_layers) layer mod slots - within one flush slots ascend with the
+        # layers, so the offset is one number
+        off = b.slot(layers[0]) - layers[0]
+        assert all(b.slot(l) == l + off for l in layers)
         if b.shift_ids is not None:   # pre-RoPE units: the caller's ids tensor takes the last layer's shift now
             ids, b.shift_ids = b.shift_ids, None
             b.c.shift_row = None
@@ -896,7 +969,7 @@ class PivotKVCache(DynamicCache):
             for l in layers:
                 if l not in b.selected:
                     if P:
-                        b.pos_new[:, l].copy_(b.pos_old[l])
+                        b.pos_new[:, l + off].copy_(b.pos_old[l + off])
                     b.selected.add(l)
                     b.scored.add(l)
         es = 4 if b.dtype == torch.float32 else 2
@@ -911,7 +984,7 @@ class PivotKVCache(DynamicCache):
             unscored = sorted(l for l in layers if l not in b.scored)
             i = 0
             def qkey(l):   # queries scored where they lie (prologue route) carry their strides; packed ones None
-                t = b.q_keep[l]
+                t = b.q_keep[l + off]
                 return None if t is None else t.stride()
 
             while i < len(unscored):  # the matrix passes of every run of consecutive slots whose queries live alike
@@ -920,6 +993,7 @@ class PivotKVCache(DynamicCache):
                     j += 1
                 l0, n = unscored[i], j - i + 1
                 mptr = [b.masks.get(l) for l in range(l0, l0 + n)]
+                l0 += off     # from here on: the run's first SLOT
                 km = (C.c_void_p * n)(*[m.data_ptr() if m is not None else None for m in mptr]) \
                     if self.skip_masked_columns and any(m is not None for m in mptr) else None
                 qk = [b.q_keep[l] for l in range(l0, l0 + n)]
@@ -940,21 +1014,22 @@ class PivotKVCache(DynamicCache):
                 su = (nv.SelectUnit * len(todo))()
                 for i, l in enumerate(todo):
                     u = su[i]
-                    u.partial = b.partials[l].data_ptr()
-                    u.score = b.score[l].data_ptr()
+                    sl = l + off
+                    u.partial = b.partials[sl].data_ptr()
+                    u.score = b.score[sl].data_ptr()
                     m = b.masks.get(l)
                     u.mask = m.data_ptr() if m is not None else None
-                    u.pos = b.pos_old[l].data_ptr() if P else None
-                    u.keep_idx = b.keep_idx[l].data_ptr()
+                    u.pos = b.pos_old[sl].data_ptr() if P else None
+                    u.keep_idx = b.keep_idx[sl].data_ptr()
                     u.rank = None
-                    u.pos_out = (b.pos_new.data_ptr() + l * keep * 8) if P else None
-                    u.workspace = b.sel_ws[l].data_ptr()
+                    u.pos_out = (b.pos_new.data_ptr() + sl * keep * 8) if P else None
+                    u.workspace = b.sel_ws[sl].data_ptr()
                 nv.check(nv.lib.rtk_pivotkv_select_batched(su, len(todo), Hkv, b.rs_n.value, b.Hq // Hkv, b.L, keep, P,
                                                            int(b.reforge), b.slots * keep, b.score_dt, nv.stream()),
                          "rtk_pivotkv_select_batched")
             b.selected.clear()
             b.masks.clear()
-            lo, hi = min(layers), max(layers)
+            lo, hi = min(layers) + off, max(layers) + off      # slots
             # reforge: K is re-rotated at the NEW ids (reference :297-306).  With the native RoPE the eviction kernel
             # computes their cos/sin itself; a third-party rotary module is called once for every pending slot and its
             # section-merged fp32 tables are handed over.
@@ -979,16 +1054,17 @@ class PivotKVCache(DynamicCache):
             nc = 0
             for i, l in enumerate(layers):
                 st = self._layers[l]
+                sl = l + off
                 cap = st.k.shape[2]
                 tail = st.length * D * es
                 u = units[i]
                 if b.reforge:
-                    u.k_src, u.k_src_stride_h = b.k_unrot[l].data_ptr(), b.L * D
+                    u.k_src, u.k_src_stride_h = b.k_unrot[sl].data_ptr(), b.L * D
                     if rope_in_kernel or defer:
                         u.cos_new = u.sin_new = None
                     else:
-                        u.cos_new = b.cos_new.data_ptr() + l * keep * D * 4
-                        u.sin_new = b.sin_new.data_ptr() + l * keep * D * 4
+                        u.cos_new = b.cos_new.data_ptr() + sl * keep * D * 4
+                        u.sin_new = b.sin_new.data_ptr() + sl * keep * D * 4
                     u.k_dst, u.k_dst_stride_h = st.k.data_ptr() + tail, cap * D  # straight into the cache
                 elif b.keep_all:   # every row already sits where the append put it
                     u.k_src, u.k_src_stride_h = st.k.data_ptr() + tail, cap * D
@@ -996,24 +1072,24 @@ class PivotKVCache(DynamicCache):
                 else:
                     u.k_src, u.k_src_stride_h = st.k.data_ptr() + tail, cap * D
                     u.cos_new = u.sin_new = None
-                    u.k_dst, u.k_dst_stride_h = b.k_stage[l].data_ptr(), keep * D
-                    places[nc].stage, places[nc].stage_stride_h_bytes = b.k_stage[l].data_ptr(), keep * D * es
+                    u.k_dst, u.k_dst_stride_h = b.k_stage[sl].data_ptr(), keep * D
+                    places[nc].stage, places[nc].stage_stride_h_bytes = b.k_stage[sl].data_ptr(), keep * D * es
                     places[nc].tail, places[nc].tail_stride_h_bytes = st.k.data_ptr() + tail, cap * D * es
-                    places[nc].keep_idx = b.keep_idx[l].data_ptr()
+                    places[nc].keep_idx = b.keep_idx[sl].data_ptr()
                     nc += 1
                 u.v_src, u.v_src_stride_h = st.v.data_ptr() + tail, cap * D
                 if b.keep_all:
                     u.v_dst = None
                 else:
-                    u.v_dst, u.v_dst_stride_h = b.v_stage[l].data_ptr(), keep * D
-                    places[nc].stage, places[nc].stage_stride_h_bytes = b.v_stage[l].data_ptr(), keep * D * es
+                    u.v_dst, u.v_dst_stride_h = b.v_stage[sl].data_ptr(), keep * D
+                    places[nc].stage, places[nc].stage_stride_h_bytes = b.v_stage[sl].data_ptr(), keep * D * es
                     places[nc].tail, places[nc].tail_stride_h_bytes = st.v.data_ptr() + tail, cap * D * es
-                    places[nc].keep_idx = b.keep_idx[l].data_ptr()
+                    places[nc].keep_idx = b.keep_idx[sl].data_ptr()
                     nc += 1
-                u.keep_idx = b.keep_idx[l].data_ptr()
+                u.keep_idx = b.keep_idx[sl].data_ptr()
                 if b.reforge and P:  # bookkeeping (reference :308-309)
                     self._pos_reserve(st, P, 3 if P == 3 else 2, keep, b.device)
-                    u.pos_src, u.pos_src_stride = b.pos_new.data_ptr() + l * keep * 8, b.slots * keep
+                    u.pos_src, u.pos_src_stride = b.pos_new.data_ptr() + sl * keep * 8, b.slots * keep
                     u.pos_dst, u.pos_dst_stride = st.pos.data_ptr() + st.pos_len * 8, st.pos.shape[1]
                 else:
                     u.pos_src = u.pos_dst = None
@@ -1037,8 +1113,8 @@ class PivotKVCache(DynamicCache):
             layers = layers_done
         for l in layers:
             st = self._layers[l]
-            b.q_keep[l] = None
-            b.q_units[l] = None
+            b.q_keep[l + off] = None
+            b.q_units[l + off] = None
             st.length += keep
             st.pending = 0
             st.pending_keep = 0
@@ -1074,19 +1150,20 @@ class PivotKVCache(DynamicCache):
         units = (nv.CompactUnit * len(layers))()
         for i, l in enumerate(layers):
             st = self._layers[l]
+            sl = b.slot(l)
             cap = st.k.shape[2]
             tail = st.length * D * es
             u = units[i]
             if b.reforge:
-                u.k_src, u.k_src_stride_h = b.k_unrot[l].data_ptr(), b.L * D
+                u.k_src, u.k_src_stride_h = b.k_unrot[sl].data_ptr(), b.L * D
             else:
                 u.k_src, u.k_src_stride_h = None, 0
             u.k_tail, u.k_tail_stride_h = st.k.data_ptr() + tail, cap * D
             u.v_tail, u.v_tail_stride_h = st.v.data_ptr() + tail, cap * D
-            u.keep_idx = b.keep_idx[l].data_ptr()
+            u.keep_idx = b.keep_idx[sl].data_ptr()
             if b.reforge and P:  # bookkeeping (reference :308-309)
                 self._pos_reserve(st, P, 3 if P == 3 else 2, keep, b.device)
-                u.pos_src, u.pos_src_stride = b.pos_new.data_ptr() + l * keep * 8, b.slots * keep
+                u.pos_src, u.pos_src_stride = b.pos_new.data_ptr() + sl * keep * 8, b.slots * keep
                 u.pos_dst, u.pos_dst_stride = st.pos.data_ptr() + st.pos_len * 8, st.pos.shape[1]
             else:
                 u.pos_src = u.pos_dst = None
@@ -1134,7 +1211,7 @@ class PivotKVCache(DynamicCache):
         Returns None - having changed nothing - when the call does not fit the batch."""
         q = ck.get("query_states") if q0 is None else q0
         pos = ck.get("position_ids")
-        if q is None or pos is None or layer_idx >= b.slots or layer_idx >= len(self._layers):
+        if q is None or pos is None or (layer_idx >= b.slots and not b.wrap) or layer_idx >= len(self._layers):
             return None
         rot_fn = ck.get("rotary_emb")
         hit = self._rotaries.get(id(rot_fn))
@@ -1177,6 +1254,7 @@ class PivotKVCache(DynamicCache):
         mode = (2 if roundtrip else 1) if pre else 0
         if b.pending and b.c.pre_rope != mode:
             self._flush()
+        slot = self._claim_slot(b, layer_idx)
         b.c.pre_rope = mode   # what the units of this batch's next flush were appended from
         qs, ks, vs = q.stride(), key_states.stride(), value_states.stride()
         if qs[3] != 1 or ks[3] != 1 or vs[3] != 1:
@@ -1199,7 +1277,7 @@ class PivotKVCache(DynamicCache):
         else:
             io.q_rot, io.flags = None, 0
         c.mask = mptr
-        rc = nv.lib.rtk_pivotkv_update(b.cref, st.cref, layer_idx, b.ioref, nv.raw_stream(idx))
+        rc = nv.lib.rtk_pivotkv_update(b.cref, st.cref, slot, b.ioref, nv.raw_stream(idx))
         if rc:
             c.mask = None
             if rc == nv.RTK_EUNSUPPORTED:
@@ -1224,14 +1302,14 @@ class PivotKVCache(DynamicCache):
             self.update_num_evicted_tokens(L - b.keep, layer_idx)
         if mask is not None:
             b.masks[layer_idx] = mask
-        b.q_keep[layer_idx] = q if q_in_place else None
+        b.q_keep[slot] = q if q_in_place else None
         if b.keep_all:
             b.scored.add(layer_idx)
         elif not b.batched_passes:
             b.scored.add(layer_idx)
         b.pending.append(layer_idx)
         b.c_pending += 1
-        self._last_slot = (b, layer_idx)
+        self._last_slot = (b, slot)
         n = P0 + L
         return st._k.narrow(2, 0, n), st._v.narrow(2, 0, n)
 
@@ -1265,7 +1343,7 @@ class PivotKVCache(DynamicCache):
         hit = self._rotaries.get(id(rotary_emb))
         if b is None or b.L != L or not b.c_capable or hit is None or hit[0] is not rotary_emb or hit[1] is None \
                 or hit[1] is not b.rot or hit[2] != _inv_stamp(rotary_emb) \
-                or layer_idx >= b.slots or layer_idx >= len(self._layers) \
+                or (layer_idx >= b.slots and not b.wrap) or layer_idx >= len(self._layers) \
                 or self._layers[layer_idx].c.length + L > self._layers[layer_idx].c.cap:
             # not the steady state: find / build the batch of this geometry, bind the rotary, make room
             dev = key_states.device
@@ -1449,6 +1527,7 @@ class PivotKVCache(DynamicCache):
         if batch.pending and batch.c.pre_rope:   # units of the prologue route are flushed among themselves
             self._flush()
         batch.c.pre_rope = 0
+        slot = self._claim_slot(batch, layer_idx)
         batch.x_like = value_states[:, :, :1]
         st = self.reserve(layer_idx, n_new, key_states)
         P0 = st.length
@@ -1458,21 +1537,21 @@ class PivotKVCache(DynamicCache):
         a_scale = float(getattr(rotary_emb_fn, "attention_scaling", 1.0)) if reforge else 1.0
         ws_bytes = batch.ws_bytes
         sel_bytes = nv.lib.rtk_pivotkv_select_workspace_bytes(L)
-        keep_idx = batch.keep_idx[layer_idx]
+        keep_idx = batch.keep_idx[slot]
         shared = {}   # values handed from one stage to the next
 
         defer_select = L >= 512   # the chip-wide selection kernels; smaller chunks select inside update
 
         def ws_pointer(ws):
             if batch.batched_passes:   # the slot's own workspace: q~ must survive until the batched passes of the flush
-                return batch.score_ws_base + layer_idx * batch.ws_stride
+                return batch.score_ws_base + slot * batch.ws_stride
             wsb = self._buf("score_ws", (ws_bytes + 256,), torch.uint8, dev, ws)
             return (wsb.data_ptr() + 255) & ~255
 
         def score_stage(ws, stages):
             ws_ptr = ws_pointer(ws)
-            score = batch.score[layer_idx]
-            k_unrot = batch.k_unrot[layer_idx] if reforge else None
+            score = batch.score[slot]
+            k_unrot = batch.k_unrot[slot] if reforge else None
             # the matrix passes of a per-update launch know the chunk's key-patch mask: pass 2 skips the columns the
             # selection overwrites with 1.0 anyway (reference :272-274)
             live = mask if (stages & nv.SCORE_PASSES) and self.skip_masked_columns else None
@@ -1481,7 +1560,7 @@ class PivotKVCache(DynamicCache):
                 nv.ptr(query_states), query_states.stride(1), query_states.stride(2),
                 nv.ptr(key_states), key_states.stride(1), key_states.stride(2),
                 Hq, Hkv, L, D, batch.score_dt, nv.ptr(shared.get("cos")), nv.ptr(shared.get("sin")), a_scale,
-                nv.ptr(score), nv.ptr(k_unrot), C.c_void_p(ws_ptr), ws_bytes, stages, nv.ptr(batch.partials[layer_idx]),
+                nv.ptr(score), nv.ptr(k_unrot), C.c_void_p(ws_ptr), ws_bytes, stages, nv.ptr(batch.partials[slot]),
                 nv.ptr(live), nv.ptr(kidx), nv.stream()), "rtk_pivotkv_score")
             return score
 
@@ -1512,7 +1591,7 @@ class PivotKVCache(DynamicCache):
             right away; larger chunks leave this to the batched selection of the flush"""
             if batch.keep_all:         # keep_idx is the identity (set once per batch); ids x 1.0 = the ids (:288-292)
                 if pos_in is not None:
-                    batch.pos_new[:, layer_idx].copy_(pos_in)
+                    batch.pos_new[:, slot].copy_(pos_in)
                 batch.selected.add(layer_idx)
                 return
             if defer_select:
@@ -1520,7 +1599,7 @@ class PivotKVCache(DynamicCache):
                 return
             score = score_stage(ws, nv.SCORE_FINALIZE)
             rank = self._buf("rank", (L,), torch.int32, dev, ws)
-            pos_out = batch.pos_new[:, layer_idx] if pos_in is not None else None
+            pos_out = batch.pos_new[:, slot] if pos_in is not None else None
             sel_ws = self._buf("select_ws", (sel_bytes,), torch.uint8, dev, ws)
             nv.check(nv.lib.rtk_pivotkv_select(nv.ptr(score), nv.ptr(mask), L, keep_len, nv.ptr(pos_in), Pn,
                                                int(reforge), nv.ptr(keep_idx), nv.ptr(rank), nv.ptr(pos_out),
@@ -1562,8 +1641,8 @@ class PivotKVCache(DynamicCache):
                 Hq, Hkv, L, D, batch.prep_dt | (nv.RTK_PREPARE_K_ONLY if k_only else 0), nv.ptr(pos_in), L, Pn,
                 nv.ptr(inv), a_scale, sec,
                 len(mrope_section) if mrope_section else 0, nv.round_mode(key_states.dtype),
-                nv.ptr(batch.k_unrot[layer_idx]), C.c_void_p(ws_ptr), ws_bytes, k_tail, v_tail, cap * D,
-                nv.ptr(batch.pos_old[layer_idx]) if defer_select else None, nv.stream())
+                nv.ptr(batch.k_unrot[slot]), C.c_void_p(ws_ptr), ws_bytes, k_tail, v_tail, cap * D,
+                nv.ptr(batch.pos_old[slot]) if defer_select else None, nv.stream())
             if rc == nv.RTK_EUNSUPPORTED:
                 return False
             nv.check(rc, "rtk_pivotkv_prepare")
@@ -1577,7 +1656,7 @@ class PivotKVCache(DynamicCache):
                     append_tail()
                     stage_pre(self._ws, pos_in)
                     if defer_select and pos_in is not None:
-                        batch.pos_old[layer_idx].copy_(pos_in)
+                        batch.pos_old[slot].copy_(pos_in)
                 stage_big(self._ws)
                 stage_post(self._ws, pos_in)
             else:
@@ -1593,7 +1672,7 @@ class PivotKVCache(DynamicCache):
                     side.stream.wait_event(ready)
                     stage_pre(side.ws, pos_in)
                     if defer_select and pos_in is not None:
-                        batch.pos_old[layer_idx].copy_(pos_in)
+                        batch.pos_old[slot].copy_(pos_in)
                     stage_big(side.ws)
                     stage_post(side.ws, pos_in)
                     done = torch.cuda.Event()
@@ -1603,7 +1682,7 @@ class PivotKVCache(DynamicCache):
         st.pending = n_new
         st.pending_keep = keep_len
         batch.pending.append(layer_idx)
-        self._last_slot = (batch, layer_idx)
+        self._last_slot = (batch, slot)
         return st.k[:, :, :P0 + n_new], st.v[:, :, :P0 + n_new]
 
 

@@ -460,6 +460,11 @@ class ShardedPivotKV:
         # the kept keys stay un-rotated (ids provisional) until `finalize` knows the block's temporal offset and rotates
         # them ONCE at their final ids - the same single rotation the sequential cache applies (reference :297-306)
         self.cache.defer_rerotation = bool(self.cache.pos_embed_reforge)
+        # ... and the attention prologue scores the PRE-RoPE operands: the reference's own operands carry the rounding of a
+        # rotation / un-rotation round trip at the chunk's FINAL ids (longvideo_cache.py:248-259), which a block does not
+        # know before the offset scan - q0 / k0 never see an id, so every rank keeps what a single GPU with
+        # prologue_operands="pre_rope" keeps, bit for bit, in every dtype
+        self.cache.prologue_operands = "pre_rope"
         self.group = group
         self.first_start = first_start
         self.expected_rows = expected_rows
@@ -710,6 +715,7 @@ def verify_sharded_equals_sequential(rank: int, world: int, dev, rotary, layers:
         frames_all = torch.cat([B.chunk_frames(c, dev, td) for c in range(n_chunks)])[None]
         _, mask = vc.memory_bank_compress_keyframe(frames_all, T, 3, sync=False)
         seq = lc.build_kvcache(B.make_cache_config(layers))
+        seq.prologue_operands = "pre_rope"    # what the blocks score (ShardedPivotKV): operands that never see an id
         for c in range(n_chunks):
             seq.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
             seq.kvcache_compression = True
