@@ -22,6 +22,37 @@ import torch
 import torch.distributed as dist
 
 
+def dpselect_blocks(rank, world, dev):
+    """DPSelect sharded by frame block over the live transport: every rank holds 12 frames (+ the halo frame in front of its
+    block), the distance rows are all-gathered, the selection runs redundantly, and at ratio < 1 the kept frames are
+    exchanged - output and key-patch mask must equal the unsharded call on the whole video, sync and per-patch, fp32 and
+    bf16, ratio 1 and ~1/3."""
+    import numpy as np
+
+    import retake.visual_compression as vc
+    import synth
+    from retake import sharded
+
+    per, N, C = 12, 6, 256
+    T = per * world
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.from_numpy(synth.frames_video(500 + world, T, N, C)).to(dev).to(dtype)     # [1, T, N, C], same on every rank
+        f0 = rank * per
+        local = x[:, max(f0 - 1, 0):f0 + per].contiguous()
+        for sync in (True, False):
+            for t in (T, T // 3 + 1):
+                ref_out, ref_mask = vc.memory_bank_compress_keyframe(x, t, 3, sync=sync)
+                out, mask, idx, dis = sharded.dpselect_sharded(local, rank > 0, t, 3, sync=sync)
+                assert torch.equal(mask, ref_mask), (str(dtype), sync, t, "mask")
+                want = ref_out if t < T else x[:, f0:f0 + per]
+                assert out.shape == want.shape and torch.equal(out, want), (str(dtype), sync, t, "frames")
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    if rank == 0:
+        print(f"sharded DPSelect over {world} ranks (halo frames, distance rows gathered, frame exchange at ratio < 1) == unsharded",
+              flush=True)
+
+
 def main():
     import bench as B
     from retake import sharded
@@ -39,9 +70,20 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     # the comparison itself lives in the library (bench.py --gpus N runs it before its timed region as well)
     counts = (2 * world, 2 * world + 1) + ((2 * world, 2 * world, 2 * world) if p2p else ())
+    state = {}
     res = sharded.verify_sharded_equals_sequential(rank, world, dev, B.Rotary(dev), layers=2, chunk_counts=counts,
-                                                   state={}, log=lambda m: print(m, flush=True))
+                                                   state=state, log=lambda m: print(m, flush=True))
     assert res["equal"] and len(res["cases"]) == 2 * len(counts) and {c["dtype"] for c in res["cases"]} == {"fp32", "bf16"}
+    # RETAKE_TEST_MORE_CASES="bf16:64,65": further chunk counts per dtype (world size 8: BASELINE's 64-chunk video in blocks
+    # of 8 chunks, and the ragged 65-chunk split)
+    for spec in filter(None, os.environ.get("RETAKE_TEST_MORE_CASES", "").split(";")):
+        dname, cc = spec.split(":")
+        cc = tuple(int(x) for x in cc.split(","))
+        res = sharded.verify_sharded_equals_sequential(rank, world, dev, B.Rotary(dev), layers=2, chunk_counts=cc, state=state,
+                                                       log=lambda m: print(m, flush=True), dtypes=(dname,))
+        assert res["equal"] and len(res["cases"]) == len(cc)
+    if os.environ.get("RETAKE_TEST_DPSELECT") == "1":
+        dpselect_blocks(rank, world, dev)
     if p2p:
         sharded.disable_p2p()
     dist.destroy_process_group()
