@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """SURVEY §8(f)1 - "fuse PivotKV scoring into the chunk's attention": what could the two contractions share?
 
-CPU-only evidence behind DESIGN.md §9 (no reference code, no GPU):
+CPU-only evidence behind DESIGN.md §8 (no reference code, no GPU):
 
   1. logits.   With `pos_embed_reforge` (every shipped config: configs/retake_demo.yaml:21, configs/qwen2_vl/*.yaml) the
      score contracts the UN-rotated q~ k~ (longvideo_cache.py:248-264) while the layer's attention contracts the rotated

@@ -71,7 +71,9 @@ def main():
 
         staged_b = bool(rng.uniform() < 0.5)
         inplace_b = bool(rng.uniform() < 0.5)
-        desc += f" staged_twin={staged_b} twin_in_place_compaction={inplace_b}"
+        fel_b = int(rng.choice([0, 0, 1, 2]))            # twin flushed every N layers (slot = layer mod N)
+        ops_p = str(rng.choice(["reference", "pre_rope"]))   # what the prologue cache scores
+        desc += f" staged_twin={staged_b} twin_in_place_compaction={inplace_b} twin_flush_every_layers={fel_b} prologue_operands={ops_p}"
 
         def make(skip, **extra):
             kw = {"compression_ratio": ratio, "compression_method": "pivotkv", "pos_embed_reforge": reforge,
@@ -84,10 +86,11 @@ def main():
                                         longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": kw})
             return lc.build_kvcache(cfg)
 
-        ca, cb = make(True), make(False, one_call_update=not staged_b, in_place_compaction=inplace_b)
-        # the prologue route, where it applies (reforging cache, inv_freq rotary, chunks of >= 512 tokens)
-        pre = reforge and native and L >= 512 and rounding != "reference"
-        cp = make(True, score_when_keeping_all=True) if pre else None
+        ca, cb = make(True), make(False, one_call_update=not staged_b, in_place_compaction=inplace_b, flush_every_layers=fel_b)
+        # the prologue route, where it applies (reforging cache, inv_freq rotary, chunks of >= 512 tokens; the reference's
+        # rounding chain needs the reference's operands)
+        pre = reforge and native and L >= 512 and (rounding != "reference" or ops_p == "reference")
+        cp = make(True, score_when_keeping_all=True, prologue_operands=ops_p) if pre else None
         ocp = [orc.OraclePivotKV(Hq, Hkv, D, ratio, reforge) for _ in range(layers)] if pre and dtype == torch.float32 and L <= 1000 else None
         oc = [orc.OraclePivotKV(Hq, Hkv, D, ratio, reforge) for _ in range(layers)] if dtype == torch.float32 and L <= 1000 else None
         keep = max(1, int(ratio * L))
@@ -167,17 +170,19 @@ def main():
                                                       last["pos"].reshape(-1, keep))
                             n_pre += 1
                 for l in range(layers):
-                    sb = cb._batch.score[l]
+                    # (a twin flushed every N layers reuses its slots: its per-layer scores are gone, its caches are not)
+                    sb = cb._batch.score[l] if not fel_b else None
                     sa = ca._batch.score[l] if ca._batch.score is not None else sb   # (keep-all batches allocate no scores)
                     if ca._batch.keep_all:
                         assert keep == L and ca.last_scores is None
                         sa = sb   # nothing was scored on the default route; the oracle checks the scored twin
-                    assert torch.equal(sa, sb), "scores (after the mask override) differ between live-key and full pass 2"
-                    assert torch.equal(ca._batch.keep_idx[l], cb._batch.keep_idx[l]), "kept sets differ"
+                    if sb is not None:
+                        assert torch.equal(sa, sb), "scores (after the mask override) differ between live-key and full pass 2"
+                        assert torch.equal(ca._batch.keep_idx[l], cb._batch.keep_idx[l]), "kept sets differ"
                     assert torch.equal(ca.key_cache[l], cb.key_cache[l]) and torch.equal(ca.value_cache[l], cb.value_cache[l])
                     if reforge:
                         assert torch.equal(ca.position_cache[l], cb.position_cache[l])
-                    if oc is not None:
+                    if oc is not None and sa is not None:
                         last = oc[l].last
                         so = last["score"]
                         err = float(np.abs(sa.cpu().numpy() - so).max())

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void unrotate_pack_kernel(const void* __restri
 //   fp32: 32 chunks/row; the k axis is re-associated so that half `hf` owns k in [64hf, 64hf+64):
 //         chunk 16hf + c feeds MFMAs 4c..4c+3 (K=2 each).  The same permutation is applied to both
 //         operands, so every product a_k*b_k still meets its partner; only the summation order
-//         differs from index order, which fp32 parity tolerates (DESIGN.md §numerics).
+//         differs from index order, which fp32 parity tolerates (DESIGN.md §5).
 // ------------------------------------------------------------------------------------------------
 template <int DT> struct MM;
 
@@ -603,7 +603,7 @@ struct RowStat {  // online max / sum of one query row, over the keys this lane 
     }
 };
 
-// Shape of the kernels (DESIGN.md §4 has the same-box A/B numbers behind every choice):
+// Shape of the kernels (HISTORY.md §4 has the same-box A/B numbers behind every choice):
 //   fp32 register-staged kernels: one 32-row register block per wave, loads one tile ahead (RegBlocks below; two
 //       blocks need ~250 VGPRs and a second staging set bought nothing: the kernels are bound by instruction issue).
 //   bf16 LDS-DMA kernels: two 32-row register blocks per wave (every A fragment read from LDS feeds two MFMAs on
