@@ -737,14 +737,19 @@ def gen_pivotkv_bf16(lc, outdir):
 # call), then PivotKVCache.update (:217-323).  Pins PivotKVCache.update_pre_rope - the route the build's own attention
 # patch takes - which is handed the same q0 / k0 and never sees the rotated tensors.
 # --------------------------------------------------------------------------------------
-def gen_pivotkv_prerope_bf16(lc, outdir):
+def gen_pivotkv_prerope_bf16(lc, outdir, only=None):
     S = synth.YARN_FACTOR4_ATTENTION_SCALING
     M = [16, 24, 24]
     # name, gh, gw, grids per chunk, chunks, ratio, mask rate, seed, raw, mrope
     cases = [("prerope_bf16_qwen_L256", 8, 8, 4, 2, 0.25, 0.3, 231, True, M),
              ("prerope_bf16_qwen_L1568", 14, 14, 8, 2, 0.25, 0.3, 232, False, M),
              ("prerope_bf16_qwen_L6272", 14, 14, 32, 1, 0.25, 0.3, 233, False, M),
-             ("prerope_bf16_llava_L1568", 14, 14, 8, 2, 0.25, 0.3, 234, False, None)]
+             ("prerope_bf16_llava_L1568", 14, 14, 8, 2, 0.25, 0.3, 234, False, None),
+             # BASELINE configs[4]'s own setting: LLaVA-Video chunk (32 frames x 196 pooled tokens), plain RoPE, the dynamic
+             # ratio of a 2048-frame prompt (max_input_length 40000 / 401409 tokens: keep 624 of 6272)
+             ("prerope_bf16_llava_L6272_dyn", 14, 14, 32, 1, 40000 / (2048 * 196 + 1), 0.3, 235, False, None)]
+    if only:
+        cases = [c for c in cases if c[0] in only]
     Hq, Hkv, D = 28, 4, 128
     for (name, gh, gw, gpc, nch, ratio, mrate, seed, raw, mrope) in cases:
         L = gpc * gh * gw
@@ -989,6 +994,8 @@ def main():
         gen_pivotkv(lc, HERE, only=("qwen_L1568", "llava_L1568", "qwen_L6272"))
     if args.only in (None, "pivotkv_prerope_bf16"):
         gen_pivotkv_prerope_bf16(lc, HERE)
+    if args.only == "pivotkv_prerope_llava_dyn":
+        gen_pivotkv_prerope_bf16(lc, HERE, only=("prerope_bf16_llava_L6272_dyn",))
     if args.only in (None, "glue"):
         gen_glue(HERE)
     if args.only in (None, "mallm"):
