@@ -943,3 +943,51 @@ def test_prologue_bf16_against_the_reference_run_from_pre_rope_projections(name,
                       f"worst {worst:.1f} bf16 ulp (of the pair norm) apart, mean |K - exact| {e_mine:.3e} (prologue) vs {e_theirs:.3e} (reference)")
         if not torch.equal(cache.position_cache[0][..., -1:].cpu(), torch.from_numpy(g[pre + "position_cache"][..., -1:])):
             break   # the next chunk's continuity shift starts from another id than the reference's did
+
+
+@pytest.mark.parametrize("rounding", ["fp32", "reference", "fast"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("mrope", [True, False])
+def test_prologue_with_reference_operands_equals_the_update_route_bitwise(dtype, rounding, mrope):
+    """The product-default route (update_pre_rope, prologue_operands="reference") and the reference's protocol (`update` on
+    tensors rotated op by op with the same tables) are the SAME computation: identical scoring operands, hence identical
+    scores, kept sets, kept keys, values and ids - bit for bit, in every dtype and score arithmetic, M-RoPE and plain ids,
+    two chunks x three layers, key-patch mask on."""
+    import retake.longvideo_cache as lc
+
+    if rounding != "fp32" and dtype == torch.float32:
+        pytest.skip("score_rounding applies to 16-bit tensors")
+    if rounding == "fast" and dtype == torch.float16:
+        pytest.skip("the fast mode is a bf16 mode")
+    layers, L = 3, 640
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    sec = SEC if mrope else None
+    pro = lc.build_kvcache(cfg(layers, score_rounding=rounding))
+    upd = lc.build_kvcache(cfg(layers, score_rounding=rounding))
+    for c in range(2):
+        mask = torch.from_numpy(np.random.default_rng(40 + c).uniform(size=L) < 0.3).to(dev())
+        ids_p, ids_u = chunk_ids(c, L, mrope), chunk_ids(c, L, mrope)
+        for cache in (pro, upd):
+            cache.keypatches_mask_chunk = mask
+            cache.kvcache_compression = True
+        for l in range(layers):
+            q0, k0, v0 = projections(300 + 10 * c + l, L, dtype)
+            out = pro.update_pre_rope(q0.clone(), k0, v0, l, ids_p, rot, sec, shift_ids_in_place=mrope)
+            assert out is not None
+            ids_l = ids_u if mrope else ids_u.clone()        # (LLaVA's patch shifts a clone per layer)
+            upd.shift_temporal_ids_(ids_l, l)
+            cos, sin = native_tables(ids_l, rot, dtype, mrope)
+            qr = (q0 * cos) + (rot_half(q0) * sin)
+            kr = (k0 * cos) + (rot_half(k0) * sin)
+            assert torch.equal(out[0], qr)
+            upd.update(kr, v0, l, {"query_states": qr, "position_ids": ids_l, "rotary_emb": rot, "mrope_section": sec})
+        pb, ub = pro._batch, upd._batch
+        pro.after_forward()
+        upd.after_forward()
+        for l in range(layers):
+            assert torch.equal(pb.score[l], ub.score[l]), (c, l, "scores")
+            assert torch.equal(pb.keep_idx[l], ub.keep_idx[l]), (c, l, "kept set")
+    for l in range(layers):
+        assert torch.equal(pro.key_cache[l], upd.key_cache[l]) and torch.equal(pro.value_cache[l], upd.value_cache[l])
+        assert torch.equal(pro.position_cache[l], upd.position_cache[l])
+    assert pro.num_evicted_tokens == upd.num_evicted_tokens
