@@ -183,6 +183,35 @@ def test_host_argument_blocks_match_the_header(tmp_path):
             assert int(got[f"{cname}.{fname}"]) == getattr(st, fname).offset, f"{cname}.{fname}"
 
 
+def test_flag_and_code_constants_match_the_header(tmp_path):
+    """The enum values Python passes through the ABI (dtype codes, update flags, compaction modes, error codes) are the
+    header's."""
+    import subprocess
+
+    import retake._native as nv
+
+    names = {"RTK_F32": nv.RTK_F32, "RTK_BF16": nv.RTK_BF16, "RTK_BF16_REFROUND": nv.RTK_BF16_REFROUND, "RTK_BF16_FAST": nv.RTK_BF16_FAST,
+             "RTK_F16": nv.RTK_F16, "RTK_F16_REFROUND": nv.RTK_F16_REFROUND, "RTK_SCORE_MANY_UNITS": nv.RTK_SCORE_MANY_UNITS,
+             "RTK_PREPARE_K_ONLY": nv.RTK_PREPARE_K_ONLY, "RTK_UPDATE_PRE_ROPE": nv.RTK_UPDATE_PRE_ROPE,
+             "RTK_UPDATE_Q_IN_PLACE": nv.RTK_UPDATE_Q_IN_PLACE, "RTK_UPDATE_ROUNDTRIP": nv.RTK_UPDATE_ROUNDTRIP,
+             "RTK_COMPACT_K_ROTATE": nv.COMPACT_K_ROTATE, "RTK_COMPACT_K_COPY": nv.COMPACT_K_COPY,
+             "RTK_COMPACT_K_INPLACE": nv.COMPACT_K_INPLACE, "RTK_EINVAL": nv.RTK_EINVAL, "RTK_EUNSUPPORTED": nv.RTK_EUNSUPPORTED,
+             "RTK_EWORKSPACE": nv.RTK_EWORKSPACE, "RTK_EHIP": nv.RTK_EHIP, "RTK_EREFCRASH": nv.RTK_EREFCRASH,
+             "RTK_SCORE_PREPARE": nv.SCORE_PREPARE, "RTK_SCORE_PASSES": nv.SCORE_PASSES, "RTK_SCORE_FINALIZE": nv.SCORE_FINALIZE,
+             "RTK_P2P_MAX_RANKS": nv.P2P_MAX_RANKS}
+    lines = ['#include <stdio.h>', '#include "retake_hip.h"', "int main(void) {"]
+    lines += [f'  printf("{n} %d\\n", (int)({n}));' for n in names]
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "consts.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "consts"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n, v in names.items():
+        assert int(got[n]) == v, n
+    assert nv.lib.rtk_version() == nv.ABI_VERSION == 15
+
+
 def test_round4_entry_points_validate_on_the_host():
     """rtk_pivotkv_update / _flush / rtk_mallm_hard_chain / rtk_rope_rotate_rows reject bad argument blocks before any
     launch (no GPU here), with a message."""
@@ -264,6 +293,15 @@ def test_product_defaults_are_the_benched_configuration():
     assert c.native_rope is True and c.one_call_update is True and c.score_rounding == "fp32" and c.overlap_streams == 0
     assert c.defer_rerotation is False and c.score_queries_in_place is True and c.in_place_compaction is True
     assert c.skip_masked_columns is True and c.score_when_keeping_all is False
+    assert c.prologue_operands == "reference" and c.flush_every_layers == 0    # round 5: the reference's operands; one flush per chunk
+    import pytest
+
+    for bad in ({"prologue_operands": "rotated"}, {"flush_every_layers": -1}, {"score_rounding": "exact"}):
+        cfg = bench.make_cache_config(2)
+        cfg.longvideo_kwargs["kvcache_compression_kwargs"].update(bad)
+        with pytest.raises(ValueError):
+            lc.build_kvcache(cfg)
+    assert lc.build_kvcache(bench.make_cache_config(2)).memory_footprint()["total"] == 0   # nothing allocated before the first update
 
     class Dyn:   # a rotary module whose frequencies depend on the sequence length has to be CALLED
         inv_freq, attention_scaling, rope_type = torch.ones(4), 1.0, "dynamic"

@@ -87,6 +87,12 @@ def test_flush_every_layers_equals_one_flush_per_chunk(dtype, route):
         ratio = scratch(fp) / scratch(ref_fp)
         # per-slot scratch scales with the slots; the fp32 / per-unit score passes keep one slot-independent workspace
         assert -0.05 < ratio - min(n, layers) / layers < (0.05 if dtype != torch.float32 else 0.15), (n, ratio)
+    if route == "update":   # ... and together with worker streams (scoring of each update on one of two side streams)
+        cache = lc.build_kvcache(cfg(layers, flush_every_layers=2, overlap_streams=2))
+        run_video(cache, pool, layers, n_chunks, L, rot, route)
+        for l in range(layers):
+            assert torch.equal(cache.key_cache[l], ref.key_cache[l]) and torch.equal(cache.value_cache[l], ref.value_cache[l])
+            assert torch.equal(cache.position_cache[l], ref.position_cache[l])
 
 
 def test_footprint_accounts_for_the_cache_and_bounds_the_peak():

@@ -15,8 +15,8 @@ for k, v in d.get("kernels_timed_region", {}).items():
 for k in ("roofline", "roofline_hbm_kernels", "cpu_baseline", "speedup_vs_cpu_baseline"):
     if k in d:
         print(k, d[k])
-comp = {k: d[k] for k in ("real_geometry", "rotary_module_called", "reference_rounding", "fast_rounding", "fp16_dtype",
-                         "fp32_parity_dtype") if k in d}
+comp = {k: d[k] for k in ("real_geometry", "no_keypatch_mask", "rotary_module_called", "reference_rounding", "fast_rounding",
+                         "fp16_dtype", "fp32_parity_dtype") if k in d}
 for g, c in (d.get("pre_rope_prologue") or {}).items():
     if isinstance(c, dict):
         comp["pre_rope_prologue/" + g] = c
@@ -26,6 +26,18 @@ for k, c in comp.items():
         print(f"{k}: {c['value']:.1f} frames/s  ms_per_step={c['ms_per_step']:.1f}  roofline {c['roofline']['kernel']} "
               f"frac={c['roofline']['frac']:.3f}  " + " ".join(f"{n}={v['avg_us']:.0f}us" for n, v in c["kernels_timed_region"].items())
               + (f"  per-update kernels {100 * share:.1f} % of GPU time" if share is not None else ""))
+if "llava_workload" in d:
+    c = d["llava_workload"]
+    print(f"llava_workload: {c['value']:.1f} frames/s  ms_per_step={c['ms_per_step']:.1f}  pass 1 of 2.5 PF {c['score_pass1_frac_of_2.5PF']:.3f}  "
+          + " ".join(f"{n}={v['avg_us']:.0f}us" for n, v in c["kernels_timed_region"].items()))
+if "memory" in d:
+    m = d["memory"]
+    print(f"memory: product peak {m['product_peak_bytes'] / 1e9:.2f} GB (allocator peak {m['peak_allocated_bytes'] / 1e9:.2f} - resident inputs "
+          f"{m['resident_inputs_bytes'] / 1e9:.2f}); reference by formula {m['reference_peak_by_formula']['bytes'] / 1e9:.2f} GB "
+          f"(x{m['product_peak_over_reference_formula']:.2f}); scratch / cache rows {m['scratch_over_cache_rows']:.2f}")
+    print("  split GB:", {k: round(v / 1e9, 3) for k, v in m["split_bytes"].items()})
+if "hbm_achievable" in d:
+    print("hbm_achievable", {k: (round(v, 1) if isinstance(v, float) else v) for k, v in d["hbm_achievable"].items() if k != "note"})
 if "decode_prologue" in d:
     for k in ("decode_token", "text_segment_64"):
         c = d["decode_prologue"][k]

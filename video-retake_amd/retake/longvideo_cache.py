@@ -2,26 +2,27 @@
 
 `PivotKVCache.update` (reference :217-323) keeps its signature, its `cache_kwargs` protocol (pops
 `position_ids`, `query_states`, `rotary_emb`, `mrope_section`) and its return value (the UNCOMPRESSED
-keys/values of the layer); scoring, selection and the eviction scan run as HIP kernels:
-    rtk_rope_merge / rtk_rope_table   M-RoPE section merge, cos/sin tables        (:68-74, :249, :298)
-    rtk_pivotkv_score                 un-rotate + softmax column mass per key     (:248-270)
-    rtk_pivotkv_select                mask override, top-k, id gather + rescale    (:272-295)
-    rtk_pivotkv_evict                 append + gather + re-rotate + compaction     (:238, :278-318)
-
-    rtk_pivotkv_append                chunk -> pre-allocated cache tail            (:238)
-    rtk_pivotkv_evict_batched /       gather + re-rotate + compaction of EVERY layer of the chunk,
-    rtk_pivotkv_commit_batched        two launches per chunk                       (:278-318)
+keys/values of the layer); everything it computes runs as HIP kernels behind the C ABI (include/retake_hip.h):
+    rtk_pivotkv_update    one call per update: fused prepare (rotary tables + un-rotate q / k + append k / v, :238,
+                          :248-259) - or, from the pre-RoPE projections, the whole attention prologue
+                          (`update_pre_rope`: continuity shift + tables + RoPE + append + scoring operands)
+    rtk_pivotkv_flush     one call per chunk, all pending layers: the two score passes (:260-268), finalize +
+                          mask override + top-k + id gather / rescale (:269-295), and ONE in-place compaction launch
+                          (kept K re-rotated at the new ids, kept V compacted inside the tail, ids; :278-318)
+    rtk_pivotkv_append_rope   text prefill / decode segments (`append_pre_rope`; the else-branch :319-321)
+The stage-by-stage entry points (rtk_pivotkv_prepare / _score_stages / _select / _evict_batched ...) serve the shapes
+the one-call path does not: small chunks, fp32 passes, rotary modules that must be called, worker streams.
 
 Memory layout (differs from the reference on purpose): each layer owns ONE pre-allocated
 [1, Hkv, capacity, D] key and value buffer and one [P, capacity] position-id buffer.  `update` appends
-the chunk at the tail (that view is what it returns to the layer's attention), scores it and records
-which rows survive in the layer's slot of a per-chunk batch.  The eviction itself — gather of the kept
+the chunk at the tail (that view is what it returns to the layer's attention), prepares the scoring operands in the
+layer's slot of a per-chunk batch and returns.  The eviction itself - scoring, selection, gather of the kept
 rows, re-rotation of the kept keys at their new ids, compaction over the head of the tail, position
-bookkeeping — is deferred until the view has been consumed and then flushed for ALL pending layers at
+bookkeeping - is deferred until the view has been consumed and then flushed for ALL pending layers at
 once (`after_forward`, which the reference calls after every video chunk; or the next `update` of a
-pending layer; or any access to `key_cache` / `value_cache` / `position_cache`).  This removes the
-reference's two O(cache) torch.cat rebuilds per (layer, chunk) and turns 28 launch-bound evictions
-into one bandwidth-bound launch.
+pending layer; or any access to `key_cache` / `value_cache` / `position_cache`; or, with `flush_every_layers: N`, every N
+layers).  This removes the reference's two O(cache) torch.cat rebuilds per (layer, chunk) and turns 28 launch-bound
+evictions into one bandwidth-bound launch.  `memory_footprint()` says what all of it costs in bytes.
 """
 from __future__ import annotations
 
@@ -1323,17 +1324,22 @@ class PivotKVCache(DynamicCache):
         """The attention patch's whole prologue as ONE kernel (not in the reference: there it is the continuity shift,
         the rotary module, apply_multimodal_rotary_pos_emb and PivotKVCache.update, qwen2_vl.py:68-86 + :217-259).
         query_states [1, Hq, L, D], key_states / value_states [1, Hkv, L, D] are the PRE-RoPE projections of a video
-        chunk.  Returns (rotated queries - written over `query_states` -, keys, values) with keys / values as `update`
-        returns them, or None - nothing touched - when this call has to take the eager route (first chunk of a
-        geometry, text segments, score_rounding="reference", rotary modules that must be called, small chunks).
+        chunk.  Returns (rotated queries - written over `query_states` unless `query_out` says otherwise -, keys, values)
+        with keys / values as `update` returns them, or None - nothing touched - when this call has to take the eager
+        route (text segments, chunks below 512 tokens, rotary modules that must be called, worker streams,
+        score_rounding="reference" combined with prologue_operands="pre_rope").
+        What the deferred score passes and the re-rotation are handed is `prologue_operands`: "reference" (default) - the
+        un-rotation of the rotated rows in the model dtype, the reference's own operands (longvideo_cache.py:76-78,
+        :248-259), so scores / kept sets / kept keys follow the reference's bf16 run bit for bit; "pre_rope" - the
+        projections themselves.
         shift_ids_in_place: the Qwen2-VL patch shifts the ids tensor it was handed (qwen2_vl.py:73; done here by the
         chunk's flush, with the last layer's rule - what the reference's layer loop leaves behind); the LLaVA patch
         shifts a private clone (llava_onevision.py:76-88), i.e. leaves the caller's tensor alone.
         query_out: where the rotated queries go (same shape and dtype, head_dim contiguous); it is the first element of
-        the returned tuple.  None: the library's pick - a fresh tensor when the chunk-batched score passes can then read
-        `query_states` where it lies (no copy of the queries is made; `query_states` must stay unmodified until the
-        chunk's flush, and is kept alive by the cache), else over `query_states`; pass `query_states` itself to force
-        the in-place rotation."""
+        the returned tuple.  None: the library's pick - with prologue_operands="pre_rope" a fresh tensor when the
+        chunk-batched score passes can then read `query_states` where it lies (no copy of the queries is made;
+        `query_states` must stay unmodified until the chunk's flush, and is kept alive by the cache), else over
+        `query_states`; pass `query_states` itself to force the in-place rotation."""
         if not (self.kvcache_compression and self.pos_embed_reforge and self.one_call_update) or self.overlap_streams > 0 \
                 or position_ids is None or not key_states.is_cuda or key_states.shape[0] != 1 \
                 or (torch.is_grad_enabled() and query_states.requires_grad):
