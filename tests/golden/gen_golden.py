@@ -747,18 +747,21 @@ def gen_pivotkv_prerope_bf16(lc, outdir, only=None):
              ("prerope_bf16_llava_L1568", 14, 14, 8, 2, 0.25, 0.3, 234, False, None),
              # BASELINE configs[4]'s own setting: LLaVA-Video chunk (32 frames x 196 pooled tokens), plain RoPE, the dynamic
              # ratio of a 2048-frame prompt (max_input_length 40000 / 401409 tokens: keep 624 of 6272)
-             ("prerope_bf16_llava_L6272_dyn", 14, 14, 32, 1, 40000 / (2048 * 196 + 1), 0.3, 235, False, None)]
+             ("prerope_bf16_llava_L6272_dyn", 14, 14, 32, 1, 40000 / (2048 * 196 + 1), 0.3, 235, False, None),
+             # the same chain on a float16 model (the reference guards its eager attention for fp16, qwen2_vl.py:98-101)
+             ("prerope_fp16_qwen_L1568", 14, 14, 8, 2, 0.25, 0.3, 236, False, M)]
     if only:
         cases = [c for c in cases if c[0] in only]
     Hq, Hkv, D = 28, 4, 128
     for (name, gh, gw, gpc, nch, ratio, mrate, seed, raw, mrope) in cases:
+        tdt = torch.float16 if "_fp16_" in name else torch.bfloat16
         L = gpc * gh * gw
         inv_f = synth.inv_freq(D, 1e6)
         rotary = synth.RotaryStub(inv_f, S)
         cache = lc.PivotKVCache(make_config(Hq, Hkv, D, 1, ratio, True, llava=(mrope is None)))
         rec = dict(Hq=Hq, Hkv=Hkv, D=D, L=L, gh=gh, gw=gw, grids_per_chunk=gpc, n_chunks=nch, ratio=ratio, reforge=True,
                    mrope_section=np.array(mrope if mrope else [], dtype=np.int64), attention_scaling=S, inv_freq=inv_f,
-                   seed=seed, layer=0, raw=raw, theta=1e6, dtype="bf16")
+                   seed=seed, layer=0, raw=raw, theta=1e6, dtype="fp16" if tdt is torch.float16 else "bf16")
         rng = np.random.default_rng(seed + 7)
         captured = {}
         orig_topk = torch.Tensor.topk
@@ -768,7 +771,7 @@ def gen_pivotkv_prerope_bf16(lc, outdir, only=None):
             return orig_topk(self, *args, **kw)
 
         for c in range(nch):
-            q0, k0, v = (torch.from_numpy(a).bfloat16() for a in synth.qkv_chunk(seed * 100 + c, Hq, Hkv, L, D))
+            q0, k0, v = (torch.from_numpy(a).to(tdt) for a in synth.qkv_chunk(seed * 100 + c, Hq, Hkv, L, D))
             if mrope:
                 pos_in = torch.from_numpy(synth.mrope_position_ids(5 + c * gpc, gpc, gh, gw, hw0=5))
             else:
@@ -783,12 +786,12 @@ def gen_pivotkv_prerope_bf16(lc, outdir, only=None):
                 else:
                     pos[0, :] += prev + 1 - cur
             cos, sin = rotary(v, pos)                      # bf16 tables, like HF's rotary module on a bf16 model
-            assert cos.dtype == torch.bfloat16
+            assert cos.dtype == tdt
             if mrope:
                 q, k = lc.apply_multimodal_rotary_pos_emb(q0, k0, cos, sin, list(mrope))
             else:
                 q, k = lc.apply_rotary_pos_emb(q0, k0, cos, sin)
-            assert q.dtype == torch.bfloat16
+            assert q.dtype == tdt
             mask = torch.from_numpy(rng.uniform(size=L) < mrate)
             cache.keypatches_mask_chunk = mask
             cache.kvcache_compression = True
@@ -816,7 +819,7 @@ def gen_pivotkv_prerope_bf16(lc, outdir, only=None):
                 idx[r] = m[0]
             assert (np.diff(idx) > 0).all()
             score_ref = captured["score"]                  # bf16 [L], after masked_fill_
-            assert score_ref.dtype == torch.bfloat16
+            assert score_ref.dtype == tdt
             s64_pre = score_fp64(q0, k0, Hkv)              # the exact score of the PRE-RoPE operands (what the prologue scores)
             # ... and of the reference's own round-tripped operands (its helper, its dtype)
             if mrope:
@@ -996,6 +999,8 @@ def main():
         gen_pivotkv_prerope_bf16(lc, HERE)
     if args.only == "pivotkv_prerope_llava_dyn":
         gen_pivotkv_prerope_bf16(lc, HERE, only=("prerope_bf16_llava_L6272_dyn",))
+    if args.only == "pivotkv_prerope_fp16":
+        gen_pivotkv_prerope_bf16(lc, HERE, only=("prerope_fp16_qwen_L1568",))
     if args.only in (None, "glue"):
         gen_glue(HERE)
     if args.only in (None, "mallm"):

@@ -252,8 +252,10 @@ def pivotkv_prerope_chunk_inputs(g, c: int):
         return g[pre + "q0_bits"], g[pre + "k0_bits"], g[pre + "v_bits"], pos_in, pos, mask
     Hq, Hkv, D, L = (int(g[k]) for k in ("Hq", "Hkv", "D", "L"))
 
+    tdt = torch.float16 if str(g["dtype"]) == "fp16" else torch.bfloat16
+
     def bits(a):
-        return torch.from_numpy(a).bfloat16().contiguous().view(torch.int16).numpy().view(np.uint16)
+        return torch.from_numpy(a).to(tdt).contiguous().view(torch.int16).numpy().view(np.uint16)
 
     q0, k0, v = (bits(a) for a in synth.qkv_chunk(int(g["seed"]) * 100 + c, Hq, Hkv, L, D))
     assert synth.checksum(q0) == int(g[pre + "q0_crc"]) and synth.checksum(k0) == int(g[pre + "k0_crc"])
@@ -262,8 +264,8 @@ def pivotkv_prerope_chunk_inputs(g, c: int):
 
 
 def rotate_like_a_bf16_model(g, c: int, q0_bits: np.ndarray, k0_bits: np.ndarray):
-    """The rotated q, k a bf16 HF model hands to PivotKVCache.update (uint16 bits): the rotary module's tables rounded to
-    bf16, then (x*cos) + (rotate_half(x)*sin) with one bf16 rounding per torch op (longvideo_cache.py:68-81 / :109-114).
+    """The rotated q, k a bf16 (fp16: fixtures with dtype "fp16") HF model hands to PivotKVCache.update (uint16 bits): the
+    rotary module's tables rounded to the model dtype, then (x*cos) + (rotate_half(x)*sin) with one rounding per torch op (longvideo_cache.py:68-81 / :109-114).
     Verified against the crc of the tensors the reference's own helper produced at generation time."""
     import torch
 
@@ -272,8 +274,10 @@ def rotate_like_a_bf16_model(g, c: int, q0_bits: np.ndarray, k0_bits: np.ndarray
     sec = [int(s) for s in g["mrope_section"]]
     rotary = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]))
 
+    tdt = torch.float16 if str(g["dtype"]) == "fp16" else torch.bfloat16
+
     def bf(bits):
-        return torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16)
+        return torch.from_numpy(bits.view(np.int16)).view(tdt)
 
     q0, k0 = bf(q0_bits), bf(k0_bits)
     cos, sin = rotary(k0, pos)

@@ -45,6 +45,28 @@ def main():
         held.append((out.clone(), want, i))
     for kept, want, i in held:
         assert torch.equal(kept.cpu(), want), f"clone of all_gather case {i} changed"
+    if os.environ.get("RETAKE_TEST_BIG") == "1":
+        # the sharded prefill's ragged assembly at 8 ranks: tiny exchanges (counts, flags, offsets), then a payload that
+        # makes the landing buffer grow to ~1 GB, then a small one right behind it (the ids) - all on alternating halves
+        seq = [((1,), torch.int64), ((2,), torch.int64), ((2,), torch.int64), ((1,), torch.int64),
+               ((2, 2, 4, 14112, 128), torch.bfloat16), ((2, 3, 14112), torch.int64), ((1,), torch.int64),
+               ((2, 2, 4, 14112, 128), torch.bfloat16), ((2, 3, 14112), torch.int64)]
+        for j, (shape, dtype) in enumerate(seq):
+            i = 1000 + j
+            mine = block(rank, i, shape, dtype).to(dev)
+            out = g.all_gather(mine)
+            got = torch.cat([out[r].reshape(-1)[: 1 << 22] for r in range(world)]).clone()   # a copy kernel reads the landing buffer
+            full = out.clone()
+            del mine
+            for r in range(world):
+                want = block(r, i, shape, dtype)
+                if not torch.equal(full[r].cpu(), want):
+                    bad = (full[r].cpu().reshape(-1) != want.reshape(-1)).nonzero().reshape(-1)
+                    raise AssertionError(f"rank {rank}: big all_gather step {j} {shape}: block of rank {r} differs in {bad.numel()} "
+                                         f"elements, first at {int(bad[0])}, last at {int(bad[-1])}")
+            del got, full
+        if rank == 0:
+            print("MP_P2P_BIG_OK", flush=True)
     for i in range(8, 40):   # many epochs through the same halves
         out = g.all_gather(block(rank, i, (64, 128), torch.float32).to(dev))
         assert torch.equal(out.cpu(), torch.stack([block(r, i, (64, 128), torch.float32) for r in range(world)]))

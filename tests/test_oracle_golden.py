@@ -221,6 +221,43 @@ def test_pivotkv_bf16_chain_from_pre_rope_projections_matches_reference(name):
             break   # later chunks depend on which tied tokens were kept
 
 
+@pytest.mark.parametrize("name", gu.names("pivotkv_prerope_fp16_"))
+def test_pivotkv_fp16_chain_from_pre_rope_projections_matches_reference(name):
+    """The float16 twin of the fixtures above: the reference's whole attention-side chain on an fp16 model from the fp16
+    pre-RoPE projections; the oracle's fp16 chain (numpy-float16 RoPE, score_rounding 'reference16') reproduces its scores
+    up to isolated 1-ulp entries, kept sets up to threshold ties, kept keys bit for bit."""
+    g = gu.load(name)
+    Hq, Hkv, D, L, keep = (int(g[k]) for k in ("Hq", "Hkv", "D", "L", "keep"))
+    sec = [int(x) for x in g["mrope_section"]] or None
+    rot = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]))
+    oc = orc.OraclePivotKV(Hq, Hkv, D, float(g["ratio"]), True, fp16=True, score_rounding="reference16")
+    for c in range(int(g["n_chunks"])):
+        pre = f"c{c}_"
+        q0, k0, v, pos_in, pos, mask = gu.pivotkv_prerope_chunk_inputs(g, c)
+        q, k = gu.rotate_like_a_bf16_model(g, c, q0, k0)
+        f32 = lambda b: b.view(np.float16).astype(np.float32)   # noqa: E731
+        oc.keypatches_mask_chunk = mask
+        oc.update(f32(k), f32(v), 0, q=f32(q), position_ids=pos, rotary=rot, mrope_section=sec)
+        last = oc.last
+        ref = f32(g[pre + "score_bf16"])                        # (the key's name is historical: bits of the model dtype)
+        score = last["score"]
+        bad = np.nonzero(score != ref)[0]
+        assert bad.size <= max(4, L // 200), bad.size
+        assert (np.abs(score[bad] - ref[bad]) <= gu.fp16_ulp(np.minimum(np.abs(score[bad]), np.abs(ref[bad])))).all()
+        thr = np.sort(ref)[::-1][keep - 1]
+        xor = np.setxor1d(last["keep_idx"], g[pre + "keep_idx"])
+        assert (np.abs(ref[xor] - thr) <= gu.fp16_ulp(np.full(xor.size, thr))).all()
+        ref_pos = g[pre + "position_cache"][..., -keep:].reshape(-1, keep)
+        common, ia, ib = np.intersect1d(last["keep_idx"], g[pre + "keep_idx"], return_indices=True)
+        same = (last["pos"].reshape(-1, keep)[:, ia] == ref_pos[:, ib]).all(0)
+        a = last["kept_k"].astype(np.float16).view(np.uint16).reshape(-1, keep, D)[:, ia[same]]
+        b = g[pre + "kept_k_bits"].reshape(-1, keep, D)[:, ib[same]]
+        np.testing.assert_array_equal(a, b)
+        print(f"\n[{name} c{c}] oracle fp16 chain: {bad.size} of {L} scores off by one fp16 ulp, kept xor {xor.size}")
+        if xor.size:
+            break
+
+
 def test_topk_ties_lowest_index_first():
     v = np.array([1, 3, 3, 2, 3, 0, 3], dtype=np.float32)
     import ctypes as C

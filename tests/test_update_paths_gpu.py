@@ -991,3 +991,84 @@ def test_prologue_with_reference_operands_equals_the_update_route_bitwise(dtype,
         assert torch.equal(pro.key_cache[l], upd.key_cache[l]) and torch.equal(pro.value_cache[l], upd.value_cache[l])
         assert torch.equal(pro.position_cache[l], upd.position_cache[l])
     assert pro.num_evicted_tokens == upd.num_evicted_tokens
+
+
+@pytest.mark.parametrize("mode", ["reference/fp32", "reference/reference", "pre_rope/fp32"])
+@pytest.mark.parametrize("name", gu.names("pivotkv_prerope_fp16_"))
+def test_prologue_fp16_against_the_reference_run_from_pre_rope_projections(name, mode):
+    """The float16 twin: the reference run on an fp16 model's tensors from the fp16 pre-RoPE projections (its rotation helper
+    in fp16, then PivotKVCache.update), against update_pre_rope on the same q0 / k0 / v, three layers per chunk.  Same
+    statements as the bf16 test with fp16 ulps: ids equal; rotated queries equal to the helper's up to table midpoints;
+    reference operands -> kept K bit-exact, kept sets differ only within one fp16 ulp of the reference's threshold (fp32
+    score arithmetic) or by threshold ties (the reference's fp16 chain, RTK_F16_REFROUND); pre-RoPE operands -> within 2E."""
+    operands, rounding = mode.split("/")
+    g = gu.load(name)
+    Hq_, Hkv_, D_, L, keep = (int(g[k]) for k in ("Hq", "Hkv", "D", "L", "keep"))
+    sec = [int(s) for s in g["mrope_section"]] or None
+    n_layers = 2
+    cache = _fixture_cache(g, n_layers, prologue_operands=operands, score_rounding=rounding)
+    rot = synth.RotaryStub(g["inv_freq"], float(g["attention_scaling"]), device=dev())
+
+    def f32(bits):
+        return np.ascontiguousarray(bits).view(np.float16).astype(np.float32)
+
+    def f16(bits):
+        return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(torch.float16)
+
+    for c in range(int(g["n_chunks"])):
+        pre = f"c{c}_"
+        q0b, k0b, vb, pos_in, pos, mask = gu.pivotkv_prerope_chunk_inputs(g, c)
+        q0, k0, v = (_as_projection(f16(x).to(dev())) for x in (q0b, k0b, vb))
+        cache.keypatches_mask_chunk = torch.from_numpy(mask).to(dev())
+        cache.kvcache_compression = True
+        ids = torch.from_numpy(pos_in).to(dev())
+        outs = [cache.update_pre_rope(q0.clone(), k0, v, l, ids, rot, sec) for l in range(n_layers)]
+        assert all(o is not None for o in outs)
+        b = cache._batch
+        want_ids = torch.from_numpy(pos).to(dev())
+        assert all(torch.equal(b.pos_old[l].reshape(want_ids.shape), want_ids) for l in range(n_layers))
+        cache.after_forward()
+        qr_ref, _ = gu.rotate_like_a_bf16_model(g, c, q0b, k0b)
+        qr = outs[0][0].cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+        n_q = int((qr != qr_ref).sum())
+        assert (np.abs(f32(qr) - f32(qr_ref)) <= gu.fp16_ulp(f32(qr_ref))).all() and n_q <= max(8, qr.size // 20000)
+        ref = f32(g[pre + "score_bf16"])
+        ref_idx = g[pre + "keep_idx"]
+        thr = np.sort(ref)[::-1][keep - 1]
+        ref_pos = g[pre + "position_cache"][..., -keep:].reshape(-1, keep)
+        s64 = g[pre + ("score64" if operands == "reference" else "score64_pre")].copy()
+        s64[mask] = 1.0
+        E = np.abs(ref - s64).max()
+        for l in range(n_layers):
+            score, idx = b.score[l].cpu().numpy(), b.keep_idx[l].cpu().numpy()
+            xor = np.setxor1d(idx, ref_idx)
+            vv = cache.value_cache[l][:, :, -keep:].cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+            assert np.array_equal(vv[0], vb[0][:, idx])
+            pos_new = cache.position_cache[l][..., -keep:].cpu().numpy().reshape(-1, keep)
+            kk = cache.key_cache[l][:, :, -keep:].cpu().contiguous().view(torch.int16).numpy().view(np.uint16)[0]
+            common, ia, ib = np.intersect1d(idx, ref_idx, return_indices=True)
+            same_pos = (pos_new[:, ia] == ref_pos[:, ib]).all(0)
+            assert same_pos.mean() > 0.9
+            if rounding == "reference":
+                bad = np.nonzero(score != ref)[0]
+                assert np.array_equal(score.astype(np.float16).astype(np.float32), score) and bad.size <= 16, bad.size
+                assert (np.abs(score[bad] - ref[bad]) <= gu.fp16_ulp(np.minimum(np.abs(score[bad]), np.abs(ref[bad])))).all()
+                assert (np.abs(ref[xor] - thr) <= gu.fp16_ulp(np.full(xor.size, thr))).all()
+                np.testing.assert_array_equal(kk[:, ia[same_pos]], g[pre + "kept_k_bits"][0][:, ib[same_pos]])
+                note = f"{bad.size} of {L} scores off by one fp16 ulp, kept xor {xor.size}, kept K bit-exact"
+            else:
+                err = np.abs(score - s64).max()
+                assert err < 2e-5, err
+                if operands == "reference":
+                    assert (np.abs(ref[xor] - thr) <= gu.fp16_ulp(np.full(xor.size, thr))).all()
+                    np.testing.assert_array_equal(kk[:, ia[same_pos]], g[pre + "kept_k_bits"][0][:, ib[same_pos]])
+                    note = f"{xor.size // 2} of {keep} kept tokens differ (within one fp16 ulp of the threshold), kept K bit-exact"
+                else:
+                    assert (np.abs(ref[xor] - thr) <= 2 * E + 4e-5).all()
+                    note = f"{xor.size // 2} of {keep} kept tokens differ (all within 2E = {2 * E:.4f})"
+                note += f"; max |score - exact| {err:.2e}"
+            assert xor.size <= 16
+            if l == 0:
+                print(f"\n[{name} c{c}] {mode}: {note}; q_rot: {n_q} of {qr.size} entries differ by one fp16 ulp")
+        if not torch.equal(cache.position_cache[0][..., -1:].cpu(), torch.from_numpy(g[pre + "position_cache"][..., -1:])):
+            break

@@ -169,6 +169,7 @@ class P2PGroup:
         self._slot = 0
         self._calls = 0
         self._buffers: List[SymmetricBuffer] = []
+        self._last_src: Optional[torch.Tensor] = None
 
     def symmetric(self, nbytes: int) -> SymmetricBuffer:
         b = SymmetricBuffer(self, nbytes)
@@ -203,6 +204,7 @@ class P2PGroup:
             else:
                 buf.push(src, 0, 0, 16, half, 16)
             buf.wait()
+            self._last_src = src   # read by the push kernel after this call has returned: kept until the next call
         out = buf.local[half:half + self.world * self._slot].view(self.world, self._slot)[:, :nb]
         if nb == slot:
             return out.view(x.dtype).view((self.world,) + tuple(x.shape))

@@ -293,6 +293,7 @@ class ChunkGatherP2P:
         self.bufs = [p2p.symmetric(self.capacity), p2p.symmetric(self.capacity)]
         self.side = torch.cuda.Stream(device=p2p.device)
         self.gen, self.at = 1, 0
+        self._sources: List[torch.Tensor] = []
         self.begin_video(total, n_layers, Hkv, D, dtype)
 
     @staticmethod
@@ -312,6 +313,7 @@ class ChunkGatherP2P:
             self.es = torch.empty((), dtype=dtype).element_size()
         self.gen ^= 1
         self.at = 0
+        self._sources = []   # the previous video's push sources: every rank has long waited for them
 
     def start(self, k_new: List[torch.Tensor], v_new: List[torch.Tensor]):
         n_layers = len(k_new)
@@ -327,6 +329,9 @@ class ChunkGatherP2P:
         world, rank = self.p2p.world, self.p2p.rank
         self.bufs[self.gen].push(send, n * row, 2 * n_layers * Hkv, n * row, (rank * self.total + self.at) * row,
                                  world * self.total * row, stream=self.side)
+        # the push kernel reads `send` on the side stream after this function has returned: the tensor is kept until the
+        # next video begins (record_stream above only protects it under torch's caching allocator)
+        self._sources.append(send)
         self.at += n
 
     def rows(self) -> int:
