@@ -19,6 +19,7 @@ the launch stream inside the timed region (rtk_profile_*); `cpu_baseline` times 
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import math
 import os
@@ -281,7 +282,8 @@ def memory_block(cache, peak_alloc, peak_reserved, resident_inputs, dpselect_out
     keep = max(1, int(RATIO * L))
     in_flight = 2 * layers * Hkv * L * D * es
     ref = reference_peak_formula(L, (n_chunks - 1) * keep, es)
-    ref_total = ref["total"] + (layers - 1) * 2 * Hkv * D * es * n_chunks * keep   # the other layers' compressed rows
+    # + the other layers' compressed rows + DPSelect's output, which the reference materialises as well (:138 / :173)
+    ref_total = ref["total"] + (layers - 1) * 2 * Hkv * D * es * n_chunks * keep + dpselect_out_bytes
     product_peak = peak_alloc - resident_inputs
     return {
         "peak_allocated_bytes": peak_alloc, "peak_reserved_bytes": peak_reserved,
@@ -303,7 +305,7 @@ def memory_block(cache, peak_alloc, peak_reserved, resident_inputs, dpselect_out
         "scratch_over_cache_rows": (fp["total"] - fp["cache_rows"] - in_flight) / max(1, fp["cache_rows"]),
         "reference_peak_by_formula": {"bytes": ref_total, "one_update_terms": ref,
                                       "note": "last chunk of the video, one layer inside update + the other layers' compressed "
-                                              "rows; the [Hq, L, L] tensors dominate"},
+                                              "rows + DPSelect's output copy; the [Hq, L, L] tensors dominate"},
         "product_peak_over_reference_formula": product_peak / ref_total,
     }
 
@@ -464,7 +466,10 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
         ids = nv.profile_kernel_ids()
         nv.check(nv.lib.rtk_profile_reset(), "profile_reset")
         nv.check(nv.lib.rtk_profile_enable_mask((1 << ids["score_pass1"]) | (1 << ids["score_pass2"])), "profile_enable")
+        gc.collect()
         torch.cuda.synchronize()
+        resident_inputs = torch.cuda.memory_allocated()
+        torch.cuda.reset_peak_memory_stats()
         t0 = time.perf_counter()
         cache = kp_mask = None
         step_ms = []
@@ -478,6 +483,10 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
             torch.cuda.synchronize()
             step_ms.append((time.perf_counter() - ts) * 1e3)
         dt = time.perf_counter() - t0
+        es_ = 4 if dtype == "fp32" else 2
+        mem = memory_block(cache, torch.cuda.max_memory_allocated(), torch.cuda.max_memory_reserved(), resident_inputs,
+                           0 if NO_VISUAL_COMPRESSION else frames.numel() * frames.element_size() + 5 * rows * N_PATCH, layers, L,
+                           n_chunks, es_)
         nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
         kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in nv.profile_read().items()}
         kern_all = None
@@ -505,6 +514,9 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
                "kernels_timed_region": kern,
                "roofline": score_roofline(kern, dtype, L, rows, n_chunks * layers * steps)}
         res["config"]["cache_kwargs"] = cache_kwargs()
+        res["memory"] = {k: mem[k] for k in ("product_peak_bytes", "split_bytes", "scratch_over_cache_rows",
+                                             "product_peak_over_reference_formula")}
+        res["memory"]["reference_peak_by_formula_bytes"] = mem["reference_peak_by_formula"]["bytes"]
         if pre_rope:
             res["config"]["update_call"] = "PivotKVCache.update_pre_rope (pre-RoPE projections, [L, H*D] layout)"
         if kern_all is not None:
@@ -743,6 +755,7 @@ def main():
         ids = nv.profile_kernel_ids()
         nv.check(nv.lib.rtk_profile_reset(), "profile_reset")
         nv.check(nv.lib.rtk_profile_enable_mask((1 << ids["score_pass1"]) | (1 << ids["score_pass2"])), "profile_enable")
+    gc.collect()
     torch.cuda.synchronize()
     resident_inputs = torch.cuda.memory_allocated()     # frame bank + (q, k, v) pool + ids: the bench's own tensors
     torch.cuda.reset_peak_memory_stats()

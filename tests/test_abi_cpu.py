@@ -313,3 +313,27 @@ def test_product_defaults_are_the_benched_configuration():
     ra, rb = c._rotary(a, torch.device("cpu")), c._rotary(b2, torch.device("cpu"))
     assert ra is not None and ra is rb                       # equal contents: one entry, one batch for all layers
     assert c._rotary(Dyn(), torch.device("cpu")) is None
+
+
+def test_a_dropped_cache_is_released_without_the_garbage_collector():
+    """The key_cache / value_cache list views hold a WEAK reference to their cache: dropping the cache frees it (and its
+    gigabytes of device buffers) at once instead of whenever a reference cycle gets collected."""
+    import gc
+    import sys
+    import weakref
+
+    sys.path.insert(0, ROOT)
+    import bench
+    import retake.longvideo_cache as lc
+
+    gc.disable()
+    try:
+        c = lc.build_kvcache(bench.make_cache_config(2))
+        r, view = weakref.ref(c), c.key_cache
+        assert len(view) == 0
+        del c
+        assert r() is None
+        with pytest.raises(ReferenceError):
+            len(view)
+    finally:
+        gc.enable()

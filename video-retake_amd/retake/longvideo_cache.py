@@ -29,6 +29,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import sys
+import weakref
 from typing import Any, Dict, List, Optional, Tuple
 
 import torch
@@ -409,7 +410,16 @@ class _CacheView:
     first, so readers always see the compacted cache exactly like the reference's lists."""
 
     def __init__(self, owner: "PivotKVCache", which: str):
-        self._o, self._w = owner, which
+        # a weak reference: the cache owns its views, not the other way round - with a strong one the pair is a reference
+        # cycle and a dropped cache (gigabytes of device memory) lives on until the garbage collector happens to run
+        self._ref, self._w = weakref.ref(owner), which
+
+    @property
+    def _o(self) -> "PivotKVCache":
+        o = self._ref()
+        if o is None:
+            raise ReferenceError("the PivotKVCache this view belongs to has been released")
+        return o
 
     def __len__(self):
         return len(self._o._layers)
