@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Pretty-print a bench.py JSON line from stdin."""
+"""Pretty-print a bench.py JSON line: `show_bench.py FILE`, or from stdin."""
 import json
 import sys
 
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+text = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
+d = json.loads(text.strip().splitlines()[-1])
 print(f"value={d['value']:.1f} {d['unit']}  ms_per_step={d['ms_per_step']:.1f}  n_gpus={d['n_gpus']} dtype={d['dtype']}")
 tot = 0.0
 for k, v in (d.get("kernels") or d.get("kernels_untimed_single_stream", {})).items():
