@@ -575,7 +575,10 @@ typedef struct rtk_update_io {
     void* q_rot; int64_t qr_stride_h, qr_stride_l;   /* RTK_UPDATE_PRE_ROPE: rotated queries out (may alias q) */
     int32_t flags;
     int32_t pad0;
-} rtk_update_io;
+    const int64_t* next_prev;                        /* RTK_UPDATE_SHIFT_NEXT (ABI 16): the NEXT layer's last cached temporal id */
+    int32_t* ticket; int64_t ticket_ints;            /*   (device; NULL = -1); rtk_pivotkv_shift_ticket_ints(L, D) device words, */
+} rtk_update_io;                                     /*   zeroed ONCE by the caller (launch count + arrival counters)            */
+size_t rtk_pivotkv_shift_ticket_ints(int L, int D);
 enum rtk_update_flags {
     /* q, k are the PRE-RoPE projections (what q_proj / k_proj return).  One launch then does the whole prologue of the
      * attention patch (qwen2_vl.py:55-86, llava_onevision.py:59-141) and of PivotKVCache.update (:238, :248-259):
@@ -599,7 +602,16 @@ enum rtk_update_flags {
      * round trip moves an operand by up to a few ulps, which is what the reference's scores and kept keys carry; with this
      * flag the score operands and the kept keys equal the reference's bit for bit (tables within one fp32 ulp of the rotary
      * module's).  Excludes RTK_UPDATE_Q_IN_PLACE; allows the reference-rounding score modes. */
-    RTK_UPDATE_ROUNDTRIP = 4
+    RTK_UPDATE_ROUNDTRIP = 4,
+    /* without RTK_UPDATE_PRE_ROPE (ABI 16; the reference's protocol: q, k rotated by the caller): the launch that
+     * un-rotates and appends the chunk also applies the continuity shift the NEXT layer's attention patch would launch
+     * before its RoPE (qwen2_vl.py:68-73):  pos[0, 0:L] += (*next_prev + 1) - pos[0, 0], in place, once every workgroup
+     * has read the ids this layer works with (each counts itself in on one of the counters in io->ticket; one extra
+     * workgroup watches them, shifts and zeroes them again: nobody else waits).  `pos` is written despite its const.
+     * Launches that share the ticket words must be stream ordered.
+     * The caller's next rtk_position_shift for that layer is then a no-op and may be skipped - the attention patch of a
+     * 28-layer model launches it 27 times per chunk otherwise.  Only with the native prepare kernel (batch.inv_freq). */
+    RTK_UPDATE_SHIFT_NEXT = 8
 };
 /* longvideo_cache.py:217-310 up to the deferred selection, for layer slot `slot`.  Rows go to the layer's tail
  * (ls->k/v + length rows; the caller has made sure length + L <= cap), ls->pending / pending_keep are set. */

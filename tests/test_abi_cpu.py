@@ -194,6 +194,7 @@ def test_flag_and_code_constants_match_the_header(tmp_path):
              "RTK_F16": nv.RTK_F16, "RTK_F16_REFROUND": nv.RTK_F16_REFROUND, "RTK_SCORE_MANY_UNITS": nv.RTK_SCORE_MANY_UNITS,
              "RTK_PREPARE_K_ONLY": nv.RTK_PREPARE_K_ONLY, "RTK_UPDATE_PRE_ROPE": nv.RTK_UPDATE_PRE_ROPE,
              "RTK_UPDATE_Q_IN_PLACE": nv.RTK_UPDATE_Q_IN_PLACE, "RTK_UPDATE_ROUNDTRIP": nv.RTK_UPDATE_ROUNDTRIP,
+             "RTK_UPDATE_SHIFT_NEXT": nv.RTK_UPDATE_SHIFT_NEXT,
              "RTK_COMPACT_K_ROTATE": nv.COMPACT_K_ROTATE, "RTK_COMPACT_K_COPY": nv.COMPACT_K_COPY,
              "RTK_COMPACT_K_INPLACE": nv.COMPACT_K_INPLACE, "RTK_EINVAL": nv.RTK_EINVAL, "RTK_EUNSUPPORTED": nv.RTK_EUNSUPPORTED,
              "RTK_EWORKSPACE": nv.RTK_EWORKSPACE, "RTK_EHIP": nv.RTK_EHIP, "RTK_EREFCRASH": nv.RTK_EREFCRASH,
@@ -209,7 +210,7 @@ def test_flag_and_code_constants_match_the_header(tmp_path):
     got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
     for n, v in names.items():
         assert int(got[n]) == v, n
-    assert nv.lib.rtk_version() == nv.ABI_VERSION == 15
+    assert nv.lib.rtk_version() == nv.ABI_VERSION == 16
 
 
 def test_round4_entry_points_validate_on_the_host():

@@ -1072,3 +1072,102 @@ def test_prologue_fp16_against_the_reference_run_from_pre_rope_projections(name,
                 print(f"\n[{name} c{c}] {mode}: {note}; q_rot: {n_q} of {qr.size} entries differ by one fp16 ulp")
         if not torch.equal(cache.position_cache[0][..., -1:].cpu(), torch.from_numpy(g[pre + "position_cache"][..., -1:])):
             break
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("L,mrope", [(640, True), (2304, True), (6272, False)])
+def test_the_next_layers_shift_rides_in_the_update_launch(L, mrope, dtype):
+    """qwen2_vl.py:68-73 on the reference's protocol: every layer shifts the shared ids tensor to follow ITS last cached
+    temporal id before its RoPE.  rtk_pivotkv_update(RTK_UPDATE_SHIFT_NEXT) applies layer l + 1's shift inside layer l's
+    launch (after every workgroup has read the ids layer l works with), so `shift_temporal_ids_` launches once per chunk.
+    The ids every layer sees, the ids left in the caller's tensor and the caches equal the launch-per-layer route's bit
+    for bit; the number of shift launches is counted."""
+    import retake._native as nv
+    import retake.longvideo_cache as lc
+
+    layers, n_chunks = 4, 3
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    sec = SEC if mrope else None
+    g = torch.Generator(device=dev()).manual_seed(5)
+    pool = [tuple((1.7 * torch.randn((1, h, L, D), generator=g, device=dev())).to(dtype) for h in (Hq, Hkv, Hkv)) for _ in range(3)]
+    kid = nv.profile_kernel_ids()["position_shift"]
+
+    def run(cache):
+        seen = []
+        nv.check(nv.lib.rtk_profile_reset(), "profile_reset")
+        nv.check(nv.lib.rtk_profile_enable_mask(1 << kid), "profile_enable")
+        for c in range(n_chunks):
+            # (many temporal steps, so that the layers' last kept ids - the bases of their shifts - differ)
+            pos = torch.from_numpy(synth.mrope_position_ids(10 + 7 * c, L // 4, 2, 2, hw0=2)).to(dev()) if mrope \
+                else chunk_ids(c, L, False)
+            cache.keypatches_mask_chunk = torch.from_numpy(np.random.default_rng(c).uniform(size=L) < 0.3).to(dev())
+            cache.kvcache_compression = True
+            for l in range(layers):
+                q, k, v = pool[(c + l) % 3]
+                cache.shift_temporal_ids_(pos, l)
+                seen.append(pos.clone())
+                kw = {"query_states": q, "position_ids": pos, "rotary_emb": rot}
+                if mrope:
+                    kw["mrope_section"] = sec
+                cache.update(k, v, l, kw)
+            seen.append(pos.clone())    # what the reference's loop leaves in the caller's tensor: the LAST layer's shift
+            cache.after_forward()
+        torch.cuda.synchronize()
+        nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
+        n = nv.profile_read().get("position_shift", (0, 0.0))[0]
+        return seen, n, int(cache._batch.shift_ticket[0])   # closed epochs = launches that carried a shift
+
+    fused, apart = lc.build_kvcache(cfg(layers)), lc.build_kvcache(cfg(layers, shift_next_in_update=False))
+    seen_f, n_f, epochs_f = run(fused)
+    seen_a, n_a, epochs_a = run(apart)
+    assert n_a == n_chunks * layers and epochs_a == 0
+    # every layer's shift was either its own launch or rode in the previous layer's update (layer 0's never does; the
+    # first chunk creates the layers' stores on the general route, a growing store re-binds: a launch per layer there)
+    assert n_f + epochs_f == n_chunks * layers and epochs_f >= layers - 1, (n_f, epochs_f)
+    assert len(seen_f) == len(seen_a)
+    for i, (a, b) in enumerate(zip(seen_f, seen_a)):
+        assert torch.equal(a, b), f"ids differ at step {i}"
+    for l in range(layers):
+        assert torch.equal(fused.key_cache[l], apart.key_cache[l])
+        assert torch.equal(fused.value_cache[l], apart.value_cache[l])
+        assert torch.equal(fused.position_cache[l], apart.position_cache[l])
+    # the layers' last ids differ (each keeps its own tokens), so the shifts were real ones
+    assert len({int(fused.position_cache[l][0, 0, -1] if mrope else fused.position_cache[l][0, -1]) for l in range(layers)}) > 1
+
+
+def test_a_preshifted_tensor_is_recognised_only_as_itself():
+    """The memo of the in-launch shift names the tensor OBJECT, its version, the layer and the stream: a clone, a tensor
+    modified in between, another layer or a skipped layer all get their own launch (which is idempotent)."""
+    import retake._native as nv
+    import retake.longvideo_cache as lc
+
+    layers, L = 4, 640
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    g = torch.Generator(device=dev()).manual_seed(6)
+    q, k, v = ((1.7 * torch.randn((1, h, L, D), generator=g, device=dev())).to(torch.bfloat16) for h in (Hq, Hkv, Hkv))
+    cache = lc.PivotKVCache(cfg(layers), reserve_tokens=8 * L)   # (no store grows inside the test: growth re-binds on the general route)
+    kid = nv.profile_kernel_ids()["position_shift"]
+
+    def chunk(c, between):
+        pos = chunk_ids(c, L)
+        cache.kvcache_compression = True
+        cache.keypatches_mask_chunk = None
+        launches = []
+        for l in range(layers):
+            nv.check(nv.lib.rtk_profile_reset(), "profile_reset")
+            nv.check(nv.lib.rtk_profile_enable_mask(1 << kid), "profile_enable")
+            pos = between(l, pos)
+            cache.shift_temporal_ids_(pos, l)
+            torch.cuda.synchronize()
+            nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
+            launches.append(nv.profile_read().get("position_shift", (0, 0.0))[0])
+            prev = cache.get_prev_temporal_idx(l)
+            assert int(pos[0, 0, 0]) == int(prev) + 1
+            cache.update(k, v, l, {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": SEC})
+        cache.after_forward()
+        return launches
+
+    chunk(0, lambda l, p: p)                                          # creates the layers' stores (general route)
+    assert chunk(1, lambda l, p: p) == [1, 0, 0, 0]
+    assert chunk(2, lambda l, p: p.clone()) == [1, 1, 1, 1]           # LLaVA's patch: a clone per layer
+    assert chunk(3, lambda l, p: p.add_(0) if l == 2 else p) == [1, 0, 1, 0]   # touched through torch: version moved

@@ -73,7 +73,9 @@ def main():
         inplace_b = bool(rng.uniform() < 0.5)
         fel_b = int(rng.choice([0, 0, 1, 2]))            # twin flushed every N layers (slot = layer mod N)
         ops_p = str(rng.choice(["reference", "pre_rope"]))   # what the prologue cache scores
-        desc += f" staged_twin={staged_b} twin_in_place_compaction={inplace_b} twin_flush_every_layers={fel_b} prologue_operands={ops_p}"
+        shn_b = bool(rng.uniform() < 0.5)                # twin: the next layer's id shift rides in the update launch
+        desc += (f" staged_twin={staged_b} twin_in_place_compaction={inplace_b} twin_flush_every_layers={fel_b} "
+                 f"twin_shift_next={shn_b} prologue_operands={ops_p}")
 
         def make(skip, **extra):
             kw = {"compression_ratio": ratio, "compression_method": "pivotkv", "pos_embed_reforge": reforge,
@@ -86,7 +88,8 @@ def main():
                                         longvideo_kwargs={"kvcache_compression": True, "kvcache_compression_kwargs": kw})
             return lc.build_kvcache(cfg)
 
-        ca, cb = make(True), make(False, one_call_update=not staged_b, in_place_compaction=inplace_b, flush_every_layers=fel_b)
+        ca, cb = make(True), make(False, one_call_update=not staged_b, in_place_compaction=inplace_b, flush_every_layers=fel_b,
+                                    shift_next_in_update=shn_b)
         # the prologue route, where it applies (reforging cache, inv_freq rotary, chunks of >= 512 tokens; the reference's
         # rounding chain needs the reference's operands)
         pre = reforge and native and L >= 512 and (rounding != "reference" or ops_p == "reference")

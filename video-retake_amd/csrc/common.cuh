@@ -305,6 +305,14 @@ __device__ __forceinline__ void rope_chunk(const float* __restrict__ inv_freq, c
 
 // bf16(x * (1/a2)) == bf16(x / a2) for every finite bf16 x?  (pivotkv_score.hip; exhaustive, cached per a2)
 bool bf16_rcp_is_exact(float a2);
+// rtk_pivotkv_prepare with the next layer's id shift in the launch (pivotkv_score.hip; used by rtk_pivotkv_update)
+int pivotkv_prepare_shift(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k, int64_t k_stride_h,
+                          int64_t k_stride_l, const void* v, int64_t v_stride_h, int64_t v_stride_l, int Hq, int Hkv, int L,
+                          int D, int dtype, const int64_t* pos, int64_t pos_stride, int P, const float* inv_freq,
+                          float attention_scaling, const int* sections_host, int nsec, int round_bf16, void* k_unrot,
+                          void* workspace, size_t workspace_bytes, void* k_tail, void* v_tail, int64_t tail_stride_h,
+                          int64_t* pos_copy, int64_t* shift_row, const int64_t* next_prev, int32_t* ticket,
+                          int64_t ticket_ints, rtk_stream_t stream);
 
 inline int make_rowsel(RowSel& rs, int P, int D, const int* sections, int nsec, const char* who) {
     if (D > 256 || (D & 1)) {

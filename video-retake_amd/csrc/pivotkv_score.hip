@@ -217,25 +217,77 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
 // by the serial instruction stream of its waves.  Narrow chunks split the same work over 4x the waves; what remains is the
 // read + write traffic (45 MB per call at L = 2304) at ~3 TB/s plus the launch ramp.
 
+constexpr int RTK_SHIFT_COUNTERS = 64;   // arrival counters of RTK_UPDATE_SHIFT_NEXT (<= RTK_PREP_BLOCK: one per watching thread)
+constexpr int RTK_SHIFT_STRIDE = 32;     // ... 128 bytes apart
+static_assert(RTK_SHIFT_COUNTERS <= RTK_PREP_BLOCK, "one watching thread per counter");
+
 template <int DT, int DIV, bool FAST = false, int NW = 4>
 __global__ __launch_bounds__(RTK_PREP_BLOCK) void prepare_native_kernel(const char* __restrict__ q, int64_t q_sh, int64_t q_sl,
                                                             const char* __restrict__ k, int64_t k_sh, int64_t k_sl,
                                                             const char* __restrict__ v, int64_t v_sh, int64_t v_sl,
                                                             int Hq, int Hkv, int L, int D,
-                                                            const int64_t* __restrict__ pos, int64_t pos_ld,
+                                                            const int64_t* pos, int64_t pos_ld,
                                                             const float* __restrict__ inv_freq, float scaling, RowSel rs,
                                                             int round_bf16, float a2, float rcp_a2,
                                                             char* __restrict__ q_out, char* __restrict__ k_out,
                                                             char* __restrict__ k_tail, char* __restrict__ v_tail,
                                                             int64_t tail_sh, int P, int64_t* __restrict__ pos_copy,
-                                                            char* __restrict__ k_fast = nullptr, float qscale = 1.f) {
+                                                            char* __restrict__ k_fast = nullptr, float qscale = 1.f,
+                                                            int64_t* shift_row = nullptr, const int64_t* next_prev = nullptr,
+                                                            int* ticket = nullptr) {
     using V = Vec16<DT>;
     static_assert(NW == 4 || ((NW == 2 || NW == 1) && DT != RTK_F32), "8- / 4-byte chunks: 16-bit dtypes only");
     constexpr int ES = 16 / V::VE;          // bytes per element
     constexpr int VE = 4 * NW / ES;         // elements per thread and row half
     using W = WV<NW>;
     const int h2 = D / 2, lpr = h2 / VE;
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    // RTK_UPDATE_SHIFT_NEXT: the NEXT layer's continuity shift (qwen2_vl.py:68-73) rides in this launch.  Every working
+    // workgroup reads the chunk's ids, so the row may only be rewritten once all of them have.  Each adds one to one of
+    // RTK_SHIFT_COUNTERS counters (own cache lines) once its ids are in registers - fire and forget, nobody waits; the
+    // FIRST workgroup of the grid (an extra column) does no other work: it watches the counters reach the launch's totals,
+    // zeroes them for the next launch, rewrites the row and counts the launch in ticket[0], beside the others' work.
+    const int bx = (int)blockIdx.x - (shift_row ? 1 : 0), gx = (int)gridDim.x - (shift_row ? 1 : 0);
+    if (bx < 0) {
+        if (blockIdx.y != 0) return;
+        constexpr int E = 8;   // ids per thread and round, two rounds in flight
+        const int nwork = gx * (int)gridDim.y, step = E * (int)blockDim.x;
+        const long long delta = (next_prev ? (long long)next_prev[0] : -1ll) + 1 - (long long)shift_row[0];
+        long long v[2][E];
+        auto fetch = [&](long long* r, int base) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = base + e * (int)blockDim.x + (int)threadIdx.x;
+                r[e] = i < L ? (long long)shift_row[i] : 0;
+            }
+        };
+        fetch(v[0], 0);        // the first round of the row is on its way while the others start up
+        // counter c takes the workgroups whose linear index is c modulo RTK_SHIFT_COUNTERS
+        const int c = (int)threadIdx.x;   // (blockDim.x >= RTK_SHIFT_COUNTERS: one counter per thread)
+        unsigned* mine = (unsigned*)ticket + RTK_SHIFT_STRIDE * (1 + c);
+        const unsigned want = (unsigned)(nwork / RTK_SHIFT_COUNTERS + (c < nwork % RTK_SHIFT_COUNTERS ? 1 : 0));
+        const unsigned long long t0 = wall_clock64();   // (100 MHz)  bounded at 0.2 s: never a hung GPU
+        for (;;) {
+            int ok = 1;
+            if (c < RTK_SHIFT_COUNTERS) ok = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+            if (__syncthreads_and(ok || wall_clock64() - t0 > 20000000ull)) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (c < RTK_SHIFT_COUNTERS) __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (delta != 0) {      // t[0:L] += (prev_next + 1) - t[0]
+            int cur = 0;
+            for (int base = 0; base < L; base += step, cur ^= 1) {
+                if (base + step < L) fetch(v[cur ^ 1], base + step);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = base + e * (int)blockDim.x + (int)threadIdx.x;
+                    if (i < L) shift_row[i] = v[cur][e] + delta;
+                }
+            }
+        }
+        if (threadIdx.x == 0) ticket[0] += 1;   // launches that carried a shift (diagnostics)
+        return;
+    }
+    const int id = bx * (int)blockDim.x + (int)threadIdx.x;
     if (id >= L * lpr) return;
     const int l = id / lpr, d = (id - l * lpr) * VE;
     if (pos_copy && blockIdx.y == 0 && d == 0)   // the ids the caller may shift in place before the deferred selection runs
@@ -278,6 +330,12 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prepare_native_kernel(const ch
     else if (nkv) load_kv(lo, hi, 0);
     float c1[VE], s1[VE], c2[VE], s2[VE];
     rope_chunk<VE>(inv_freq, rs, d, h2, pid, scaling, round_bf16, c1, s1, c2, s2);
+    if (shift_row) {   // (kernel argument: uniform)  this workgroup holds its ids: count it in (see the top of the kernel)
+        __syncthreads();   // every wave is past rope_chunk (pid consumed) and past the pos_copy stores (their loads returned)
+        if (threadIdx.x == 0)
+            __hip_atomic_fetch_add((unsigned*)ticket + RTK_SHIFT_STRIDE * (1 + ((int)blockIdx.y * gx + bx) % RTK_SHIFT_COUNTERS),
+                                   1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // x~ = ((x*cos) - (rotate_half(x)*sin)) / a^2 for one head's chunk pair, one rounding per torch op (:76-78)
     auto unrot = [&](const W& lo, const W& hi, W& olo, W& ohi) {
         if constexpr (DT != RTK_F32) {
@@ -2370,7 +2428,8 @@ template <int DT>
 static int prepare_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, int64_t ksh, int64_t ksl, const void* v,
                         int64_t vsh, int64_t vsl, int Hq, int Hkv, int L, int D, const int64_t* pos, int64_t pos_stride,
                         const float* inv_freq, float a, const RowSel& rs, int round_bf16, char* qt, char* kt, void* k_tail,
-                        void* v_tail, int64_t tail_sh, int P, int64_t* pos_copy, hipStream_t st, char* k_fast = nullptr) {
+                        void* v_tail, int64_t tail_sh, int P, int64_t* pos_copy, hipStream_t st, char* k_fast = nullptr,
+                        int64_t* shift_row = nullptr, const int64_t* next_prev = nullptr, int* ticket = nullptr) {
     const float a2 = (float)((double)a * (double)a);
     const int div = (a2 == 1.0f) ? 0 : ((DT == RTK_BF16 && bf16_rcp_is_exact(a2)) ? 1 : 2);
     const float rcp = 1.0f / a2;
@@ -2381,13 +2440,14 @@ static int prepare_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, 
     const int VE = nw * 4 / (DT == RTK_F32 ? 4 : 2);
     const int threads = L * (D / 2 / VE);
     static_assert(RTK_PREP_YSPLIT >= 2, "the first y-slice takes k and the LAST one v: one slice would never append v");
-    const dim3 grid((threads + RTK_PREP_BLOCK - 1) / RTK_PREP_BLOCK, RTK_PREP_YSPLIT);
+    // (+ one column of workgroups when the next layer's id shift rides along: its last one does the shift)
+    const dim3 grid((threads + RTK_PREP_BLOCK - 1) / RTK_PREP_BLOCK + (shift_row ? 1 : 0), RTK_PREP_YSPLIT);
     char* kf = nullptr;
     float qscale = 1.f;
     auto launch = [&](auto kern) {
         RTK_LAUNCH(KID_UNROT, kern, grid, dim3(RTK_PREP_BLOCK), 0, st, (const char*)q, qsh, qsl, (const char*)k, ksh, ksl, (const char*)v,
                    vsh, vsl, Hq, Hkv, L, D, pos, pos_stride, inv_freq, a, rs, round_bf16, a2, rcp, qt, kt, (char*)k_tail,
-                   (char*)v_tail, tail_sh, P, pos_copy, kf, qscale);
+                   (char*)v_tail, tail_sh, P, pos_copy, kf, qscale, shift_row, next_prev, ticket);
     };
 #define RTK_PREP_NWSEL(DIV, FASTV)                                                            \
     do {                                                                                      \
@@ -2424,6 +2484,29 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
                                    const int* sections_host, int nsec, int round_bf16, void* k_unrot, void* workspace,
                                    size_t workspace_bytes, void* k_tail, void* v_tail, int64_t tail_stride_h,
                                    int64_t* pos_copy, rtk_stream_t stream) {
+    return rtk::pivotkv_prepare_shift(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv,
+                                      L, D, dtype, pos, pos_stride, P, inv_freq, attention_scaling, sections_host, nsec,
+                                      round_bf16, k_unrot, workspace, workspace_bytes, k_tail, v_tail, tail_stride_h, pos_copy,
+                                      nullptr, nullptr, nullptr, 0, stream);
+}
+
+// words of rtk_update_io.ticket: the launch count + the arrival counters of the prepare launch, a cache line each
+extern "C" size_t rtk_pivotkv_shift_ticket_ints(int L, int D) {
+    (void)L; (void)D;   // one line for the launch count, one per counter
+    return (size_t)RTK_SHIFT_STRIDE * (1 + RTK_SHIFT_COUNTERS);
+}
+
+// rtk_pivotkv_prepare + (shift_row != NULL) the next layer's continuity shift in the same launch: rtk_pivotkv_update's
+// RTK_UPDATE_SHIFT_NEXT.  shift_row is the temporal row of `pos` itself, ticket one zeroed device word (left zero).
+int rtk::pivotkv_prepare_shift(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k, int64_t k_stride_h,
+                               int64_t k_stride_l, const void* v, int64_t v_stride_h, int64_t v_stride_l, int Hq, int Hkv,
+                               int L, int D, int dtype, const int64_t* pos, int64_t pos_stride, int P,
+                               const float* inv_freq, float attention_scaling, const int* sections_host, int nsec,
+                               int round_bf16, void* k_unrot, void* workspace, size_t workspace_bytes, void* k_tail,
+                               void* v_tail, int64_t tail_stride_h, int64_t* pos_copy, int64_t* shift_row,
+                               const int64_t* next_prev, int32_t* ticket, int64_t ticket_ints, rtk_stream_t stream) {
+    RTK_CHECK_ARG(!shift_row || (ticket && ticket_ints >= (int64_t)rtk_pivotkv_shift_ticket_ints(L, D)),
+                  "rtk_pivotkv_prepare: the in-launch id shift needs rtk_pivotkv_shift_ticket_ints(L, D) zeroed device words");
     const bool k_only = (dtype & RTK_PREPARE_K_ONLY) != 0;   // keep-all chunk: no q~
     dtype &= ~RTK_PREPARE_K_ONLY;
     const int dtype_full = dtype;              // may carry RTK_SCORE_MANY_UNITS: the workspace layout follows the split policy
@@ -2462,13 +2545,13 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
     if (dtype == RTK_F16)
         return prepare_impl<RTK_F16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv, L,
                                      D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot, k_tail,
-                                     v_tail, tail_stride_h, P, pos_copy, st);
+                                     v_tail, tail_stride_h, P, pos_copy, st, nullptr, shift_row, next_prev, ticket);
     if (dtype != RTK_F32)
         return prepare_impl<RTK_BF16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv,
                                       L, D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot,
                                       k_tail, v_tail, tail_stride_h, P, pos_copy, st,
-                                      fast ? (char*)workspace + w.k_off : nullptr);
+                                      fast ? (char*)workspace + w.k_off : nullptr, shift_row, next_prev, ticket);
     return prepare_impl<RTK_F32>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv, L,
                                  D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot, k_tail,
-                                 v_tail, tail_stride_h, P, pos_copy, st);
+                                 v_tail, tail_stride_h, P, pos_copy, st, nullptr, shift_row, next_prev, ticket);
 }

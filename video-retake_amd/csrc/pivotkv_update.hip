@@ -433,10 +433,17 @@ extern "C" int rtk_pivotkv_update(rtk_pivotkv_batch* b, rtk_layer_state* ls, int
     } else {
         if (b->q_units) b->q_units[slot] = nullptr;
         const int dt = b->prep_dtype | (b->keep_all ? RTK_PREPARE_K_ONLY : 0);
-        rc = rtk_pivotkv_prepare(io->q, io->q_stride_h, io->q_stride_l, io->k, io->k_stride_h, io->k_stride_l, io->v,
-                                 io->v_stride_h, io->v_stride_l, b->Hq, Hkv, L, D, dt, io->pos, io->pos_stride, b->P,
-                                 b->inv_freq, b->attention_scaling, b->nsec ? b->sections : nullptr, b->nsec, b->round_mode,
-                                 k_unrot, ws, b->score_ws_bytes, k_tail, v_tail, tail_sh, pos_copy, stream);
+        // RTK_UPDATE_SHIFT_NEXT: the launch also leaves the caller's temporal row shifted for the NEXT layer (qwen2_vl.py:68-73)
+        const bool shift_next = (io->flags & RTK_UPDATE_SHIFT_NEXT) != 0;
+        if (shift_next && !io->ticket) {
+            set_error("rtk_pivotkv_update: RTK_UPDATE_SHIFT_NEXT needs io->ticket (rtk_pivotkv_shift_ticket_ints zeroed device words)");
+            return RTK_EINVAL;
+        }
+        rc = pivotkv_prepare_shift(io->q, io->q_stride_h, io->q_stride_l, io->k, io->k_stride_h, io->k_stride_l, io->v,
+                                   io->v_stride_h, io->v_stride_l, b->Hq, Hkv, L, D, dt, io->pos, io->pos_stride, b->P,
+                                   b->inv_freq, b->attention_scaling, b->nsec ? b->sections : nullptr, b->nsec, b->round_mode,
+                                   k_unrot, ws, b->score_ws_bytes, k_tail, v_tail, tail_sh, pos_copy,
+                                   shift_next ? (int64_t*)io->pos : nullptr, io->next_prev, io->ticket, io->ticket_ints, stream);
         if (rc) return rc;
     }
     if (!b->keep_all && !b->batched_passes) {

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 RTK_F32, RTK_BF16, RTK_BF16_REFROUND, RTK_BF16_FAST, RTK_F16, RTK_F16_REFROUND = 0, 1, 2, 3, 4, 5
 RTK_SCORE_MANY_UNITS = 0x100   # flag for the dtype argument of the scoring entry points (split policy of batched launches)
@@ -21,6 +21,7 @@ RTK_PREPARE_K_ONLY = 0x200     # flag for the dtype argument of rtk_pivotkv_prep
 RTK_UPDATE_PRE_ROPE = 1        # rtk_update_io.flags: q / k are the pre-RoPE projections (attention prologue)
 RTK_UPDATE_Q_IN_PLACE = 2      # ... and the score passes read q where it is (no packed copy)
 RTK_UPDATE_ROUNDTRIP = 4       # ... or: q~ / k~ = the reference's un-rotation of the rotated rows (its bf16 round trip)
+RTK_UPDATE_SHIFT_NEXT = 8      # rotated q / k: the launch also applies the NEXT layer's continuity shift to the caller's ids
 SCORE_PREPARE, SCORE_PASSES, SCORE_FINALIZE = 1, 2, 4
 RTK_EINVAL, RTK_EUNSUPPORTED, RTK_EWORKSPACE, RTK_EHIP, RTK_EREFCRASH = -1, -2, -3, -4, -5
 
@@ -96,7 +97,7 @@ class UpdateIO(C.Structure):
     _fields_ = [("q", _vp), ("q_stride_h", _i64), ("q_stride_l", _i64), ("k", _vp), ("k_stride_h", _i64),
                 ("k_stride_l", _i64), ("v", _vp), ("v_stride_h", _i64), ("v_stride_l", _i64), ("pos", _vp),
                 ("pos_stride", _i64), ("q_rot", _vp), ("qr_stride_h", _i64), ("qr_stride_l", _i64), ("flags", _i32),
-                ("pad0", _i32)]
+                ("pad0", _i32), ("next_prev", _vp), ("ticket", _vp), ("ticket_ints", _i64)]
 
 
 _SIGNATURES = {
@@ -143,6 +144,7 @@ _SIGNATURES = {
     "rtk_pivotkv_compact_sync_ints": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "rtk_pivotkv_compact_batched": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _i, _i, _vp, _sz, _vp]),
     "rtk_position_shift": (C.c_int, [_vp, _i, _vp, _vp]),
+    "rtk_pivotkv_shift_ticket_ints": (_sz, [_i, _i]),
     "rtk_pivotkv_update": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
     "rtk_pivotkv_flush": (C.c_int, [_vp, _vp, _vp, _i, _vp]),
     "rtk_pivotkv_append_rope": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _i, _i, _i, _vp]),

@@ -332,6 +332,9 @@ class _Batch:
         self.cref = C.addressof(self.c)
         self.io = nv.UpdateIO()
         self.ioref = C.addressof(self.io)
+        # RTK_UPDATE_SHIFT_NEXT's words (launch count + arrival counters of the prepare launch), zeroed once
+        self.shift_ticket = torch.zeros(max(1, nv.lib.rtk_pivotkv_shift_ticket_ints(L, D)), dtype=torch.int32, device=device)
+        self.io.ticket, self.io.ticket_ints = self.shift_ticket.data_ptr(), self.shift_ticket.numel()
         # prologue route: queries that are scored where they lie (no packed copy) - the pointers the library reads at
         # the flush, and the tensors themselves, kept alive until then
         self.q_units = (C.c_void_p * slots)()
@@ -540,6 +543,12 @@ class PivotKVCache(DynamicCache):
         # elements: 1.4 GB at L = 6272, 28 layers, bf16).  N > 0: the batch has N slots (slot = layer mod N) and is flushed
         # whenever the next layer's slot is taken, i.e. every N layers - scratch / launches-per-chunk trade N/layers : layers/N
         self.flush_every_layers = int(kv_compression_kwargs.get("flush_every_layers", 0))
+        # MI355X build option (tests / A-B): on the reference's protocol (`update` on rotated tensors) the launch that
+        # un-rotates and appends layer l's chunk also applies layer l + 1's continuity shift (qwen2_vl.py:68-73) to the
+        # caller's ids, so that `shift_temporal_ids_` of the attention patch launches once per chunk instead of once per
+        # layer.  False: every layer's shift is its own launch.
+        self.shift_next_in_update = bool(kv_compression_kwargs.get("shift_next_in_update", True))
+        self._preshifted = None       # (ids tensor, its version, layer, stream) an update launch has already shifted for
         if self.flush_every_layers < 0:
             raise ValueError("flush_every_layers must be >= 0")
         self._sides: List[_Side] = []
@@ -762,6 +771,11 @@ class PivotKVCache(DynamicCache):
             prev = self.get_prev_temporal_idx(layer_idx)
             row += prev + 1 - row[0].clone()
             return position_ids
+        done, self._preshifted = self._preshifted, None
+        idx = position_ids.get_device()
+        if done is not None and done[0]() is position_ids and done[1] == position_ids._version and done[2] == layer_idx \
+                and nv.current_device() == idx and done[3] == nv.raw_stream(idx):
+            return position_ids   # the previous layer's update launch has shifted this very tensor for this layer
         prev_ptr = None
         if len(self._layers) > layer_idx:
             c = self._layers[layer_idx].c
@@ -770,7 +784,6 @@ class PivotKVCache(DynamicCache):
             if layer_idx < self._pos_layers and c.pos and c.pos_len:
                 prev_ptr = c.pos + 8 * (c.pos_len - 1)
         # the temporal row ([0, 0, :] of [3, 1, n] ids, [0, :] of [1, n] ids) starts at the tensor's first element
-        idx = position_ids.get_device()
         if nv.current_device() == idx:
             rc = nv.lib.rtk_position_shift(position_ids.data_ptr(), position_ids.shape[-1], prev_ptr, nv.raw_stream(idx))
         else:
@@ -1287,13 +1300,21 @@ class PivotKVCache(DynamicCache):
                 io.flags = nv.RTK_UPDATE_PRE_ROPE | rt | (nv.RTK_UPDATE_Q_IN_PLACE if q_in_place else 0)
         else:
             io.q_rot, io.flags = None, 0
+            # the NEXT layer's continuity shift rides in this launch (its `shift_temporal_ids_` then finds it done)
+            nxt = self._next_layer_prev(layer_idx) if self.shift_next_in_update else False
+            if nxt is not False:
+                io.flags, io.next_prev = nv.RTK_UPDATE_SHIFT_NEXT, nxt
+        self._preshifted = None
         c.mask = mptr
-        rc = nv.lib.rtk_pivotkv_update(b.cref, st.cref, slot, b.ioref, nv.raw_stream(idx))
+        stream = nv.raw_stream(idx)
+        rc = nv.lib.rtk_pivotkv_update(b.cref, st.cref, slot, b.ioref, stream)
         if rc:
             c.mask = None
             if rc == nv.RTK_EUNSUPPORTED:
                 return None
             nv.check(rc, "rtk_pivotkv_update")
+        if io.flags & nv.RTK_UPDATE_SHIFT_NEXT:
+            self._preshifted = (weakref.ref(pos), pos._version, layer_idx + 1, stream)
         if not self._warned:  # the reference's logger.warning_once (:232)
             self._warned = True
             _warn_once("Enable PivotKVCache compression: length after compression %.2f" % (self.compression_ratio))
@@ -1323,6 +1344,20 @@ class PivotKVCache(DynamicCache):
         self._last_slot = (b, slot)
         n = P0 + L
         return st._k.narrow(2, 0, n), st._v.narrow(2, 0, n)
+
+    def _next_layer_prev(self, layer_idx: int):
+        """Address of the last temporal id cached for layer_idx + 1 (None: nothing cached, the rule's prev = -1), or
+        False when this launch must not shift for it: there is no such layer, or its previous chunk is still pending."""
+        nxt = layer_idx + 1
+        if nxt >= int(self.num_hidden_layers):
+            return False
+        if len(self._layers) > nxt:
+            c = self._layers[nxt].c
+            if c.pending:
+                return False
+            if nxt < self._pos_layers and c.pos and c.pos_len:
+                return c.pos + 8 * (c.pos_len - 1)
+        return None
 
     def _scores_q0_in_place(self, b: _Batch) -> bool:
         """Can the chunk-batched passes read the pre-RoPE queries where they lie?  Only when q~ IS q0."""
