@@ -23,6 +23,23 @@
  *     mode-carrying codes as well); scores, distances and RoPE
  *     tables are always fp32; indices are int64 and masks are 1 byte per element (torch.bool layout);
  *   - strides are in ELEMENTS; the innermost (channel / head_dim) axis is always contiguous.
+ *
+ * Contents (56 entry points; search for the section title).  A binding of the hot path needs §A, §B, §E and the four
+ * calls of §G; §D / §F are the stage-by-stage forms the same kernels are also reachable through.
+ *   §A  version / errors                rtk_version, rtk_last_error, rtk_arch
+ *   §B  "DPSelect"                      rtk_dpselect_dis, rtk_dpselect_select, rtk_gather_frames
+ *   §C  "MA-LLM / MA-LLM-hard merges"   rtk_adjacent_cosine, rtk_mallm_argmax, rtk_mallm_merge, rtk_mallm_hard_chain
+ *   §D  "RoPE tables"                   rtk_rope_merge, rtk_rope_table, rtk_rope_rotate_rows, rtk_rope_shift(_segments)
+ *   §E  "PivotKV" (one unit, by stage)  rtk_pivotkv_score(_stages, _stages_masked, _passes_batched(_q), _partials),
+ *                                       rtk_pivotkv_prepare, rtk_pivotkv_select(_batched), rtk_pivotkv_evict,
+ *                                       rtk_pivotkv_commit, rtk_copy_rows, *_workspace_bytes
+ *   §F  "Chunk-batched cache maintenance"  rtk_pivotkv_append, rtk_pivotkv_evict_batched(_rope), _commit_batched,
+ *                                       _place_batched, rtk_pivotkv_compact_batched (+ _compact_sync_ints)
+ *   §G  "One-call update and one-call flush"  rtk_pivotkv_update, rtk_pivotkv_flush, rtk_pivotkv_append_rope,
+ *                                       rtk_position_shift (+ rtk_pivotkv_shift_ticket_ints): what the shipped
+ *                                       package calls per update / per chunk / per decode step
+ *   §H  "Direct peer-to-peer all-gather over xGMI"  rtk_p2p_alloc / _free / _export / _open / _close / _push / _wait
+ *   §I  "Measurement support"           rtk_profile_* (off by default)
  */
 #ifndef RETAKE_HIP_H
 #define RETAKE_HIP_H
