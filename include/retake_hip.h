@@ -594,7 +594,8 @@ typedef struct rtk_update_io {
     int32_t pad0;
     const int64_t* next_prev;                        /* RTK_UPDATE_SHIFT_NEXT (ABI 16): the NEXT layer's last cached temporal id */
     int32_t* ticket; int64_t ticket_ints;            /*   (device; NULL = -1); rtk_pivotkv_shift_ticket_ints(L, D) device words, */
-} rtk_update_io;                                     /*   zeroed ONCE by the caller (launch count + arrival counters)            */
+} rtk_update_io;                                     /*   zeroed ONCE by the caller (launch count + arrival counters; word 31   */
+                                                     /*   counts launches whose bounded wait ran out - stays 0)                 */
 size_t rtk_pivotkv_shift_ticket_ints(int L, int D);
 enum rtk_update_flags {
     /* q, k are the PRE-RoPE projections (what q_proj / k_proj return).  One launch then does the whole prologue of the

@@ -1115,7 +1115,9 @@ def test_the_next_layers_shift_rides_in_the_update_launch(L, mrope, dtype):
         torch.cuda.synchronize()
         nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
         n = nv.profile_read().get("position_shift", (0, 0.0))[0]
-        return seen, n, int(cache._batch.shift_ticket[0])   # closed epochs = launches that carried a shift
+        tk = cache._batch.shift_ticket.cpu()
+        assert int(tk[31]) == 0 and int(tk[32:].abs().max()) == 0   # no wait ran out; the arrival counters are back at zero
+        return seen, n, int(tk[0])   # launches that carried a shift
 
     fused, apart = lc.build_kvcache(cfg(layers)), lc.build_kvcache(cfg(layers, shift_next_in_update=False))
     seen_f, n_f, epochs_f = run(fused)

@@ -269,7 +269,11 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prepare_native_kernel(const ch
         for (;;) {
             int ok = 1;
             if (c < RTK_SHIFT_COUNTERS) ok = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
-            if (__syncthreads_and(ok || wall_clock64() - t0 > 20000000ull)) break;
+            const int all = __syncthreads_and(ok), late = __syncthreads_or(wall_clock64() - t0 > 20000000ull);
+            if (all || late) {
+                if (threadIdx.x == 0 && !all) ticket[RTK_SHIFT_STRIDE - 1] += 1;   // gave up waiting (diagnostics; never seen)
+                break;
+            }
             __builtin_amdgcn_s_sleep(4);
         }
         if (c < RTK_SHIFT_COUNTERS) __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
