@@ -746,7 +746,11 @@ def verify_sharded_equals_sequential(rank: int, world: int, dev, rotary, layers:
                 raise AssertionError(f"rank {rank} layer {l} {dname}: ids differ; wrong ids per kept chunk {bad.tolist()}; first "
                                      f"rows {pos[l].reshape(-1, pos[l].shape[-1])[0, ::keep].tolist()} vs "
                                      f"{seq.position_cache[l].reshape(-1, pos[l].shape[-1])[0, ::keep].tolist()}")
-            assert torch.equal(values[l], seq.value_cache[l]), f"rank {rank} layer {l} {dname}: V differs"
+            if not torch.equal(values[l], seq.value_cache[l]):   # say where: differing rows per kept chunk of the assembled rows
+                rows = (values[l] != seq.value_cache[l]).any(dim=3).any(dim=1)[0].reshape(-1, keep).sum(1)
+                raise AssertionError(f"rank {rank} layer {l} {dname}: V differs; wrong rows per kept chunk {rows.tolist()}; "
+                                     f"NaN entries {int(torch.isnan(values[l].float()).sum())}, all-zero rows "
+                                     f"{int((values[l] == 0).all(dim=3).all(dim=1).sum())}")
             if not torch.equal(keys[l], seq.key_cache[l]):   # say where: per kept chunk of the assembled rows
                 d = (keys[l].float() - seq.key_cache[l].float()).abs().amax(dim=(0, 1, 3)).reshape(-1, keep).amax(dim=1)
                 raise AssertionError(f"rank {rank} layer {l} {dname}: K differs; max |diff| per kept chunk {d.tolist()}")
