@@ -668,9 +668,9 @@ int rtk_position_shift(int64_t* temporal_ids, int n, const int64_t* prev_dev, rt
  *   - buffers: rtk_p2p_alloc (device memory; uncached != 0 for the flag words, which are polled while
  *     kernels of other ranks write them), exported / opened as hipIpc handles between the processes of a node;
  *   - rtk_p2p_push: nseg segments of seg_bytes from src (+ s * src_stride) to byte dst_offset + s * dst_stride
- *     of EVERY mapped buffer (the own one included), then - after all of it, system-scope release - the value
- *     `epoch` into word `rank` of every peer's flag array.  `counter` is one zero-initialised device word
- *     owned by the caller's context; pushes that share it must be stream ordered;
+ *     of EVERY mapped buffer (the own one included), then - from a second launch behind the copy, so that a kernel
+ *     boundary orders it after every workgroup of it; system-scope release - the value `epoch` into word `rank` of
+ *     every peer's flag array.  `counter` (one device word of the caller's context) is no longer used;
  *   - rtk_p2p_wait: returns (on the stream) once every sender has published an epoch >= `epoch`; bounded:
  *     after ~timeout_ms the kernel gives up and stores 1 + (first missing sender) into *status (device word,
  *     0 = fine), so that a lost peer is an error, not a hung GPU.

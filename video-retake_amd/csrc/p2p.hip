@@ -18,26 +18,25 @@ namespace rtk {
 // peer's flag array: each thread fences its stores to system scope before the workgroup counts itself done, so the
 // flag can only be seen after all the data (the threadfence-reduction pattern, at system scope).
 __global__ __launch_bounds__(256) void p2p_push_kernel(const char* __restrict__ src, size_t seg_bytes, int nseg,
-                                                       size_t src_stride, rtk_p2p_peers peers, int rank, int world,
-                                                       size_t dst_off, size_t dst_stride, uint32_t epoch,
-                                                       unsigned* counter) {
+                                                       size_t src_stride, rtk_p2p_peers peers, size_t dst_off,
+                                                       size_t dst_stride) {
     char* dst = (char*)peers.buf[blockIdx.y] + dst_off;
     const size_t vec_per_seg = seg_bytes / 16, total = vec_per_seg * (size_t)nseg;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t s = i / vec_per_seg, v = i - s * vec_per_seg;
         *(uint4*)(dst + s * dst_stride + v * 16) = *(const uint4*)(src + s * src_stride + v * 16);
     }
+    __threadfence_system();   // this wave's rows are visible system-wide before the wave ends
+}
+
+// The arrival flags of a push, as their own launch behind the data launch: a kernel boundary orders them behind EVERY
+// workgroup of the copy (the first form counted finished workgroups on a device word inside the copy kernel and let the
+// last one publish - one premature "last" and the receivers read rows that had not landed).
+__global__ void p2p_flag_kernel(rtk_p2p_peers peers, int rank, int world, uint32_t epoch) {
+    const int q = threadIdx.x;
+    if (q >= world) return;
     __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned nblk = gridDim.x * gridDim.y;
-        if (atomicAdd(counter, 1u) == nblk - 1) {
-            *counter = 0;   // for the next push of this context (launches of one context are stream ordered)
-            __threadfence_system();
-            for (int q = 0; q < world; ++q)
-                __hip_atomic_store(peers.flag[q] + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    __hip_atomic_store(peers.flag[q] + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Thread r waits until sender r has published an epoch >= `epoch` (wrap-safe compare).  Bounded: after max_spins
@@ -117,10 +116,14 @@ extern "C" int rtk_p2p_push(const void* src, size_t seg_bytes, int nseg, size_t 
     const size_t vecs = seg_bytes / 16 * (size_t)nseg;
     // enough workgroups per peer to keep a link busy, few enough that world of them share the chip
     const unsigned per_peer = (unsigned)std::max<size_t>(1, std::min<size_t>((vecs + 1023) / 1024, 2048 / (unsigned)world));
-    hipLaunchKernelGGL(p2p_push_kernel, dim3(per_peer, world), dim3(256), 0, (hipStream_t)stream, (const char*)src,
-                       seg_bytes, nseg, src_stride_bytes, *peers, rank, world, dst_offset_bytes, dst_stride_bytes, epoch,
-                       counter);
-    RTK_LAUNCH_CHECK("rtk_p2p_push");
+    (void)counter;   // (ABI: the word the first form counted finished workgroups on; unused since the flags are their own launch)
+    if (vecs) {
+        hipLaunchKernelGGL(p2p_push_kernel, dim3(per_peer, world), dim3(256), 0, (hipStream_t)stream, (const char*)src,
+                           seg_bytes, nseg, src_stride_bytes, *peers, dst_offset_bytes, dst_stride_bytes);
+        RTK_LAUNCH_CHECK("rtk_p2p_push");
+    }
+    hipLaunchKernelGGL(p2p_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *peers, rank, world, epoch);
+    RTK_LAUNCH_CHECK("rtk_p2p_push: flags");
     return RTK_OK;
 }
 

@@ -79,7 +79,7 @@ class SymmetricBuffer:
         g, dev = owner, owner.device
         self.nbytes = (int(nbytes) + 15) // 16 * 16
         with torch.cuda.device(dev):
-            self.mem = _DeviceMem(self.nbytes)
+            self.mem = _DeviceMem(self.nbytes, uncached=os.environ.get("RETAKE_P2P_UNCACHED_LANDING") == "1")   # (A/B aid)
             self.flags = _DeviceMem(4 * nv.P2P_MAX_RANKS, uncached=True)
             self.local = self.mem.tensor(dev)                        # uint8 [nbytes]
             self.counter = torch.zeros(1, dtype=torch.int32, device=dev)

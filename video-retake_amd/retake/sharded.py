@@ -719,17 +719,31 @@ def verify_sharded_equals_sequential(rank: int, world: int, dev, rotary, layers:
 
         frames_all = torch.cat([B.chunk_frames(c, dev, td) for c in range(n_chunks)])[None]
         _, mask = vc.memory_bank_compress_keyframe(frames_all, T, 3, sync=False)
-        seq = lc.build_kvcache(B.make_cache_config(layers))
-        seq.prologue_operands = "pre_rope"    # what the blocks score (ShardedPivotKV): operands that never see an id
-        for c in range(n_chunks):
-            seq.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
-            seq.kvcache_compression = True
-            pos = B.chunk_position_ids(c, dev)
+        def sequential():
+            seq = lc.build_kvcache(B.make_cache_config(layers))
+            seq.prologue_operands = "pre_rope"    # what the blocks score (ShardedPivotKV): operands that never see an id
+            for c in range(n_chunks):
+                seq.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
+                seq.kvcache_compression = True
+                pos = B.chunk_position_ids(c, dev)
+                for l in range(layers):
+                    q0, k0, v = inputs(c, l, pos)
+                    if seq.update_pre_rope(q0, k0, v, l, pos, rotary, B.MROPE, query_out=torch.empty_like(q0)) is None:
+                        raise AssertionError("update_pre_rope declined a chunk of the sequential reference run")
+                seq.after_forward()
+            return seq
+
+        seq = sequential()
+        if os.environ.get("RETAKE_VERIFY_SEQ_TWICE") == "1":   # debugging aid: is the single-GPU build itself reproducible here?
+            again = sequential()
             for l in range(layers):
-                q0, k0, v = inputs(c, l, pos)
-                if seq.update_pre_rope(q0, k0, v, l, pos, rotary, B.MROPE, query_out=torch.empty_like(q0)) is None:
-                    raise AssertionError("update_pre_rope declined a chunk of the sequential reference run")
-            seq.after_forward()
+                for what, a, b in (("ids", seq.position_cache[l], again.position_cache[l]),
+                                   ("V", seq.value_cache[l], again.value_cache[l]), ("K", seq.key_cache[l], again.key_cache[l])):
+                    if not torch.equal(a, b):
+                        d = (a != b).reshape(-1, a.shape[-1]) if what == "ids" else (a != b).any(dim=3).any(dim=1)
+                        raise AssertionError(f"rank {rank} layer {l} {dname}: two SEQUENTIAL builds of the same video differ in {what}; "
+                                             f"differing entries per kept chunk {d.any(0).reshape(-1, keep).sum(1).tolist()}")
+            del again
         blocks = shard_chunks(n_chunks, world)
         c0, c1 = blocks[rank]
         even = len({b - a for a, b in blocks}) == 1
@@ -739,6 +753,8 @@ def verify_sharded_equals_sequential(rank: int, world: int, dev, rotary, layers:
         pos_base = [B.chunk_position_ids(c, dev) for c in range(c0, c1)]
         _, (keys, values, pos) = sharded_video_step(fr, halo, T, c0, c1, layers, pool, pos_base, rotary, even, group=group,
                                                     state=state, inputs=inputs, pre_rope=True)
+        if _P2P.get(group) is not None:
+            _P2P.get(group).check()   # a bounded wait that ran out is reported as that, not as the mismatch it leaves behind
         for l in range(layers):
             assert keys[l].shape[2] == n_chunks * keep, (keys[l].shape, n_chunks * keep)
             if not torch.equal(pos[l], seq.position_cache[l]):
