@@ -4,7 +4,7 @@ xGMI is point to point: every GPU has its own link to every other GPU of the nod
 world - 1 serial steps; the exchanges of this path are small (distance rows 1.6 MB, id offsets a few hundred bytes, one
 chunk's kept rows 11 MB per rank at 8 ranks), so they are bound by those steps, not by the links.  Here every rank maps
 its peers' landing buffers once (hipIpc handles, exchanged through the process group's control plane) and then PUSHES
-its block into all of them with one kernel: one hop, all links at once, no intermediate copies - the landing buffer can
+its block into all of them with one kernel (+ a one-wave launch behind it for the arrival flags): one hop, all links at once, no intermediate copies - the landing buffer can
 be the final layout (`SymmetricBuffer.push` takes strided segments).
 
     p2p = P2PGroup(group)                 # once per process group
