@@ -295,6 +295,7 @@ def test_product_defaults_are_the_benched_configuration():
     assert c.defer_rerotation is False and c.score_queries_in_place is True and c.in_place_compaction is True
     assert c.skip_masked_columns is True and c.score_when_keeping_all is False
     assert c.prologue_operands == "reference" and c.flush_every_layers == 0    # round 5: the reference's operands; one flush per chunk
+    assert c.shift_next_in_update is True    # ... and the next layer's id shift rides in the update launch
     import pytest
 
     for bad in ({"prologue_operands": "rotated"}, {"flush_every_layers": -1}, {"score_rounding": "exact"}):
