@@ -247,6 +247,8 @@ def test_round4_entry_points_validate_on_the_host():
     assert lib.rtk_rope_rotate_rows(p, 0, 128, 1, 1, 4, 128, nv.RTK_BF16, p, 0, 2, 3, p, 1.0, None, 0, 1, None) == nv.RTK_EINVAL
     assert b"pos_stride_p" in lib.rtk_last_error()
     assert lib.rtk_profile_copy(p, p, 24, None) == nv.RTK_EINVAL
+    # RTK_UPDATE_SHIFT_NEXT (ABI 16): one cache line for the launch count + one per arrival counter, whatever the geometry
+    assert lib.rtk_pivotkv_shift_ticket_ints(6272, 128) == lib.rtk_pivotkv_shift_ticket_ints(640, 64) == 32 * 65
 
 
 def test_compaction_entry_point_validates_on_the_host():
