@@ -150,11 +150,24 @@ def chunk_position_ids(c, device):
     return torch.stack([t, h, w]).view(3, 1, L)
 
 
+def _settled(dev, *temporaries):
+    """Without torch's caching allocator (PYTORCH_NO_CUDA_MEMORY_CACHING=1, a debugging mode) a dropped temporary is
+    hipFree'd at once, while the kernels that read it may still be queued - with eight rank processes on one GPU they
+    queue for long, and a generated input then occasionally holds other numbers than its seed says (seen: one k tensor
+    of 390, on one rank).  In that mode the generators wait for the device before they let go of a temporary."""
+    if os.environ.get("PYTORCH_NO_CUDA_MEMORY_CACHING") == "1":
+        torch.cuda.synchronize(dev)
+    del temporaries
+
+
 def chunk_frames(c, dev, tdtype):
     """The 32 frame embeddings of frame chunk c: a function of c alone, so that any rank of a sharded run regenerates
     exactly the frames (and the halo frame) the single-GPU run sees."""
     g = torch.Generator(device=dev).manual_seed(5000 + c)
-    return torch.randn((FRAMES_PER_CHUNK, N_PATCH, C_EMB), generator=g, device=dev, dtype=torch.float32).to(tdtype)
+    x = torch.randn((FRAMES_PER_CHUNK, N_PATCH, C_EMB), generator=g, device=dev, dtype=torch.float32)
+    out = x.to(tdtype)
+    _settled(dev, x)
+    return out
 
 
 def pool_set(i, dev, tdtype, projection_layout=False):
@@ -163,11 +176,14 @@ def pool_set(i, dev, tdtype, projection_layout=False):
     [1, H, L, D] view, qwen2_vl.py:55-57) instead of head-major tensors."""
     g = torch.Generator(device=dev).manual_seed(9000 + i)
     L = FRAMES_PER_CHUNK * N_PATCH
-    if projection_layout:
-        return tuple((1.7 * torch.randn((1, L, h, D), generator=g, device=dev, dtype=torch.float32)).to(tdtype).transpose(1, 2)
-                     for h in (Hq, Hkv, Hkv))
-    return tuple((1.7 * torch.randn((1, h, L, D), generator=g, device=dev, dtype=torch.float32)).to(tdtype)
-                 for h in (Hq, Hkv, Hkv))
+    out = []
+    for h in (Hq, Hkv, Hkv):
+        x = torch.randn((1, L, h, D) if projection_layout else (1, h, L, D), generator=g, device=dev, dtype=torch.float32)
+        y = 1.7 * x
+        z = y.to(tdtype)
+        _settled(dev, x, y)
+        out.append(z.transpose(1, 2) if projection_layout else z)
+    return tuple(out)
 
 
 def cache_checksum(keys, values, pos):

@@ -62,6 +62,9 @@ extern "C" int rtk_p2p_alloc(size_t bytes, int uncached, void** ptr) {
     RTK_CHECK_ARG(ptr && bytes > 0, "rtk_p2p_alloc: null pointer or zero size");
     hipError_t e = uncached ? hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocUncached) : hipMalloc(ptr, bytes);
     if (e != hipSuccess) return hip_fail(e, "rtk_p2p_alloc");
+    // flag words start at zero; a landing buffer is only ever read where a push has landed, and zeroing it would leave
+    // lines of it in this device's caches for peers' rows to race with
+    if (!uncached) return RTK_OK;
     e = hipMemset(*ptr, 0, bytes);
     if (e != hipSuccess) return hip_fail(e, "rtk_p2p_alloc: memset");
     // the fill is asynchronous; peers may write as soon as they hold the handle, and nothing orders THEIR kernels behind it

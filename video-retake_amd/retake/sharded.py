@@ -646,6 +646,7 @@ def sharded_video_step(frames, has_halo: bool, T: int, c0: int, c1: int, layers:
     sh = ShardedPivotKV(B.make_cache_config(layers), group=group, expected_rows=(c1 - c0) * keep if overlap else None,
                         chunk_gather=(state or {}).get("chunk_gather"), reserve_tokens=(c1 - c0) * keep + L)
     cache = sh.cache
+    q_rot = None
     for ci, c in enumerate(range(c0, c1)):
         cache.keypatches_mask_chunk = mask[c * L:(c + 1) * L]
         cache.kvcache_compression = True
@@ -653,7 +654,9 @@ def sharded_video_step(frames, has_halo: bool, T: int, c0: int, c1: int, layers:
         for layer in range(layers):
             if pre_rope:
                 q0, k0, v = inputs(c, layer, pos)
-                if cache.update_pre_rope(q0, k0, v, layer, pos, rotary, B.MROPE, query_out=torch.empty_like(q0)) is None:
+                if q_rot is None or q_rot.shape != q0.shape or q_rot.dtype != q0.dtype:
+                    q_rot = torch.empty_like(q0)   # where the rotated queries go: one scratch per video, not one per update
+                if cache.update_pre_rope(q0, k0, v, layer, pos, rotary, B.MROPE, query_out=q_rot) is None:
                     raise RuntimeError("update_pre_rope declined a video chunk of the sharded step")
                 continue
             cache.shift_temporal_ids_(pos, layer)       # block-local ids start at 0 (provisional)
@@ -720,6 +723,7 @@ def verify_sharded_equals_sequential(rank: int, world: int, dev, rotary, layers:
         frames_all = torch.cat([B.chunk_frames(c, dev, td) for c in range(n_chunks)])[None]
         _, mask = vc.memory_bank_compress_keyframe(frames_all, T, 3, sync=False)
         def sequential():
+            q_rot = torch.empty_like(pool[0][0])   # where the rotated queries go (one scratch per build)
             seq = lc.build_kvcache(B.make_cache_config(layers))
             seq.prologue_operands = "pre_rope"    # what the blocks score (ShardedPivotKV): operands that never see an id
             for c in range(n_chunks):
@@ -728,7 +732,7 @@ def verify_sharded_equals_sequential(rank: int, world: int, dev, rotary, layers:
                 pos = B.chunk_position_ids(c, dev)
                 for l in range(layers):
                     q0, k0, v = inputs(c, l, pos)
-                    if seq.update_pre_rope(q0, k0, v, l, pos, rotary, B.MROPE, query_out=torch.empty_like(q0)) is None:
+                    if seq.update_pre_rope(q0, k0, v, l, pos, rotary, B.MROPE, query_out=q_rot) is None:
                         raise AssertionError("update_pre_rope declined a chunk of the sequential reference run")
                 seq.after_forward()
             return seq
@@ -759,11 +763,45 @@ def verify_sharded_equals_sequential(rank: int, world: int, dev, rotary, layers:
             assert keys[l].shape[2] == n_chunks * keep, (keys[l].shape, n_chunks * keep)
             if not torch.equal(pos[l], seq.position_cache[l]):
                 bad = (pos[l] != seq.position_cache[l]).reshape(-1, pos[l].shape[-1]).any(0).reshape(-1, keep).sum(1)
+                if os.environ.get("RETAKE_VERIFY_LOOK_AGAIN") == "1":   # debugging aid: late, or never?  ids only, or the rows too?
+                    torch.cuda.synchronize(dev)
+                    time.sleep(2.0)
+                    torch.cuda.synchronize(dev)
+                    again = (pos[l] != seq.position_cache[l]).reshape(-1, pos[l].shape[-1]).any(0).reshape(-1, keep).sum(1)
+                    vrows = (values[l] != seq.value_cache[l]).any(dim=3).any(dim=1)[0].reshape(-1, keep).sum(1)
+                    c = int(bad.nonzero()[0])
+
+                    def bits(t):
+                        return int(t.contiguous().view(torch.int16 if t.element_size() == 2 else torch.int32).to(torch.int64).sum())
+
+                    fresh = B.pool_set((c * layers + l) % len(pool), dev, td, projection_layout=True)
+                    sums = {"q k v as used": [bits(t) for t in inputs(c, l, None)], "q k v regenerated": [bits(t) for t in fresh],
+                            "frames as used": bits(frames_all[0, c * B.FRAMES_PER_CHUNK:(c + 1) * B.FRAMES_PER_CHUNK]),
+                            "frames regenerated": bits(B.chunk_frames(c, dev, td)), "mask": int(mask[c * L:(c + 1) * L].sum())}
+                    print(f"LOOK rank {rank} chunk {c} layer {l}: {sums}", flush=True)
+                    got = pos[l].reshape(-1, pos[l].shape[-1])[:, c * keep:(c + 1) * keep]
+                    want = seq.position_cache[l].reshape(-1, pos[l].shape[-1])[:, c * keep:(c + 1) * keep]
+                    raise AssertionError(f"rank {rank} layer {l} {dname}: ids differ; wrong ids per kept chunk "
+                                         f"{[(i, int(x)) for i, x in enumerate(bad.tolist()) if x]}; two seconds later "
+                                         f"{[(i, int(x)) for i, x in enumerate(again.tolist()) if x]}; V rows wrong "
+                                         f"{[(i, int(x)) for i, x in enumerate(vrows.tolist()) if x]}; chunk {c}: got "
+                                         f"{got[:, :6].tolist()} .. {got[:, -3:].tolist()} want {want[:, :6].tolist()} .. {want[:, -3:].tolist()}")
                 raise AssertionError(f"rank {rank} layer {l} {dname}: ids differ; wrong ids per kept chunk {bad.tolist()}; first "
                                      f"rows {pos[l].reshape(-1, pos[l].shape[-1])[0, ::keep].tolist()} vs "
                                      f"{seq.position_cache[l].reshape(-1, pos[l].shape[-1])[0, ::keep].tolist()}")
             if not torch.equal(values[l], seq.value_cache[l]):   # say where: differing rows per kept chunk of the assembled rows
                 rows = (values[l] != seq.value_cache[l]).any(dim=3).any(dim=1)[0].reshape(-1, keep).sum(1)
+                if os.environ.get("RETAKE_VERIFY_LOOK_AGAIN") == "1":   # debugging aid: late, or never?
+                    bad = (values[l] != seq.value_cache[l]).any(dim=3).any(dim=1)[0].nonzero().flatten()
+                    torch.cuda.synchronize(dev)
+                    time.sleep(2.0)
+                    torch.cuda.synchronize(dev)
+                    again = (values[l] != seq.value_cache[l]).any(dim=3).any(dim=1)[0].reshape(-1, keep).sum(1)
+                    elems = (values[l] != seq.value_cache[l])[0, :, bad[0]].sum(-1).tolist()
+                    raise AssertionError(f"rank {rank} layer {l} {dname}: V differs; wrong rows per kept chunk "
+                                         f"{[(i, int(x)) for i, x in enumerate(rows.tolist()) if x]}; two seconds later "
+                                         f"{[(i, int(x)) for i, x in enumerate(again.tolist()) if x]}; first wrong rows "
+                                         f"{bad[:12].tolist()} (+{int(bad.numel())}), wrong elements per head in the first {elems}")
                 raise AssertionError(f"rank {rank} layer {l} {dname}: V differs; wrong rows per kept chunk {rows.tolist()}; "
                                      f"NaN entries {int(torch.isnan(values[l].float()).sum())}, all-zero rows "
                                      f"{int((values[l] == 0).all(dim=3).all(dim=1).sum())}")
