@@ -341,3 +341,23 @@ def test_a_dropped_cache_is_released_without_the_garbage_collector():
             len(view)
     finally:
         gc.enable()
+
+
+def test_inference_mode_tensors_have_no_version_counter_and_are_served():
+    """Tensors created under torch.inference_mode() raise on `._version`; the two places that consult the counter (the
+    snapshot stamp of a rotary module's inv_freq, the memo of an id tensor the previous layer's launch has shifted) must
+    take them as "cannot tell" instead of raising inside `update`."""
+    import types
+
+    import torch
+
+    import retake.longvideo_cache as lc
+
+    with torch.inference_mode():
+        inv = torch.arange(8, dtype=torch.float32)
+        ids = torch.arange(16).view(1, 16)
+    with pytest.raises(RuntimeError):
+        inv._version
+    assert lc._version_of(inv) is None and lc._version_of(ids) is None and lc._version_of(torch.arange(3)) == 0
+    stamp = lc._inv_stamp(types.SimpleNamespace(inv_freq=inv, attention_scaling=1.0))
+    assert stamp is not None and stamp[1] is None

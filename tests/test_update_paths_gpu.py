@@ -1173,3 +1173,32 @@ def test_a_preshifted_tensor_is_recognised_only_as_itself():
     assert chunk(1, lambda l, p: p) == [1, 0, 0, 0]
     assert chunk(2, lambda l, p: p.clone()) == [1, 1, 1, 1]           # LLaVA's patch: a clone per layer
     assert chunk(3, lambda l, p: p.add_(0) if l == 2 else p) == [1, 0, 1, 0]   # touched through torch: version moved
+
+
+def test_update_and_shift_under_inference_mode():
+    """torch.inference_mode() tensors keep no version counter (`._version` raises): the shift memo and the inv_freq stamp take
+    them as "cannot tell" - every layer then launches its own (idempotent) shift - and the caches equal a no_grad run's."""
+    import retake.longvideo_cache as lc
+
+    layers, n_chunks, L = 3, 2, 640
+    g = torch.Generator(device=dev()).manual_seed(8)
+    q, k, v = ((1.7 * torch.randn((1, h, L, D), generator=g, device=dev())).to(torch.bfloat16) for h in (Hq, Hkv, Hkv))
+
+    def run(ctx):
+        with ctx():
+            rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+            cache = lc.PivotKVCache(cfg(layers), reserve_tokens=8 * L)
+            for c in range(n_chunks):
+                pos = chunk_ids(c, L) + 0   # (created inside the context)
+                cache.kvcache_compression = True
+                cache.keypatches_mask_chunk = None
+                for l in range(layers):
+                    cache.shift_temporal_ids_(pos, l)
+                    cache.update(k, v, l, {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": SEC})
+                cache.after_forward()
+            return [cache.key_cache[l].clone() for l in range(layers)], [cache.position_cache[l].clone() for l in range(layers)]
+
+    ka, pa = run(torch.no_grad)
+    kb, pb = run(torch.inference_mode)
+    for l in range(layers):
+        assert torch.equal(ka[l], kb[l]) and torch.equal(pa[l], pb[l])

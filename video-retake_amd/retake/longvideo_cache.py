@@ -260,11 +260,17 @@ class _Rotary:
         self.inv, self.scaling, self.device = inv, scaling, device
 
 
+def _version_of(t: torch.Tensor):
+    """The tensor's version counter, None for tensors that do not keep one (created under torch.inference_mode()): for
+    those a shift the previous layer's launch has already applied is simply applied again (it is idempotent)."""
+    return None if t.is_inference() else t._version
+
+
 def _inv_stamp(rotary_emb_fn):
     """Identity + write counter of a rotary module's inv_freq: the native-RoPE snapshot of the module (_Rotary) is only
     valid while this is unchanged (a module whose inv_freq is re-assigned or modified in place is snapshotted again)."""
     inv = getattr(rotary_emb_fn, "inv_freq", None)
-    return (inv.data_ptr(), inv._version) if isinstance(inv, torch.Tensor) else None
+    return (inv.data_ptr(), _version_of(inv)) if isinstance(inv, torch.Tensor) else None
 
 
 class _Batch:
@@ -773,8 +779,8 @@ class PivotKVCache(DynamicCache):
             return position_ids
         done, self._preshifted = self._preshifted, None
         idx = position_ids.get_device()
-        if done is not None and done[0]() is position_ids and done[1] == position_ids._version and done[2] == layer_idx \
-                and nv.current_device() == idx and done[3] == nv.raw_stream(idx):
+        if done is not None and done[0]() is position_ids and done[1] is not None and done[1] == _version_of(position_ids) \
+                and done[2] == layer_idx and nv.current_device() == idx and done[3] == nv.raw_stream(idx):
             return position_ids   # the previous layer's update launch has shifted this very tensor for this layer
         prev_ptr = None
         if len(self._layers) > layer_idx:
@@ -1314,7 +1320,7 @@ class PivotKVCache(DynamicCache):
                 return None
             nv.check(rc, "rtk_pivotkv_update")
         if io.flags & nv.RTK_UPDATE_SHIFT_NEXT:
-            self._preshifted = (weakref.ref(pos), pos._version, layer_idx + 1, stream)
+            self._preshifted = (weakref.ref(pos), _version_of(pos), layer_idx + 1, stream)
         if not self._warned:  # the reference's logger.warning_once (:232)
             self._warned = True
             _warn_once("Enable PivotKVCache compression: length after compression %.2f" % (self.compression_ratio))
