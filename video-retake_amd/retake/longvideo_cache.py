@@ -1307,7 +1307,7 @@ class PivotKVCache(DynamicCache):
         else:
             io.q_rot, io.flags = None, 0
             # the NEXT layer's continuity shift rides in this launch (its `shift_temporal_ids_` then finds it done)
-            nxt = self._next_layer_prev(layer_idx) if self.shift_next_in_update else False
+            nxt = self._next_layer_prev(layer_idx, idx) if self.shift_next_in_update else False
             if nxt is not False:
                 io.flags, io.next_prev = nv.RTK_UPDATE_SHIFT_NEXT, nxt
         self._preshifted = None
@@ -1351,17 +1351,21 @@ class PivotKVCache(DynamicCache):
         n = P0 + L
         return st._k.narrow(2, 0, n), st._v.narrow(2, 0, n)
 
-    def _next_layer_prev(self, layer_idx: int):
+    def _next_layer_prev(self, layer_idx: int, dev_index: int):
         """Address of the last temporal id cached for layer_idx + 1 (None: nothing cached, the rule's prev = -1), or
-        False when this launch must not shift for it: there is no such layer, or its previous chunk is still pending."""
+        False when this launch must not shift for it: there is no such layer, its previous chunk is still pending, or its
+        ids live on another device (a model spread over GPUs by device_map: that layer gets its own launch there)."""
         nxt = layer_idx + 1
         if nxt >= int(self.num_hidden_layers):
             return False
         if len(self._layers) > nxt:
-            c = self._layers[nxt].c
+            st = self._layers[nxt]
+            c = st.c
             if c.pending:
                 return False
             if nxt < self._pos_layers and c.pos and c.pos_len:
+                if st.pos is None or st.pos.get_device() != dev_index:
+                    return False
                 return c.pos + 8 * (c.pos_len - 1)
         return None
 
