@@ -12,9 +12,11 @@ All of it goes through the product's plugin surface (retake.visual_compression /
 retake.longvideo_cache), i.e. the C ABI of libretake_hip.so.  N > 1: one process per GPU over RCCL,
 the video's frame chunks are sharded across ranks (strong scaling), see retake/sharded.py.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, measured with HIP events on
-the launch stream inside the timed region (rtk_profile_*); `cpu_baseline` times the CPU oracle
-(oracle/, test infrastructure) on a bounded sample of the same workload on this host's cores.
+Prints ONE short JSON line (rank 0, stdout, < 4 KB: the contract keys + one number per extra measurement); the full
+report (per-kernel tables, companions, memory split) goes to bench_report.json and stderr (`contract_line` / `emit`).
+`roofline` is for the dominant kernel, measured with HIP events on the launch stream inside the timed region
+(rtk_profile_*); `cpu_baseline` times the CPU oracle (oracle/, test infrastructure) on a bounded sample of the same
+workload on this host's cores.
 """
 from __future__ import annotations
 
@@ -94,6 +96,8 @@ def parse():
                          "projections in the projection layout); not the contract line")
     ap.add_argument("--cache-option", action="append", default=[], metavar="KEY=VALUE",
                     help="extra kvcache_compression_kwargs entry of the measured cache (A/B runs), e.g. score_queries_in_place=0")
+    ap.add_argument("--report", default=None, metavar="PATH",
+                    help="where the full report goes (default: bench_report.json at the repo root and in gpurun_out/)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-check", action="store_true")
@@ -364,7 +368,7 @@ def score_roofline(kern, dtype, L, T, n_updates):
     traffic, src = pmc_traffic(dom + "_dma_kernel") if dtype == "bf16" and units_per_launch == LAYERS else (None, None)
     return {"kernel": dom, "bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": peak, "unit": "TFLOP/s",
             "frac": flops / avg_s / 1e12 / peak, "traffic": traffic, "traffic_source": src,
-            "units_per_launch": units_per_launch, "algorithmic_flops_per_launch": flops}
+            "units_per_launch": units_per_launch, "algorithmic_flops_per_launch": flops, "avg_launch_us": kern[dom]["avg_us"]}
 
 
 def hbm_achievable(dev):
@@ -444,9 +448,12 @@ def cpu_baseline(args, frames_cpu_sample, n_updates):
     n_chunks = rows // FRAMES_PER_CHUNK
     total = t_dp * (rows / Ts) + t_up * n_chunks * args.layers
     return {"value": args.frames / total, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/ (C+OpenMP, fp32): DPSelect on {Ts} of {rows} bank rows ({t_dp:.2f} s) + "
-                      f"one PivotKV update at L={L} ({t_up:.2f} s, one warm-up then best of {reps_up}; DPSelect: best of 3); extrapolated to "
-                      f"{n_chunks}x{args.layers} updates",
+            # (short: the driver's record truncates strings; the long form is `sample_detail` in the report)
+            "sample": f"oracle C+OpenMP fp32: DPSelect {Ts}/{rows} rows + 1 PivotKV update L={L} (best of {reps_up}) "
+                      f"x {n_chunks}x{args.layers} updates",
+            "sample_detail": f"oracle/ (C+OpenMP, fp32): DPSelect on {Ts} of {rows} bank rows ({t_dp:.2f} s) + "
+                             f"one PivotKV update at L={L} ({t_up:.2f} s, one warm-up then best of {reps_up}; DPSelect: best of 3); "
+                             f"extrapolated to {n_chunks}x{args.layers} updates",
             "dpselect_s_per_2048": t_dp * (rows / Ts), "pivotkv_update_s": t_up}
 
 
@@ -712,6 +719,150 @@ def decode_prologue_measurement(dev, tokens=100, prefix=40000):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------
+# The contract line.  stdout carries ONE short JSON line (< 4 KB: the driver keeps an 8 KB tail of stdout and parses the
+# last line of it; a 32 KB line once left it with nothing to parse).  Everything else bench.py measures - per-kernel tables,
+# the companions' full records, the memory split - is the REPORT: written to bench_report.json (repo root, and gpurun_out/
+# when that directory exists) and to stderr; tools/show_bench.py reads the file.
+# ---------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+REPORT_NAME = "bench_report.json"
+_COMPANIONS = ("real_geometry", "no_keypatch_mask", "llava_workload", "rotary_module_called", "reference_rounding",
+               "fast_rounding", "fp16_dtype", "fp32_parity_dtype")
+
+
+def _sig(x, digits=6):
+    """Floats to `digits` significant digits (the report file keeps full precision)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x == 0.0 or x != x or x in (float("inf"), float("-inf")):
+        return x
+    return float(f"{x:.{digits}g}")
+
+
+def _short(s, n=120):
+    return s if len(s) <= n else s[: n - 3] + "..."
+
+
+def contract_line(report: dict, report_path=None) -> dict:
+    """The short line of a full report: exactly the contract keys + one number per extra measurement."""
+    line = {}
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data"):
+        if k in report:
+            line[k] = _sig(report[k], 8)
+    cfg = report.get("config", {})
+    line["config"] = {k: (_short(v) if isinstance(v, str) else _sig(v)) for k, v in cfg.items()
+                      if k in ("workload", "geometry", "score_rounding", "frames", "chunks", "layers", "chunk_tokens", "keep",
+                               "parallelism", "transport", "key_patch_mask_rate", "assembled_cache_tokens")}
+    if report.get("roofline") is not None:
+        r = report["roofline"]
+        line["roofline"] = {k: _sig(r.get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                        "units_per_launch")}
+        line["roofline"]["avg_launch_us"] = _sig(r.get("avg_launch_us"))
+    cb = report.get("cpu_baseline")
+    line["cpu_baseline"] = None if cb is None else {
+        "value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": _short(cb["sample"], 128)}
+    for k in ("speedup_vs_cpu_baseline", "retained_kv_tokens_per_s"):
+        if k in report:
+            line[k] = _sig(report[k])
+    sc = report.get("self_check")
+    if sc is not None:
+        line["self_check"] = sc["status"] if isinstance(sc, dict) else sc
+    for k in ("sharded_equals_sequential", "rccl_world_size", "p2p_world_size", "phase_ms"):
+        if k in report:
+            line[k] = report[k]
+    n1 = report.get("n1_same_arithmetic")
+    if isinstance(n1, dict):   # frames/s of the sharded path at world size 1: the base of the --gpus N curve
+        line["n1_same_arithmetic"] = _sig(n1["value"]) if "value" in n1 else _short(n1.get("error", "failed"), 80)
+    m = report.get("memory")
+    if m:
+        line["memory"] = {"product_peak_bytes": m["product_peak_bytes"], "peak_allocated_bytes": m["peak_allocated_bytes"],
+                          "product_peak_over_reference_formula": _sig(m["product_peak_over_reference_formula"], 4)}
+    hk = report.get("roofline_hbm_kernels")
+    if hk:
+        line["roofline_hbm_kernels"] = {k: _sig(v["frac"], 3) for k, v in hk.items()}
+    comp = {k: _sig(report[k]["value"], 5) for k in _COMPANIONS if isinstance(report.get(k), dict) and "value" in report[k]}
+    for g, c in (report.get("pre_rope_prologue") or {}).items():
+        if isinstance(c, dict) and "value" in c:
+            comp["pre_rope/" + g] = _sig(c["value"], 5)
+    if "overlap" in report:
+        comp["overlap_streams"] = _sig(report["overlap"]["value"], 5)
+    dp = report.get("decode_prologue")
+    if dp:
+        comp["decode_prologue_fused_us"] = _sig(dp["decode_token"]["fused_us_per_step"], 4)
+    if comp:
+        line["companions_frames_per_s"] = comp
+    if report_path:
+        line["report"] = report_path
+    # never above the limit: the optional summaries go first, the contract keys stay
+    for drop in ("companions_frames_per_s", "roofline_hbm_kernels", "memory", "phase_ms"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    if len(json.dumps(line)) >= LINE_LIMIT:
+        raise AssertionError("bench.py: the contract line exceeds %d bytes" % LINE_LIMIT)
+    return line
+
+
+def emit(report: dict, path=None):
+    """Report -> `path` (default: bench_report.json at the repo root + in gpurun_out/) and stderr; the short contract line
+    -> stdout, LAST."""
+    text = json.dumps(report)
+    where = None
+    targets = [path] if path else [os.path.join(d, REPORT_NAME) for d in (ROOT, os.path.join(ROOT, "gpurun_out")) if os.path.isdir(d)]
+    for t in targets:
+        try:
+            with open(t, "w") as f:
+                f.write(text + "\n")
+            where = where or os.path.relpath(t, ROOT)
+        except OSError:
+            pass
+    line = contract_line(report, where)
+    sys.stderr.write(text + "\n")
+    sys.stderr.flush()
+    try:   # anything a C library left in stdio's buffer (RCCL's banner) goes out BEFORE the line, not at exit after it
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
+    return line
+
+
+def n1_same_arithmetic(args, timeout=300):
+    """frames/s of the SHARDED path at world size 1 over RCCL (RETAKE_FORCE_SHARDED=1) on the same video: the point a
+    scaling curve over `bench.py --gpus N` should be held against - same host code (ShardedPivotKV: provisional ids,
+    deferred rotation, offsets, assembly) and kernels as the N > 1 lines, where the plain N = 1 line runs the sequential
+    cache.  Measured in a CHILD process after this process has released its tensors (RCCL never enters the process that
+    prints the contract line; a child that hangs is killed after `timeout` s and reported as such)."""
+    import socket
+    import subprocess
+    import tempfile
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    with tempfile.TemporaryDirectory() as td:
+        rep = os.path.join(td, "world1.json")
+        cmd = [sys.executable, os.path.abspath(__file__), "--frames", str(args.frames), "--layers", str(args.layers),
+               "--steps", "2", "--warmup", "1", "--dtype", args.dtype, "--pool", str(args.pool), "--no-cpu-baseline",
+               "--no-self-check", "--no-extras", "--report", rep]
+        env = {**os.environ, "RETAKE_FORCE_SHARDED": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+        env.pop("RANK", None)
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+        except subprocess.TimeoutExpired:
+            return {"error": f"the world-size-1 sharded run did not finish in {timeout} s"}
+        if r.returncode != 0 or not os.path.exists(rep):
+            return {"error": "the world-size-1 sharded run failed: " + r.stderr[-400:]}
+        full = json.load(open(rep))
+    return {k: full[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "phase_ms", "roofline", "rccl_world_size")
+            if k in full}
+
+
 def main():
     global OVERLAP_STREAMS, SCORE_ROUNDING
     args = parse()
@@ -822,10 +973,12 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "retained_kv_tokens_per_s": retained / dt,
-        "config": {"workload": f"Qwen2-VL-7B geometry, {args.frames}-frame synthetic video: DPSelect (async, ratio 1.0) on "
-                               f"[1,{T},{N_PATCH},{C_EMB}] + PivotKV 4x on {n_chunks} chunks x {args.layers} layers, "
-                               f"L={L}, Hq={Hq}, Hkv={Hkv}, D={D}, reforge+M-RoPE "
-                               + ("(BASELINE configs[2])" if args.geometry == "baseline" else f"({GEOMETRIES[args.geometry][6]})"),
+        # (kept under 120 characters: the driver's record truncates longer strings)
+        "config": {"workload": ("BASELINE configs[2]" if args.geometry == "baseline" else GEOMETRIES[args.geometry][6])
+                               + f": {args.frames}-frame video, DPSelect [1,{T},{N_PATCH},{C_EMB}] + PivotKV 4x, "
+                                 f"{n_chunks} chunks x {args.layers} layers, L={L}",
+                   "workload_detail": f"Qwen2-VL-7B head geometry Hq={Hq}, Hkv={Hkv}, D={D}; DPSelect async at ratio 1.0 (shipped "
+                                      f"default); PivotKV with pos_embed_reforge + M-RoPE {MROPE}, YaRN attention_scaling",
                    "geometry": args.geometry, "score_rounding": args.score_rounding,
                    "cache_kwargs": cache_kwargs(),
                    "native_rope": "product default: on for inv_freq rotary modules (no config key set)",
@@ -1020,12 +1173,14 @@ def main():
                                                          warmup_chunks=2)
         # decode / text prefill: the same patch's prologue for segments that are not compressed
         out["decode_prologue"] = decode_prologue_measurement(dev)
+        # the base of the scaling curve: the SHARDED path (`bench.py --gpus N`'s host code and kernels) at world size 1
+        out["n1_same_arithmetic"] = n1_same_arithmetic(args)
         frames = torch.cat([chunk_frames(c, dev, tdtype) for c in range(min(n_chunks, 4))])[None]
     if not args.no_cpu_baseline:
         sample_T = 128
         out["cpu_baseline"] = cpu_baseline(args, frames[:, :sample_T].float().cpu().numpy(), args.cpu_sample_updates)
         out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
-    print(json.dumps(out))
+    emit(out, args.report)
 
 
 if __name__ == "__main__":

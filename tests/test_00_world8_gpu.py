@@ -77,17 +77,23 @@ def test_sharded_prefill_8_ranks_over_p2p():
     assert "sharded DPSelect over 8 ranks" in r.stdout and "chunks 65 on 8 rank(s)" in r.stdout
 
 
-def test_bench_eight_ranks_share_one_gpu_p2p():
+def test_bench_eight_ranks_share_one_gpu_p2p(tmp_path):
     """`bench.py --gpus 8 --transport p2p` end to end with all eight ranks on GPU 0 (RETAKE_BENCH_SHARE_GPU=1) on a 512-frame /
     2-layer video (16 chunks: blocks of 2): world size 8 through rank start-up, halo frames, the in-process
     self-verification in fp32 and bf16 (16- and 17-chunk videos) and the timed loop."""
     _fresh_parent()
     common = ["--frames", "512", "--layers", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
-    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--transport", "p2p"] + common,
+    rep = os.path.join(str(tmp_path), "report.json")
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--transport", "p2p", "--report", rep] + common,
              env={"RETAKE_BENCH_SHARE_GPU": "1"})
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
-    b = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    last = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
+    assert len(last) < 4096, len(last)     # the short contract line; the report file holds the rest
+    b, full = json.loads(last), json.load(open(rep))
     assert b["n_gpus"] == 8 and b["scaling"] == "strong" and b["config"]["transport"] == "p2p" and b["value"] > 0
     assert b["sharded_equals_sequential"] is True and b["p2p_world_size"] == 8
-    assert [(c["dtype"], c["chunks"]) for c in b["sharded_check"]["cases"]] == [("fp32", 16), ("fp32", 17), ("bf16", 16), ("bf16", 17)]
-    assert b["config"]["assembled_cache_tokens"] == 16 * 1568 and b["cache_checksum"]["tokens_per_layer"] == 16 * 1568
+    assert [(c["dtype"], c["chunks"]) for c in full["sharded_check"]["cases"]] == [("fp32", 16), ("fp32", 17), ("bf16", 16), ("bf16", 17)]
+    assert b["config"]["assembled_cache_tokens"] == 16 * 1568 and full["cache_checksum"]["tokens_per_layer"] == 16 * 1568
+    # per-phase timing, [max, min] over the eight ranks, in the line itself
+    for ph in ("dpselect", "blocks", "finalize", "step"):
+        assert b["phase_ms"][ph][0] >= b["phase_ms"][ph][1] >= 0.0, b["phase_ms"]

@@ -2315,62 +2315,85 @@ def test_p2p_across_gpus():
     assert r.returncode == 0 and "MP_SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
-def test_bench_two_ranks_share_one_gpu_p2p():
+def _bench(args, tmp_path, name, env=None):
+    """Run bench.py in a child process -> (the short contract line of its stdout, the full report it wrote)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rep = os.path.join(str(tmp_path), name + ".json")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args + ["--report", rep], capture_output=True,
+                       text=True, timeout=600, cwd=root, env={**os.environ, **(env or {})})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    last = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
+    assert len(last) < 4096, len(last)            # the contract: a line the driver's 8 KB stdout tail always holds whole
+    assert r.stdout.strip().splitlines()[-1] == last
+    line = json.loads(last)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "data", "config", "roofline",
+                "cpu_baseline"):
+        assert key in line, key
+    return line, json.load(open(rep))
+
+
+def test_bench_two_ranks_share_one_gpu_p2p(tmp_path):
     """`bench.py --gpus 2 --transport p2p` end to end (rank start-up, halo frame, chunk blocks, timed loop, JSON line) with
     both ranks on GPU 0 (RETAKE_BENCH_SHARE_GPU=1: gloo control plane, p2p data plane), on a
     256-frame / 2-layer video.  The assembled cache must have the single-GPU run's size; its CONTENT is not comparable
     (the bench takes its resident tensors as the rotated inputs at whatever ids a block runs at, i.e. later blocks see
     different content - equality of sharded and sequential caches is tests/mp_sharded_gpu.py's job)."""
-    import json
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--frames", "256", "--layers", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True,
-                         timeout=600, cwd=root)
-    assert one.returncode == 0, one.stderr[-3000:]
-    a = json.loads(one.stdout.strip().splitlines()[-1])
-    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--transport", "p2p"] + common,
-                         capture_output=True, text=True, timeout=600, cwd=root,
-                         env={**os.environ, "RETAKE_BENCH_SHARE_GPU": "1"})
-    assert two.returncode == 0, (two.stdout[-2000:], two.stderr[-3000:])
-    b = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    a, ra = _bench(common + ["--no-extras"], tmp_path, "one")
+    b, rb = _bench(["--gpus", "2", "--transport", "p2p"] + common, tmp_path, "two", env={"RETAKE_BENCH_SHARE_GPU": "1"})
     assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["config"]["transport"] == "p2p"
     assert b["metric"] == a["metric"] and b["unit"] == a["unit"] and b["value"] > 0
     for key in ("tokens_per_layer", "layers"):
-        assert b["cache_checksum"][key] == a["cache_checksum"][key], (key, a["cache_checksum"], b["cache_checksum"])
-    assert b["config"]["assembled_cache_tokens"] == a["cache_checksum"]["tokens_per_layer"]
+        assert rb["cache_checksum"][key] == ra["cache_checksum"][key], (key, ra["cache_checksum"], rb["cache_checksum"])
+    assert b["config"]["assembled_cache_tokens"] == ra["cache_checksum"]["tokens_per_layer"]
     assert b["roofline"]["frac"] > 0 and b["cpu_baseline"] is None
     # the line carries its own proof: sharded == sequential was checked in process, over the same transport, before timing
     assert b["sharded_equals_sequential"] is True and b["p2p_world_size"] == 2
-    assert [(c["dtype"], c["chunks"]) for c in b["sharded_check"]["cases"]] == [("fp32", 4), ("fp32", 5), ("bf16", 4), ("bf16", 5)]
+    assert [(c["dtype"], c["chunks"]) for c in rb["sharded_check"]["cases"]] == [("fp32", 4), ("fp32", 5), ("bf16", 4), ("bf16", 5)]
+    # per-phase timing of the sharded step, max / min over the ranks (the first real multi-GPU run must say where time goes)
+    for ph in ("dpselect", "blocks", "finalize", "step"):
+        assert b["phase_ms"][ph][0] >= b["phase_ms"][ph][1] >= 0.0, b["phase_ms"]
 
 
-def test_bench_forced_sharded_world1_rccl_self_verifies():
+def test_bench_forced_sharded_world1_rccl_self_verifies(tmp_path):
     """`RETAKE_FORCE_SHARDED=1 python bench.py`: the sharded path at world size 1 over RCCL.  The line must carry
     `sharded_equals_sequential: true` (checked in process before the timed region) and - world size 1 being the one
     case where the bench's resident tensors mean the same thing in both paths - the plain run's cache fingerprint."""
-    import json
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--frames", "256", "--layers", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True,
-                         timeout=600, cwd=root)
-    assert one.returncode == 0, one.stderr[-3000:]
-    a = json.loads(one.stdout.strip().splitlines()[-1])
-    sh = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True,
-                        timeout=600, cwd=root, env={**os.environ, "RETAKE_FORCE_SHARDED": "1", "MASTER_ADDR": "127.0.0.1",
+    a, ra = _bench(common + ["--no-extras"], tmp_path, "one")
+    b, rb = _bench(common, tmp_path, "forced", env={"RETAKE_FORCE_SHARDED": "1", "MASTER_ADDR": "127.0.0.1",
                                                     "MASTER_PORT": str(_free_port())})
-    assert sh.returncode == 0, (sh.stdout[-2000:], sh.stderr[-3000:])
-    b = json.loads([ln for ln in sh.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert b["sharded_equals_sequential"] is True and b["rccl_world_size"] == 1
-    assert [(c["dtype"], c["chunks"]) for c in b["sharded_check"]["cases"]] == [("fp32", 2), ("fp32", 3), ("bf16", 2), ("bf16", 3)]
+    assert [(c["dtype"], c["chunks"]) for c in rb["sharded_check"]["cases"]] == [("fp32", 2), ("fp32", 3), ("bf16", 2), ("bf16", 3)]
     for key in ("tokens_per_layer", "layers", "ids_sum", "v_bits_sum"):
-        assert b["cache_checksum"][key] == a["cache_checksum"][key], (key, a["cache_checksum"], b["cache_checksum"])
-    assert abs(b["cache_checksum"]["k_abs_sum"] - a["cache_checksum"]["k_abs_sum"]) <= 1e-6 * a["cache_checksum"]["k_abs_sum"]
+        assert rb["cache_checksum"][key] == ra["cache_checksum"][key], (key, ra["cache_checksum"], rb["cache_checksum"])
+    assert abs(rb["cache_checksum"]["k_abs_sum"] - ra["cache_checksum"]["k_abs_sum"]) <= 1e-6 * ra["cache_checksum"]["k_abs_sum"]
+    assert set(b["phase_ms"]) >= {"dpselect", "blocks", "offsets", "rotate", "assembly", "finalize", "step", "barrier_idle"}
+
+
+def test_bench_default_line_is_short_and_names_every_companion(tmp_path):
+    """The default bench run in small (256 frames, 2 layers, every companion): stdout ends in ONE line below 4 KB with the
+    contract keys, `roofline`, `cpu_baseline`, one number per companion and `n1_same_arithmetic` (the sharded path at
+    world size 1, measured in a child process); the report file holds the full records."""
+    a, rep = _bench(["--frames", "256", "--layers", "2", "--steps", "2", "--warmup", "1", "--cpu-sample-updates", "1"],
+                    tmp_path, "default")
+    assert a["config"]["workload"].startswith("BASELINE configs[2]") and len(a["config"]["workload"]) <= 120
+    assert a["roofline"]["bound"] == "mfma" and 0 < a["roofline"]["frac"] < 1 and a["roofline"]["avg_launch_us"] > 0
+    assert a["cpu_baseline"]["kind"] == "port" and a["cpu_baseline"]["value"] > 0 and a["cpu_baseline"]["cores"] >= 1
+    assert a["self_check"] == "ok" and a["speedup_vs_cpu_baseline"] > 0
+    comp = a["companions_frames_per_s"]
+    for k in ("real_geometry", "no_keypatch_mask", "llava_workload", "reference_rounding", "fast_rounding", "fp16_dtype",
+              "fp32_parity_dtype", "rotary_module_called", "pre_rope/real_geometry", "pre_rope/baseline_geometry"):
+        assert comp[k] > 0, k
+    assert isinstance(a["n1_same_arithmetic"], float) and a["n1_same_arithmetic"] > 0, a["n1_same_arithmetic"]
+    assert rep["n1_same_arithmetic"]["rccl_world_size"] == 1 and "blocks" in rep["n1_same_arithmetic"]["phase_ms"]
+    assert set(a["memory"]) == {"product_peak_bytes", "peak_allocated_bytes", "product_peak_over_reference_formula"}
+    assert all(isinstance(v, float) for v in a["roofline_hbm_kernels"].values())
+    assert "kernels_timed_region" in rep and "split_bytes" in rep["memory"] and "step_ms" in rep["real_geometry"]
 
 
 @pytest.mark.parametrize("L,Hq,Hkv", [(1, 28, 4), (31, 28, 4), (130, 28, 4), (257, 28, 4), (515, 28, 4), (1000, 28, 4),

@@ -20,7 +20,7 @@ for geo in baseline qwen448; do
     n=$(basename $f .so); n=${n#libretake_hip_}
     [ $mode = fp32 ] && [ $f != default ] && continue
     if [ $f = default ]; then unset RETAKE_HIP_LIB; else export RETAKE_HIP_LIB=$PWD/$f; fi
-    timeout 300 python bench.py --geometry $geo --score-rounding $mode --steps $steps --warmup 1 --no-cpu-baseline --no-extras --no-self-check > $out/$geo.$mode.$n.$rep.json 2> $out/$geo.$mode.$n.$rep.err < /dev/null
+    timeout 300 python bench.py --geometry $geo --score-rounding $mode --steps $steps --warmup 1 --no-cpu-baseline --no-extras --no-self-check --report $out/$geo.$mode.$n.$rep.json > $out/$geo.$mode.$n.$rep.line 2> $out/$geo.$mode.$n.$rep.err < /dev/null
     echo -n "$geo rep$rep $mode $n: "; summ $out/$geo.$mode.$n.$rep.json 2>&1 | tail -1
   done; done
 done; done | tee $out/ab.txt

@@ -16,7 +16,7 @@ for geo in qwen448 baseline; do
   for f in default $V/libretake_hip_*.so; do
     n=$(basename $f .so); n=${n#libretake_hip_}
     if [ $f = default ]; then unset RETAKE_HIP_LIB; else export RETAKE_HIP_LIB=$PWD/$f; fi
-    timeout 300 python bench.py --geometry $geo --steps $steps --warmup 1 --no-cpu-baseline --no-extras > $out/$geo.$n.$rep.json 2> $out/$geo.$n.$rep.err < /dev/null
+    timeout 300 python bench.py --geometry $geo --steps $steps --warmup 1 --no-cpu-baseline --no-extras --report $out/$geo.$n.$rep.json > $out/$geo.$n.$rep.line 2> $out/$geo.$n.$rep.err < /dev/null
     echo -n "$geo rep$rep $n: "; summ $out/$geo.$n.$rep.json 2>&1 | tail -1
   done
 done; done | tee $out/ab.txt

@@ -10,8 +10,8 @@ timeout 1500 python -m pytest tests -m gpu -x -q -s > $out/pytest.log 2>&1 < /de
 grep -E "passed|failed" $out/pytest.log
 # the parity statistics the tests print (per row / per fixture), kept with the round's numbers
 grep -E "^\[|^[a-z0-9_]+: |scores differ|kept tokens differ|mode vs" $out/pytest.log | grep -v "^tests/" > $out/parity_stats.txt
-timeout 1500 python bench.py > $out/bench_bf16.json 2> $out/bench_bf16.err < /dev/null
-python tools/show_bench.py < $out/bench_bf16.json | head -40
+timeout 1500 python bench.py --report $out/bench_bf16.json > $out/bench_bf16.line 2> $out/bench_bf16.err < /dev/null
+python tools/show_bench.py $out/bench_bf16.json | head -40
 timeout 600 python tools/bench_ratio1.py > $out/bench_ratio1.json 2>/dev/null < /dev/null
 timeout 900 python tools/bench_mallm.py > $out/bench_mallm.json 2>/dev/null < /dev/null
 timeout 900 python tools/bench_llava.py > $out/bench_llava.json 2>/dev/null < /dev/null

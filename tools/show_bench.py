@@ -1,10 +1,19 @@
 #!/usr/bin/env python3
-"""Pretty-print a bench.py JSON line: `show_bench.py FILE`, or from stdin."""
+"""Pretty-print a bench.py REPORT (bench_report.json; bench.py's stdout is only the short contract line):
+`show_bench.py [FILE]` (default: bench_report.json at the repo root), or a report / line from stdin with `-`."""
 import json
+import os
 import sys
 
-text = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
+if len(sys.argv) > 1 and sys.argv[1] != "-":
+    text = open(sys.argv[1]).read()
+elif len(sys.argv) > 1:
+    text = sys.stdin.read()
+else:
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_report.json")).read()
 d = json.loads(text.strip().splitlines()[-1])
+if "report" in d and "kernels_timed_region" not in d and os.path.exists(d["report"]):   # handed the short line: follow it
+    d = json.loads(open(d["report"]).read())
 print(f"value={d['value']:.1f} {d['unit']}  ms_per_step={d['ms_per_step']:.1f}  n_gpus={d['n_gpus']} dtype={d['dtype']}")
 tot = 0.0
 for k, v in (d.get("kernels") or d.get("kernels_untimed_single_stream", {})).items():
@@ -44,6 +53,10 @@ if "decode_prologue" in d:
         c = d["decode_prologue"][k]
         print(f"decode_prologue/{k}: fused {c['fused_us_per_step']:.0f} us  op-by-op {c['op_by_op_us_per_step']:.0f} us  ({c['speedup']:.1f}x), "
               f"{d['decode_prologue']['layers']} layers")
-for k in ("sharded_equals_sequential", "rccl_world_size", "p2p_world_size"):
+for k in ("sharded_equals_sequential", "rccl_world_size", "p2p_world_size", "phase_ms", "phase_bytes_rank0"):
     if k in d:
         print(k, d[k])
+if isinstance(d.get("n1_same_arithmetic"), dict):
+    c = d["n1_same_arithmetic"]
+    print("n1_same_arithmetic (sharded path at world size 1):", c.get("error") or
+          f"{c['value']:.1f} frames/s  ms_per_step={c['ms_per_step']:.1f}  phase_ms {c['phase_ms']}")

@@ -391,6 +391,58 @@ def plan_frame_exchange(idx: torch.Tensor, T_own: int, world: int):
     return start, cmax, local.contiguous(), place.contiguous()
 
 
+class PhaseTimer:
+    """Where a sharded step spends its time, per rank: marks on the CURRENT stream (HIP events on a GPU, the host clock
+    under gloo), one list per step.  A phase is the span between two consecutive marks as the launch stream sees it, so
+    it includes what that stream waited for (a collective, the side stream's pushes, a host round trip that left it
+    idle).  `sharded_video_step` marks  dpselect | blocks | offsets | rotate | assembly;  read `per_step_ms()` after a
+    device synchronisation."""
+
+    ORDER = ("dpselect", "blocks", "offsets", "rotate", "assembly")
+
+    def __init__(self, device):
+        self.cuda = torch.device(device).type == "cuda"
+        self.steps: List[list] = []
+        self.bytes = {}
+
+    def begin(self):
+        self.steps.append([])
+        self.mark("start")
+
+    def mark(self, name: str):
+        if not self.steps:
+            return
+        if self.cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.steps[-1].append((name, e))
+        else:
+            self.steps[-1].append((name, time.perf_counter()))
+
+    def note_bytes(self, name: str, n: int):
+        self.bytes[name] = int(n)
+
+    def per_step_ms(self) -> dict:
+        """{phase: mean ms per step} over the recorded steps (+ "step": start -> last mark)."""
+        tot = {k: 0.0 for k in self.ORDER}
+        tot["step"] = 0.0
+        n = 0
+        for marks in self.steps:
+            if len(marks) < 2:
+                continue
+            n += 1
+            for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+                tot[name] = tot.get(name, 0.0) + (a.elapsed_time(b) if self.cuda else (b - a) * 1e3)
+            a, b = marks[0][1], marks[-1][1]
+            tot["step"] += a.elapsed_time(b) if self.cuda else (b - a) * 1e3
+        return {k: v / max(1, n) for k, v in tot.items()}
+
+
+def _mark(phases, name):
+    if phases is not None:
+        phases.mark(name)
+
+
 # ---------------------------------------------------------------------------------------------------
 # device path
 # ---------------------------------------------------------------------------------------------------
@@ -521,7 +573,7 @@ class ShardedPivotKV:
         self._gather.start(ks, vs)
 
     def finalize(self, inv_freq: torch.Tensor, mrope_section: Optional[List[int]], assemble: bool = True,
-                 attention_scaling: Optional[float] = None):
+                 attention_scaling: Optional[float] = None, phases: Optional["PhaseTimer"] = None):
         """Exchange offsets, shift this rank's ids to their true temporal position, rotate the kept keys - un-rotated
         until now - ONCE at those final ids (what the sequential cache does per chunk, reference :297-306: same tables,
         same roundings, so a block's keys carry the bits they would have had in a single-GPU run), and optionally
@@ -536,6 +588,7 @@ class ShardedPivotKV:
         last = torch.stack([pc.reshape(-1, pc.shape[-1])[0, -1] for pc in cache.position_cache])   # [layers]
         table = exchange_temporal_offsets(last, self.first_start, self.group, all_ranks=True)      # [world, layers]
         delta = table[dist.get_rank(self.group)]                                                   # [layers]
+        _mark(phases, "offsets")
         sec = (C.c_int * len(mrope_section))(*mrope_section) if mrope_section else None
         nsec = len(mrope_section) if mrope_section else 0
         if attention_scaling is None:   # (a cache that never saw a compressed update has no batch: plain RoPE scaling)
@@ -601,6 +654,9 @@ class ShardedPivotKV:
             if assemble and g is not None:
                 kv = g.finish()                                   # [2, layers, Hkv, world*n, D], keys still un-rotated
                 pos = all_gather_ids(pos, self.group, counts)     # the final ids of every rank's rows
+                _mark(phases, "assembly")                         # (the rows travelled beside the blocks: this is the wait)
+                if phases is not None:
+                    phases.note_bytes("assembly_rows_received", kv.numel() * kv.element_size() * (len(counts) - 1) // len(counts))
                 # every row of every layer -> rotated at its final ids, ONE launch over the assembled cache
                 P = 3 if pos[0].ndim == 3 else 1
                 rows = kv.shape[3]
@@ -611,13 +667,19 @@ class ShardedPivotKV:
                                                      nv.round_mode(kv.dtype), st), "rtk_rope_rotate_rows")
                 keys = [kv[0, layer][None] for layer in range(n_layers)]
                 values = [kv[1, layer][None] for layer in range(n_layers)]
+                _mark(phases, "rotate")
                 p2p = _P2P.get(self.group)
                 if p2p is not None:
                     p2p.check()   # synchronises; a wait that timed out left a partly filled landing buffer: raise
             else:
                 rotate_own()
+                _mark(phases, "rotate")
                 if assemble:
+                    own = sum(k.numel() * k.element_size() + v.numel() * v.element_size() for k, v in zip(keys, values))
                     keys, values, pos = all_gather_caches(keys, values, pos, self.group)
+                    _mark(phases, "assembly")
+                    if phases is not None:
+                        phases.note_bytes("assembly_rows_received", own * (len(counts) - 1))
         return keys, values, pos
 
 
@@ -641,7 +703,11 @@ def sharded_video_step(frames, has_halo: bool, T: int, c0: int, c1: int, layers:
     import bench as B
 
     L = B.FRAMES_PER_CHUNK * B.N_PATCH
+    phases = (state or {}).get("phases")     # a PhaseTimer the caller wants filled (bench.py --gpus N)
+    if phases is not None:
+        phases.begin()
     out, mask, idx, dis = dpselect_sharded(frames, has_halo, T, 3, sync=False, group=group)
+    _mark(phases, "dpselect")
     keep = max(1, int(B.RATIO * L))
     sh = ShardedPivotKV(B.make_cache_config(layers), group=group, expected_rows=(c1 - c0) * keep if overlap else None,
                         chunk_gather=(state or {}).get("chunk_gather"), reserve_tokens=(c1 - c0) * keep + L)
@@ -666,7 +732,8 @@ def sharded_video_step(frames, has_halo: bool, T: int, c0: int, c1: int, layers:
         cache.after_forward()
         if overlap:
             sh.gather_chunk()   # this chunk's kept rows leave now, beside the next chunk's scoring
-    keys, values, pos = sh.finalize(rotary.inv_freq, B.MROPE, assemble=True)
+    _mark(phases, "blocks")
+    keys, values, pos = sh.finalize(rotary.inv_freq, B.MROPE, assemble=True, phases=phases)
     if state is not None:
         state["chunk_gather"] = sh.chunk_gather
     return (c1 - c0) * layers * keep, (keys, values, pos)
@@ -832,26 +899,17 @@ def verify_sharded_equals_sequential(rank: int, world: int, dev, rotary, layers:
                        "ids, V and K bit patterns equal in every listed dtype"}
 
 
-def bench_main(args, rank: int, world: int, local_rank: int):
+def measure_sharded(args, rank: int, world: int, dev, transport: str, share: bool, steps: int, warmup: int,
+                    verify: bool = True) -> Optional[dict]:
+    """The timed sharded run on an initialised process group: -> the report dict on rank 0, None elsewhere.
+    Besides the whole-job rate the report says where a step's time goes on the ranks (`phase_ms`: [max, min] over the
+    ranks of the mean ms per step of each PhaseTimer phase, of the host's wall time per step and of the idle time at the
+    closing barrier) - what the first real multi-GPU run needs to explain a shortfall."""
     import bench as B
     from . import _native as nv
 
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")   # world size 1 without a launcher (RETAKE_FORCE_SHARDED=1)
-    os.environ.setdefault("MASTER_PORT", "29544")
-    transport = getattr(args, "transport", "rccl")
-    # RETAKE_BENCH_SHARE_GPU=1 (tests only, p2p transport): every rank runs on GPU 0 over a gloo control plane, so that
-    # the multi-rank bench path can run on a 1-GPU box (RCCL refuses two ranks on one device)
-    share = os.environ.get("RETAKE_BENCH_SHARE_GPU") == "1" and transport == "p2p"
-    dev = torch.device("cuda", 0 if share else local_rank)
-    torch.cuda.set_device(dev)
-    if not dist.is_initialized():
-        if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     red_dev = torch.device("cpu") if share else dev     # gloo reduces host tensors
-    p2p = enable_p2p(device=dev) if transport == "p2p" else None
+    p2p = _P2P.get(None)
     tdtype = B.TORCH_DTYPE[args.dtype]
     T = args.frames
     n_chunks = T // B.FRAMES_PER_CHUNK
@@ -879,59 +937,103 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     # Before anything is timed: is the cache this transport assembles the cache one GPU builds?  (tests/mp_sharded_gpu.py's
     # check, in process, over the transport of the timed loop.)  A mismatch raises: no value is printed for a wrong path.
     verdict = None
-    if not getattr(args, "no_self_check", False):
+    if verify:
         verdict = verify_sharded_equals_sequential(rank, world, dev, rotary, layers=2, state=state)
         torch.cuda.empty_cache()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     ids = nv.profile_kernel_ids()   # HIP events around the dominant kernels, on their launch stream, in the timed region
     nv.check(nv.lib.rtk_profile_reset(), "profile_reset")
     nv.check(nv.lib.rtk_profile_enable_mask((1 << ids["score_pass1"]) | (1 << ids["score_pass2"])), "profile_enable")
+    phases = state["phases"] = PhaseTimer(dev)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     retained = 0
-    for _ in range(args.steps):
+    for _ in range(steps):
         r, (keys, values, pos) = step()
         retained += r
     torch.cuda.synchronize()
+    t_done = time.perf_counter()
     dist.barrier()
     torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+    t_end = time.perf_counter()
+    state.pop("phases")
+    dt = torch.tensor([t_end - t0], dtype=torch.float64, device=red_dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     tot = torch.tensor([float(retained)], dtype=torch.float64, device=red_dev)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt = float(dt.item())
     nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
     kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "total_ms": ms} for k, (n, ms) in nv.profile_read().items()}
+    # per-phase times of this rank (mean per step) -> [max, min] over the ranks
+    pm = phases.per_step_ms()
+    pm["finalize"] = pm["offsets"] + pm["rotate"] + pm["assembly"]
+    pm["host_wall"] = (t_done - t0) / steps * 1e3
+    pm["barrier_idle"] = (t_end - t_done) / steps * 1e3
+    names = sorted(pm)
+    hi = torch.tensor([pm[k] for k in names], dtype=torch.float64, device=red_dev)
+    lo = hi.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    phase_ms = {k: [float(f"{a:.4g}"), float(f"{b:.4g}")] for k, a, b in zip(names, hi.tolist(), lo.tolist())}
     # untimed; the token count equals the N = 1 line's, the sums only at N = 1 (see sharded_video_step on `inputs`)
     checksum = B.cache_checksum(keys, values, pos) if rank == 0 else None
     if p2p is not None:
         p2p.check()   # a bounded wait that gave up would have left garbage: fail the run instead
-    if rank == 0:
-        out = {
-            "metric": "frames/sec through DPSelect+PivotKV @2048 frames; retained-KV-tokens/sec",
-            "value": T * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "retained_kv_tokens_per_s": float(tot.item()) / dt,
-            "config": {"workload": f"Qwen2-VL-7B geometry, one {T}-frame synthetic video sharded by frame chunk over "
-                                   f"{world} GPUs: DPSelect (distance rows all-gathered) + PivotKV 4x on "
-                                   f"{n_chunks} chunks x {args.layers} layers, L={L}; offsets + whole-cache "
-                                   f"all-gather over {'RCCL' if p2p is None else 'direct xGMI pushes (retake/p2p.py)'} "
-                                   f"(BASELINE configs[3])",
-                       "frames": T, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L,
-                       "parallelism": f"chunk-sharded x{world}", "transport": transport,
-                       "assembled_cache_tokens": int(keys[0].shape[2])},
-            "cache_checksum": checksum,
-            # untimed, before the timed region, over the same transport and through the same function the loop times
-            "sharded_equals_sequential": bool(verdict and verdict["equal"]),
-            "sharded_check": verdict,
-            ("rccl_world_size" if p2p is None and not share else "p2p_world_size"): dist.get_world_size(),
-            "cpu_baseline": None,   # timed on rank 0 of the N = 1 run only (bench contract); see that line
-            "kernels_timed_region_rank0": kern,
-            "roofline": B.score_roofline(kern, args.dtype, L, T, (c1 - c0) * args.layers * args.steps),
-        }
+    if rank != 0:
+        return None
+    return {
+        "metric": "frames/sec through DPSelect+PivotKV @2048 frames; retained-KV-tokens/sec",
+        "value": T * steps / dt, "unit": "frames/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "retained_kv_tokens_per_s": float(tot.item()) / dt,
+        "config": {"workload": f"BASELINE configs[3]: {T}-frame video sharded by frame chunk over {world} GPU(s), "
+                               f"{n_chunks} chunks x {args.layers} layers, L={L}",
+                   "workload_detail": f"Qwen2-VL-7B geometry: DPSelect (distance rows all-gathered) + PivotKV 4x; offsets + "
+                                      f"whole-cache all-gather over "
+                                      f"{'RCCL' if p2p is None else 'direct xGMI pushes (retake/p2p.py)'}",
+                   "frames": T, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L,
+                   "parallelism": f"chunk-sharded x{world}", "transport": transport,
+                   "assembled_cache_tokens": int(keys[0].shape[2])},
+        "cache_checksum": checksum,
+        # untimed, before the timed region, over the same transport and through the same function the loop times
+        "sharded_equals_sequential": bool(verdict and verdict["equal"]),
+        "sharded_check": verdict,
+        ("rccl_world_size" if p2p is None and not share else "p2p_world_size"): dist.get_world_size(),
+        "cpu_baseline": None,   # timed on rank 0 of the N = 1 run only (bench contract); see that line
+        "kernels_timed_region_rank0": kern,
+        "roofline": B.score_roofline(kern, args.dtype, L, T, (c1 - c0) * args.layers * steps),
+        # [max, min] over the ranks, mean ms per step: PhaseTimer phases on the launch stream (dpselect: local distances +
+        # all-gather + select; blocks: the rank's chunks x layers incl. starting the per-chunk gathers; offsets: the id scan;
+        # rotate: kept keys at their final ids; assembly: waiting for / gathering the other ranks' rows; finalize = the
+        # last three), the host's wall time per step and the idle time at the closing barrier
+        "phase_ms": phase_ms,
+        "phase_bytes_rank0": dict(phases.bytes),
+    }
+
+
+def bench_main(args, rank: int, world: int, local_rank: int):
+    import bench as B
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")   # world size 1 without a launcher (RETAKE_FORCE_SHARDED=1)
+    os.environ.setdefault("MASTER_PORT", "29544")
+    transport = getattr(args, "transport", "rccl")
+    # RETAKE_BENCH_SHARE_GPU=1 (tests only, p2p transport): every rank runs on GPU 0 over a gloo control plane, so that
+    # the multi-rank bench path can run on a 1-GPU box (RCCL refuses two ranks on one device)
+    share = os.environ.get("RETAKE_BENCH_SHARE_GPU") == "1" and transport == "p2p"
+    dev = torch.device("cuda", 0 if share else local_rank)
+    torch.cuda.set_device(dev)
+    if not dist.is_initialized():
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    p2p = enable_p2p(device=dev) if transport == "p2p" else None
+    out = measure_sharded(args, rank, world, dev, transport, share, args.steps, args.warmup,
+                          verify=not getattr(args, "no_self_check", False))
     dist.barrier()
     if p2p is not None:
         disable_p2p()
@@ -944,4 +1046,4 @@ def bench_main(args, rank: int, world: int, local_rank: int):
         except OSError:
             pass
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        B.emit(out, getattr(args, "report", None))
