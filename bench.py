@@ -242,7 +242,10 @@ def run_video(frames, pool, masks, pos_base, rotary, layers, tdtype, pre_rope=Fa
             # what the attention patch does (qwen2_vl.py:68-73): the ids tensor is shared by the layers of
             # the chunk and shifted in place, on the device (no host sync)
             cache.shift_temporal_ids_(pos, layer)
-            kw = {"query_states": q, "position_ids": pos, "rotary_emb": rotary, "mrope_section": MROPE}
+            # ("shift_next_position_ids": this build's Qwen2-VL patch sets it - retake/qwen2_vl.py - because it shifts the
+            # shared ids tensor in place for every layer anyway; the next layer's shift may then ride in this launch)
+            kw = {"query_states": q, "position_ids": pos, "rotary_emb": rotary, "mrope_section": MROPE,
+                  "shift_next_position_ids": True}
             cache.update(k, v, layer, kw)
         cache.after_forward()
         retained += layers * max(1, int(RATIO * L))
@@ -506,6 +509,7 @@ def companion_measurement(dev, frames_total, layers, dtype, steps, warmup, pool_
             torch.cuda.synchronize()
             step_ms.append((time.perf_counter() - ts) * 1e3)
         dt = time.perf_counter() - t0
+        cache.check()
         es_ = 4 if dtype == "fp32" else 2
         mem = memory_block(cache, torch.cuda.max_memory_allocated(), torch.cuda.max_memory_reserved(), resident_inputs,
                            0 if NO_VISUAL_COMPRESSION else frames.numel() * frames.element_size() + 5 * rows * N_PATCH, layers, L,
@@ -935,6 +939,7 @@ def main():
         retained += r
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    cache.check()   # a bounded device-side wait that ran out (the in-launch id shift) raises: no number for a wrong path
     peak_alloc, peak_reserved = torch.cuda.max_memory_allocated(), torch.cuda.max_memory_reserved()
     mem = memory_block(cache, peak_alloc, peak_reserved, resident_inputs,
                        frames.numel() * frames.element_size() + 5 * T * N_PATCH, args.layers, L, n_chunks, es)

@@ -594,8 +594,11 @@ typedef struct rtk_update_io {
     int32_t pad0;
     const int64_t* next_prev;                        /* RTK_UPDATE_SHIFT_NEXT (ABI 16): the NEXT layer's last cached temporal id */
     int32_t* ticket; int64_t ticket_ints;            /*   (device; NULL = -1); rtk_pivotkv_shift_ticket_ints(L, D) device words, */
-} rtk_update_io;                                     /*   zeroed ONCE by the caller (launch count + arrival counters; word 31   */
-                                                     /*   counts launches whose bounded wait ran out - stays 0)                 */
+                                                     /*   zeroed ONCE by the caller: word 0 launch count, word 31 the run-out   */
+                                                     /*   LATCH (below), then the arrival counters, a cache line each           */
+    int32_t* status;                                 /* (ABI 17) optional HOST-VISIBLE word (pinned host memory the device can   */
+} rtk_update_io;                                     /*   write), zeroed by the caller: incremented when a launch's bounded     */
+                                                     /*   wait runs out, so the host can see the latch without a device sync    */
 size_t rtk_pivotkv_shift_ticket_ints(int L, int D);
 enum rtk_update_flags {
     /* q, k are the PRE-RoPE projections (what q_proj / k_proj return).  One launch then does the whole prologue of the
@@ -627,6 +630,13 @@ enum rtk_update_flags {
      * has read the ids this layer works with (each counts itself in on one of the counters in io->ticket; one extra
      * workgroup watches them, shifts and zeroes them again: nobody else waits).  `pos` is written despite its const.
      * Launches that share the ticket words must be stream ordered.
+     * The watcher's wait is bounded by a poll count (~seconds; the workers need microseconds).  If it runs out - the
+     * counters were not zero at launch: words shared between streams, or never zeroed - the ids are NOT shifted and the
+     * counters NOT zeroed: the launch increments ticket[31] (and *io->status) and returns, and so does the watcher of every
+     * later launch on these words (without waiting) until the caller has zeroed ticket and status again.  A caller that
+     * skips its own rtk_position_shift on the strength of this flag must check the latch before it trusts the ids
+     * (PivotKVCache raises RuntimeError).  Needs the chunk-batched passes or a keep-all batch: otherwise
+     * RTK_EUNSUPPORTED is returned BEFORE anything is launched (nothing touched).
      * The caller's next rtk_position_shift for that layer is then a no-op and may be skipped - the attention patch of a
      * 28-layer model launches it 27 times per chunk otherwise.  Only with the native prepare kernel (batch.inv_freq). */
     RTK_UPDATE_SHIFT_NEXT = 8
@@ -670,7 +680,7 @@ int rtk_position_shift(int64_t* temporal_ids, int n, const int64_t* prev_dev, rt
  *   - rtk_p2p_push: nseg segments of seg_bytes from src (+ s * src_stride) to byte dst_offset + s * dst_stride
  *     of EVERY mapped buffer (the own one included), then - from a second launch behind the copy, so that a kernel
  *     boundary orders it after every workgroup of it; system-scope release - the value `epoch` into word `rank` of
- *     every peer's flag array.  `counter` (one device word of the caller's context) is no longer used;
+ *     every peer's flag array  (ABI 17: the unused `counter` argument of ABI <= 16 is gone);
  *   - rtk_p2p_wait: returns (on the stream) once every sender has published an epoch >= `epoch`; bounded:
  *     after ~timeout_ms the kernel gives up and stores 1 + (first missing sender) into *status (device word,
  *     0 = fine), so that a lost peer is an error, not a hung GPU.
@@ -693,7 +703,7 @@ int rtk_p2p_open(const void* handle, void** base_out);          /* ptr in this p
 int rtk_p2p_close(void* base);
 int rtk_p2p_push(const void* src, size_t seg_bytes, int nseg, size_t src_stride_bytes, const rtk_p2p_peers* peers,
                  int rank, int world, size_t dst_offset_bytes, size_t dst_stride_bytes, uint32_t epoch,
-                 uint32_t* counter, rtk_stream_t stream);
+                 rtk_stream_t stream);
 int rtk_p2p_wait(const uint32_t* own_flags, int world, uint32_t epoch, int timeout_ms, uint32_t* status,
                  rtk_stream_t stream);
 

@@ -23,6 +23,12 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from retake.p2p import P2PGroup
 
+    if os.environ.get("RETAKE_TEST_HANG_RANK") == str(rank):
+        # test hook (tests/test_00_world8_gpu.py): this rank never joins the group's set-up - a deadlocked rank.  Its peers
+        # block in the control plane's collectives (handle exchange): what the caller sees is a job that does not finish.
+        import time
+
+        time.sleep(3600)
     g = P2PGroup(device=dev)
 
     def block(r, i, shape, dtype):

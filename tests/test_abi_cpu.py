@@ -210,7 +210,7 @@ def test_flag_and_code_constants_match_the_header(tmp_path):
     got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
     for n, v in names.items():
         assert int(got[n]) == v, n
-    assert nv.lib.rtk_version() == nv.ABI_VERSION == 16
+    assert nv.lib.rtk_version() == nv.ABI_VERSION == 17
 
 
 def test_round4_entry_points_validate_on_the_host():

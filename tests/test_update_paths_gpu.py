@@ -1106,26 +1106,39 @@ def test_the_next_layers_shift_rides_in_the_update_launch(L, mrope, dtype):
                 q, k, v = pool[(c + l) % 3]
                 cache.shift_temporal_ids_(pos, l)
                 seen.append(pos.clone())
-                kw = {"query_states": q, "position_ids": pos, "rotary_emb": rot}
+                # "shift_next_position_ids": the Qwen2-VL patch's opt-in (it shares `pos` between the layers)
+                kw = {"query_states": q, "position_ids": pos, "rotary_emb": rot, "shift_next_position_ids": ask}
                 if mrope:
                     kw["mrope_section"] = sec
                 cache.update(k, v, l, kw)
+                assert "shift_next_position_ids" not in kw and "position_ids" not in kw   # popped like the reference's keys
             seen.append(pos.clone())    # what the reference's loop leaves in the caller's tensor: the LAST layer's shift
             cache.after_forward()
-        torch.cuda.synchronize()
+        cache.check()                    # synchronises; raises if a bounded wait ran out
         nv.check(nv.lib.rtk_profile_enable(0), "profile_enable")
         n = nv.profile_read().get("position_shift", (0, 0.0))[0]
         tk = cache._batch.shift_ticket.cpu()
         assert int(tk[31]) == 0 and int(tk[32:].abs().max()) == 0   # no wait ran out; the arrival counters are back at zero
+        assert int(cache._batch.shift_latch[0]) == 0                # ... nor was the host-visible word touched
         return seen, n, int(tk[0])   # launches that carried a shift
 
+    ask = True
     fused, apart = lc.build_kvcache(cfg(layers)), lc.build_kvcache(cfg(layers, shift_next_in_update=False))
     seen_f, n_f, epochs_f = run(fused)
     seen_a, n_a, epochs_a = run(apart)
     assert n_a == n_chunks * layers and epochs_a == 0
     # every layer's shift was either its own launch or rode in the previous layer's update (layer 0's never does; the
-    # first chunk creates the layers' stores on the general route, a growing store re-binds: a launch per layer there)
-    assert n_f + epochs_f == n_chunks * layers and epochs_f >= layers - 1, (n_f, epochs_f)
+    # first chunk creates the layers' stores on the general route, a growing store re-binds: a launch per layer there).
+    # fp32 chunks run their score passes inside update, where the library could still decline AFTER the launch: they never
+    # carry the shift
+    assert n_f + epochs_f == n_chunks * layers, (n_f, epochs_f)
+    assert epochs_f >= layers - 1 if dtype is not torch.float32 else epochs_f == 0, (n_f, epochs_f)
+    # a caller that does NOT ask (the reference's own cache_kwargs; the LLaVA patch) never has its ids written by update
+    ask = False
+    plain = lc.build_kvcache(cfg(layers))
+    seen_p, n_p, epochs_p = run(plain)
+    assert n_p == n_chunks * layers and epochs_p == 0
+    assert all(torch.equal(a, b) for a, b in zip(seen_p, seen_a))
     assert len(seen_f) == len(seen_a)
     for i, (a, b) in enumerate(zip(seen_f, seen_a)):
         assert torch.equal(a, b), f"ids differ at step {i}"
@@ -1165,7 +1178,8 @@ def test_a_preshifted_tensor_is_recognised_only_as_itself():
             launches.append(nv.profile_read().get("position_shift", (0, 0.0))[0])
             prev = cache.get_prev_temporal_idx(l)
             assert int(pos[0, 0, 0]) == int(prev) + 1
-            cache.update(k, v, l, {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": SEC})
+            cache.update(k, v, l, {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": SEC,
+                                   "shift_next_position_ids": True})
         cache.after_forward()
         return launches
 
@@ -1173,6 +1187,111 @@ def test_a_preshifted_tensor_is_recognised_only_as_itself():
     assert chunk(1, lambda l, p: p) == [1, 0, 0, 0]
     assert chunk(2, lambda l, p: p.clone()) == [1, 1, 1, 1]           # LLaVA's patch: a clone per layer
     assert chunk(3, lambda l, p: p.add_(0) if l == 2 else p) == [1, 0, 1, 0]   # touched through torch: version moved
+
+
+def test_in_launch_shift_that_runs_out_shifts_nothing_and_raises():
+    """The watcher's wait is bounded by polls; when it runs out (forced: one arrival counter pre-loaded so the total can never
+    match - what sharing the words between two streams would do) the launch must NOT rewrite the ids and must NOT zero the
+    counters: it latches ticket[31] and the host-visible word, the watcher of the next launch returns at once, and the
+    cache raises at its next entry point (and from check()).  Afterwards the cache shifts with one launch per layer again
+    and a fresh cache is unaffected."""
+    import time
+
+    import retake.longvideo_cache as lc
+
+    layers, L = 4, 640
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    g = torch.Generator(device=dev()).manual_seed(7)
+    q, k, v = ((1.7 * torch.randn((1, h, L, D), generator=g, device=dev())).to(torch.bfloat16) for h in (Hq, Hkv, Hkv))
+    cache = lc.PivotKVCache(cfg(layers), reserve_tokens=8 * L)
+
+    def kw(pos):
+        return {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": SEC, "shift_next_position_ids": True}
+
+    def chunk(c):
+        pos = chunk_ids(c, L)
+        cache.kvcache_compression, cache.keypatches_mask_chunk = True, None
+        for l in range(layers):
+            cache.shift_temporal_ids_(pos, l)
+            cache.update(k, v, l, kw(pos))
+        cache.after_forward()
+
+    chunk(0)            # creates the stores (general route)
+    chunk(1)            # steady state: the shifts ride in the update launches
+    cache.check()
+    b = cache._batch
+    assert int(b.shift_ticket[0]) >= layers - 1 and int(b.shift_latch[0]) == 0
+    # --- force the run-out: counter 0 can never equal its share of the workgroups
+    launches_before = int(b.shift_ticket[0])
+    b.shift_ticket[32] = 1000
+    pos = chunk_ids(2, L)
+    cache.kvcache_compression = True
+    cache.shift_temporal_ids_(pos, 0)
+    before = pos.clone()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cache.update(k, v, 0, kw(pos))                       # its watcher polls, gives up, latches - seconds later
+    # the host is ahead of the device: it still believes layer 1's shift rode in that launch (no launch of its own) and
+    # issues layer 1's update on the same words - whose watcher must return AT ONCE on the latched words, shifting nothing
+    cache.shift_temporal_ids_(pos, 1)
+    cache.update(k, v, 1, kw(pos))
+    torch.cuda.synchronize()
+    waited = time.perf_counter() - t0
+    assert torch.equal(pos, before), "a failed wait must leave the ids untouched"
+    tk = b.shift_ticket.cpu()
+    assert int(tk[31]) == 1 and int(b.shift_latch[0]) == 1, (int(tk[31]), int(b.shift_latch[0]))   # device latch + pinned host word, once
+    assert int(tk[32]) > 1000 and int(tk[33:].abs().max()) > 0, "a failed wait must leave the counters alone"
+    assert int(tk[0]) == launches_before                 # neither launch counted itself as having shifted
+    assert 0.05 < waited < 30, waited                    # bounded: seconds, not a hung queue
+    # --- the host raises at its next entry point, without having been asked to synchronise ...
+    with pytest.raises(RuntimeError, match="ran out of its bounded wait"):
+        cache.shift_temporal_ids_(pos, 2)
+    # ... has put the words back, and has switched the feature off for this cache
+    assert int(b.shift_latch[0]) == 0 and int(b.shift_ticket.abs().max()) == 0 and cache.shift_next_in_update is False
+    cache.check()
+    # a fresh cache on the same device is unaffected
+    other = lc.PivotKVCache(cfg(layers), reserve_tokens=8 * L)
+    cache = other
+    chunk(0)
+    chunk(1)
+    other.check()
+    assert int(other._batch.shift_ticket[0]) >= layers - 1
+
+
+def test_in_launch_shift_words_serve_one_stream_at_a_time():
+    """The arrival counters belong to the batch: two update launches of one cache on DIFFERENT streams must not share them
+    in flight.  A caller that switches its current stream between two layers gets a device synchronisation first (as the
+    in-place compaction's words do, `_order_compaction`), so the result equals the single-stream run and nothing latches."""
+    import retake.longvideo_cache as lc
+
+    layers, L = 4, 640
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    g = torch.Generator(device=dev()).manual_seed(9)
+    q, k, v = ((1.7 * torch.randn((1, h, L, D), generator=g, device=dev())).to(torch.bfloat16) for h in (Hq, Hkv, Hkv))
+    side = torch.cuda.Stream(device=dev())
+
+    def run(alternate):
+        cache = lc.PivotKVCache(cfg(layers), reserve_tokens=8 * L)
+        for c in range(3):
+            pos = chunk_ids(c, L)
+            cache.kvcache_compression, cache.keypatches_mask_chunk = True, None
+            for l in range(layers):
+                use = side if (alternate and l % 2) else torch.cuda.current_stream(dev())
+                use.wait_stream(torch.cuda.current_stream(dev()))
+                with torch.cuda.stream(use):
+                    cache.shift_temporal_ids_(pos, l)
+                    cache.update(k, v, l, {"query_states": q, "position_ids": pos, "rotary_emb": rot, "mrope_section": SEC,
+                                           "shift_next_position_ids": True})
+                torch.cuda.current_stream(dev()).wait_stream(use)
+            cache.after_forward()
+        cache.check()
+        assert int(cache._batch.shift_ticket[31]) == 0 and int(cache._batch.shift_ticket[32:].abs().max()) == 0
+        return [cache.key_cache[l].clone() for l in range(layers)], [cache.position_cache[l].clone() for l in range(layers)]
+
+    ka, pa = run(False)
+    kb, pb = run(True)
+    for l in range(layers):
+        assert torch.equal(ka[l], kb[l]) and torch.equal(pa[l], pb[l])
 
 
 def test_update_and_shift_under_inference_mode():

@@ -138,6 +138,6 @@ extern "C" int rtk_profile_copy(void* dst, const void* src, size_t bytes, rtk_st
     return RTK_OK;
 }
 
-extern "C" int rtk_version(void) { return 16; }
+extern "C" int rtk_version(void) { return 17; }
 extern "C" const char* rtk_last_error(void) { return rtk::g_err; }
 extern "C" const char* rtk_arch(void) { return "gfx950"; }

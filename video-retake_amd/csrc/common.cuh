@@ -312,7 +312,7 @@ int pivotkv_prepare_shift(const void* q, int64_t q_stride_h, int64_t q_stride_l,
                           float attention_scaling, const int* sections_host, int nsec, int round_bf16, void* k_unrot,
                           void* workspace, size_t workspace_bytes, void* k_tail, void* v_tail, int64_t tail_stride_h,
                           int64_t* pos_copy, int64_t* shift_row, const int64_t* next_prev, int32_t* ticket,
-                          int64_t ticket_ints, rtk_stream_t stream);
+                          int64_t ticket_ints, int32_t* status, rtk_stream_t stream);
 
 inline int make_rowsel(RowSel& rs, int P, int D, const int* sections, int nsec, const char* who) {
     if (D > 256 || (D & 1)) {

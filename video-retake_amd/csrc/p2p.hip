@@ -14,9 +14,8 @@
 namespace rtk {
 
 // Segment s (seg_bytes, a multiple of 16) of the source goes to byte dst_off + s * dst_stride of EVERY peer's buffer
-// (blockIdx.y = peer, own rank included).  The last workgroup to finish publishes `epoch` in word `rank` of every
-// peer's flag array: each thread fences its stores to system scope before the workgroup counts itself done, so the
-// flag can only be seen after all the data (the threadfence-reduction pattern, at system scope).
+// (blockIdx.y = peer, own rank included).  Data only: every wave fences its stores to system scope before it ends; the
+// arrival flags are published by p2p_flag_kernel, a second launch behind this one on the same stream.
 __global__ __launch_bounds__(256) void p2p_push_kernel(const char* __restrict__ src, size_t seg_bytes, int nseg,
                                                        size_t src_stride, rtk_p2p_peers peers, size_t dst_off,
                                                        size_t dst_stride) {
@@ -108,8 +107,8 @@ extern "C" int rtk_p2p_close(void* base) {
 
 extern "C" int rtk_p2p_push(const void* src, size_t seg_bytes, int nseg, size_t src_stride_bytes,
                             const rtk_p2p_peers* peers, int rank, int world, size_t dst_offset_bytes,
-                            size_t dst_stride_bytes, uint32_t epoch, uint32_t* counter, rtk_stream_t stream) {
-    RTK_CHECK_ARG(peers && counter, "rtk_p2p_push: null argument");
+                            size_t dst_stride_bytes, uint32_t epoch, rtk_stream_t stream) {
+    RTK_CHECK_ARG(peers, "rtk_p2p_push: null argument");
     RTK_CHECK_ARG(world >= 1 && world <= RTK_P2P_MAX_RANKS && rank >= 0 && rank < world,
                   "rtk_p2p_push: rank %d / world %d outside [1, %d]", rank, world, RTK_P2P_MAX_RANKS);
     RTK_CHECK_ARG(nseg >= 0 && seg_bytes % 16 == 0 && src_stride_bytes % 16 == 0 && dst_stride_bytes % 16 == 0 &&
@@ -119,7 +118,6 @@ extern "C" int rtk_p2p_push(const void* src, size_t seg_bytes, int nseg, size_t 
     const size_t vecs = seg_bytes / 16 * (size_t)nseg;
     // enough workgroups per peer to keep a link busy, few enough that world of them share the chip
     const unsigned per_peer = (unsigned)std::max<size_t>(1, std::min<size_t>((vecs + 1023) / 1024, 2048 / (unsigned)world));
-    (void)counter;   // (ABI: the word the first form counted finished workgroups on; unused since the flags are their own launch)
     if (vecs) {
         hipLaunchKernelGGL(p2p_push_kernel, dim3(per_peer, world), dim3(256), 0, (hipStream_t)stream, (const char*)src,
                            seg_bytes, nseg, src_stride_bytes, *peers, dst_offset_bytes, dst_stride_bytes);

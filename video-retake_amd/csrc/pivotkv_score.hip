@@ -219,6 +219,11 @@ __global__ __launch_bounds__(256) void unrotate_pack_vec_kernel(const char* __re
 
 constexpr int RTK_SHIFT_COUNTERS = 64;   // arrival counters of RTK_UPDATE_SHIFT_NEXT (<= RTK_PREP_BLOCK: one per watching thread)
 constexpr int RTK_SHIFT_STRIDE = 32;     // ... 128 bytes apart
+constexpr int RTK_SHIFT_STATUS = RTK_SHIFT_STRIDE - 1;     // word of the first line that latches a wait that ran out
+// polls of the watching workgroup before it gives up (an agent-scope load, a barrier and s_sleep 4 per poll: ~2-3 s; the
+// workers need microseconds).  Same policy as compact_units_kernel's bounded wait, but latched instead of trapped: the
+// host can raise, reset and carry on, and the test suite can force it.
+constexpr unsigned RTK_SHIFT_MAX_POLLS = 1u << 21;
 static_assert(RTK_SHIFT_COUNTERS <= RTK_PREP_BLOCK, "one watching thread per counter");
 
 template <int DT, int DIV, bool FAST = false, int NW = 4>
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prepare_native_kernel(const ch
                                                             int64_t tail_sh, int P, int64_t* __restrict__ pos_copy,
                                                             char* __restrict__ k_fast = nullptr, float qscale = 1.f,
                                                             int64_t* shift_row = nullptr, const int64_t* next_prev = nullptr,
-                                                            int* ticket = nullptr) {
+                                                            int* ticket = nullptr, int* status = nullptr) {
     using V = Vec16<DT>;
     static_assert(NW == 4 || ((NW == 2 || NW == 1) && DT != RTK_F32), "8- / 4-byte chunks: 16-bit dtypes only");
     constexpr int ES = 16 / V::VE;          // bytes per element
@@ -246,9 +251,20 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prepare_native_kernel(const ch
     // RTK_SHIFT_COUNTERS counters (own cache lines) once its ids are in registers - fire and forget, nobody waits; the
     // FIRST workgroup of the grid (an extra column) does no other work: it watches the counters reach the launch's totals,
     // zeroes them for the next launch, rewrites the row and counts the launch in ticket[0], beside the others' work.
+    // The wait is bounded by a POLL count (polls only advance while this wave runs: a process that is switched out, a
+    // debugger, a throttled clock cannot trip it - a wall-clock bound could).  If it ever runs out - the counters were
+    // not zero at launch, i.e. the words were shared or not zeroed - NOTHING is shifted and NOTHING is zeroed: the watcher
+    // latches ticket[RTK_SHIFT_STATUS] (and the host-visible *status, if given) and returns, and so does the watcher of
+    // every later launch until the host has seen the latch and reset the words (PivotKVCache raises: the ids of the layers
+    // after the failed launch were not shifted).  A row is only ever rewritten after every reader was counted in.
     const int bx = (int)blockIdx.x - (shift_row ? 1 : 0), gx = (int)gridDim.x - (shift_row ? 1 : 0);
     if (bx < 0) {
         if (blockIdx.y != 0) return;
+        __shared__ int s_latched;
+        if (threadIdx.x == 0)
+            s_latched = __hip_atomic_load(ticket + RTK_SHIFT_STATUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        __syncthreads();
+        if (s_latched) return;   // an earlier launch's wait ran out: the counters are not trustworthy until the host resets them
         constexpr int E = 8;   // ids per thread and round, two rounds in flight
         const int nwork = gx * (int)gridDim.y, step = E * (int)blockDim.x;
         const long long delta = (next_prev ? (long long)next_prev[0] : -1ll) + 1 - (long long)shift_row[0];
@@ -265,14 +281,20 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prepare_native_kernel(const ch
         const int c = (int)threadIdx.x;   // (blockDim.x >= RTK_SHIFT_COUNTERS: one counter per thread)
         unsigned* mine = (unsigned*)ticket + RTK_SHIFT_STRIDE * (1 + c);
         const unsigned want = (unsigned)(nwork / RTK_SHIFT_COUNTERS + (c < nwork % RTK_SHIFT_COUNTERS ? 1 : 0));
-        const unsigned long long t0 = wall_clock64();   // (100 MHz)  bounded at 0.2 s: never a hung GPU
+        unsigned polls = 0;
         for (;;) {
             int ok = 1;
             if (c < RTK_SHIFT_COUNTERS) ok = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
-            const int all = __syncthreads_and(ok), late = __syncthreads_or(wall_clock64() - t0 > 20000000ull);
-            if (all || late) {
-                if (threadIdx.x == 0 && !all) ticket[RTK_SHIFT_STRIDE - 1] += 1;   // gave up waiting (diagnostics; never seen)
-                break;
+            if (__syncthreads_and(ok)) break;
+            if (++polls > RTK_SHIFT_MAX_POLLS) {   // (uniform: every thread counts the same polls)
+                if (threadIdx.x == 0) {
+                    __hip_atomic_fetch_add(ticket + RTK_SHIFT_STATUS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (status) {
+                        __hip_atomic_fetch_add(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __threadfence_system();
+                    }
+                }
+                return;        // ids untouched, counters untouched
             }
             __builtin_amdgcn_s_sleep(4);
         }
@@ -2433,7 +2455,8 @@ static int prepare_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, 
                         int64_t vsh, int64_t vsl, int Hq, int Hkv, int L, int D, const int64_t* pos, int64_t pos_stride,
                         const float* inv_freq, float a, const RowSel& rs, int round_bf16, char* qt, char* kt, void* k_tail,
                         void* v_tail, int64_t tail_sh, int P, int64_t* pos_copy, hipStream_t st, char* k_fast = nullptr,
-                        int64_t* shift_row = nullptr, const int64_t* next_prev = nullptr, int* ticket = nullptr) {
+                        int64_t* shift_row = nullptr, const int64_t* next_prev = nullptr, int* ticket = nullptr,
+                        int* status = nullptr) {
     const float a2 = (float)((double)a * (double)a);
     const int div = (a2 == 1.0f) ? 0 : ((DT == RTK_BF16 && bf16_rcp_is_exact(a2)) ? 1 : 2);
     const float rcp = 1.0f / a2;
@@ -2451,7 +2474,7 @@ static int prepare_impl(const void* q, int64_t qsh, int64_t qsl, const void* k, 
     auto launch = [&](auto kern) {
         RTK_LAUNCH(KID_UNROT, kern, grid, dim3(RTK_PREP_BLOCK), 0, st, (const char*)q, qsh, qsl, (const char*)k, ksh, ksl, (const char*)v,
                    vsh, vsl, Hq, Hkv, L, D, pos, pos_stride, inv_freq, a, rs, round_bf16, a2, rcp, qt, kt, (char*)k_tail,
-                   (char*)v_tail, tail_sh, P, pos_copy, kf, qscale, shift_row, next_prev, ticket);
+                   (char*)v_tail, tail_sh, P, pos_copy, kf, qscale, shift_row, next_prev, ticket, status);
     };
 #define RTK_PREP_NWSEL(DIV, FASTV)                                                            \
     do {                                                                                      \
@@ -2491,24 +2514,27 @@ extern "C" int rtk_pivotkv_prepare(const void* q, int64_t q_stride_h, int64_t q_
     return rtk::pivotkv_prepare_shift(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv,
                                       L, D, dtype, pos, pos_stride, P, inv_freq, attention_scaling, sections_host, nsec,
                                       round_bf16, k_unrot, workspace, workspace_bytes, k_tail, v_tail, tail_stride_h, pos_copy,
-                                      nullptr, nullptr, nullptr, 0, stream);
+                                      nullptr, nullptr, nullptr, 0, nullptr, stream);
 }
 
-// words of rtk_update_io.ticket: the launch count + the arrival counters of the prepare launch, a cache line each
+// words of rtk_update_io.ticket: the launch count (word 0) and the run-out latch (word 31) in the first cache line, then
+// the arrival counters of the prepare launch, a cache line each
 extern "C" size_t rtk_pivotkv_shift_ticket_ints(int L, int D) {
     (void)L; (void)D;   // one line for the launch count, one per counter
     return (size_t)RTK_SHIFT_STRIDE * (1 + RTK_SHIFT_COUNTERS);
 }
 
 // rtk_pivotkv_prepare + (shift_row != NULL) the next layer's continuity shift in the same launch: rtk_pivotkv_update's
-// RTK_UPDATE_SHIFT_NEXT.  shift_row is the temporal row of `pos` itself, ticket one zeroed device word (left zero).
+// RTK_UPDATE_SHIFT_NEXT.  shift_row is the temporal row of `pos` itself, ticket the zeroed device words (counters left zero);
+// status (optional, host-visible memory) is incremented if the watcher's bounded wait runs out (see the kernel).
 int rtk::pivotkv_prepare_shift(const void* q, int64_t q_stride_h, int64_t q_stride_l, const void* k, int64_t k_stride_h,
                                int64_t k_stride_l, const void* v, int64_t v_stride_h, int64_t v_stride_l, int Hq, int Hkv,
                                int L, int D, int dtype, const int64_t* pos, int64_t pos_stride, int P,
                                const float* inv_freq, float attention_scaling, const int* sections_host, int nsec,
                                int round_bf16, void* k_unrot, void* workspace, size_t workspace_bytes, void* k_tail,
                                void* v_tail, int64_t tail_stride_h, int64_t* pos_copy, int64_t* shift_row,
-                               const int64_t* next_prev, int32_t* ticket, int64_t ticket_ints, rtk_stream_t stream) {
+                               const int64_t* next_prev, int32_t* ticket, int64_t ticket_ints, int32_t* status,
+                               rtk_stream_t stream) {
     RTK_CHECK_ARG(!shift_row || (ticket && ticket_ints >= (int64_t)rtk_pivotkv_shift_ticket_ints(L, D)),
                   "rtk_pivotkv_prepare: the in-launch id shift needs rtk_pivotkv_shift_ticket_ints(L, D) zeroed device words");
     const bool k_only = (dtype & RTK_PREPARE_K_ONLY) != 0;   // keep-all chunk: no q~
@@ -2549,13 +2575,13 @@ int rtk::pivotkv_prepare_shift(const void* q, int64_t q_stride_h, int64_t q_stri
     if (dtype == RTK_F16)
         return prepare_impl<RTK_F16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv, L,
                                      D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot, k_tail,
-                                     v_tail, tail_stride_h, P, pos_copy, st, nullptr, shift_row, next_prev, ticket);
+                                     v_tail, tail_stride_h, P, pos_copy, st, nullptr, shift_row, next_prev, ticket, status);
     if (dtype != RTK_F32)
         return prepare_impl<RTK_BF16>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv,
                                       L, D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot,
                                       k_tail, v_tail, tail_stride_h, P, pos_copy, st,
-                                      fast ? (char*)workspace + w.k_off : nullptr, shift_row, next_prev, ticket);
+                                      fast ? (char*)workspace + w.k_off : nullptr, shift_row, next_prev, ticket, status);
     return prepare_impl<RTK_F32>(q, q_stride_h, q_stride_l, k, k_stride_h, k_stride_l, v, v_stride_h, v_stride_l, Hq, Hkv, L,
                                  D, pos, pos_stride, inv_freq, attention_scaling, rs, round_bf16, qt, (char*)k_unrot, k_tail,
-                                 v_tail, tail_stride_h, P, pos_copy, st, nullptr, shift_row, next_prev, ticket);
+                                 v_tail, tail_stride_h, P, pos_copy, st, nullptr, shift_row, next_prev, ticket, status);
 }

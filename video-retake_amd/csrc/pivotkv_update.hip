@@ -439,11 +439,19 @@ extern "C" int rtk_pivotkv_update(rtk_pivotkv_batch* b, rtk_layer_state* ls, int
             set_error("rtk_pivotkv_update: RTK_UPDATE_SHIFT_NEXT needs io->ticket (rtk_pivotkv_shift_ticket_ints zeroed device words)");
             return RTK_EINVAL;
         }
+        if (shift_next && !b->keep_all && !b->batched_passes) {
+            // the per-unit passes below may still decline (RTK_EUNSUPPORTED) AFTER the prepare launch has shifted the ids:
+            // a caller that falls back to the stage-by-stage route would then re-prepare this layer from the NEXT layer's
+            // ids.  Decline first, with nothing launched.
+            set_error("rtk_pivotkv_update: RTK_UPDATE_SHIFT_NEXT needs the chunk-batched passes or a keep-all batch");
+            return RTK_EUNSUPPORTED;
+        }
         rc = pivotkv_prepare_shift(io->q, io->q_stride_h, io->q_stride_l, io->k, io->k_stride_h, io->k_stride_l, io->v,
                                    io->v_stride_h, io->v_stride_l, b->Hq, Hkv, L, D, dt, io->pos, io->pos_stride, b->P,
                                    b->inv_freq, b->attention_scaling, b->nsec ? b->sections : nullptr, b->nsec, b->round_mode,
                                    k_unrot, ws, b->score_ws_bytes, k_tail, v_tail, tail_sh, pos_copy,
-                                   shift_next ? (int64_t*)io->pos : nullptr, io->next_prev, io->ticket, io->ticket_ints, stream);
+                                   shift_next ? (int64_t*)io->pos : nullptr, io->next_prev, io->ticket, io->ticket_ints,
+                                   shift_next ? io->status : nullptr, stream);
         if (rc) return rc;
     }
     if (!b->keep_all && !b->batched_passes) {

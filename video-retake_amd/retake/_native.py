@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RETAKE_HIP_LIB lets kernel developers A/B an alternative build of the same ABI (tools/variants.sh)
 LIB_PATH = os.environ.get("RETAKE_HIP_LIB") or os.path.join(_HERE, "_lib", "libretake_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 RTK_F32, RTK_BF16, RTK_BF16_REFROUND, RTK_BF16_FAST, RTK_F16, RTK_F16_REFROUND = 0, 1, 2, 3, 4, 5
 RTK_SCORE_MANY_UNITS = 0x100   # flag for the dtype argument of the scoring entry points (split policy of batched launches)
@@ -97,7 +97,7 @@ class UpdateIO(C.Structure):
     _fields_ = [("q", _vp), ("q_stride_h", _i64), ("q_stride_l", _i64), ("k", _vp), ("k_stride_h", _i64),
                 ("k_stride_l", _i64), ("v", _vp), ("v_stride_h", _i64), ("v_stride_l", _i64), ("pos", _vp),
                 ("pos_stride", _i64), ("q_rot", _vp), ("qr_stride_h", _i64), ("qr_stride_l", _i64), ("flags", _i32),
-                ("pad0", _i32), ("next_prev", _vp), ("ticket", _vp), ("ticket_ints", _i64)]
+                ("pad0", _i32), ("next_prev", _vp), ("ticket", _vp), ("ticket_ints", _i64), ("status", _vp)]
 
 
 _SIGNATURES = {
@@ -153,7 +153,7 @@ _SIGNATURES = {
     "rtk_p2p_export": (C.c_int, [_vp, _vp, C.POINTER(_sz)]),
     "rtk_p2p_open": (C.c_int, [_vp, C.POINTER(_vp)]),
     "rtk_p2p_close": (C.c_int, [_vp]),
-    "rtk_p2p_push": (C.c_int, [_vp, _sz, _i, _sz, C.POINTER(P2PPeers), _i, _i, _sz, _sz, C.c_uint32, _vp, _vp]),
+    "rtk_p2p_push": (C.c_int, [_vp, _sz, _i, _sz, C.POINTER(P2PPeers), _i, _i, _sz, _sz, C.c_uint32, _vp]),
     "rtk_p2p_wait": (C.c_int, [_vp, _i, C.c_uint32, _i, _vp, _vp]),
     "rtk_profile_enable": (C.c_int, [_i]),
     "rtk_profile_enable_mask": (C.c_int, [C.c_uint]),

@@ -341,6 +341,12 @@ class _Batch:
         # RTK_UPDATE_SHIFT_NEXT's words (launch count + arrival counters of the prepare launch), zeroed once
         self.shift_ticket = torch.zeros(max(1, nv.lib.rtk_pivotkv_shift_ticket_ints(L, D)), dtype=torch.int32, device=device)
         self.io.ticket, self.io.ticket_ints = self.shift_ticket.data_ptr(), self.shift_ticket.numel()
+        # ... and a word of PINNED HOST memory the watching workgroup increments if its bounded wait ever runs out (it then
+        # shifts nothing): the host reads it without a device synchronisation (PivotKVCache._shift_latch_check raises)
+        self.shift_status = torch.zeros(1, dtype=torch.int32, pin_memory=True) if device.type == "cuda" else None
+        self.shift_latch = self.shift_status.numpy() if self.shift_status is not None else None
+        self.io.status = self.shift_status.data_ptr() if self.shift_status is not None else None
+        self.shift_stream = None   # the stream of the batch's last RTK_UPDATE_SHIFT_NEXT launch (the words serve one stream at a time)
         # prologue route: queries that are scored where they lie (no packed copy) - the pointers the library reads at
         # the flush, and the tensors themselves, kept alive until then
         self.q_units = (C.c_void_p * slots)()
@@ -549,10 +555,13 @@ class PivotKVCache(DynamicCache):
         # elements: 1.4 GB at L = 6272, 28 layers, bf16).  N > 0: the batch has N slots (slot = layer mod N) and is flushed
         # whenever the next layer's slot is taken, i.e. every N layers - scratch / launches-per-chunk trade N/layers : layers/N
         self.flush_every_layers = int(kv_compression_kwargs.get("flush_every_layers", 0))
-        # MI355X build option (tests / A-B): on the reference's protocol (`update` on rotated tensors) the launch that
-        # un-rotates and appends layer l's chunk also applies layer l + 1's continuity shift (qwen2_vl.py:68-73) to the
-        # caller's ids, so that `shift_temporal_ids_` of the attention patch launches once per chunk instead of once per
-        # layer.  False: every layer's shift is its own launch.
+        # MI355X build option: on the reference's protocol (`update` on rotated tensors) the launch that un-rotates and
+        # appends layer l's chunk can also apply layer l + 1's continuity shift (qwen2_vl.py:68-73) to the caller's ids, so
+        # that `shift_temporal_ids_` of the attention patch launches once per chunk instead of once per layer.  It WRITES
+        # the caller's `position_ids` - which the reference's `update` never does - so it is OPT-IN per call: only a caller
+        # that passes cache_kwargs["shift_next_position_ids"] = True gets it (the Qwen2-VL patch does: it shares one ids
+        # tensor between the layers and shifts it in place itself; the LLaVA patch, which shifts a private clone per layer,
+        # does not).  This key is the kill switch: False = every layer's shift is its own launch, whatever the caller says.
         self.shift_next_in_update = bool(kv_compression_kwargs.get("shift_next_in_update", True))
         self._preshifted = None       # (ids tensor, its version, layer, stream) an update launch has already shifted for
         if self.flush_every_layers < 0:
@@ -760,6 +769,43 @@ class PivotKVCache(DynamicCache):
             return -1
         return st.pos[0, st.pos_len - 1]
 
+    def _shift_latch_check(self):
+        """The in-launch id shift (RTK_UPDATE_SHIFT_NEXT) bounds its wait; a wait that ran out shifted NOTHING and latched a
+        host-visible word.  Every entry point looks at it (one read of pinned host memory, no device sync) before it
+        trusts ids a launch was supposed to have shifted - same policy as p2p.check(): a bounded wait that gives up is an
+        error, never a silent continuation."""
+        b = self._batch
+        if b is not None and b.shift_latch is not None and b.shift_latch[0]:
+            self._shift_failed(b)
+
+    def _shift_failed(self, b: "_Batch"):
+        n = int(b.shift_latch[0])
+        self._preshifted = None
+        self.shift_next_in_update = False     # this cache goes back to one shift launch per layer
+        try:   # put the words back (the failed launches left residue in the counters, the latch stops every later watcher)
+            torch.cuda.synchronize(b.device)
+            b.shift_ticket.zero_()
+            torch.cuda.synchronize(b.device)
+        except Exception:  # noqa: BLE001  (the error below is the one to report)
+            pass
+        b.shift_latch[0] = 0
+        b.shift_stream = None
+        raise RuntimeError(
+            f"PivotKVCache: the in-launch position-id shift of {n} update launch(es) ran out of its bounded wait and shifted "
+            "nothing (the arrival counters were not zero at launch: were update launches of one cache issued on two streams "
+            "at once?).  The layers after the first such launch ran on UNSHIFTED temporal ids: the cache contents of the "
+            "current video are invalid - rebuild the cache.  The feature is now off for this cache (one rtk_position_shift "
+            "launch per layer).")
+
+    def check(self):
+        """Synchronise the cache's device and raise if a bounded device-side wait of this cache has run out (the in-launch
+        id shift).  The entry points look at the latch on every call without synchronising; call this after the last
+        update of a run when nothing else of the cache is called before its contents are used."""
+        b = self._batch
+        if b is not None and b.device.type == "cuda":
+            torch.cuda.synchronize(b.device)
+        self._shift_latch_check()
+
     def shift_temporal_ids_(self, position_ids: torch.Tensor, layer_idx: int):
         """The attention patch's continuity fix (qwen2_vl.py:68-73, llava_onevision.py:68-72) on the device:
         position_ids[0, 0, :] (or [0, :]) += prev + 1 - its first element, in place, where prev is the last
@@ -777,6 +823,7 @@ class PivotKVCache(DynamicCache):
             prev = self.get_prev_temporal_idx(layer_idx)
             row += prev + 1 - row[0].clone()
             return position_ids
+        self._shift_latch_check()   # (before the memo below is trusted)
         done, self._preshifted = self._preshifted, None
         idx = position_ids.get_device()
         if done is not None and done[0]() is position_ids and done[1] is not None and done[1] == _version_of(position_ids) \
@@ -933,6 +980,8 @@ class PivotKVCache(DynamicCache):
         """Evict every pending (layer, chunk) unit (reference :260-318 for all layers of the chunk): the score passes,
         the selection, one batched gather / re-rotate launch and one batched placement launch."""
         b = self._batch
+        if b is not None and b.shift_latch is not None and b.shift_latch[0]:
+            self._shift_failed(b)
         if b is None or not b.pending:
             return
         if b.c_pending == len(b.pending) and self._flush_c(b):
@@ -1226,8 +1275,17 @@ class PivotKVCache(DynamicCache):
         A chunk whose geometry matches the current batch goes through ONE library call (rtk_pivotkv_update: argument
         blocks bound once per batch and per layer); everything else - the first update of a geometry, text / decode
         appends, worker streams, small chunks, rotary modules that must be called - through `_update_general`.
+
+        Like the reference, `update` pops position_ids / query_states / rotary_emb / mrope_section from `cache_kwargs` and
+        leaves every tensor it is handed untouched - with ONE opt-in exception the reference does not have:
+        cache_kwargs["shift_next_position_ids"] = True lets the launch apply the NEXT layer's continuity shift
+        (qwen2_vl.py:68-73) to `position_ids` in place, i.e. after update(l) the caller's ids tensor may already carry layer
+        l + 1's temporal offset.  Only a caller that shares one ids tensor between its layers and shifts it in place itself
+        (the Qwen2-VL attention patch: `shift_temporal_ids_` then finds the shift done) should set it.
         """
         b = self._batch
+        if b is not None and b.shift_latch is not None and b.shift_latch[0]:
+            self._shift_failed(b)
         if b is not None and b.c_capable and cache_kwargs is not None and self.kvcache_compression \
                 and self.overlap_streams <= 0 and self.one_call_update:
             out = self._update_c(b, key_states, value_states, layer_idx, cache_kwargs, None)
@@ -1290,6 +1348,7 @@ class PivotKVCache(DynamicCache):
         if qs[3] != 1 or ks[3] != 1 or vs[3] != 1:
             return None
         io = b.io
+        stream = nv.raw_stream(idx)
         io.q, io.q_stride_h, io.q_stride_l = q.data_ptr(), qs[1], qs[2]
         io.k, io.k_stride_h, io.k_stride_l = key_states.data_ptr(), ks[1], ks[2]
         io.v, io.v_stride_h, io.v_stride_l = value_states.data_ptr(), vs[1], vs[2]
@@ -1306,19 +1365,28 @@ class PivotKVCache(DynamicCache):
                 io.flags = nv.RTK_UPDATE_PRE_ROPE | rt | (nv.RTK_UPDATE_Q_IN_PLACE if q_in_place else 0)
         else:
             io.q_rot, io.flags = None, 0
-            # the NEXT layer's continuity shift rides in this launch (its `shift_temporal_ids_` then finds it done)
-            nxt = self._next_layer_prev(layer_idx, idx) if self.shift_next_in_update else False
+            # the NEXT layer's continuity shift rides in this launch (its `shift_temporal_ids_` then finds it done) - for a
+            # caller that asked for it (it writes the caller's ids: the attention patch's own in-place shift, one layer
+            # early), and only where the library cannot decline AFTER the launch (batched passes / keep-all batches)
+            nxt = False
+            if self.shift_next_in_update and ck.get("shift_next_position_ids") and (b.batched_passes or b.keep_all) \
+                    and b.shift_latch is not None:
+                nxt = self._next_layer_prev(layer_idx, idx)
             if nxt is not False:
                 io.flags, io.next_prev = nv.RTK_UPDATE_SHIFT_NEXT, nxt
+                # the arrival counters serve ONE launch at a time: launches that share them are ordered on one stream.  A
+                # caller that switched its current stream between two layers first waits for the device (rare)
+                if b.shift_stream is not None and b.shift_stream != stream:
+                    torch.cuda.synchronize(b.device)
+                b.shift_stream = stream
         self._preshifted = None
         c.mask = mptr
-        stream = nv.raw_stream(idx)
         rc = nv.lib.rtk_pivotkv_update(b.cref, st.cref, slot, b.ioref, stream)
         if rc:
             c.mask = None
-            if rc == nv.RTK_EUNSUPPORTED:
-                return None
-            nv.check(rc, "rtk_pivotkv_update")
+            if rc == nv.RTK_EUNSUPPORTED and not (io.flags & nv.RTK_UPDATE_SHIFT_NEXT):
+                return None   # declined before anything was launched
+            nv.check(rc, "rtk_pivotkv_update")   # (with the in-launch shift a decline is a hard error: the ids may be shifted)
         if io.flags & nv.RTK_UPDATE_SHIFT_NEXT:
             self._preshifted = (weakref.ref(pos), _version_of(pos), layer_idx + 1, stream)
         if not self._warned:  # the reference's logger.warning_once (:232)
@@ -1329,6 +1397,7 @@ class PivotKVCache(DynamicCache):
             ck.pop("query_states", None)
             ck.pop("rotary_emb", None)
             ck.pop("mrope_section", None)
+            ck.pop("shift_next_position_ids", None)   # (the build's own key)
         else:
             if shift_ids_in_place:     # the flush shifts the caller's ids in place (qwen2_vl.py:73)
                 b.shift_ids = pos
@@ -1395,6 +1464,7 @@ class PivotKVCache(DynamicCache):
         chunk-batched score passes can then read `query_states` where it lies (no copy of the queries is made;
         `query_states` must stay unmodified until the chunk's flush, and is kept alive by the cache), else over
         `query_states`; pass `query_states` itself to force the in-place rotation."""
+        self._shift_latch_check()
         if not (self.kvcache_compression and self.pos_embed_reforge and self.one_call_update) or self.overlap_streams > 0 \
                 or position_ids is None or not key_states.is_cuda or key_states.shape[0] != 1 \
                 or (torch.is_grad_enabled() and query_states.requires_grad):
@@ -1446,6 +1516,7 @@ class PivotKVCache(DynamicCache):
         clone).  Replaces ~25 eager launches per layer and token.  Returns (rotated q, keys, values) like `update`, or
         None - nothing touched - when the op-by-op route has to run (compression on: `update_pre_rope`; no reforging;
         rotary modules that must be called; CPU tensors)."""
+        self._shift_latch_check()
         if self.kvcache_compression or not (self.pos_embed_reforge and self.one_call_update) or position_ids is None \
                 or not key_states.is_cuda or key_states.shape[0] != 1 \
                 or (torch.is_grad_enabled() and query_states.requires_grad):
@@ -1537,6 +1608,7 @@ class PivotKVCache(DynamicCache):
             _warn_once("Enable PivotKVCache compression: length after compression %.2f" % (self.compression_ratio))
         cache_kwargs = cache_kwargs if cache_kwargs is not None else {}
         position_ids = cache_kwargs.pop("position_ids", None)
+        cache_kwargs.pop("shift_next_position_ids", None)   # (the build's own key: only the one-call route acts on it)
         nv.require_device(key_states, value_states)
         assert key_states.shape[0] == 1, "PivotKVCache supports bsz == 1 only"
 

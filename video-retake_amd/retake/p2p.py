@@ -20,10 +20,11 @@ environment BEFORE the HIP runtime initialises (it is exported on the build and 
 as a default too) - without it `hipIpcGetMemHandle` fails with "invalid argument".  This module sets the default at
 import, which is early enough only if nothing has touched the GPU yet.
 
-Status: opt-in.  The protocol has run with 2 and 3 processes sharing ONE GPU (tests/mp_p2p_gpu.py, tests/mp_sharded_gpu.py);
-it has never run across xGMI links.  The landing buffers are ordinary coarse-grained `hipMalloc` memory written by remote
-GPUs: a consumer kernel launched after the wait kernel sees the data through the kernel-boundary cache invalidate, which
-the single-GPU runs cannot exercise - run those two scripts on a node with >= 2 GPUs before relying on it.
+Status: opt-in.  The protocol has run with 2, 3 AND 8 rank processes sharing ONE GPU (tests/mp_p2p_gpu.py,
+tests/mp_sharded_gpu.py, tests/test_00_world8_gpu.py); what has never been exercised is a LINK: the landing buffers are
+ordinary coarse-grained `hipMalloc` memory written by remote GPUs, and a consumer kernel launched after the wait kernel
+sees that data through the kernel-boundary cache invalidate, which runs on one GPU cannot show - run those scripts on a
+node with >= 2 GPUs before relying on it.
 """
 from __future__ import annotations
 
@@ -82,7 +83,6 @@ class SymmetricBuffer:
             self.mem = _DeviceMem(self.nbytes, uncached=os.environ.get("RETAKE_P2P_UNCACHED_LANDING") == "1")   # (A/B aid)
             self.flags = _DeviceMem(4 * nv.P2P_MAX_RANKS, uncached=True)
             self.local = self.mem.tensor(dev)                        # uint8 [nbytes]
-            self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
             self.status = torch.zeros(1, dtype=torch.int32, device=dev)
             handles = []
             for m in (self.mem, self.flags):
@@ -119,7 +119,7 @@ class SymmetricBuffer:
         self.epoch += 1
         st = nv.stream() if stream is None else C.c_void_p(stream.cuda_stream)
         nv.check(nv.lib.rtk_p2p_push(C.c_void_p(src.data_ptr()), seg_bytes, nseg, src_stride, C.byref(self.peers),
-                                     g.rank, g.world, dst_offset, dst_stride, self.epoch, nv.ptr(self.counter), st),
+                                     g.rank, g.world, dst_offset, dst_stride, self.epoch, st),
                  "rtk_p2p_push")
 
     def wait(self, stream=None, timeout_ms: int = _TIMEOUT_MS):

@@ -76,6 +76,10 @@ def _qkv_and_cache_update(self, hidden_states, position_ids, past_key_value, cac
                         # PivotKV extras (reference :84-85)
                         "query_states": query_states, "position_ids": position_ids,
                         "rotary_emb": self.rotary_emb, "mrope_section": mrope_section}
+        if reforge and hasattr(past_key_value, "shift_temporal_ids_"):
+            # (build) this patch shifts `position_ids` in place for every layer anyway (above): the cache's update launch
+            # may do the NEXT layer's shift on the way - not a key of the reference's protocol, ignored by other caches
+            cache_kwargs["shift_next_position_ids"] = True
         key_states, value_states = past_key_value.update(key_states, value_states, self.layer_idx, cache_kwargs)
     return query_states, key_states, value_states
 

@@ -728,7 +728,7 @@ def sharded_video_step(frames, has_halo: bool, T: int, c0: int, c1: int, layers:
             cache.shift_temporal_ids_(pos, layer)       # block-local ids start at 0 (provisional)
             q, k, v = pool[(c * layers + layer) % len(pool)] if inputs is None else inputs(c, layer, pos)
             cache.update(k, v, layer, {"query_states": q, "position_ids": pos, "rotary_emb": rotary,
-                                       "mrope_section": B.MROPE})
+                                       "mrope_section": B.MROPE, "shift_next_position_ids": True})   # as the Qwen2-VL patch does
         cache.after_forward()
         if overlap:
             sh.gather_chunk()   # this chunk's kept rows leave now, beside the next chunk's scoring
