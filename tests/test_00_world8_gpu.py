@@ -27,24 +27,20 @@ def _fresh_parent():
 
 
 def _run(cmd, env=None, timeout=300):
-    """Run `cmd` in its own process group; normal run times here are 4-15 s.  If it is not done after `timeout` seconds the
-    whole group is killed (no orphaned ranks on the GPU) and the test FAILS with the ranks' last output: this file is the
-    dress rehearsal of the first 8-GPU run, and a deadlock of the eight-rank path must be red, not a skip `pytest -x` sails
-    past.  (The one benign cause of slowness - a ninth GPU process oversubscribing the hardware scheduler - is this pytest
-    process itself, and `_fresh_parent` has skipped before we get here if it holds a HIP context.)"""
-    import signal
+    """Run `cmd` (launcher + ranks); normal run times here are 4-15 s.  If it is not done after `timeout` seconds the launcher
+    and every rank are killed (tests/proc_util.py: torchrun's ranks live in their own sessions) and the test FAILS with the
+    ranks' last output: this file is the dress rehearsal of the first 8-GPU run, and a deadlock of the eight-rank path must
+    be red, not a skip `pytest -x` sails past.  (The one benign cause of slowness - a ninth GPU process oversubscribing the
+    hardware scheduler - is this pytest process itself, and `_fresh_parent` has skipped before we get here if it holds a
+    HIP context.)"""
+    import proc_util
 
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
-                         env={**os.environ, **(env or {})}, start_new_session=True)
     try:
-        out, err = p.communicate(timeout=timeout)
-    except subprocess.TimeoutExpired:
-        os.killpg(p.pid, signal.SIGKILL)
-        out, err = p.communicate()
+        return proc_util.run_job(cmd, env, timeout, cwd=ROOT)
+    except proc_util.JobTimeout as e:
         pytest.fail(f"eight ranks on one GPU did not finish in {timeout} s (normally < 20 s) - a hang of the eight-rank path "
-                    f"(or a foreign GPU process oversubscribing the hardware scheduler).  stdout tail: {out[-1500:]!r}  "
-                    f"stderr tail: {err[-3000:]!r}")
-    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+                    f"(or a foreign GPU process oversubscribing the hardware scheduler); killed pids {e.killed}.  "
+                    f"stdout tail: {e.stdout[-1500:]!r}  stderr tail: {e.stderr[-3000:]!r}")
 
 
 def _launch_ranks(script, world, env=None, timeout=300):

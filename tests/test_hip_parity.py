@@ -2256,8 +2256,20 @@ def test_sharded_multi_rank_rccl():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "mp_sharded_gpu.py")]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    r = _run_job(cmd, None, 600, root)
     assert r.returncode == 0 and "MP_SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def _run_job(cmd, env, timeout, cwd):
+    """A launcher + ranks with a hard time limit: on a hang EVERY process of the job is killed (torchrun's ranks live in their
+    own sessions, tests/proc_util.py) and the test fails with the output tails - it never waits on orphaned ranks' pipes."""
+    import proc_util
+
+    try:
+        return proc_util.run_job(cmd, env, timeout, cwd=cwd)
+    except proc_util.JobTimeout as e:
+        pytest.fail(f"{' '.join(cmd[-3:])} did not finish in {timeout} s; killed pids {e.killed}.  stdout tail: "
+                    f"{e.stdout[-1500:]!r}  stderr tail: {e.stderr[-3000:]!r}")
 
 
 def _free_port():
@@ -2279,7 +2291,7 @@ def _launch_ranks(script, world, env=None, timeout=600):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", script)]
-    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root, env={**os.environ, **(env or {})})
+    return _run_job(cmd, env, timeout, root)
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -2323,8 +2335,7 @@ def _bench(args, tmp_path, name, env=None):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rep = os.path.join(str(tmp_path), name + ".json")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args + ["--report", rep], capture_output=True,
-                       text=True, timeout=600, cwd=root, env={**os.environ, **(env or {})})
+    r = _run_job([sys.executable, os.path.join(root, "bench.py")] + args + ["--report", rep], env, 600, root)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     last = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
     assert len(last) < 4096, len(last)            # the contract: a line the driver's 8 KB stdout tail always holds whole
