@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.cuh"
@@ -59,8 +60,16 @@ using namespace rtk;
 
 extern "C" int rtk_p2p_alloc(size_t bytes, int uncached, void** ptr) {
     RTK_CHECK_ARG(ptr && bytes > 0, "rtk_p2p_alloc: null pointer or zero size");
-    hipError_t e = uncached ? hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocUncached) : hipMalloc(ptr, bytes);
+    // Every buffer peers map is its own allocation of whole 2 MiB granules: the runtime sub-allocates smaller requests from
+    // shared 2 MiB blocks, and exporting such a fragment (hipIpcGetMemHandle) hands the peers a mapping of the WHOLE block -
+    // i.e. of whatever else of this process lives in it (without torch's caching allocator: its small tensors).
+    const size_t granule = (size_t)2 << 20;
+    // (RETAKE_P2P_EXACT_ALLOC=1, debugging aid: the request as it is - the behaviour before round 6, for A/B runs)
+    const char* exact = getenv("RETAKE_P2P_EXACT_ALLOC");
+    const size_t rounded = (exact && exact[0] == '1') ? bytes : (bytes + granule - 1) / granule * granule;
+    hipError_t e = uncached ? hipExtMallocWithFlags(ptr, rounded, hipDeviceMallocUncached) : hipMalloc(ptr, rounded);
     if (e != hipSuccess) return hip_fail(e, "rtk_p2p_alloc");
+    bytes = uncached ? rounded : bytes;   // (the flag words of the whole granule start at zero)
     // flag words start at zero; a landing buffer is only ever read where a push has landed, and zeroing it would leave
     // lines of it in this device's caches for peers' rows to race with
     if (!uncached) return RTK_OK;

@@ -43,13 +43,35 @@ from . import _native as nv  # noqa: E402
 _TIMEOUT_MS = 20000
 
 
+_GUARD = (2 << 20) if os.environ.get("RETAKE_P2P_GUARD") == "1" else 0    # debugging aid: pattern-filled guard regions
+_NO_REMOTE = os.environ.get("RETAKE_P2P_NO_REMOTE_WRITES") == "1"          # debugging aid: mappings opened, never written
+
+
 class _DeviceMem:
-    """Device memory owned by the library (rtk_p2p_alloc), viewable as a torch tensor without a copy."""
+    """Device memory owned by the library (rtk_p2p_alloc: whole 2 MiB granules, never a fragment of a block shared with
+    other allocations), viewable as a torch tensor without a copy.  RETAKE_P2P_GUARD=1 (debugging aid) puts 2 MiB of a
+    fixed byte pattern either side of it inside the same allocation - what peers map is then guard | buffer | guard - and
+    `guards_intact()` says whether anything wrote there."""
+
+    PATTERN = 0xC3
 
     def __init__(self, nbytes: int, uncached: bool = False):
         p = C.c_void_p()
-        nv.check(nv.lib.rtk_p2p_alloc(nbytes, int(uncached), C.byref(p)), "rtk_p2p_alloc")
-        self.ptr, self.nbytes = int(p.value), int(nbytes)
+        nv.check(nv.lib.rtk_p2p_alloc(nbytes + 2 * _GUARD, int(uncached), C.byref(p)), "rtk_p2p_alloc")
+        self.base, self.guard = int(p.value), _GUARD
+        self.ptr, self.nbytes = self.base + _GUARD, int(nbytes)
+        self._guards = None
+
+    def fill_guards(self, device):
+        if self.guard:
+            raw = _RawView(self.base, self.nbytes + 2 * self.guard).tensor(device)
+            raw[: self.guard].fill_(self.PATTERN)
+            raw[self.guard + self.nbytes:].fill_(self.PATTERN)
+            torch.cuda.synchronize(device)
+            self._guards = (raw[: self.guard], raw[self.guard + self.nbytes:])
+
+    def guards_intact(self) -> bool:
+        return self._guards is None or all(bool((g == self.PATTERN).all().item()) for g in self._guards)
 
     @property
     def __cuda_array_interface__(self):
@@ -63,8 +85,21 @@ class _DeviceMem:
 
     def free(self):
         if self.ptr:
-            nv.lib.rtk_p2p_free(C.c_void_p(self.ptr))
-            self.ptr = 0
+            self._guards = None
+            nv.lib.rtk_p2p_free(C.c_void_p(self.base))
+            self.ptr = self.base = 0
+
+
+class _RawView:
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3, "strides": None}
+
+    def tensor(self, device):
+        return torch.as_tensor(self, device=device)
 
 
 class SymmetricBuffer:
@@ -83,6 +118,8 @@ class SymmetricBuffer:
             self.mem = _DeviceMem(self.nbytes, uncached=os.environ.get("RETAKE_P2P_UNCACHED_LANDING") == "1")   # (A/B aid)
             self.flags = _DeviceMem(4 * nv.P2P_MAX_RANKS, uncached=True)
             self.local = self.mem.tensor(dev)                        # uint8 [nbytes]
+            self.mem.fill_guards(dev)
+            self.flags.fill_guards(dev)
             self.status = torch.zeros(1, dtype=torch.int32, device=dev)
             handles = []
             for m in (self.mem, self.flags):
@@ -106,6 +143,11 @@ class SymmetricBuffer:
                     self._opened.append(int(base.value))
                     ptrs.append(int(base.value) + off)
                 self.peers.buf[r], self.peers.flag[r] = ptrs
+            self.mapped = [(r, int(self.peers.buf[r]), self.nbytes, int(self.peers.flag[r])) for r in range(g.world)]
+            if _NO_REMOTE:   # this rank's kernels only ever see its OWN buffers; the peers' data comes through the host
+                self.peers_all, self.peers = self.peers, nv.P2PPeers()
+                for r in range(g.world):
+                    self.peers.buf[r], self.peers.flag[r] = self.peers_all.buf[g.rank], self.peers_all.flag[g.rank]
         self.epoch = 0
         dist.barrier(group=g.group)   # nobody pushes before everybody has mapped everybody
 
@@ -117,10 +159,42 @@ class SymmetricBuffer:
             raise ValueError("p2p push outside the symmetric buffer")
         g = self.owner
         self.epoch += 1
+        if _NO_REMOTE:
+            return self._push_through_host(src, seg_bytes, nseg, src_stride, dst_offset, dst_stride, stream)
         st = nv.stream() if stream is None else C.c_void_p(stream.cuda_stream)
         nv.check(nv.lib.rtk_p2p_push(C.c_void_p(src.data_ptr()), seg_bytes, nseg, src_stride, C.byref(self.peers),
                                      g.rank, g.world, dst_offset, dst_stride, self.epoch, st),
                  "rtk_p2p_push")
+
+    def _push_through_host(self, src, seg_bytes, nseg, src_stride, dst_offset, dst_stride, stream):
+        """RETAKE_P2P_NO_REMOTE_WRITES=1 (debugging aid): the same call sequence with the peers' buffers MAPPED but never
+        written - every rank's segments travel through the host (gloo all-gather, blocking) and each rank stores all of
+        them, and all arrival flags, into its OWN buffers.  If a failure that needs the mappings disappears here, the
+        writes through them are implicated; if it stays, they are not."""
+        g = self.owner
+        ts = torch.cuda.current_stream(g.device) if stream is None else stream
+        with torch.cuda.stream(ts):
+            raw = _RawView(src.data_ptr(), max(16, (nseg - 1) * src_stride + seg_bytes)).tensor(g.device) if nseg and seg_bytes \
+                else torch.empty(0, dtype=torch.uint8, device=g.device)
+            if nseg and seg_bytes:
+                segs = torch.as_strided(raw, (nseg, seg_bytes), (src_stride, 1)).contiguous()
+            else:
+                segs = torch.empty((0, 0), dtype=torch.uint8, device=g.device)
+            meta = torch.tensor([dst_offset, dst_stride, nseg, seg_bytes], dtype=torch.int64)
+            ts.synchronize()
+            host = segs.cpu()
+        metas = [torch.empty_like(meta) for _ in range(g.world)]
+        dist.all_gather(metas, meta, group=g.group)
+        blobs: List[Optional[torch.Tensor]] = [None] * g.world
+        dist.all_gather_object(blobs, host, group=g.group)
+        with torch.cuda.stream(ts):
+            for r in range(g.world):
+                off, stride, n, sb = (int(v) for v in metas[r].tolist())
+                if n and sb:
+                    dst = torch.as_strided(self.local, (n, sb), (stride, 1), off)
+                    dst.copy_(blobs[r].to(g.device))
+            fl = _RawView(self.flags.ptr, 4 * g.world).tensor(g.device).view(torch.int32)
+            fl.fill_(self.epoch if self.epoch < 2 ** 31 else self.epoch - 2 ** 32)
 
     def wait(self, stream=None, timeout_ms: int = _TIMEOUT_MS):
         g = self.owner
@@ -213,6 +287,14 @@ class P2PGroup:
     def check(self):
         for b in self._buffers:
             b.check()
+
+    def guards_intact(self) -> bool:
+        """RETAKE_P2P_GUARD=1: the guard regions either side of every landing / flag buffer of this rank still hold their pattern."""
+        return all(b.mem.guards_intact() and b.flags.guards_intact() for b in self._buffers)
+
+    def mapped_ranges(self):
+        """[(buffer index, peer, address of the peer's landing buffer in THIS process, bytes, address of its flags)]."""
+        return [(i,) + m for i, b in enumerate(self._buffers) for m in b.mapped]
 
     def close(self):
         torch.cuda.synchronize(self.device)

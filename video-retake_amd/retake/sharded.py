@@ -293,7 +293,7 @@ class ChunkGatherP2P:
         self.bufs = [p2p.symmetric(self.capacity), p2p.symmetric(self.capacity)]
         self.side = torch.cuda.Stream(device=p2p.device)
         self.gen, self.at = 1, 0
-        self._sources: List[torch.Tensor] = []
+        self._sources: List[Tuple[torch.cuda.Event, torch.Tensor]] = []   # push sources whose copy kernel may still run
         self.begin_video(total, n_layers, Hkv, D, dtype)
 
     @staticmethod
@@ -313,7 +313,7 @@ class ChunkGatherP2P:
             self.es = torch.empty((), dtype=dtype).element_size()
         self.gen ^= 1
         self.at = 0
-        self._sources = []   # the previous video's push sources: every rank has long waited for them
+        self._release_sources()
 
     def start(self, k_new: List[torch.Tensor], v_new: List[torch.Tensor]):
         n_layers = len(k_new)
@@ -329,10 +329,17 @@ class ChunkGatherP2P:
         world, rank = self.p2p.world, self.p2p.rank
         self.bufs[self.gen].push(send, n * row, 2 * n_layers * Hkv, n * row, (rank * self.total + self.at) * row,
                                  world * self.total * row, stream=self.side)
-        # the push kernel reads `send` on the side stream after this function has returned: the tensor is kept until the
-        # next video begins (record_stream above only protects it under torch's caching allocator)
-        self._sources.append(send)
+        # the push kernel reads `send` on the side stream after this function has returned (record_stream above only
+        # protects it under torch's caching allocator): the tensor is kept until an event behind its push has completed -
+        # one or two chunks' rows at a time, not a second copy of everything the rank kept over the video
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        self._release_sources()
+        self._sources.append((ev, send))
         self.at += n
+
+    def _release_sources(self):
+        self._sources = [(e, t) for e, t in self._sources if not e.query()]
 
     def rows(self) -> int:
         return self.at
@@ -704,6 +711,7 @@ def sharded_video_step(frames, has_halo: bool, T: int, c0: int, c1: int, layers:
 
     L = B.FRAMES_PER_CHUNK * B.N_PATCH
     phases = (state or {}).get("phases")     # a PhaseTimer the caller wants filled (bench.py --gpus N)
+    watch = (state or {}).get("watch")       # debugging aid: called with a label after every chunk / the assembly
     if phases is not None:
         phases.begin()
     out, mask, idx, dis = dpselect_sharded(frames, has_halo, T, 3, sync=False, group=group)
@@ -732,8 +740,12 @@ def sharded_video_step(frames, has_halo: bool, T: int, c0: int, c1: int, layers:
         cache.after_forward()
         if overlap:
             sh.gather_chunk()   # this chunk's kept rows leave now, beside the next chunk's scoring
+        if watch is not None:
+            watch(f"after chunk {c} of the block (its push started: {overlap})")
     _mark(phases, "blocks")
     keys, values, pos = sh.finalize(rotary.inv_freq, B.MROPE, assemble=True, phases=phases)
+    if watch is not None:
+        watch("after finalize")
     if state is not None:
         state["chunk_gather"] = sh.chunk_gather
     return (c1 - c0) * layers * keep, (keys, values, pos)
@@ -751,6 +763,69 @@ def _rotate_at(x0: torch.Tensor, pos: torch.Tensor, rotary, mrope_section):
         cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
     D = x0.shape[-1]
     return x0 * cos + torch.cat((-x0[..., D // 2:], x0[..., : D // 2]), dim=-1) * sin
+
+
+class _PoolWatch:
+    """RETAKE_VERIFY_POOL_WATCH=1 (debugging aid of the multi-rank check): did a LIVE input tensor of this process change,
+    when, where and into what?  One int64 fingerprint (sum of the bit patterns) per resident tensor at construction;
+    every call recomputes them and, on the first difference, regenerates that tensor from its seed, reports the damaged
+    256-byte rows (count, runs, first values), the tensor's address beside the ranges this process has MAPPED from its
+    peers, whether the guard regions of its own landing buffers are intact (RETAKE_P2P_GUARD=1) - and raises."""
+
+    def __init__(self, rank, world, pool, frames_all, mask, layers, n_chunks, dname, dev, td, group):
+        self.rank, self.world, self.pool, self.layers, self.dname, self.dev, self.td, self.group = rank, world, pool, layers, dname, dev, td, group
+        self.n_chunks = n_chunks
+        self.extra = [("frames", frames_all), ("mask", mask.view(torch.uint8))]
+        self.calls = 0
+        self.ref = self._sums()
+
+    @staticmethod
+    def _bits(t):
+        t = t.contiguous() if t.is_contiguous() else t.transpose(1, 2).contiguous()
+        v = t.view(torch.int16) if t.element_size() == 2 else (t.view(torch.int32) if t.element_size() == 4 else t.view(torch.uint8))
+        return v.sum(dtype=torch.int64)
+
+    def _sums(self):
+        s = [self._bits(t) for trip in self.pool for t in trip] + [self._bits(t) for _, t in self.extra]
+        return torch.stack(s).cpu()
+
+    def __call__(self, label):
+        self.calls += 1
+        now = self._sums()
+        bad = (now != self.ref).nonzero().flatten().tolist()
+        p2p = _P2P.get(self.group)
+        guards = p2p.guards_intact() if p2p is not None else None
+        if not bad and guards in (None, True):
+            return
+        import bench as B
+
+        lines = [f"POOLWATCH rank {self.rank} ({self.dname}, {self.n_chunks} chunks): {len(bad)} resident tensor(s) changed, first seen "
+                 f"{label} (look {self.calls}); guard regions intact: {guards}"]
+        for i in bad[:3]:
+            if i >= 3 * len(self.pool):
+                lines.append(f"  {self.extra[i - 3 * len(self.pool)][0]} changed")
+                continue
+            si, j = divmod(i, 3)
+            t = self.pool[si][j]
+            fresh = B.pool_set(si, self.dev, self.td, projection_layout=True)[j]
+            mem = t.transpose(1, 2).contiguous().view(-1)         # the projection layout's memory order [L, H, D]
+            ref = fresh.transpose(1, 2).contiguous().view(-1)
+            D = t.shape[-1]
+            rows = (mem.view(-1, D) != ref.view(-1, D)).any(dim=1).nonzero().flatten()
+            r0, r1, n = int(rows[0]), int(rows[-1]), int(rows.numel())
+            runs = int((rows[1:] - rows[:-1] != 1).sum().item()) + 1
+            row_b = D * t.element_size()
+            lines.append(f"  pool set {si} (chunk {si // self.layers}, layer {si % self.layers}) {'qkv'[j]}: {n} of {mem.numel() // D} rows of "
+                         f"{row_b} B differ, rows {r0}..{r1} in {runs} run(s); tensor at {t.data_ptr():#x} (+{r0 * row_b:#x}), "
+                         f"{t.numel() * t.element_size()} B; first damaged row now {mem.view(-1, D)[r0, :6].float().tolist()} "
+                         f"was {ref.view(-1, D)[r0, :6].float().tolist()}; all-zero damaged rows "
+                         f"{int((mem.view(-1, D)[rows] == 0).all(dim=1).sum())}")
+        if p2p is not None:
+            rng = p2p.mapped_ranges()
+            lines.append("  ranges mapped from peers (buffer, peer, address, bytes): "
+                         + ", ".join(f"({b},{r},{a:#x},{nb})" for b, r, a, nb, _ in rng if r != self.rank)[:1500])
+        print("\n".join(lines), flush=True)
+        raise AssertionError(lines[0])
 
 
 def verify_sharded_equals_sequential(rank: int, world: int, dev, rotary, layers: int = 2, chunk_counts=None,
@@ -804,7 +879,14 @@ def verify_sharded_equals_sequential(rank: int, world: int, dev, rotary, layers:
                 seq.after_forward()
             return seq
 
+        if os.environ.get("RETAKE_VERIFY_POOL_WATCH") == "1":
+            # debugging aid (profiles/r15_p2p_hunt.log): fingerprints of every resident input tensor of this rank, taken now
+            # and looked at again after every push epoch - the first label at which one differs, which tensor, where in it
+            # and what was written there
+            state["watch"] = _PoolWatch(rank, world, pool, frames_all, mask, layers, n_chunks, dname, dev, td, group)
         seq = sequential()
+        if state.get("watch") is not None:
+            state["watch"]("after the sequential build")
         if os.environ.get("RETAKE_VERIFY_SEQ_TWICE") == "1":   # debugging aid: is the single-GPU build itself reproducible here?
             again = sequential()
             for l in range(layers):
@@ -824,6 +906,7 @@ def verify_sharded_equals_sequential(rank: int, world: int, dev, rotary, layers:
         pos_base = [B.chunk_position_ids(c, dev) for c in range(c0, c1)]
         _, (keys, values, pos) = sharded_video_step(fr, halo, T, c0, c1, layers, pool, pos_base, rotary, even, group=group,
                                                     state=state, inputs=inputs, pre_rope=True)
+        state.pop("watch", None)
         if _P2P.get(group) is not None:
             _P2P.get(group).check()   # a bounded wait that ran out is reported as that, not as the mismatch it leaves behind
         for l in range(layers):
