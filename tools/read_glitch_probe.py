@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=60)
     ap.add_argument("--gb", type=float, default=4.0)
     ap.add_argument("--map", action="store_true")
+    ap.add_argument("--push", type=float, default=0.0, metavar="MB",
+                    help="with --map: every look also all-gathers a payload of this size through the mapped buffers (peers WRITE "
+                         "into each other's landing buffers) and checks what arrived")
     a = ap.parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -58,8 +61,32 @@ def main():
     assert torch.equal(ref, again), "fingerprints not reproducible before anybody competes"
     dist.barrier()
     t_end = time.perf_counter() + a.seconds
-    looks = reads = transient = persistent = 0
-    while time.perf_counter() < t_end:
+    looks = reads = transient = persistent = landed_wrong = 0
+    payload = want = None
+    if a.map and a.push > 0:
+        n_pay = int(a.push * 1e6 / 2) // 8 * 8
+
+        def pay(r):
+            g = torch.Generator(device=dev).manual_seed(555 + r)
+            return torch.randn(n_pay, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+
+        payload = pay(rank)
+        want = torch.stack([pay(r).view(torch.int16).sum(dtype=torch.int64) for r in range(world)]).cpu()
+        torch.cuda.synchronize()
+    stop = torch.zeros(1, dtype=torch.int64)
+    while True:
+        # (the pushes are collective: every rank leaves the loop at the same look)
+        stop[0] = int(time.perf_counter() >= t_end)
+        dist.all_reduce(stop, op=dist.ReduceOp.MAX)
+        if int(stop[0]):
+            break
+        if payload is not None:
+            got = keep.all_gather(payload)
+            s = torch.stack([got[r].view(torch.int16).sum(dtype=torch.int64) for r in range(world)]).cpu()
+            for r in (s != want).nonzero().flatten().tolist():
+                landed_wrong += 1
+                print(f"rank {rank}: look {looks + 1}: the block of rank {r} read from the landing buffer has fingerprint {int(s[r])} != {int(want[r])}",
+                      flush=True)
         for i in range(0, n_t, 7):               # the churn of an op sequence: temporaries come and go
             tmp = pool[i].float()
             tmp2 = tmp * 2.0
@@ -74,12 +101,12 @@ def main():
             persistent += int(not same)
             print(f"rank {rank}: look {looks}: tensor {i} fingerprint {int(now[i])} != {int(ref[i])}; tensor equals its regeneration: {same}",
                   flush=True)
-    res = torch.tensor([reads, transient, persistent], dtype=torch.int64)
+    res = torch.tensor([reads, transient, persistent, landed_wrong], dtype=torch.int64)
     dist.all_reduce(res)
     dist.barrier()
     if rank == 0:
         mode = "no caching allocator" if os.environ.get("PYTORCH_NO_CUDA_MEMORY_CACHING") == "1" else "caching allocator"
-        print(f"READ_GLITCH {world} process(es), {mode}, peer mappings {'OPEN (idle)' if a.map else 'none'}, {n_t} x {2 * n_el / 1e6:.0f} MB "
+        print(f"READ_GLITCH {world} process(es), {mode}, peer mappings {('WRITTEN (%.0f MB all-gather per look; %d wrong blocks read from landing buffers)' % (a.push, int(res[3]))) if payload is not None else ('OPEN (idle)' if a.map else 'none')}, {n_t} x {2 * n_el / 1e6:.0f} MB "
               f"resident per process, {a.seconds:.0f} s: {int(res[0])} tensor reads fingerprinted, {int(res[1])} TRANSIENT wrong reads "
               f"(tensor intact), {int(res[2])} tensors really changed", flush=True)
     if keep is not None:
