@@ -83,6 +83,9 @@ def main():
     if p2p:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         sharded.enable_p2p(device=dev)
+    elif os.environ.get("RETAKE_TEST_TRANSPORT") == "host":
+        # debugging aid: no device-side transport at all (no RCCL, no peer mapping) - every exchange staged through the host
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     # the comparison itself lives in the library (bench.py --gpus N runs it before its timed region as well)

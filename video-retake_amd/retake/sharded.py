@@ -76,6 +76,13 @@ def _gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
     if g is not None:
         return g.all_gather(t).clone()   # the landing buffer is only valid until this rank's next exchange
     world = dist.get_world_size(group)
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # device tensors over a gloo group (tests/mp_sharded_gpu.py with RETAKE_TEST_TRANSPORT=host, a debugging aid: the
+        # sharded path with NO device-side transport at all - no RCCL, no peer mapping): staged through the host
+        h = t.cpu()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h, group=group)
+        return torch.stack(parts).to(t.device)
     recv = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
     if t.is_cuda:
         dist.all_gather_into_tensor(recv, t, group=group)
@@ -210,6 +217,11 @@ def all_gather_ids(pos: List[torch.Tensor], group=None, counts: Optional[List[in
     return [pall[l].reshape(pshape + (total,)) for l in range(n_layers)]
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
 class ChunkGather:
     """Cache assembly overlapped with the compression of the following chunks: after each chunk's flush the rows it
     kept in every layer go out in ONE asynchronous all-gather (RCCL runs it on its own stream beside the score
@@ -230,6 +242,9 @@ class ChunkGather:
         torch.stack(list(k_new), out=send[0])
         torch.stack(list(v_new), out=send[1])
         world = dist.get_world_size(self.group)
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":   # host-staged (see _gather_stack): done when it returns
+            self.items.append((_Done(), _gather_stack(send, self.group), send))
+            return
         recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
         if send.is_cuda:
             work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
