@@ -62,6 +62,10 @@ template <> struct H16<RTK_F16> {
         return __builtin_amdgcn_fdot2(__builtin_bit_cast(rtk_f16x2, a), __builtin_bit_cast(rtk_f16x2, b), acc, false);
     }
 };
+// A wave-uniform int the compiler keeps in a scalar register (readfirstlane makes the uniformity provable): the head index
+// of the per-update kernels, whose row offsets then travel in the soffset operand of buffer loads / stores (buf_load).
+__device__ __forceinline__ int uniform_int(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
 // round x to the 16-bit format named by `mode` (0 = keep fp32, 1 = bf16, 2 = fp16): the dtype a rotary module casts its
 // cos / sin tables to (`.to(x.dtype)`)
 __device__ __forceinline__ float round_to(float x, int mode) { return mode == 1 ? rbf(x) : (mode == 2 ? rhf(x) : x); }
@@ -227,6 +231,41 @@ __device__ __forceinline__ void rotate_chunk_pair(const u32x4& lo, const u32x4& 
 // NW 32-bit words of a row as one aligned load / store (the narrow-chunk forms of the per-update kernels)
 template <int NW> struct alignas(4 * NW) WV { uint32_t w[NW]; };
 
+// NW-dword accesses through a buffer descriptor: address = descriptor base + soff (SGPR: the head's offset) + voff (VGPR: the
+// thread's offset inside a head, computed once) + a compile-time immediate - no vector ALU work per access (the per-update
+// kernels touch 2 x 18 rows per thread and were spending a third of their vector instructions on 64-bit row addresses).
+// Offsets are 32-bit: the launchers check that a tensor's extent fits (RTK_EUNSUPPORTED otherwise).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {   // p must be wave-uniform (readfirstlane says so)
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned long long u = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, 0xfffffffc, 0x00020000);
+}
+template <int NW, int IMM = 0> __device__ __forceinline__ WV<NW> buf_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    WV<NW> o;
+    if constexpr (NW == 1) {
+        o.w[0] = __builtin_amdgcn_raw_buffer_load_b32(r, voff + IMM, soff, 0);
+    } else if constexpr (NW == 2) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM, soff, 0);
+        o.w[0] = v[0]; o.w[1] = v[1];
+    } else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM, soff, 0);
+        o.w[0] = v[0]; o.w[1] = v[1]; o.w[2] = v[2]; o.w[3] = v[3];
+    }
+    return o;
+}
+template <int NW, int IMM = 0> __device__ __forceinline__ void buf_store(const WV<NW>& x, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    if constexpr (NW == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(x.w[0], r, voff + IMM, soff, 0);
+    } else if constexpr (NW == 2) {
+        using u2 = __attribute__((ext_vector_type(2))) unsigned int;
+        __builtin_amdgcn_raw_buffer_store_b64(u2{x.w[0], x.w[1]}, r, voff + IMM, soff, 0);
+    } else {
+        using u4 = __attribute__((ext_vector_type(4))) unsigned int;
+        __builtin_amdgcn_raw_buffer_store_b128(u4{x.w[0], x.w[1], x.w[2], x.w[3]}, r, voff + IMM, soff, 0);
+    }
+}
+
 }  // namespace rtk
 
 // ---- host-side error plumbing --------------------------------------------------------------------
@@ -313,6 +352,15 @@ int pivotkv_prepare_shift(const void* q, int64_t q_stride_h, int64_t q_stride_l,
                           void* workspace, size_t workspace_bytes, void* k_tail, void* v_tail, int64_t tail_stride_h,
                           int64_t* pos_copy, int64_t* shift_row, const int64_t* next_prev, int32_t* ticket,
                           int64_t ticket_ints, int32_t* status, rtk_stream_t stream);
+
+// The per-update kernels address rows as (descriptor base + 32-bit head offset + 32-bit thread offset): every byte of a
+// [H, L, D] operand with element strides (sh, sl, 1) must lie below 2 GiB from its base, strides non-negative.
+inline bool fits_buffer_offsets(int64_t H, int64_t L, int64_t D, int64_t sh, int64_t sl, size_t es) {
+    if (sh < 0 || sl < 0) return false;
+    const unsigned long long last = ((unsigned long long)(H > 0 ? H - 1 : 0) * (unsigned long long)sh +
+                                     (unsigned long long)(L > 0 ? L - 1 : 0) * (unsigned long long)sl + (unsigned long long)D) * es;
+    return last < (1ull << 31);
+}
 
 inline int make_rowsel(RowSel& rs, int P, int D, const int* sections, int nsec, const char* who) {
     if (D > 256 || (D & 1)) {

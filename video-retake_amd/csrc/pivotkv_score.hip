@@ -320,7 +320,11 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prepare_native_kernel(const ch
         for (int p = 0; p < P; ++p) pos_copy[(size_t)p * L + l] = pos[(size_t)p * pos_ld + l];
     constexpr int HU = RTK_PREP_HU;   // heads per batch: all loads of a batch are issued before its arithmetic and stores
     const int ny = gridDim.y, qper = (Hq + ny - 1) / ny;
+#if RTK_PREP_UBASE
+    const int qb = uniform_int(min((int)blockIdx.y * qper, Hq)), qe = uniform_int(min(qb + qper, Hq));   // (head loops in SGPRs)
+#else
     const int qb = min((int)blockIdx.y * qper, Hq), qe = min(qb + qper, Hq);
+#endif
     // the KV heads: y = 0 takes k (k~ for the scoring / eviction + the rotated rows for the tail), the last y takes v
     const bool has_kv = blockIdx.y == 0 || (int)blockIdx.y == ny - 1;
     const char* src = blockIdx.y == 0 ? k : v;
@@ -331,22 +335,45 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prepare_native_kernel(const ch
     // are requested before batch b is un-rotated and stored, and the first batch before the table arithmetic
     // (sin / cos are ~25 fp64 operations per value) - with ~1.5 waves per SIMD nothing else hides a round trip.
     W lo[HU], hi[HU], lon[HU], hin[HU];
+#if RTK_PREP_UBASE
+    // a row's address = descriptor (tensor base) + soffset (the head: wave-uniform, a scalar multiply) + voffset (this
+    // thread's byte offset inside a head, computed once); the launcher has checked that every extent fits 31 bits
+    const uint32_t off_q = (uint32_t)(((int64_t)l * q_sl + d) * ES), off_kv = (uint32_t)(((int64_t)l * sl + d) * ES);
+    const uint32_t off_o = (uint32_t)(((int64_t)l * D + d) * ES), half = (uint32_t)(h2 * ES);
+    const uint32_t off_q2 = off_q + half, off_kv2 = off_kv + half, off_o2 = off_o + half;
+    const __amdgpu_buffer_rsrc_t r_q = buf_rsrc(q), r_src = buf_rsrc(src), r_qo = buf_rsrc(q_out), r_ko = buf_rsrc(k_out),
+                                 r_tail = buf_rsrc(tail), r_kf = buf_rsrc(k_fast);
+    const uint32_t hs_q = (uint32_t)(q_sh * ES), hs_kv = (uint32_t)(sh * ES), hs_o = (uint32_t)((int64_t)L * D * ES),
+                   hs_t = (uint32_t)(tail_sh * ES);
+#endif
     auto load_q = [&](W* a, W* b, int hb) {
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
             const int h = min(hb + u, qe - 1);
+#if RTK_PREP_UBASE
+            const uint32_t so = (uint32_t)uniform_int((int)((uint32_t)h * hs_q));
+            a[u] = buf_load<NW>(r_q, off_q, so);
+            b[u] = buf_load<NW>(r_q, off_q2, so);
+#else
             const char* row = q + ((size_t)h * q_sh + (size_t)l * q_sl) * ES;
             a[u] = *(const W*)(row + (size_t)d * ES);
             b[u] = *(const W*)(row + (size_t)(d + h2) * ES);
+#endif
         }
     };
     auto load_kv = [&](W* a, W* b, int hb) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int h = min(hb + u, Hkv - 1);
+#if RTK_PREP_UBASE
+            const uint32_t so = (uint32_t)uniform_int((int)((uint32_t)h * hs_kv));
+            a[u] = buf_load<NW>(r_src, off_kv, so);
+            b[u] = buf_load<NW>(r_src, off_kv2, so);
+#else
             const char* row = src + ((size_t)h * sh + (size_t)l * sl) * ES;
             a[u] = *(const W*)(row + (size_t)d * ES);
             b[u] = *(const W*)(row + (size_t)(d + h2) * ES);
+#endif
         }
     };
     float pid[3];   // the token's ids (t / h / w rows; a 1-D id fills all three)
@@ -421,9 +448,15 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prepare_native_kernel(const ch
                 olo = to_f16(olo, qscale);
                 ohi = to_f16(ohi, qscale);
             }
+#if RTK_PREP_UBASE
+            const uint32_t so = (uint32_t)uniform_int((int)((uint32_t)h * hs_o));
+            buf_store<NW>(olo, r_qo, off_o, so);
+            buf_store<NW>(ohi, r_qo, off_o2, so);
+#else
             char* orow = q_out + ((size_t)h * L + l) * D * ES;
             *(W*)(orow + (size_t)d * ES) = olo;
             *(W*)(orow + (size_t)(d + h2) * ES) = ohi;
+#endif
         }
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
@@ -437,12 +470,27 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prepare_native_kernel(const ch
         for (int u = 0; u < 4; ++u) {
             const int h = hb + u;
             if (h >= nkv) break;
+#if RTK_PREP_UBASE
+            const uint32_t sot = (uint32_t)uniform_int((int)((uint32_t)h * hs_t));
+            buf_store<NW>(lo[u], r_tail, off_o, sot);
+            buf_store<NW>(hi[u], r_tail, off_o2, sot);
+#else
             char* trow = tail + ((size_t)h * tail_sh + (size_t)l * D) * ES;
             *(W*)(trow + (size_t)d * ES) = lo[u];
             *(W*)(trow + (size_t)(d + h2) * ES) = hi[u];
+#endif
             if (blockIdx.y == 0) {
                 W olo, ohi;
                 unrot(lo[u], hi[u], olo, ohi);
+#if RTK_PREP_UBASE
+                const uint32_t so = (uint32_t)uniform_int((int)((uint32_t)h * hs_o));
+                buf_store<NW>(olo, r_ko, off_o, so);
+                buf_store<NW>(ohi, r_ko, off_o2, so);
+                if constexpr (FAST) {   // the same k~ as fp16 for the score passes (exact re-encoding)
+                    buf_store<NW>(to_f16(olo, 1.f), r_kf, off_o, so);
+                    buf_store<NW>(to_f16(ohi, 1.f), r_kf, off_o2, so);
+                }
+#else
                 char* orow = k_out + ((size_t)h * L + l) * D * ES;
                 *(W*)(orow + (size_t)d * ES) = olo;
                 *(W*)(orow + (size_t)(d + h2) * ES) = ohi;
@@ -451,6 +499,7 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prepare_native_kernel(const ch
                     *(W*)(frow + (size_t)d * ES) = to_f16(olo, 1.f);
                     *(W*)(frow + (size_t)(d + h2) * ES) = to_f16(ohi, 1.f);
                 }
+#endif
             }
         }
 #pragma unroll
@@ -2566,6 +2615,12 @@ int rtk::pivotkv_prepare_shift(const void* q, int64_t q_stride_h, int64_t q_stri
     if (!ok) {
         set_error("rtk_pivotkv_prepare: needs 16-byte aligned pointers / strides and head_dim a multiple of %d", 2 * ve);
         return RTK_EUNSUPPORTED;   // callers fall back to rtk_rope_table + rtk_pivotkv_score + rtk_pivotkv_append
+    }
+    if (!(fits_buffer_offsets(Hq, L, D, q_stride_h, q_stride_l, es) && fits_buffer_offsets(Hkv, L, D, k_stride_h, k_stride_l, es) &&
+          fits_buffer_offsets(Hkv, L, D, v_stride_h, v_stride_l, es) && fits_buffer_offsets(Hkv, L, D, tail_stride_h, D, es) &&
+          fits_buffer_offsets(Hq > Hkv ? Hq : Hkv, L, D, (int64_t)L * D, D, es))) {
+        set_error("rtk_pivotkv_prepare: an operand spans 2 GiB or more (or has a negative stride): 32-bit row offsets do not reach");
+        return RTK_EUNSUPPORTED;
     }
     RowSel rs;
     int rc = make_rowsel(rs, P, D, sections_host, nsec, "rtk_pivotkv_prepare");

@@ -91,7 +91,11 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
         __hip_atomic_store(shift_back, (int64_t)ids[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int HU = RTK_PREP_HU;
     const int ny = gridDim.y, qper = (Hq + ny - 1) / ny;
+#if RTK_PREP_UBASE
+    const int qb = uniform_int(min((int)blockIdx.y * qper, Hq)), qe = uniform_int(min(qb + qper, Hq));   // (head loops in SGPRs)
+#else
     const int qb = min((int)blockIdx.y * qper, Hq), qe = min(qb + qper, Hq);
+#endif
     const bool is_k = blockIdx.y == 0;
     const bool has_kv = is_k || (int)blockIdx.y == ny - 1;
     const char* src = is_k ? k : v;
@@ -99,22 +103,45 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
     char* tail = is_k ? k_tail : v_tail;
     const int nkv = has_kv ? Hkv : 0;
     W lo[HU], hi[HU], lon[HU], hin[HU];
+#if RTK_PREP_UBASE
+    // a row's address = descriptor (tensor base) + soffset (the head: wave-uniform, a scalar multiply) + voffset (this
+    // thread's byte offset inside a head, computed once); the launcher has checked that every extent fits 31 bits
+    const uint32_t off_q = (uint32_t)(((int64_t)l * q_sl + d) * ES), off_kv = (uint32_t)(((int64_t)l * sl + d) * ES);
+    const uint32_t off_qr = (uint32_t)(((int64_t)l * qr_sl + d) * ES);
+    const uint32_t off_o = (uint32_t)(((int64_t)l * D + d) * ES), half = (uint32_t)(h2 * ES);
+    const uint32_t off_q2 = off_q + half, off_kv2 = off_kv + half, off_o2 = off_o + half, off_qr2 = off_qr + half;
+    const __amdgpu_buffer_rsrc_t r_q = buf_rsrc(q), r_src = buf_rsrc(src), r_qo = buf_rsrc(q_out), r_ko = buf_rsrc(k_out),
+                                 r_tail = buf_rsrc(tail), r_kf = buf_rsrc(k_fast), r_qr = buf_rsrc(q_rot);
+    const uint32_t hs_q = (uint32_t)(q_sh * ES), hs_kv = (uint32_t)(sh * ES), hs_o = (uint32_t)((int64_t)L * D * ES),
+                   hs_t = (uint32_t)(tail_sh * ES), hs_qr = (uint32_t)(qr_sh * ES);
+    auto soff = [](int h, uint32_t hs) { return (uint32_t)uniform_int((int)((uint32_t)h * hs)); };
+#endif
     auto load_q = [&](W* a, W* b, int hb) {
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
             const int h = min(hb + u, qe - 1);
+#if RTK_PREP_UBASE
+            a[u] = buf_load<NW>(r_q, off_q, soff(h, hs_q));
+            b[u] = buf_load<NW>(r_q, off_q2, soff(h, hs_q));
+#else
             const char* row = q + ((size_t)h * q_sh + (size_t)l * q_sl) * ES;
             a[u] = *(const W*)(row + (size_t)d * ES);
             b[u] = *(const W*)(row + (size_t)(d + h2) * ES);
+#endif
         }
     };
     auto load_kv = [&](W* a, W* b, int hb) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int h = min(hb + u, Hkv - 1);
+#if RTK_PREP_UBASE
+            a[u] = buf_load<NW>(r_src, off_kv, soff(h, hs_kv));
+            b[u] = buf_load<NW>(r_src, off_kv2, soff(h, hs_kv));
+#else
             const char* row = src + ((size_t)h * sh + (size_t)l * sl) * ES;
             a[u] = *(const W*)(row + (size_t)d * ES);
             b[u] = *(const W*)(row + (size_t)(d + h2) * ES);
+#endif
         }
     };
     float pid[3];
@@ -210,18 +237,27 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
             if (q_out) {   // q~ := q0, or (RT) the un-rotation of the rotated row (keep-all chunks are not scored: no q~)
                 W ql = lo[u], qh = hi[u];
                 if constexpr (RT) unrot(olo, ohi, ql, qh);
-                char* orow = q_out + ((size_t)h * L + l) * D * ES;
                 if constexpr (FAST) {
-                    *(W*)(orow + (size_t)d * ES) = to_f16(ql, qscale);
-                    *(W*)(orow + (size_t)(d + h2) * ES) = to_f16(qh, qscale);
-                } else {
-                    *(W*)(orow + (size_t)d * ES) = ql;
-                    *(W*)(orow + (size_t)(d + h2) * ES) = qh;
+                    ql = to_f16(ql, qscale);
+                    qh = to_f16(qh, qscale);
                 }
+#if RTK_PREP_UBASE
+                buf_store<NW>(ql, r_qo, off_o, soff(h, hs_o));
+                buf_store<NW>(qh, r_qo, off_o2, soff(h, hs_o));
+#else
+                char* orow = q_out + ((size_t)h * L + l) * D * ES;
+                *(W*)(orow + (size_t)d * ES) = ql;
+                *(W*)(orow + (size_t)(d + h2) * ES) = qh;
+#endif
             }
+#if RTK_PREP_UBASE
+            buf_store<NW>(olo, r_qr, off_qr, soff(h, hs_qr));
+            buf_store<NW>(ohi, r_qr, off_qr2, soff(h, hs_qr));
+#else
             char* rrow = q_rot + ((size_t)h * qr_sh + (size_t)l * qr_sl) * ES;
             *(W*)(rrow + (size_t)d * ES) = olo;
             *(W*)(rrow + (size_t)(d + h2) * ES) = ohi;
+#endif
         }
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
@@ -235,6 +271,28 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
         for (int u = 0; u < 4; ++u) {
             const int h = hb + u;
             if (h >= nkv) break;
+#if RTK_PREP_UBASE
+            const uint32_t so_t = soff(h, hs_t), so_o = soff(h, hs_o);
+            if (is_k) {
+                W olo, ohi;
+                rot(lo[u], hi[u], olo, ohi);
+                W kl = lo[u], kh = hi[u];
+                if constexpr (RT) unrot(olo, ohi, kl, kh);
+                if (k_out) {   // k~ := k0 / (RT) un-rotated tail row (a plain append - text segments, decode - scores nothing: no k~)
+                    buf_store<NW>(kl, r_ko, off_o, so_o);
+                    buf_store<NW>(kh, r_ko, off_o2, so_o);
+                }
+                if constexpr (FAST) {
+                    buf_store<NW>(to_f16(kl, 1.f), r_kf, off_o, so_o);
+                    buf_store<NW>(to_f16(kh, 1.f), r_kf, off_o2, so_o);
+                }
+                buf_store<NW>(olo, r_tail, off_o, so_t);
+                buf_store<NW>(ohi, r_tail, off_o2, so_t);
+            } else {
+                buf_store<NW>(lo[u], r_tail, off_o, so_t);
+                buf_store<NW>(hi[u], r_tail, off_o2, so_t);
+            }
+#else
             char* trow = tail + ((size_t)h * tail_sh + (size_t)l * D) * ES;
             if (is_k) {
                 W olo, ohi;
@@ -257,6 +315,7 @@ __global__ __launch_bounds__(RTK_PREP_BLOCK) void prologue_kernel(const char* q,
                 *(W*)(trow + (size_t)d * ES) = lo[u];
                 *(W*)(trow + (size_t)(d + h2) * ES) = hi[u];
             }
+#endif
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -385,6 +444,12 @@ extern "C" int rtk_pivotkv_update(rtk_pivotkv_batch* b, rtk_layer_state* ls, int
             set_error("rtk_pivotkv_update: the prologue needs 16-byte aligned pointers / strides and head_dim a multiple of %d", 2 * ve);
             return RTK_EUNSUPPORTED;
         }
+        if (!(fits_buffer_offsets(b->Hq, L, D, io->q_stride_h, io->q_stride_l, es) && fits_buffer_offsets(b->Hq, L, D, io->qr_stride_h, io->qr_stride_l, es) &&
+              fits_buffer_offsets(Hkv, L, D, io->k_stride_h, io->k_stride_l, es) && fits_buffer_offsets(Hkv, L, D, io->v_stride_h, io->v_stride_l, es) &&
+              fits_buffer_offsets(Hkv, L, D, tail_sh, D, es) && fits_buffer_offsets(b->Hq, L, D, (int64_t)L * D, D, es))) {
+            set_error("rtk_pivotkv_update: an operand spans 2 GiB or more (or has a negative stride): 32-bit row offsets do not reach");
+            return RTK_EUNSUPPORTED;
+        }
         if (b->P == 3 && io->pos_stride < L && io->pos_stride != 0) {   // partially overlapping id rows: the eager route
             set_error("rtk_pivotkv_update: position-id rows overlap (pos_stride %lld < L %d)", (long long)io->pos_stride, L);
             return RTK_EUNSUPPORTED;
@@ -497,6 +562,12 @@ extern "C" int rtk_pivotkv_append_rope(rtk_layer_state* ls, const rtk_update_io*
                       (uintptr_t)v_tail) & 15) == 0;
     if (!ok) {
         set_error("rtk_pivotkv_append_rope: needs 16-byte aligned pointers / strides and head_dim a multiple of %d", 2 * ve);
+        return RTK_EUNSUPPORTED;
+    }
+    if (!(fits_buffer_offsets(Hq, n, D, io->q_stride_h, io->q_stride_l, es) && fits_buffer_offsets(Hq, n, D, io->qr_stride_h, io->qr_stride_l, es) &&
+          fits_buffer_offsets(Hkv, n, D, io->k_stride_h, io->k_stride_l, es) && fits_buffer_offsets(Hkv, n, D, io->v_stride_h, io->v_stride_l, es) &&
+          fits_buffer_offsets(Hkv, n, D, tail_sh, D, es))) {
+        set_error("rtk_pivotkv_append_rope: an operand spans 2 GiB or more (or has a negative stride): 32-bit row offsets do not reach");
         return RTK_EUNSUPPORTED;
     }
     RowSel rs;

@@ -43,6 +43,9 @@
 #ifndef RTK_PREP_BLOCK    // threads per workgroup of the per-update kernels (fused prepare, attention prologue)
 #define RTK_PREP_BLOCK 64
 #endif
+#ifndef RTK_PREP_UBASE    // per-update kernels: 1 = a row's address is (wave-uniform head base, kept in SGPRs) + (the thread's byte
+#define RTK_PREP_UBASE 1  // offset, computed once); 0 = the full (h * stride_h + l * stride_l) * ES per head and access (A/B: profiles/r15_ab_prepare_addressing.txt)
+#endif
 #ifndef RTK_CMP_HU        // in-place compaction: KV heads per workgroup (register batch of the row loads)
 #define RTK_CMP_HU 4
 #endif
