@@ -117,7 +117,10 @@ def main():
                     for cache in (ca, cb):
                         cache.keypatches_mask_chunk = mask
                         cache.kvcache_compression = True
-                        kw = {"query_states": q.to(dev), "position_ids": pos_t.to(dev).clone(), "rotary_emb": rot}
+                        # (the Qwen2-VL patch's opt-in: the launch may shift the ids it is handed - a clone here - for the next
+                        # layer; the twin's `shift_next_in_update` draws the kill switch, so both forms of the launch run)
+                        kw = {"query_states": q.to(dev), "position_ids": pos_t.to(dev).clone(), "rotary_emb": rot,
+                              "shift_next_position_ids": True}
                         if sec:
                             kw["mrope_section"] = list(sec)
                         cache.update(k.to(dev), vt.to(dev), l, kw)
