@@ -264,3 +264,26 @@ def test_ragged_blocks_are_padded_and_trimmed():
         assert kcol == [1, 2, 3, 4, 5, 11, 12, 13, 21, 22, 23]                      # layer 1: 10*rank + 1 + row
         assert vcol == [0.5, 1.5, 2.5, 3.5, 4.5, 10.5, 11.5, 12.5, 20.5, 21.5, 22.5]
         assert pcol == [1, 2, 3, 4, 5, 1001, 1002, 1003, 2001, 2002, 2003]
+
+
+def test_phase_timer_sums_spans_between_marks_per_step():
+    """PhaseTimer on the host clock (its form under gloo): a phase is the span up to its mark, the two orders in which
+    `finalize` marks rotate / assembly both add up, `step` is start -> last mark, means are per recorded step."""
+    import time
+
+    from retake.sharded import PhaseTimer
+
+    pt = PhaseTimer(torch.device("cpu"))
+    pt.mark("ignored")                       # nothing recorded before the first begin()
+    for order in (("dpselect", "blocks", "offsets", "assembly", "rotate"), ("dpselect", "blocks", "offsets", "rotate", "assembly")):
+        pt.begin()
+        for name in order:
+            time.sleep(0.01 if name != "blocks" else 0.03)
+            pt.mark(name)
+    pt.note_bytes("assembly_rows_received", 123)
+    ms = pt.per_step_ms()
+    assert set(ms) == {"dpselect", "blocks", "offsets", "rotate", "assembly", "step"}
+    assert 25 <= ms["blocks"] <= 60 and all(8 <= ms[k] <= 30 for k in ("dpselect", "offsets", "rotate", "assembly"))
+    assert abs(ms["step"] - sum(ms[k] for k in PhaseTimer.ORDER)) < 1e-6
+    assert pt.bytes == {"assembly_rows_received": 123}
+    assert PhaseTimer(torch.device("cpu")).per_step_ms()["step"] == 0.0
