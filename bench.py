@@ -89,8 +89,10 @@ def parse():
     ap.add_argument("--also-streams", type=int, default=0,
                     help="after the contract measurement, time the same steps again with this many worker streams "
                          "(reported under 'overlap'; 0 = skip)")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "p2p"],
-                    help="N > 1: torch.distributed collectives over RCCL, or the direct peer-to-peer pushes of retake/p2p.py")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "p2p", "host"],
+                    help="N > 1: torch.distributed collectives over RCCL, or the direct peer-to-peer pushes of retake/p2p.py; "
+                         "'host' (tests: the collective-transport code path with several ranks on ONE GPU, which RCCL refuses) "
+                         "stages every exchange through the host over gloo")
     ap.add_argument("--pre-rope", action="store_true",
                     help="measure the attention patch's fused prologue instead (PivotKVCache.update_pre_rope on pre-RoPE "
                          "projections in the projection layout); not the contract line")
@@ -773,7 +775,7 @@ def contract_line(report: dict, report_path=None) -> dict:
     sc = report.get("self_check")
     if sc is not None:
         line["self_check"] = sc["status"] if isinstance(sc, dict) else sc
-    for k in ("sharded_equals_sequential", "rccl_world_size", "p2p_world_size", "phase_ms"):
+    for k in ("sharded_equals_sequential", "rccl_world_size", "p2p_world_size", "host_staged_world_size", "phase_ms"):
         if k in report:
             line[k] = report[k]
     n1 = report.get("n1_same_arithmetic")

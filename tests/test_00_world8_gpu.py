@@ -76,6 +76,17 @@ def test_sharded_prefill_8_ranks_over_p2p():
     assert "sharded DPSelect over 8 ranks" in r.stdout and "chunks 65 on 8 rank(s)" in r.stdout
 
 
+def test_sharded_prefill_8_ranks_collective_code_path_host_staged():
+    """World size 8 through the COLLECTIVE-transport code path (`ChunkGather`, `all_gather_caches`, `all_gather_ids` - what the
+    first RCCL run on eight GPUs executes), every exchange staged through the host over gloo, all ranks on GPU 0: the 16- /
+    17-chunk videos in fp32 and bf16 and the 64- / 65-chunk ones in bf16, assembled == sequential bit for bit on every rank."""
+    _fresh_parent()
+    r = _launch_ranks("mp_sharded_gpu.py", 8, env={"RETAKE_TEST_TRANSPORT": "host", "RETAKE_TEST_ONE_GPU": "1",
+                                                   "RETAKE_TEST_MORE_CASES": "bf16:64,65"})
+    assert r.returncode == 0 and "MP_SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "chunks 64 on 8 rank(s)" in r.stdout and "chunks 65 on 8 rank(s)" in r.stdout
+
+
 def test_bench_eight_ranks_share_one_gpu_p2p(tmp_path):
     """`bench.py --gpus 8 --transport p2p` end to end with all eight ranks on GPU 0 (RETAKE_BENCH_SHARE_GPU=1) on a 512-frame /
     2-layer video (16 chunks: blocks of 2): world size 8 through rank start-up, halo frames, the in-process

@@ -2370,6 +2370,29 @@ def test_bench_two_ranks_share_one_gpu_p2p(tmp_path):
         assert b["phase_ms"][ph][0] >= b["phase_ms"][ph][1] >= 0.0, b["phase_ms"]
 
 
+def test_bench_two_ranks_collective_code_path_host_staged(tmp_path):
+    """`bench.py --gpus 2 --transport host`: the COLLECTIVE-transport code path of the sharded step - `ChunkGather` (one
+    all-gather per chunk beside the next chunk's scoring), `all_gather_caches`, the offsets scan, what an RCCL run executes -
+    with two ranks on GPU 0, every exchange staged through the host over gloo (RCCL refuses two ranks on one device; the
+    p2p tests never enter these functions).  Self-verified in process (even and ragged splits, fp32 and bf16) before timing."""
+    common = ["--frames", "256", "--layers", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    b, rb = _bench(["--gpus", "2", "--transport", "host"] + common, tmp_path, "host2", env={"RETAKE_BENCH_SHARE_GPU": "1"})
+    assert b["n_gpus"] == 2 and b["config"]["transport"] == "host" and b["host_staged_world_size"] == 2 and b["value"] > 0
+    assert b["sharded_equals_sequential"] is True
+    assert [(c["dtype"], c["chunks"], c["overlapped_gathers"]) for c in rb["sharded_check"]["cases"]] == \
+        [("fp32", 4, True), ("fp32", 5, False), ("bf16", 4, True), ("bf16", 5, False)]
+    assert b["config"]["assembled_cache_tokens"] == 8 * 1568
+    assert b["phase_ms"]["assembly"][0] > 0 and rb["phase_bytes_rank0"]["assembly_rows_received"] > 0
+
+
+def test_sharded_prefill_two_ranks_collective_code_path_host_staged():
+    """tests/mp_sharded_gpu.py with RETAKE_TEST_TRANSPORT=host at world size 2 on one GPU: assembled == sequential, bit for bit,
+    through `ChunkGather` / `all_gather_caches` / `all_gather_ids` (the functions the RCCL transport runs)."""
+    r = _launch_ranks("mp_sharded_gpu.py", 2, env={"RETAKE_TEST_TRANSPORT": "host", "RETAKE_TEST_ONE_GPU": "1", "RETAKE_TEST_DPSELECT": "1"})
+    assert r.returncode == 0 and "MP_SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "overlapped gathers True" in r.stdout and "overlapped gathers False" in r.stdout
+
+
 def test_bench_forced_sharded_world1_rccl_self_verifies(tmp_path):
     """`RETAKE_FORCE_SHARDED=1 python bench.py`: the sharded path at world size 1 over RCCL.  The line must carry
     `sharded_equals_sequential: true` (checked in process before the timed region) and - world size 1 being the one

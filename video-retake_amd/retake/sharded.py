@@ -1105,7 +1105,7 @@ def measure_sharded(args, rank: int, world: int, dev, transport: str, share: boo
                                f"{n_chunks} chunks x {args.layers} layers, L={L}",
                    "workload_detail": f"Qwen2-VL-7B geometry: DPSelect (distance rows all-gathered) + PivotKV 4x; offsets + "
                                       f"whole-cache all-gather over "
-                                      f"{'RCCL' if p2p is None else 'direct xGMI pushes (retake/p2p.py)'}",
+                                      f"{('RCCL' if transport == 'rccl' else 'gloo, host-staged (tests)') if p2p is None else 'direct xGMI pushes (retake/p2p.py)'}",
                    "frames": T, "chunks": n_chunks, "layers": args.layers, "chunk_tokens": L,
                    "parallelism": f"chunk-sharded x{world}", "transport": transport,
                    "assembled_cache_tokens": int(keys[0].shape[2])},
@@ -1113,7 +1113,8 @@ def measure_sharded(args, rank: int, world: int, dev, transport: str, share: boo
         # untimed, before the timed region, over the same transport and through the same function the loop times
         "sharded_equals_sequential": bool(verdict and verdict["equal"]),
         "sharded_check": verdict,
-        ("rccl_world_size" if p2p is None and not share else "p2p_world_size"): dist.get_world_size(),
+        ("rccl_world_size" if transport == "rccl" else ("p2p_world_size" if p2p is not None else "host_staged_world_size")):
+            dist.get_world_size(),
         "cpu_baseline": None,   # timed on rank 0 of the N = 1 run only (bench contract); see that line
         "kernels_timed_region_rank0": kern,
         "roofline": B.score_roofline(kern, args.dtype, L, T, (c1 - c0) * args.layers * steps),
@@ -1133,9 +1134,12 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")   # world size 1 without a launcher (RETAKE_FORCE_SHARDED=1)
     os.environ.setdefault("MASTER_PORT", "29544")
     transport = getattr(args, "transport", "rccl")
-    # RETAKE_BENCH_SHARE_GPU=1 (tests only, p2p transport): every rank runs on GPU 0 over a gloo control plane, so that
-    # the multi-rank bench path can run on a 1-GPU box (RCCL refuses two ranks on one device)
-    share = os.environ.get("RETAKE_BENCH_SHARE_GPU") == "1" and transport == "p2p"
+    # RETAKE_BENCH_SHARE_GPU=1 (tests only): every rank runs on GPU 0 over a gloo control plane, so that the multi-rank bench
+    # path can run on a 1-GPU box (RCCL refuses two ranks on one device) - with the p2p transport as the data plane, or
+    # (`--transport host`) with the collective-transport code path (ChunkGather, all_gather_caches) staged through the host
+    share = os.environ.get("RETAKE_BENCH_SHARE_GPU") == "1" and transport in ("p2p", "host")
+    if transport == "host" and not share:
+        raise SystemExit("--transport host is the tests' form of the collective path (RETAKE_BENCH_SHARE_GPU=1); use rccl or p2p")
     dev = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(dev)
     if not dist.is_initialized():
