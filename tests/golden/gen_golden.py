@@ -744,6 +744,9 @@ def gen_pivotkv_prerope_bf16(lc, outdir, only=None):
     cases = [("prerope_bf16_qwen_L256", 8, 8, 4, 2, 0.25, 0.3, 231, True, M),
              ("prerope_bf16_qwen_L1568", 14, 14, 8, 2, 0.25, 0.3, 232, False, M),
              ("prerope_bf16_qwen_L6272", 14, 14, 32, 1, 0.25, 0.3, 233, False, M),
+             # the REAL Qwen2-VL chunk (448 px, 16:9: 9 x 16 merged tokens per temporal grid, 16 grids = 2304 tokens,
+             # cal_flops.py:8,47), two chunks: the geometry bench.py's `real_geometry` companion times, in the production dtype
+             ("prerope_bf16_qwen_L2304", 9, 16, 16, 2, 0.25, 0.3, 237, False, M),
              ("prerope_bf16_llava_L1568", 14, 14, 8, 2, 0.25, 0.3, 234, False, None),
              # BASELINE configs[4]'s own setting: LLaVA-Video chunk (32 frames x 196 pooled tokens), plain RoPE, the dynamic
              # ratio of a 2048-frame prompt (max_input_length 40000 / 401409 tokens: keep 624 of 6272)
@@ -999,6 +1002,8 @@ def main():
         gen_pivotkv_prerope_bf16(lc, HERE)
     if args.only == "pivotkv_prerope_llava_dyn":
         gen_pivotkv_prerope_bf16(lc, HERE, only=("prerope_bf16_llava_L6272_dyn",))
+    if args.only == "pivotkv_prerope_qwen_L2304":
+        gen_pivotkv_prerope_bf16(lc, HERE, only=("prerope_bf16_qwen_L2304",))
     if args.only == "pivotkv_prerope_fp16":
         gen_pivotkv_prerope_bf16(lc, HERE, only=("prerope_fp16_qwen_L1568",))
     if args.only in (None, "glue"):

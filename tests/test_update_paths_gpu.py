@@ -809,7 +809,7 @@ def test_prologue_bf16_against_the_reference_run_from_pre_rope_projections(name,
     cache = _fixture_cache(g, n_layers, prologue_operands=operands, score_rounding=rounding)
     rot = synth.RotaryStub(g["inv_freq"], a_scale, device=dev())
     # measured on MI355X (profiles/r14_parity_stats.txt); the bars are twice the measurement (at least 2)
-    XOR_BAR = {"reference": {256: 2, 1568: 12, 6272: 48}, "pre_rope": {256: 4, 1568: 24, 6272: 80}}[operands][L]
+    XOR_BAR = {"reference": {256: 2, 1568: 12, 2304: 28, 6272: 48}, "pre_rope": {256: 4, 1568: 24, 2304: 24, 6272: 80}}[operands][L]
     for c in range(int(g["n_chunks"])):
         pre = f"c{c}_"
         q0b, k0b, vb, pos_in, pos, mask = gu.pivotkv_prerope_chunk_inputs(g, c)
@@ -879,7 +879,7 @@ def test_prologue_bf16_against_the_reference_run_from_pre_rope_projections(name,
                 continue
             if rounding == "reference":
                 nbad, nxor, a, bb = tog.check_bf16_against_reference(g, c, score, idx, kk, pos_new, "prologue, reference rounding",
-                                                                     max_bad={256: 1, 1568: 2, 6272: 10}.get(L))   # measured 0 / 0 / 1-5: twice that
+                                                                     max_bad={256: 1, 1568: 2, 2304: 4, 6272: 10}.get(L))   # measured 0 / 0 / 0-1 / 1-5: twice that
                 np.testing.assert_array_equal(a, bb)
                 if l == 0:
                     print(f"\n[{name} c{c}] {mode}: {nbad} of {L} scores differ from the reference's by one bf16 ulp, kept xor {nxor} "
