@@ -636,7 +636,8 @@ enum rtk_update_flags {
      * later launch on these words (without waiting) until the caller has zeroed ticket and status again.  A caller that
      * skips its own rtk_position_shift on the strength of this flag must check the latch before it trusts the ids
      * (PivotKVCache raises RuntimeError).  Needs the chunk-batched passes or a keep-all batch: otherwise
-     * RTK_EUNSUPPORTED is returned BEFORE anything is launched (nothing touched).
+     * RTK_EUNSUPPORTED is returned BEFORE anything is launched (nothing touched).  With this flag EVERY RTK_EUNSUPPORTED of
+     * rtk_pivotkv_update is returned before the launch (alignment, extents, shape): a caller may always fall back.
      * The caller's next rtk_position_shift for that layer is then a no-op and may be skipped - the attention patch of a
      * 28-layer model launches it 27 times per chunk otherwise.  Only with the native prepare kernel (batch.inv_freq). */
     RTK_UPDATE_SHIFT_NEXT = 8

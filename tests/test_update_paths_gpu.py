@@ -1258,6 +1258,49 @@ def test_in_launch_shift_that_runs_out_shifts_nothing_and_raises():
     assert int(other._batch.shift_ticket[0]) >= layers - 1
 
 
+def test_a_call_the_one_launch_route_declines_falls_back_also_when_it_asked_for_the_shift():
+    """rtk_pivotkv_update declines (RTK_EUNSUPPORTED) before launching anything - here: a query tensor whose address is not
+    16-byte aligned, and a cache so large that 32-bit row offsets do not reach its tail (cap x D x 2 B x 3 heads >= 2 GiB) -
+    and `update` then takes the stage-by-stage route.  That also holds for a caller that asked for the next layer's id shift
+    (the Qwen2-VL patch always does): ids, scores and caches equal an aligned / normal-sized run bit for bit."""
+    import retake.longvideo_cache as lc
+
+    layers, L = 3, 640
+    rot = synth.RotaryStub(synth.inv_freq(D), A, device=dev())
+    g = torch.Generator(device=dev()).manual_seed(12)
+    q, k, v = ((1.7 * torch.randn((1, h, L, D), generator=g, device=dev())).to(torch.bfloat16) for h in (Hq, Hkv, Hkv))
+    buf = torch.empty(q.numel() + 8, dtype=torch.bfloat16, device=dev())
+    q_off = buf[1:1 + q.numel()].view(q.shape)          # the same numbers, 2 bytes off a 16-byte boundary
+    q_off.copy_(q)
+    assert q_off.data_ptr() % 16 == 2
+
+    def run(qq, reserve):
+        cache = lc.PivotKVCache(cfg(layers), reserve_tokens=reserve)
+        seen = []
+        for c in range(3):
+            pos = chunk_ids(c, L)
+            cache.kvcache_compression, cache.keypatches_mask_chunk = True, None
+            for l in range(layers):
+                cache.shift_temporal_ids_(pos, l)
+                seen.append(pos.clone())
+                cache.update(k, v, l, {"query_states": qq, "position_ids": pos, "rotary_emb": rot, "mrope_section": SEC,
+                                       "shift_next_position_ids": True})
+            cache.after_forward()
+        cache.check()
+        return seen, [cache.key_cache[l].clone() for l in range(layers)], [cache.position_cache[l].clone() for l in range(layers)], \
+            int(cache._batch.shift_ticket[0])
+
+    seen_a, ka, pa, rode_a = run(q, 8 * L)
+    seen_b, kb, pb, rode_b = run(q_off, 8 * L)
+    big = (1 << 31) // (3 * D * 2) + 4096               # rows per head from which the KV heads' tails span 2 GiB
+    seen_c, kc, pc, rode_c = run(q, big)
+    assert rode_a >= layers - 1 and rode_b == 0 and rode_c == 0   # the declined calls never launched the fused kernel
+    for seen, ks_, ps_ in ((seen_b, kb, pb), (seen_c, kc, pc)):
+        assert all(torch.equal(x, y) for x, y in zip(seen_a, seen))
+        for l in range(layers):
+            assert torch.equal(ka[l], ks_[l]) and torch.equal(pa[l], ps_[l])
+
+
 def test_in_launch_shift_words_serve_one_stream_at_a_time():
     """The arrival counters belong to the batch: two update launches of one cache on DIFFERENT streams must not share them
     in flight.  A caller that switches its current stream between two layers gets a device synchronisation first (as the

@@ -1384,9 +1384,11 @@ class PivotKVCache(DynamicCache):
         rc = nv.lib.rtk_pivotkv_update(b.cref, st.cref, slot, b.ioref, stream)
         if rc:
             c.mask = None
-            if rc == nv.RTK_EUNSUPPORTED and not (io.flags & nv.RTK_UPDATE_SHIFT_NEXT):
-                return None   # declined before anything was launched
-            nv.check(rc, "rtk_pivotkv_update")   # (with the in-launch shift a decline is a hard error: the ids may be shifted)
+            if rc == nv.RTK_EUNSUPPORTED:
+                # declined BEFORE anything was launched - also with the in-launch shift: the library only accepts that flag
+                # where nothing can decline after the prepare launch (include/retake_hip.h, RTK_UPDATE_SHIFT_NEXT)
+                return None
+            nv.check(rc, "rtk_pivotkv_update")
         if io.flags & nv.RTK_UPDATE_SHIFT_NEXT:
             self._preshifted = (weakref.ref(pos), _version_of(pos), layer_idx + 1, stream)
         if not self._warned:  # the reference's logger.warning_once (:232)
