@@ -97,3 +97,14 @@ def test_emit_prints_the_line_last_and_writes_the_report(tmp_path, capsys):
     assert len(out) < 4096 + 1
     assert json.load(open(path)) == rep == json.loads(err.strip().splitlines()[-1])
     assert line["report"].endswith("r.json")
+
+
+def test_a_failed_world1_companion_is_reported_in_the_line_not_raised():
+    """`n1_same_arithmetic` runs in a child process; if it fails the headline must still be printed - the line then
+    carries a short reason instead of a number."""
+    rep = _canned()
+    rep["n1_same_arithmetic"] = {"error": "the world-size-1 sharded run did not finish in 300 s " + "x" * 500}
+    line = bench.contract_line(rep, None)
+    assert isinstance(line["n1_same_arithmetic"], str) and len(line["n1_same_arithmetic"]) <= 80
+    assert line["n1_same_arithmetic"].startswith("the world-size-1 sharded run did not finish")
+    assert len(json.dumps(line)) < bench.LINE_LIMIT and line["value"] == pytest.approx(rep["value"], rel=1e-6)
